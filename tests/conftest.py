@@ -1,0 +1,19 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun / round-end driver)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "prober_golden.npz")
+    return np.load(path, allow_pickle=False)

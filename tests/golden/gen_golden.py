@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE's own code.
+
+Run in the build container only (``/root/reference`` does not exist on the
+GPU box):
+
+    python tests/golden/gen_golden.py
+
+It imports ``/root/reference/utils.py`` (with ``faiss`` / ``spacy`` stubbed in
+``sys.modules`` — they are only needed by code that is not on the hot path,
+SURVEY.md §8c) and evaluates the genuine ``ImprovedProbe`` (utils.py:29-57),
+``return_prober_logit_gemma_2b`` (utils.py:389-390), ``_method_2_util``
+(utils.py:181-189) and ``return_acc`` (utils.py:158-170) on deterministic
+inputs.  Weights and inputs come from the counter-based generator
+``oracle_np.synth_rows`` so that the fixtures only need to store seeds,
+shapes and the reference's OUTPUTS (a few KB), never weights or source.
+
+The gate expressions of exp_rag.py:407-415 live inside ``main()`` and cannot
+be imported; they are evaluated here with the same torch calls
+(``torch.nn.Softmax(dim=1)``, float32 accumulation in layer order, ``.item()``
+compare) on the reference's logits.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import oracle_np as onp  # noqa: E402
+from tests.golden import cases  # noqa: E402
+
+
+def import_reference_utils():
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        raise SystemExit("reference tree not present; golden vectors can only be "
+                         "generated in the build container")
+    sys.modules.setdefault("faiss", types.ModuleType("faiss"))
+    sp = types.ModuleType("spacy")
+    sp.load = lambda name: None
+    sys.modules.setdefault("spacy", sp)
+    sys.path.insert(0, ref)
+    import utils as ref_utils  # the reference module
+    return ref_utils
+
+
+def main():
+    import torch
+    torch.set_num_threads(4)
+    ru = import_reference_utils()
+    out = {}
+
+    # ---- known-answer: parameter count (exp_parameter_check.py:52) ---------
+    p = ru.ImprovedProbe(input_size=2048, output_size=2)
+    out["param_count"] = np.int64(sum(t.numel() for t in p.parameters()))
+    out["state_keys"] = np.array(list(p.state_dict().keys()))
+
+    softmax_f = torch.nn.Softmax(dim=1)  # exp_rag.py:393
+
+    for case in cases.PROBER_CASES:
+        name, d, L, B, sigma = case["name"], case["d"], case["L"], case["B"], case["sigma"]
+        states = [cases.synth_state(case["wseed"] + l, d) for l in range(L)]
+        x = cases.case_x(case)
+        probers = []
+        for st in states:
+            m = ru.ImprovedProbe(input_size=d, output_size=2)
+            m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()})
+            m.eval()  # utils.py:329
+            probers.append(m)
+
+        # utils.py:389-390 : list of per-layer [B,2] CPU tensors
+        cfgs = list(range(L))
+        with torch.no_grad():
+            logits = ru.return_prober_logit_gemma_2b(
+                lambda cfg, prober: prober(torch.from_numpy(x[cfg])), cfgs, probers)
+        lg = torch.stack(logits).numpy()
+        out[f"{name}/logits"] = lg.astype(np.float32)
+
+        # exp_rag.py:407-415 for every (theta, ablation)
+        for ab in cases.ABLATIONS:
+            if ab >= L:
+                continue
+            acc = torch.zeros_like(logits[0])
+            for num in range(ab, len(logits)):
+                acc += softmax_f(logits[num])
+            out[f"{name}/probsum_ab{ab}"] = acc.numpy().astype(np.float32)
+            for th in cases.THETAS:
+                dec = np.array([0 if acc[b, 0].item() + th < acc[b, 1].item() else 1
+                                for b in range(B)], dtype=np.int32)
+                out[f"{name}/decision_ab{ab}_th{th}"] = dec
+
+    # ---- train/eval-time forward: ragged mean pool + double-softmax CE -----
+    for case in cases.POOL_CASES:
+        name, d, B, T = case["name"], case["d"], case["B"], case["T"]
+        st = cases.synth_state(case["wseed"], d)
+        m = ru.ImprovedProbe(input_size=d, output_size=2)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()})
+        m.eval()
+        acts, pred_lens, labels = cases.synth_pool_inputs(case)
+        args = types.SimpleNamespace(device="cpu")
+        # utils.py:456 (`from scipy.special import softmax`, baseline-RAG code)
+        # shadows the nn.Softmax(dim=-1) bound at utils.py:15 that make_loss
+        # (utils.py:130) was written against; train.py:141-151 — the copy that
+        # actually runs — uses nn.Softmax(dim=-1).  Restore that binding.
+        ru.softmax = torch.nn.Softmax(dim=-1)
+        with torch.no_grad():
+            loss, probs = ru._method_2_util(m, torch.from_numpy(acts), torch.from_numpy(labels),
+                                            torch.from_numpy(pred_lens), args)
+        out[f"{name}/probs"] = probs.numpy().astype(np.float32)
+        out[f"{name}/loss"] = np.float32(loss.item())
+        out[f"{name}/acc"] = np.float64(ru.return_acc(probs, torch.from_numpy(labels)))
+        # inference-time sum pool of the same tokens (exp_rag.py:385-387)
+        with torch.no_grad():
+            sums = torch.stack([torch.from_numpy(acts[i, T - int(n):, :]).sum(dim=0)
+                                for i, n in enumerate(pred_lens)])
+            out[f"{name}/sum_logits"] = m(sums).numpy().astype(np.float32)
+
+    path = os.path.join(HERE, "prober_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,109 @@
+"""CPU: the oracle restatement against golden vectors produced by the
+reference's own classes (tests/golden/gen_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import oracle_np as onp
+from tests.golden import cases
+
+
+def test_param_count_known_answer(golden):
+    # exp_parameter_check.py:52 — 1,318,914 parameters / 5.03 MB
+    assert int(golden["param_count"]) == 1318914
+    st = cases.synth_state(1, 2048)
+    assert sum(v.size for v in st.values()) == 1318914
+    assert list(golden["state_keys"]) == sorted(st.keys(), key=list(golden["state_keys"]).index)
+    assert set(st.keys()) == set(onp.STATE_KEYS)
+
+
+@pytest.mark.parametrize("case", cases.PROBER_CASES, ids=lambda c: c["name"])
+def test_prober_logits_match_reference(golden, case):
+    states = [cases.synth_state(case["wseed"] + l, case["d"]) for l in range(case["L"])]
+    x = cases.case_x(case)
+    got = onp.ensemble_forward(states, x)
+    ref = golden[f"{case['name']}/logits"]
+    assert got.shape == ref.shape
+    # reference is torch fp32; oracle is fp64 rounded once -> 1e-5 covers fp32 noise
+    np.testing.assert_allclose(got, ref, atol=1e-5, rtol=0)
+
+
+@pytest.mark.parametrize("case", cases.PROBER_CASES, ids=lambda c: c["name"])
+def test_gate_matches_reference(golden, case):
+    ref_logits = golden[f"{case['name']}/logits"]
+    for ab in cases.ABLATIONS:
+        if ab >= case["L"]:
+            continue
+        for th in cases.THETAS:
+            s, dec = onp.gate(ref_logits, ablation=ab, theta=th)
+            np.testing.assert_allclose(s, golden[f"{case['name']}/probsum_ab{ab}"], atol=1e-6, rtol=0)
+            ref_dec = golden[f"{case['name']}/decision_ab{ab}_th{th}"]
+            # decisions must be identical except within fp noise of the threshold
+            margin = np.abs(s[:, 0] + np.float32(th) - s[:, 1])
+            bad = (dec != ref_dec) & (margin > 1e-5)
+            assert not bad.any()
+
+
+@pytest.mark.parametrize("case", cases.POOL_CASES, ids=lambda c: c["name"])
+def test_train_eval_forward_matches_reference(golden, case):
+    st = cases.synth_state(case["wseed"], case["d"])
+    acts, pred_lens, labels = cases.synth_pool_inputs(case)
+    probs, loss, acc = onp.train_eval_forward(st, acts, pred_lens, labels)
+    np.testing.assert_allclose(probs, golden[f"{case['name']}/probs"], atol=1e-5, rtol=0)
+    assert abs(float(loss) - float(golden[f"{case['name']}/loss"])) < 1e-5
+    assert acc == float(golden[f"{case['name']}/acc"])
+    # sum pool vs mean pool feed the same LayerNorm-first prober: logits agree
+    # up to the eps term, and the sum path is pinned on its own
+    T = case["T"]
+    sums = np.stack([acts[i, T - int(n):, :].astype(np.float64).sum(axis=0)
+                     for i, n in enumerate(pred_lens)]).astype(np.float32)
+    np.testing.assert_allclose(onp.prober_forward(st, sums),
+                               golden[f"{case['name']}/sum_logits"], atol=1e-5, rtol=0)
+
+
+def test_pool_sum_skips_prompt_pass():
+    rng = np.random.default_rng(0)
+    cache = [rng.standard_normal((1, 9, 16)).astype(np.float32)] + \
+            [rng.standard_normal((1, 1, 16)).astype(np.float32) for _ in range(5)]
+    got = onp.pool_sum_decode_steps(cache)
+    want = np.sum(np.concatenate(cache[1:], axis=1), axis=1)
+    np.testing.assert_allclose(got, want, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        onp.pool_sum_decode_steps(cache[:1])
+
+
+def test_retr_count_semantics():
+    # exp_rag.py:417-468: <=4 rounds, retr_count saturates at 3
+    assert onp.retr_count_from_decisions([0]) == (0, 0)
+    assert onp.retr_count_from_decisions([1, 0]) == (1, 1)
+    assert onp.retr_count_from_decisions([1, 1, 0]) == (2, 2)
+    assert onp.retr_count_from_decisions([1, 1, 1, 0]) == (3, 3)
+    assert onp.retr_count_from_decisions([1, 1, 1, 1, 0]) == (3, 4)
+    assert onp.retr_count_from_decisions([1, 1, 1, 1, 1, 1]) == (3, 4)
+
+
+def test_flat_search_definition_and_ties():
+    xs = np.array([[0, 0], [1, 0], [1, 0], [3, 4], [0, 2]], np.float32)
+    q = np.array([[1, 0], [0, 0]], np.float32)
+    D, I = onp.flat_search(xs, q, 3, onp.METRIC_L2)
+    assert I.tolist() == [[1, 2, 0], [0, 1, 2]]   # tie -> lowest id
+    assert D.tolist() == [[0, 0, 1], [0, 1, 1]]
+    D, I = onp.flat_search(xs, q, 2, onp.METRIC_IP)
+    assert I.tolist() == [[3, 1], [0, 1]]
+    D, I = onp.flat_search(xs[:2], q, 4, onp.METRIC_L2)
+    assert I[0].tolist() == [1, 0, -1, -1]
+    # sharded merge == unsharded
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((300, 24)).astype(np.float32)
+    Q = rng.standard_normal((5, 24)).astype(np.float32)
+    for metric in (onp.METRIC_L2, onp.METRIC_IP):
+        D0, I0 = onp.flat_search(X, Q, 7, metric)
+        parts = [onp.flat_search(X[a:b], Q, 7, metric, id_offset=a) for a, b in ((0, 100), (100, 250), (250, 300))]
+        D1, I1 = onp.merge_topk([p[0] for p in parts], [p[1] for p in parts], 7, metric)
+        assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
+
+
+def test_synth_rows_is_shardable_and_normalish():
+    a = onp.synth_rows(42, 0, 64, 768)
+    b = onp.synth_rows(42, 32, 32, 768)
+    assert np.array_equal(a[32:], b)
+    assert abs(float(a.mean())) < 0.02 and abs(float(a.std()) - 1.0) < 0.02
