@@ -1,0 +1,180 @@
+/*
+ * prag.h — C ABI of libprag.so, the MI355X (gfx950) implementation of the
+ * Probing-RAG retrieval-gating hot path.
+ *
+ * The reference (baekingeol/Probing-RAG, paths relative to its root) is pure
+ * Python with no FFI of its own; the boundary it offers is a handful of
+ * duck-typed call sites.  Each entry point below names the reference call
+ * site it replaces.  The Python host side (probing-rag_amd/) binds these
+ * with ctypes and re-creates the reference's objects (`prober(x)`,
+ * `index.search(q, k)`, `batch_topk_sim(...)`) on top of them; INTEGRATION.md
+ * shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - every call returns PRAG_OK (0) or a negative PRAG_E* code and never
+ *    throws; prag_last_error() returns a thread-local message for the last
+ *    failure on the calling thread;
+ *  - `*_dev` pointers are device pointers BORROWED for the duration of the
+ *    stream work (tensor.data_ptr()); the caller keeps them alive;
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream()
+ *    .cuda_stream); all kernels are launched on it and no call synchronises
+ *    the device unless its comment says so;
+ *  - handles own their device buffers; a handle is not thread-safe (the
+ *    reference loop is single-threaded, exp_rag.py:396).
+ */
+#ifndef PRAG_H
+#define PRAG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRAG_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+#define PRAG_OK 0
+#define PRAG_EINVAL (-1)       /* bad argument / shape */
+#define PRAG_EHIP (-2)         /* a HIP runtime call failed */
+#define PRAG_ENOMEM (-3)
+#define PRAG_EUNSUPPORTED (-4) /* valid request the kernels do not cover */
+#define PRAG_ESTATE (-5)       /* e.g. forward before all layers are loaded */
+
+/* element types of caller-provided activations / stored corpus rows */
+#define PRAG_F32 0
+#define PRAG_F16 1
+
+/* weight precision of a prober handle */
+#define PRAG_W_F16 1   /* weights rounded to 11 significant bits (one fp16 MFMA term)   */
+#define PRAG_W_F32 0   /* weights kept to ~22 bits as hi+lo fp16 terms (fp32 parity)    */
+
+/* similarity metrics of the flat index */
+#define PRAG_METRIC_L2 0   /* squared L2, ascending  == faiss.IndexFlatL2 (make_indexer.py:450) */
+#define PRAG_METRIC_IP 1   /* inner product, descending == faiss.IndexFlatIP                 */
+#define PRAG_METRIC_COS 2  /* rows and queries L2-normalised, then IP (BASELINE config 3)    */
+
+int prag_version(void);
+const char* prag_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Prober ensemble + gate
+ * ---------------------------------------------------------------------- */
+typedef struct prag_prober prag_prober_t;
+
+/* Replaces `ImprovedProbe(input_size=cfg.d_model, output_size=cfg.num_classes)`
+ * x n_layers (utils.py:302, 385-387).  d_hidden must be 512 and n_classes 2
+ * (utils.py:30, 289); d_model a multiple of 64. */
+int prag_prober_create(prag_prober_t** out, int n_layers, int d_model, int d_hidden,
+                       int n_classes, int weight_mode);
+
+/* Replaces `prober.load_state_dict(torch.load(path))` + `.eval()`
+ * (utils.py:303-329) for one layer.  Host float32 arrays in the reference's
+ * state-dict layout ([out,in] row-major weights).  The data is copied (and
+ * LayerNorm affines are folded into the following Linear) before return;
+ * synchronises the device. */
+int prag_prober_load_layer(prag_prober_t* p, int layer_idx,
+                           const float* ln0_w, const float* ln0_b,
+                           const float* W1, const float* b1,
+                           const float* ln1_w, const float* ln1_b,
+                           const float* W2, const float* b2,
+                           const float* ln2_w, const float* ln2_b,
+                           const float* W3, const float* b3);
+
+/* Replaces `logit = prober(input)` (exp_rag.py:387, utils.py:45-57) for
+ * `n_run` consecutive layers starting at `layer0`, in ONE launch.
+ *   x_dev: activations, element type x_dtype (PRAG_F32 | PRAG_F16); row b of
+ *          layer l starts at element (l - layer0) * x_layer_stride + b * d_model
+ *   logits_dev: float32 [n_run, B, 2]                                        */
+int prag_prober_forward(prag_prober_t* p, const void* x_dev, int x_dtype,
+                        int64_t x_layer_stride, int layer0, int n_run, int B,
+                        float* logits_dev, void* stream);
+
+/* Replaces return_prober_logit_gemma_2b + the softmax / sum / threshold of
+ * exp_rag.py:406-415 for a whole batch: all layers' probers, then
+ * probsum[b] = sum_{n>=ablation} softmax(logits[n,b]) (float32, layer order)
+ * and decision[b] = (probsum[b,0] + theta < probsum[b,1]) ? 0 : 1
+ * (1 = retrieve).  logits_dev [L,B,2], probsum_dev [B,2], decision_dev [B]. */
+int prag_gate(prag_prober_t* p, const void* x_dev, int x_dtype, int64_t x_layer_stride,
+              int B, int ablation, float theta, float* logits_dev, float* probsum_dev,
+              int32_t* decision_dev, void* stream);
+
+/* The gate arithmetic alone (exp_rag.py:407-415) on existing logits. */
+int prag_gate_from_logits(const float* logits_dev, int L, int B, int ablation, float theta,
+                          float* probsum_dev, int32_t* decision_dev, void* stream);
+
+/* Test/inspection hook: the weights the kernels actually compute with, as a
+ * state dict whose LayerNorm affines are identity (folded into W/b).  Host
+ * float32 outputs: W1 [512,d], b1 [512], W2 [512,512], b2 [512], W3 [2,512],
+ * b3 [2].  Any pointer may be NULL. */
+int prag_prober_effective_weights(prag_prober_t* p, int layer_idx, float* W1, float* b1,
+                                  float* W2, float* b2, float* W3, float* b3);
+
+/* Pre-size the internal activation workspace for batches up to max_B rows so
+ * that later forward calls never allocate (stream-capture safe). */
+int prag_prober_reserve(prag_prober_t* p, int max_B);
+
+void prag_prober_destroy(prag_prober_t* p);
+
+/* Replaces `torch.sum(torch.concat(cache[name][1:], dim=1), dim=1)`
+ * (exp_rag.py:385-386): acc[l, b, :] (+)= h[l, b, :] for one decode step, on
+ * device, so hooks need no D2H copy.
+ * acc_dev float32 [L,B,d]; h_dev element type h_dtype, same layout; if
+ * `assign` != 0 the accumulator is overwritten instead of added to. */
+int prag_pool_accumulate(float* acc_dev, const void* h_dev, int h_dtype, int64_t n_elems,
+                         int assign, void* stream);
+
+/* Replaces input_tensor_method1 + per-sample mean (train.py:153-162, 202-205;
+ * utils.py:134-143, 184-186): out[b,:] = mean over the last pred_lens[b]
+ * positions of acts[b] ([B,T,d], element type dtype).  out float32 [B,d];
+ * pred_lens_dev int64 [B].  scale_mean=0 gives the inference-time sum pool. */
+int prag_pool_ragged(const void* acts_dev, int dtype, int B, int T, int d,
+                     const int64_t* pred_lens_dev, int scale_mean, float* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Flat (exact, brute-force) index
+ * ---------------------------------------------------------------------- */
+typedef struct prag_index prag_index_t;
+
+/* Replaces `faiss.IndexFlatL2(768)` (make_indexer.py:449-450).  store_dtype:
+ * PRAG_F32 keeps rows as given (reference parity), PRAG_F16 rounds them to
+ * fp16 (half the scan bytes).  `capacity_rows` > 0 pre-allocates. */
+int prag_index_create(prag_index_t** out, int d, int metric, int store_dtype,
+                      int64_t capacity_rows);
+
+/* Replaces `index.add(model.encode(texts[...]))` (make_indexer.py:455): append
+ * n rows of float32 [n,d] (host pointer if src_is_device == 0).  Row ids are
+ * insertion order, 0-based.  Synchronises the device. */
+int prag_index_add(prag_index_t* ix, const float* x, int64_t n, int src_is_device);
+
+/* Append n synthetic rows generated on the device by the counter-based
+ * generator shared with the oracle (oracle_np.synth_rows): row ids
+ * [row0, row0+n) of stream `seed`.  Bench / test helper. */
+int prag_index_add_synthetic(prag_index_t* ix, uint32_t seed, int64_t row0, int64_t n);
+
+int64_t prag_index_ntotal(const prag_index_t* ix);
+int prag_index_d(const prag_index_t* ix);
+
+/* Replaces `D, I = index.search(x, k)` (utils.py:379; exp_rag.py:432-436).
+ *   q: float32 [B,d] (device pointer if io_is_device, else host);
+ *   D: float32 [B,k] squared-L2 ascending (L2) or score descending (IP/COS);
+ *   I: int64 [B,k] row ids + id_offset, -1 padded when ntotal < k.
+ * With io_is_device == 0 the call copies in/out and synchronises `stream`. */
+int prag_index_search(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset,
+                      float* D, int64_t* I, int io_is_device, void* stream);
+
+/* The exchange step of the row-sharded index: merge `n_parts` per-shard
+ * results (D_parts/I_parts laid out [n_parts, B, k], e.g. straight out of an
+ * RCCL all-gather) by (score, id) into the global top-k.  Device pointers. */
+int prag_merge_topk(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts, int B,
+                    int k, int metric, float* D_dev, int64_t* I_dev, void* stream);
+
+/* Read back stored rows [row0,row0+n) as float32 (what the scan sees). */
+int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n, float* out_host);
+
+void prag_index_destroy(prag_index_t* ix);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRAG_H */

@@ -1,0 +1,17 @@
+"""probing_rag_amd — MI355X (gfx950) implementation of Probing-RAG's
+retrieval-gating hot path: fused prober ensemble + gate, and the flat dense
+index (scan + top-k), behind the reference's own call signatures.
+
+Everything computes through libprag.so (HIP kernels, C ABI in include/prag.h);
+importing this package does not need a GPU, using it does.
+"""
+from ._lib import PragError, build, lib  # noqa: F401
+from .prober import (Config_Maker, HipProber, HipProberEnsemble, gate_from_logits,  # noqa: F401
+                     load_prober_cfg_gemma_2b, load_prober_models, return_prober_logit_gemma_2b)
+from .index import (HipFlatIndex, IndexFlatIP, IndexFlatL2, batch_topk_sim, encode_query,  # noqa: F401
+                    find_topk_sim, merge_topk, read_index, write_index)
+from .sharded import ShardedFlatIndex, partition_rows, search_shards_on_one_gpu  # noqa: F401
+from .loop import HiddenStatePool, pool_ragged, retrieve_decide, return_evidences  # noqa: F401
+
+ImprovedProbe = HipProber  # utils.py:29
+__version__ = "0.1.0"

@@ -1,0 +1,115 @@
+"""ctypes binding of libprag.so (include/prag.h).
+
+There is NO fallback: if the HIP library cannot be loaded every entry point
+raises.  The reference path being replaced is pure Python + faiss-cpu; this
+module is the only way the product computes anything.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "lib", "libprag.so")
+
+PRAG_OK = 0
+PRAG_F32, PRAG_F16 = 0, 1
+PRAG_W_F32, PRAG_W_F16 = 0, 1
+METRIC_L2, METRIC_IP, METRIC_COS = 0, 1, 2
+_METRICS = {"l2": METRIC_L2, "ip": METRIC_IP, "cos": METRIC_COS, "cosine": METRIC_COS}
+_ERR = {-1: "PRAG_EINVAL", -2: "PRAG_EHIP", -3: "PRAG_ENOMEM", -4: "PRAG_EUNSUPPORTED", -5: "PRAG_ESTATE"}
+
+
+class PragError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{_ERR.get(code, code)}: {msg}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile libprag.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
+           [os.path.join(os.path.dirname(_HERE), "include", "prag.h")]
+    stale = (not os.path.exists(LIB_PATH)) or \
+        os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
+    if force or stale:
+        if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+            raise RuntimeError("libprag.so is missing/stale and hipcc is not available to build it")
+        subprocess.check_call(["make", "-s", "-j3", "-C", CSRC])
+    return LIB_PATH
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_int64
+_F = ctypes.c_float
+_FP = ctypes.POINTER(ctypes.c_float)
+
+# name -> (restype, argtypes); every symbol declared in include/prag.h
+SIGNATURES = {
+    "prag_version": (_I, []),
+    "prag_last_error": (ctypes.c_char_p, []),
+    "prag_prober_create": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I, _I]),
+    "prag_prober_load_layer": (_I, [_P, _I] + [_FP] * 12),
+    "prag_prober_forward": (_I, [_P, _P, _I, _L, _I, _I, _I, _P, _P]),
+    "prag_gate": (_I, [_P, _P, _I, _L, _I, _I, _F, _P, _P, _P, _P]),
+    "prag_gate_from_logits": (_I, [_P, _I, _I, _I, _F, _P, _P, _P]),
+    "prag_prober_effective_weights": (_I, [_P, _I] + [_FP] * 6),
+    "prag_prober_reserve": (_I, [_P, _I]),
+    "prag_prober_destroy": (None, [_P]),
+    "prag_pool_accumulate": (_I, [_P, _P, _I, _L, _I, _P]),
+    "prag_pool_ragged": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "prag_index_create": (_I, [ctypes.POINTER(_P), _I, _I, _I, _L]),
+    "prag_index_add": (_I, [_P, _P, _L, _I]),
+    "prag_index_add_synthetic": (_I, [_P, ctypes.c_uint32, _L, _L]),
+    "prag_index_ntotal": (_L, [_P]),
+    "prag_index_d": (_I, [_P]),
+    "prag_index_search": (_I, [_P, _P, _I, _I, _L, _P, _P, _I, _P]),
+    "prag_merge_topk": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "prag_index_reconstruct": (_I, [_P, _L, _L, _P]),
+    "prag_index_destroy": (None, [_P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libprag.so (building it first if it is missing and hipcc exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        try:
+            handle = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # fail loudly: there is no CPU fallback
+            raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != PRAG_OK:
+        raise PragError(rc, lib().prag_last_error().decode("utf-8", "replace"))
+
+
+def metric_id(metric) -> int:
+    if isinstance(metric, str):
+        return _METRICS[metric.lower()]
+    return int(metric)
+
+
+def current_stream_ptr(device=None):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("probing_rag_amd needs an AMD GPU (gfx950): no HIP device is visible and "
+                           "there is no CPU fallback for the hot path")

@@ -1,0 +1,863 @@
+// Flat (exact brute-force) index for MI355X (gfx950, CDNA4): the replacement for
+// faiss.IndexFlatL2.add/search on the Probing-RAG retrieval path
+// (/root/reference: make_indexer.py:449-457, utils.py:378-380, exp_rag.py:432-436).
+//
+// search = 4 launches on the caller's stream (DESIGN.md "Kernel 2"):
+//   1. prep_queries   : fp32 queries -> (cosine: normalise) -> fp16 tile + fp32 copy
+//   2. scan_topk      : ONE pass over the stored rows per tile of <=64 queries.
+//        HBM-bound: every wave streams its own 32-row slices with coalesced
+//        128-B-line loads -> XOR-swizzled per-wave LDS stage -> ds_read_b128
+//        fragments -> v_mfma_f32_32x32x16_f16 against the LDS-resident query
+//        tile.  The 32x32 score tile never leaves registers: each lane keeps a
+//        sorted top-KC list for its (query, row-half) stream; [B,N] is never
+//        materialised.  Waves never synchronise with each other in the loop.
+//   3. merge_lists    : per query, merge the per-lane lists into KC candidates
+//        ordered by (key, row id).
+//   4. rerank         : exact fp64 distance / inner product of the KC candidates
+//        against the fp32 query, final (score, id) order, write D (f32) / I (i64).
+// Step 4 makes the result independent of MFMA accumulation order: scores are the
+// float32 rounding of the float64 value, ties break by lowest row id.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "prag_common.h"
+
+namespace prag {
+
+constexpr int kIdxSentinel = 0x7fffffff;
+
+// ---------------------------------------------------------------------------
+// counter-based synthetic rows: bit-identical to oracle_np.synth_rows
+// ---------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+
+__host__ __device__ __forceinline__ float synth_value(uint32_t seed, uint64_t row, uint32_t col, uint32_t d) {
+    const uint64_t ctr = row * (uint64_t)d + col;
+    const uint32_t lo = (uint32_t)ctr, hi = (uint32_t)(ctr >> 32);
+    const uint32_t h1 = mix32(lo ^ mix32(hi ^ seed));
+    const uint32_t h2 = mix32(h1 ^ 0x9E3779B9u);
+    const int t = (int)(h1 & 0xFFFFu) + (int)(h1 >> 16) + (int)(h2 & 0xFFFFu) + (int)(h2 >> 16) - 131070;
+    return (float)t * (float)(1.0 / 37837.22);
+}
+
+// ---------------------------------------------------------------------------
+// add: one wave per row.  cosine -> normalise in fp64, round to f32; store as
+// f32 or f16; keep ||stored row||^2 (fp64 sum, rounded) for the L2 scan key.
+// ---------------------------------------------------------------------------
+template <bool STORE_F32, bool SYNTH>
+__global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ src, uint32_t seed,
+                                                      int64_t synth_row0, int64_t n, int d, int normalise,
+                                                      void* __restrict__ rows, float* __restrict__ xnorm,
+                                                      int64_t dst_row0) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* s = SYNTH ? nullptr : src + i * d;
+    auto get = [&](int c) -> float {
+        if constexpr (SYNTH) return synth_value(seed, (uint64_t)(synth_row0 + i), (uint32_t)c, (uint32_t)d);
+        else return s[c];
+    };
+    double nrm = 1.0;
+    if (normalise) {
+        double ss = 0.0;
+        for (int c = lane; c < d; c += 64) {
+            const double v = (double)get(c);
+            ss = fma(v, v, ss);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        nrm = sqrt(ss);
+        if (!(nrm > 0.0)) nrm = 1.0;
+    }
+    double q = 0.0;
+    for (int c = lane; c < d; c += 64) {
+        float v = get(c);
+        if (normalise) v = (float)((double)v / nrm);
+        double kept;
+        if constexpr (STORE_F32) {
+            reinterpret_cast<float*>(rows)[(dst_row0 + i) * d + c] = v;
+            kept = (double)v;
+        } else {
+            const _Float16 h = (_Float16)v;
+            reinterpret_cast<_Float16*>(rows)[(dst_row0 + i) * d + c] = h;
+            kept = (double)h;
+        }
+        q = fma(kept, kept, q);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if (lane == 0) xnorm[dst_row0 + i] = (float)q;
+}
+
+// ---------------------------------------------------------------------------
+// queries: q32[b] = (cosine ? q/||q|| : q) in f32 ; q16 = fp16(q32), rows padded
+// with zeros up to a multiple of the tile height.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, int B, int Bpad, int d,
+                                                          int normalise, float* __restrict__ q32,
+                                                          _Float16* __restrict__ q16) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= Bpad) return;
+    if (b >= B) {
+        for (int c = lane; c < d; c += 64) q16[(int64_t)b * d + c] = (_Float16)0.f;
+        return;
+    }
+    const float* s = q + (int64_t)b * d;
+    double nrm = 1.0;
+    if (normalise) {
+        double ss = 0.0;
+        for (int c = lane; c < d; c += 64) {
+            const double v = (double)s[c];
+            ss = fma(v, v, ss);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        nrm = sqrt(ss);
+        if (!(nrm > 0.0)) nrm = 1.0;
+    }
+    for (int c = lane; c < d; c += 64) {
+        const float v = normalise ? (float)((double)s[c] / nrm) : s[c];
+        q32[(int64_t)b * d + c] = v;
+        q16[(int64_t)b * d + c] = (_Float16)v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// scan + fused per-lane top-KC
+// ---------------------------------------------------------------------------
+struct ScanArgs {
+    const void* rows;        // [N][d] f16 or f32
+    const float* xnorm;      // [roundup(N,32)]
+    const _Float16* q16;     // [QT][d] this pass's query tile
+    int64_t N;
+    int d;
+    int qstride;             // LDS bytes per query row (multiple of 256)
+    int n_tiles;             // ceil(N / 32)
+    float alpha;             // key = bias + alpha * dot  (L2: -2, IP: -1)
+    int use_norm;            // L2: bias = ||x||^2
+    float* out_key;          // [n_lists][QT][KC]
+    int* out_idx;
+};
+
+template <int KC>
+struct TopList {
+    float k[KC];
+    int i[KC];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            k[j] = INFINITY;
+            i[j] = kIdxSentinel;
+        }
+    }
+    // strict '<': among equal keys the earlier (lower row id) entry stays in front
+    __device__ __forceinline__ void push(float key, int idx) {
+        if (key < k[KC - 1]) {
+            bool prev = false;  // c_{j-1}: key < old[j-1]
+            float ok = 0.f;
+            int oi = 0;  // old[j-1]
+#pragma unroll
+            for (int j = 0; j < KC; ++j) {
+                const float cur_k = k[j];
+                const int cur_i = i[j];
+                const bool c = key < cur_k;
+                k[j] = prev ? ok : (c ? key : cur_k);
+                i[j] = prev ? oi : (c ? idx : cur_i);
+                prev = c;
+                ok = cur_k;
+                oi = cur_i;
+            }
+        }
+    }
+};
+
+template <int QT, int KC, bool F32>
+__global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
+    constexpr int NQ = QT / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int d = a.d;
+    const int NCH = d >> 6;  // 64-element chunks per row
+    const int qstride = a.qstride;
+    char* s_q = smem;
+    char* s_st = smem + QT * qstride + w * 4096;
+
+    // ---- query tile -> LDS (swizzled 16-B pieces) --------------------------
+    {
+        const int ppr = d >> 3;  // pieces per row
+        for (int e = tid; e < QT * ppr; e += 512) {
+            const int row = e / ppr, p = e - row * ppr;
+            const uint4 v = *reinterpret_cast<const uint4*>(a.q16 + (int64_t)row * d + 8 * p);
+            *reinterpret_cast<uint4*>(s_q + row * qstride + (((p & ~15) | ((p ^ row) & 15)) << 4)) = v;
+        }
+    }
+    __syncthreads();
+
+    const int nW = gridDim.x * 8;
+    const int gw = blockIdx.x * 8 + w;
+    const int n_my = gw < a.n_tiles ? (a.n_tiles - gw + nW - 1) / nW : 0;
+
+    TopList<KC> top[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) top[t].init();
+
+    // staging geometry
+    constexpr int NLD = F32 ? 8 : 4;  // 16-B loads per lane per chunk
+    int st_doc[NLD], st_dst[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        if constexpr (F32) {
+            const int doc = 4 * i + (lane >> 4), q4 = lane & 15;
+            st_doc[i] = doc;
+            st_dst[i] = doc * 128 + (((q4 >> 1) ^ ((doc >> 1) & 7)) << 4) + (q4 & 1) * 8;
+        } else {
+            const int doc = 8 * i + (lane >> 3), q = lane & 7;
+            st_doc[i] = doc;
+            st_dst[i] = doc * 128 + ((q ^ ((doc >> 1) & 7)) << 4);
+        }
+    }
+    const int col_b = F32 ? (lane & 15) * 16 : (lane & 7) * 16;  // byte offset inside the chunk
+    const int64_t row_bytes = (int64_t)d * (F32 ? 4 : 2);
+    const int chunk_bytes = F32 ? 256 : 128;
+    const char* rows = reinterpret_cast<const char*>(a.rows);
+
+    uint4 ld[NLD];
+    auto issue = [&](int tile, int c) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            int64_t row = (int64_t)tile * 32 + st_doc[i];
+            row = row < a.N ? row : a.N - 1;
+            ld[i] = *reinterpret_cast<const uint4*>(rows + row * row_bytes + c * chunk_bytes + col_b);
+        }
+    };
+
+    const int a_off = r * 128;
+    const int a_sw = (r >> 1) & 7;
+
+    f32x16 acc[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    if (n_my > 0) issue(gw, 0);
+    for (int ti = 0; ti < n_my; ++ti) {
+        const int tile = gw + ti * nW;
+        for (int c = 0; c < NCH; ++c) {
+            // stage the chunk that is in registers, then immediately refill them
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                if constexpr (F32) {
+                    const f32x4 f = __builtin_bit_cast(f32x4, ld[i]);
+                    half4 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = (_Float16)f[e];
+                    *reinterpret_cast<half4*>(s_st + st_dst[i]) = h;
+                } else {
+                    *reinterpret_cast<uint4*>(s_st + st_dst[i]) = ld[i];
+                }
+            }
+            if (c + 1 < NCH) issue(tile, c + 1);
+            else if (ti + 1 < n_my) issue(tile + nW, 0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const half8 av = *reinterpret_cast<const half8*>(s_st + a_off + (((2 * s + hh) ^ a_sw) << 4));
+                const int P = c * 8 + 2 * s + hh;
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) {
+                    const int qrow = 32 * t + r;
+                    const half8 bv = *reinterpret_cast<const half8*>(
+                        s_q + qrow * qstride + (((P & ~15) | ((P ^ qrow) & 15)) << 4));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue: 16 rows x this lane's query -> running top-KC ---------
+        const int64_t doc0 = (int64_t)tile * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 xn = {0.f, 0.f, 0.f, 0.f};
+            if (a.use_norm) xn = *reinterpret_cast<const f32x4*>(a.xnorm + doc0 + 8 * g + 4 * hh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t doc = doc0 + 8 * g + 4 * hh + e;
+                const bool valid = doc < a.N;
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) {
+                    const float key = valid ? fmaf(a.alpha, acc[t][4 * g + e], xn[e]) : INFINITY;
+                    top[t].push(key, (int)doc);
+                    acc[t][4 * g + e] = 0.f;
+                }
+            }
+        }
+    }
+
+    // ---- per-lane lists -> global: list id = (wave_global*2 + hh) ------------
+    const int64_t list = (int64_t)gw * 2 + hh;
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        const int64_t o = (list * QT + 32 * t + r) * KC;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            a.out_key[o + j] = top[t].k[j];
+            a.out_idx[o + j] = top[t].i[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// merge the per-lane lists of one query tile: grid = queries, 256 threads
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long pack_key(float key, int idx) {
+    uint32_t u = __float_as_uint(key);
+    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;  // monotone float -> uint
+    return ((unsigned long long)u << 32) | (uint32_t)idx;
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restrict__ part_key,
+                                                         const int* __restrict__ part_idx, int n_lists,
+                                                         int QT, int* __restrict__ cand_idx /*[q][KC]*/) {
+    __shared__ unsigned long long s_min[4];
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const unsigned long long kInf = ~0ull;
+    unsigned long long loc[KC];
+#pragma unroll
+    for (int j = 0; j < KC; ++j) loc[j] = kInf;
+    for (int l = tid; l < n_lists; l += 256) {
+        const int64_t o = ((int64_t)l * QT + q) * KC;
+        for (int j = 0; j < KC; ++j) {
+            const int idx = part_idx[o + j];
+            if (idx == kIdxSentinel) break;  // lists are sorted, sentinels last
+            const unsigned long long v = pack_key(part_key[o + j], idx);
+            if (!(v < loc[KC - 1])) break;
+            bool prev = false;
+            unsigned long long old = 0;
+#pragma unroll
+            for (int i = 0; i < KC; ++i) {
+                const unsigned long long cur = loc[i];
+                const bool c = v < cur;
+                loc[i] = prev ? old : (c ? v : cur);
+                prev = c;
+                old = cur;
+            }
+        }
+    }
+    for (int round = 0; round < KC; ++round) {
+        unsigned long long m = loc[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(m, o, 64);
+            m = other < m ? other : m;
+        }
+        if ((tid & 63) == 0) s_min[tid >> 6] = m;
+        __syncthreads();
+        unsigned long long g = s_min[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) g = s_min[i] < g ? s_min[i] : g;
+        __syncthreads();
+        if (loc[0] == g && g != kInf) {  // unique owner: every row id appears once
+#pragma unroll
+            for (int i = 0; i + 1 < KC; ++i) loc[i] = loc[i + 1];
+            loc[KC - 1] = kInf;
+        }
+        if (tid == 0) cand_idx[(int64_t)q * KC + round] = (g == kInf) ? -1 : (int)(uint32_t)g;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// exact rerank: grid = queries, 256 threads (4 waves take candidates round-robin)
+// ---------------------------------------------------------------------------
+template <bool F32>
+__global__ __launch_bounds__(256) void rerank_kernel(const void* __restrict__ rows, int d, int metric_l2,
+                                                    const float* __restrict__ q32,
+                                                    const int* __restrict__ cand_idx, int KC, int k,
+                                                    int64_t id_offset, float* __restrict__ D,
+                                                    int64_t* __restrict__ I) {
+    __shared__ double s_score[64];
+    __shared__ int s_idx[64];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* q = q32 + (int64_t)b * d;
+    for (int c = w; c < KC; c += 4) {
+        const int idx = cand_idx[(int64_t)b * KC + c];
+        double s = 0.0;
+        if (idx >= 0) {
+            for (int e = lane; e < d; e += 64) {
+                double x;
+                if constexpr (F32) x = (double)reinterpret_cast<const float*>(rows)[(int64_t)idx * d + e];
+                else x = (double)reinterpret_cast<const _Float16*>(rows)[(int64_t)idx * d + e];
+                const double qv = (double)q[e];
+                if (metric_l2) {
+                    const double t = qv - x;
+                    s = fma(t, t, s);
+                } else {
+                    s = fma(qv, x, s);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        }
+        if (lane == 0) {
+            s_score[c] = s;
+            s_idx[c] = idx;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // insertion sort by (score better, id lower); invalid (-1) entries last
+        for (int i = 1; i < KC; ++i) {
+            const double sv = s_score[i];
+            const int iv = s_idx[i];
+            int j = i - 1;
+            while (j >= 0) {
+                const double sj = s_score[j];
+                const int ij = s_idx[j];
+                bool before;  // does (sv,iv) go before (sj,ij)?
+                if (iv < 0) before = false;
+                else if (ij < 0) before = true;
+                else if (sv != sj) before = metric_l2 ? (sv < sj) : (sv > sj);
+                else before = iv < ij;
+                if (!before) break;
+                s_score[j + 1] = sj;
+                s_idx[j + 1] = ij;
+                --j;
+            }
+            s_score[j + 1] = sv;
+            s_idx[j + 1] = iv;
+        }
+        for (int j = 0; j < k; ++j) {
+            const bool ok = j < KC && s_idx[j] >= 0;
+            D[(int64_t)b * k + j] = ok ? (float)s_score[j] : (metric_l2 ? FLT_MAX : -FLT_MAX);
+            I[(int64_t)b * k + j] = ok ? (int64_t)s_idx[j] + id_offset : -1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// cross-shard merge: one thread per query, n_parts sorted lists of k
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void merge_shards_kernel(const float* __restrict__ Dp,
+                                                         const int64_t* __restrict__ Ip, int n_parts, int B,
+                                                         int k, int metric_l2, float* __restrict__ D,
+                                                         int64_t* __restrict__ I) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    // every part is already ordered, so a head pointer per part is enough;
+    // heads live in a bitmap-free form: re-scan from the stored head positions
+    int head[64];
+    for (int p = 0; p < n_parts; ++p) head[p] = 0;
+    for (int j = 0; j < k; ++j) {
+        int best = -1;
+        float bd = 0.f;
+        int64_t bi = 0;
+        for (int p = 0; p < n_parts; ++p) {
+            if (head[p] >= k) continue;
+            const int64_t o = ((int64_t)p * B + b) * k + head[p];
+            const int64_t id = Ip[o];
+            if (id < 0) continue;  // padding sorts last
+            const float dv = Dp[o];
+            bool take;
+            if (best < 0) take = true;
+            else if (dv != bd) take = metric_l2 ? (dv < bd) : (dv > bd);
+            else take = id < bi;
+            if (take) {
+                best = p;
+                bd = dv;
+                bi = id;
+            }
+        }
+        if (best >= 0) {
+            D[(int64_t)b * k + j] = bd;
+            I[(int64_t)b * k + j] = bi;
+            head[best]++;
+        } else {
+            D[(int64_t)b * k + j] = metric_l2 ? FLT_MAX : -FLT_MAX;
+            I[(int64_t)b * k + j] = -1;
+        }
+    }
+}
+
+template <bool F32>
+__global__ __launch_bounds__(256) void reconstruct_kernel(const void* __restrict__ rows, int64_t n_elems,
+                                                         float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n_elems; i += stride) {
+        if constexpr (F32) out[i] = reinterpret_cast<const float*>(rows)[i];
+        else out[i] = (float)reinterpret_cast<const _Float16*>(rows)[i];
+    }
+}
+
+}  // namespace prag
+
+// ===========================================================================
+// host side
+// ===========================================================================
+using namespace prag;
+
+struct prag_index {
+    int d, metric, store;
+    int64_t ntotal = 0, cap = 0;
+    void* rows = nullptr;
+    float* xnorm = nullptr;
+    // search workspace
+    float* q32 = nullptr;
+    _Float16* q16 = nullptr;
+    int q_cap = 0;
+    float* part_key = nullptr;
+    int* part_idx = nullptr;
+    size_t part_cap = 0;  // entries
+    int* cand = nullptr;
+    size_t cand_cap = 0;
+    // host-io staging
+    float* io_q = nullptr;
+    float* io_D = nullptr;
+    int64_t* io_I = nullptr;
+    int io_B = 0, io_k = 0;
+    int n_cu = 256;
+};
+
+static size_t elt(const prag_index* ix) { return ix->store == PRAG_F32 ? 4 : 2; }
+
+static int ensure_capacity(prag_index* ix, int64_t want) {
+    if (want <= ix->cap) return PRAG_OK;
+    int64_t ncap = std::max<int64_t>(want, ix->cap + ix->cap / 2);
+    ncap = (ncap + 31) / 32 * 32;
+    void* nrows = nullptr;
+    float* nnorm = nullptr;
+    PRAG_HIP(hipMalloc(&nrows, (size_t)ncap * ix->d * elt(ix)));
+    PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&nnorm), (size_t)ncap * sizeof(float)));
+    PRAG_HIP(hipMemset(nnorm, 0, (size_t)ncap * sizeof(float)));
+    if (ix->ntotal > 0) {
+        PRAG_HIP(hipMemcpy(nrows, ix->rows, (size_t)ix->ntotal * ix->d * elt(ix), hipMemcpyDeviceToDevice));
+        PRAG_HIP(hipMemcpy(nnorm, ix->xnorm, (size_t)ix->ntotal * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    if (ix->rows) (void)hipFree(ix->rows);
+    if (ix->xnorm) (void)hipFree(ix->xnorm);
+    ix->rows = nrows;
+    ix->xnorm = nnorm;
+    ix->cap = ncap;
+    return PRAG_OK;
+}
+
+extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int store_dtype,
+                                 int64_t capacity_rows) {
+    PRAG_REQUIRE(out != nullptr, PRAG_EINVAL, "prag_index_create: out is NULL");
+    PRAG_REQUIRE(d >= 64 && d % 64 == 0 && d <= 1536, PRAG_EUNSUPPORTED,
+                 "d=%d: the scan kernel needs a multiple of 64 in [64,1536]", d);
+    PRAG_REQUIRE(metric == PRAG_METRIC_L2 || metric == PRAG_METRIC_IP || metric == PRAG_METRIC_COS,
+                 PRAG_EINVAL, "metric=%d", metric);
+    PRAG_REQUIRE(store_dtype == PRAG_F32 || store_dtype == PRAG_F16, PRAG_EINVAL, "store_dtype=%d",
+                 store_dtype);
+    PRAG_REQUIRE(capacity_rows >= 0, PRAG_EINVAL, "capacity_rows < 0");
+    prag_index* ix = new (std::nothrow) prag_index();
+    PRAG_REQUIRE(ix != nullptr, PRAG_ENOMEM, "out of host memory");
+    ix->d = d;
+    ix->metric = metric;
+    ix->store = store_dtype;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (capacity_rows > 0) {
+        int rc = ensure_capacity(ix, capacity_rows);
+        if (rc != PRAG_OK) {
+            delete ix;
+            return rc;
+        }
+    }
+    *out = ix;
+    return PRAG_OK;
+}
+
+static int launch_add(prag_index* ix, const float* src_dev, bool synth, uint32_t seed, int64_t synth_row0,
+                      int64_t n) {
+    const int normalise = ix->metric == PRAG_METRIC_COS;
+    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+#define PRAG_ADD(F32_, SY_)                                                                          \
+    hipLaunchKernelGGL((add_rows_kernel<F32_, SY_>), grid, block, 0, 0, src_dev, seed, synth_row0, n, \
+                       ix->d, normalise, ix->rows, ix->xnorm, ix->ntotal)
+    if (ix->store == PRAG_F32) {
+        if (synth) PRAG_ADD(true, true); else PRAG_ADD(true, false);
+    } else {
+        if (synth) PRAG_ADD(false, true); else PRAG_ADD(false, false);
+    }
+#undef PRAG_ADD
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+extern "C" int prag_index_add(prag_index_t* ix, const float* x, int64_t n, int src_is_device) {
+    PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
+    PRAG_REQUIRE(n >= 0, PRAG_EINVAL, "n=%lld", (long long)n);
+    if (n == 0) return PRAG_OK;  // index.add of an empty batch is a no-op
+    PRAG_REQUIRE(x != nullptr, PRAG_EINVAL, "prag_index_add: x is NULL");
+    PRAG_REQUIRE(ix->ntotal + n <= 0x7fffffffLL - 64, PRAG_EUNSUPPORTED,
+                 "more than 2^31 rows per shard: shard the corpus across devices");
+    int rc = ensure_capacity(ix, ix->ntotal + n);
+    if (rc != PRAG_OK) return rc;
+    if (src_is_device) {
+        rc = launch_add(ix, x, false, 0, 0, n);
+        if (rc != PRAG_OK) return rc;
+        PRAG_HIP(hipDeviceSynchronize());
+        ix->ntotal += n;
+        return PRAG_OK;
+    }
+    // host rows: stream through a bounded device staging buffer
+    const int64_t chunk = std::min<int64_t>(n, std::max<int64_t>(1, (64ll << 20) / ((int64_t)ix->d * 4)));
+    float* stage = nullptr;
+    PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&stage), (size_t)chunk * ix->d * sizeof(float)));
+    for (int64_t o = 0; o < n; o += chunk) {
+        const int64_t m = std::min(chunk, n - o);
+        hipError_t e = hipMemcpy(stage, x + o * ix->d, (size_t)m * ix->d * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            rc = launch_add(ix, stage, false, 0, 0, m);
+            if (rc == PRAG_OK) e = hipDeviceSynchronize();
+        }
+        if (e != hipSuccess || rc != PRAG_OK) {
+            (void)hipFree(stage);
+            if (e != hipSuccess) set_error("prag_index_add: %s", hipGetErrorString(e));
+            return e != hipSuccess ? PRAG_EHIP : rc;
+        }
+        ix->ntotal += m;
+    }
+    (void)hipFree(stage);
+    return PRAG_OK;
+}
+
+extern "C" int prag_index_add_synthetic(prag_index_t* ix, uint32_t seed, int64_t row0, int64_t n) {
+    PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
+    PRAG_REQUIRE(n >= 0 && row0 >= 0, PRAG_EINVAL, "row0=%lld n=%lld", (long long)row0, (long long)n);
+    if (n == 0) return PRAG_OK;
+    PRAG_REQUIRE(ix->ntotal + n <= 0x7fffffffLL - 64, PRAG_EUNSUPPORTED, "more than 2^31 rows per shard");
+    int rc = ensure_capacity(ix, ix->ntotal + n);
+    if (rc != PRAG_OK) return rc;
+    rc = launch_add(ix, nullptr, true, seed, row0, n);
+    if (rc != PRAG_OK) return rc;
+    PRAG_HIP(hipDeviceSynchronize());
+    ix->ntotal += n;
+    return PRAG_OK;
+}
+
+extern "C" int64_t prag_index_ntotal(const prag_index_t* ix) { return ix ? ix->ntotal : -1; }
+extern "C" int prag_index_d(const prag_index_t* ix) { return ix ? ix->d : -1; }
+
+static int pick_kc(int k) {
+    if (k <= 5) return 8;
+    if (k <= 12) return 16;
+    if (k <= 26) return 32;
+    return 0;  // a 64-deep per-lane list does not fit the 256-VGPR budget of 2 waves/SIMD
+}
+
+template <int QT, int KC, bool F32>
+static int launch_scan(const ScanArgs& a, int grid, hipStream_t st) {
+    const int lds = QT * a.qstride + 8 * 4096;
+    auto kern = scan_topk_kernel<QT, KC, F32>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+template <int QT, bool F32>
+static int dispatch_scan_kc(int kc, const ScanArgs& a, int grid, hipStream_t st) {
+    switch (kc) {
+        case 8: return launch_scan<QT, 8, F32>(a, grid, st);
+        case 16: return launch_scan<QT, 16, F32>(a, grid, st);
+        case 32: return launch_scan<QT, 32, F32>(a, grid, st);
+    }
+    set_error("internal: KC=%d", kc);
+    return PRAG_EUNSUPPORTED;
+}
+
+static int launch_merge(int kc, const float* pk, const int* pi, int n_lists, int QT, int nq, int* cand,
+                        hipStream_t st) {
+    switch (kc) {
+        case 8: hipLaunchKernelGGL(merge_lists_kernel<8>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand); break;
+        case 16: hipLaunchKernelGGL(merge_lists_kernel<16>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand); break;
+        case 32: hipLaunchKernelGGL(merge_lists_kernel<32>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand); break;
+        default: set_error("internal: KC=%d", kc); return PRAG_EUNSUPPORTED;
+    }
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D,
+                                 int64_t* I, int io_is_device, void* stream) {
+    PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
+    PRAG_REQUIRE(B >= 0 && k >= 1, PRAG_EINVAL, "B=%d k=%d", B, k);
+    if (B == 0) return PRAG_OK;
+    PRAG_REQUIRE(q && D && I, PRAG_EINVAL, "prag_index_search: NULL pointer");
+    const int kc = pick_kc(k);
+    PRAG_REQUIRE(kc != 0, PRAG_EUNSUPPORTED, "k=%d: the fused top-k keeps at most 26 results per query", k);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+    // ---- host i/o staging -----------------------------------------------------
+    const float* q_dev = q;
+    float* D_dev = D;
+    int64_t* I_dev = I;
+    if (!io_is_device) {
+        if (B > ix->io_B || k > ix->io_k) {
+            if (ix->io_q) (void)hipFree(ix->io_q);
+            if (ix->io_D) (void)hipFree(ix->io_D);
+            if (ix->io_I) (void)hipFree(ix->io_I);
+            ix->io_q = nullptr; ix->io_D = nullptr; ix->io_I = nullptr;
+            const int nb = std::max(B, ix->io_B), nk = std::max(k, ix->io_k);
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->io_q), (size_t)nb * ix->d * sizeof(float)));
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->io_D), (size_t)nb * nk * sizeof(float)));
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->io_I), (size_t)nb * nk * sizeof(int64_t)));
+            ix->io_B = nb;
+            ix->io_k = nk;
+        }
+        PRAG_HIP(hipMemcpyAsync(ix->io_q, q, (size_t)B * ix->d * sizeof(float), hipMemcpyHostToDevice, st));
+        q_dev = ix->io_q;
+        D_dev = ix->io_D;
+        I_dev = ix->io_I;
+    }
+
+    // ---- workspace --------------------------------------------------------------
+    const int qstride = (ix->d * 2 + 255) / 256 * 256;
+    const int QT = (B > 32 && 64 * qstride + 8 * 4096 <= 160 * 1024) ? 64 : 32;
+    const int Bpad = (B + QT - 1) / QT * QT;
+    if (Bpad > ix->q_cap) {
+        if (ix->q32) (void)hipFree(ix->q32);
+        if (ix->q16) (void)hipFree(ix->q16);
+        ix->q32 = nullptr; ix->q16 = nullptr; ix->q_cap = 0;
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->q32), (size_t)Bpad * ix->d * sizeof(float)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->q16), (size_t)Bpad * ix->d * sizeof(_Float16)));
+        ix->q_cap = Bpad;
+    }
+    const int n_tiles = (int)((ix->ntotal + 31) / 32);
+    const int grid = std::max(1, std::min(ix->n_cu, (n_tiles + 7) / 8));
+    const int n_lists = grid * 16;
+    const size_t part_need = (size_t)n_lists * QT * kc;
+    if (part_need > ix->part_cap) {
+        if (ix->part_key) (void)hipFree(ix->part_key);
+        if (ix->part_idx) (void)hipFree(ix->part_idx);
+        ix->part_key = nullptr; ix->part_idx = nullptr; ix->part_cap = 0;
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->part_key), part_need * sizeof(float)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->part_idx), part_need * sizeof(int)));
+        ix->part_cap = part_need;
+    }
+    const size_t cand_need = (size_t)Bpad * kc;
+    if (cand_need > ix->cand_cap) {
+        if (ix->cand) (void)hipFree(ix->cand);
+        ix->cand = nullptr; ix->cand_cap = 0;
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->cand), cand_need * sizeof(int)));
+        ix->cand_cap = cand_need;
+    }
+
+    const int metric_l2 = ix->metric == PRAG_METRIC_L2;
+    hipLaunchKernelGGL(prep_queries_kernel, dim3((Bpad + 3) / 4), dim3(256), 0, st, q_dev, B, Bpad, ix->d,
+                       ix->metric == PRAG_METRIC_COS ? 1 : 0, ix->q32, ix->q16);
+    PRAG_LAUNCH_CHECK();
+
+    if (ix->ntotal == 0) {
+        PRAG_HIP(hipMemsetAsync(ix->cand, 0xFF, cand_need * sizeof(int), st));  // all -1
+    } else {
+        ScanArgs a;
+        a.rows = ix->rows;
+        a.xnorm = ix->xnorm;
+        a.N = ix->ntotal;
+        a.d = ix->d;
+        a.qstride = qstride;
+        a.n_tiles = n_tiles;
+        a.alpha = metric_l2 ? -2.0f : -1.0f;
+        a.use_norm = metric_l2;
+        a.out_key = ix->part_key;
+        a.out_idx = ix->part_idx;
+        for (int p0 = 0; p0 < Bpad; p0 += QT) {
+            a.q16 = ix->q16 + (size_t)p0 * ix->d;
+            int rc;
+            if (QT == 32)
+                rc = ix->store == PRAG_F32 ? dispatch_scan_kc<32, true>(kc, a, grid, st)
+                                           : dispatch_scan_kc<32, false>(kc, a, grid, st);
+            else
+                rc = ix->store == PRAG_F32 ? dispatch_scan_kc<64, true>(kc, a, grid, st)
+                                           : dispatch_scan_kc<64, false>(kc, a, grid, st);
+            if (rc != PRAG_OK) return rc;
+            const int nq = std::min(QT, B - p0);
+            rc = launch_merge(kc, ix->part_key, ix->part_idx, n_lists, QT, nq, ix->cand + (size_t)p0 * kc, st);
+            if (rc != PRAG_OK) return rc;
+        }
+    }
+    if (ix->store == PRAG_F32)
+        hipLaunchKernelGGL(rerank_kernel<true>, dim3(B), dim3(256), 0, st, ix->rows, ix->d, metric_l2, ix->q32,
+                           ix->cand, kc, k, id_offset, D_dev, I_dev);
+    else
+        hipLaunchKernelGGL(rerank_kernel<false>, dim3(B), dim3(256), 0, st, ix->rows, ix->d, metric_l2, ix->q32,
+                           ix->cand, kc, k, id_offset, D_dev, I_dev);
+    PRAG_LAUNCH_CHECK();
+
+    if (!io_is_device) {
+        PRAG_HIP(hipMemcpyAsync(D, D_dev, (size_t)B * k * sizeof(float), hipMemcpyDeviceToHost, st));
+        PRAG_HIP(hipMemcpyAsync(I, I_dev, (size_t)B * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        PRAG_HIP(hipStreamSynchronize(st));
+    }
+    return PRAG_OK;
+}
+
+extern "C" int prag_merge_topk(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts, int B, int k,
+                               int metric, float* D_dev, int64_t* I_dev, void* stream) {
+    PRAG_REQUIRE(D_parts_dev && I_parts_dev && D_dev && I_dev, PRAG_EINVAL, "prag_merge_topk: NULL pointer");
+    PRAG_REQUIRE(n_parts >= 1 && n_parts <= 64, PRAG_EINVAL, "n_parts=%d outside [1,64]", n_parts);
+    PRAG_REQUIRE(B >= 0 && k >= 1, PRAG_EINVAL, "B=%d k=%d", B, k);
+    if (B == 0) return PRAG_OK;
+    hipLaunchKernelGGL(merge_shards_kernel, dim3((B + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
+                       D_parts_dev, I_parts_dev, n_parts, B, k, metric == PRAG_METRIC_L2 ? 1 : 0, D_dev, I_dev);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+extern "C" int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n, float* out_host) {
+    PRAG_REQUIRE(ix != nullptr && out_host != nullptr, PRAG_EINVAL, "prag_index_reconstruct: NULL pointer");
+    PRAG_REQUIRE(row0 >= 0 && n >= 0 && row0 + n <= ix->ntotal, PRAG_EINVAL, "rows [%lld,%lld) outside [0,%lld)",
+                 (long long)row0, (long long)(row0 + n), (long long)ix->ntotal);
+    if (n == 0) return PRAG_OK;
+    float* tmp = nullptr;
+    const int64_t ne = n * ix->d;
+    PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)ne * sizeof(float)));
+    const char* src = reinterpret_cast<const char*>(ix->rows) + (size_t)row0 * ix->d * elt(ix);
+    const int blocks = (int)std::min<int64_t>((ne + 255) / 256, 4096);
+    if (ix->store == PRAG_F32)
+        hipLaunchKernelGGL(reconstruct_kernel<true>, dim3(blocks), dim3(256), 0, 0, src, ne, tmp);
+    else
+        hipLaunchKernelGGL(reconstruct_kernel<false>, dim3(blocks), dim3(256), 0, 0, src, ne, tmp);
+    hipError_t e = hipMemcpy(out_host, tmp, (size_t)ne * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    PRAG_HIP(e);
+    return PRAG_OK;
+}
+
+extern "C" void prag_index_destroy(prag_index_t* ix) {
+    if (!ix) return;
+    void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->part_key, ix->part_idx, ix->cand,
+                    ix->io_q, ix->io_D, ix->io_I};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete ix;
+}

@@ -1,0 +1,975 @@
+// Fused prober ensemble + gate for MI355X (gfx950, CDNA4).
+//
+// What it computes (reference: /root/reference, utils.py:29-57 ImprovedProbe,
+// exp_rag.py:381-389, 406-415):
+//   LN(d) -> fc1(d->512) -> SiLU -> LN(512) -> fc2(512->512) -> SiLU -> LN(512)
+//   -> fc3(512->2), one weight set per probed layer, then per-layer softmax,
+//   sum over layers and the threshold compare.
+//
+// How (DESIGN.md "Kernel 1"):
+//   * One workgroup = 4 waves (one per SIMD) = one tile of 32*CT batch rows of
+//     one layer.  The GEMMs are computed TRANSPOSED, H^T[n, m] = W[n, :] . x[m, :]
+//     on v_mfma_f32_32x32x16_f16: the weight rows sit on the MFMA A operand, the
+//     batch rows on the B operand, so every wave owns 128 of the 512 hidden units
+//     for all of the tile's rows.
+//   * Weights are pre-packed at load time in MFMA-fragment-major order (one
+//     fully coalesced 1 KiB global_load_dwordx4 per fragment per wave, straight
+//     to VGPRs - a wave's weight rows are not shared with the other waves, so
+//     an LDS round trip would be pure overhead).  LayerNorm affines are folded
+//     into the following Linear at load time.
+//   * Activations (shared by the 4 waves) are staged through LDS in full 128-B
+//     lines with an XOR swizzle that makes the ds_read_b128 fragment reads
+//     conflict-free; double-buffered, one barrier per 64-wide K step.
+//   * fp16 activations are fed to the MFMA *raw* (exact); LayerNorm-0 is
+//     applied in the epilogue:  rstd*(W~x - mu*rowsum(W~)) + b~ , with mu/rstd
+//     computed in-flight from the staged fragments (shifted sums + Chan merge).
+//   * The fc1 accumulator tile has the hidden index in its registers and the
+//     batch row on its lane - exactly the B-operand layout of the next MFMA
+//     (k order permuted; W2 is pre-permuted to match), so LN1/SiLU run
+//     lane-locally and fc2's operand crosses waves through LDS as ready-made
+//     1 KiB fragments (hi + lo fp16 terms: ~22 bits).
+//   * fc3 (512->2), the cross-wave reductions and the logits store finish the
+//     launch; a second tiny kernel does softmax / sum over layers / threshold in
+//     the reference's own order (deterministic, no float atomics).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <type_traits>
+#include <vector>
+
+#include "prag_common.h"
+
+namespace prag {
+
+constexpr int kHidden = 512;
+constexpr int kClasses = 2;
+constexpr float kLnEps = 1e-5f;
+
+struct LayerDev {
+    const uint4* W1f;    // [NA][d/16][16 row tiles][64 lanes] x 16 B
+    const uint4* W2f;    // [NA][32 k steps][16 row tiles][64 lanes] x 16 B
+    const float* wsum1;  // [512] row sums of the packed (scaled) W1
+    const float* b1;     // [512] b1 + W1 . ln0_b
+    const float* b2;     // [512] b2 + W2 . ln1_b
+    const float* W3;     // [2][512] W3 * ln2_w
+    float b3[2];         // b3 + W3 . ln2_b
+    float sc1, sc2;      // 2^-e of the packed fc1 / fc2 weights
+};
+
+struct ProberArgs {
+    const LayerDev* layers;
+    const _Float16* xh;  // raw fp16 activations, or hi part of the normalised ones
+    const _Float16* xl;  // lo part (NB == 2) or nullptr
+    int64_t x_layer_stride;
+    int layer0;
+    int B;
+    int d;
+    float* logits;  // [n_run][B][2]
+};
+
+__device__ __forceinline__ float silu_f(float h) {
+    // h * sigmoid(h); v_exp_f32 / v_rcp_f32 are ~1 ulp, far inside the 1e-4 budget
+    return h * __frcp_rn(1.0f + __expf(-h));
+}
+
+__device__ __forceinline__ float xor32(float v) { return v + __shfl_xor(v, 32, 64); }
+
+template <int NA, int NB, int CT>
+__global__ __launch_bounds__(256, 1) void prober_fused_kernel(ProberArgs a) {
+    constexpr int G = CT >= 2 ? 2 : 1;  // column tiles per fc2 pass
+    constexpr int NG = CT / G;
+    constexpr bool RAW = (NB == 1);
+    constexpr int ROWS = 32 * CT;
+    constexpr int XPART = ROWS * 128;          // bytes of one staged part (64 halves per row)
+    constexpr int XSTAGE = NB * XPART;
+    constexpr int EXCH = 2 * 16 * 2 * G * 1024;  // hi/lo x 16 row tiles x 2 k-steps x G tiles
+    constexpr int REGION_A = (2 * XSTAGE > EXCH) ? 2 * XSTAGE : EXCH;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_x = smem;                                   // staging ring (fc1)
+    char* s_ex = smem;                                  // exchange fragments (fc2), same bytes
+    float* s_red = reinterpret_cast<float*>(smem + REGION_A);  // [4 bufs][4 waves][ROWS]
+    float* s_mu0 = s_red + 4 * 4 * ROWS;                // [ROWS]
+    float* s_rs0 = s_mu0 + ROWS;                        // [ROWS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31;
+    const int hh = lane >> 5;
+    const int lrun = blockIdx.y;
+    const LayerDev& L = a.layers[a.layer0 + lrun];
+    const int m0 = blockIdx.x * ROWS;
+    const int d = a.d;
+    const int S16 = d >> 4;
+    const int T = d >> 6;
+
+    // ---- activation staging addresses (thread -> 16-B piece of a row) -----
+    const int st_row = tid >> 3;  // + 32*c per pass
+    const int st_q = tid & 7;
+    const _Float16* xsrc[NB][CT];
+    int st_off[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int row = 32 * c + st_row;
+        int grow = m0 + row;
+        grow = grow < a.B ? grow : a.B - 1;
+        const int64_t base = (int64_t)lrun * a.x_layer_stride + (int64_t)grow * d + 8 * st_q;
+        xsrc[0][c] = a.xh + base;
+        if constexpr (NB == 2) xsrc[1][c] = a.xl + base;
+        st_off[c] = row * 128 + ((st_q ^ ((row >> 1) & 7)) << 4);
+    }
+    // fragment read offsets: lane (r,hh), tile ct, sub-step s16 -> piece 2*s16+hh
+    int rd_row_off[CT], rd_sw[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int row = 32 * c + r;
+        rd_row_off[c] = row * 128;
+        rd_sw[c] = (row >> 1) & 7;
+    }
+
+    uint4 xreg[NB][CT];
+    auto x_load = [&](int t) {
+#pragma unroll
+        for (int p = 0; p < NB; ++p)
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                xreg[p][c] = *reinterpret_cast<const uint4*>(xsrc[p][c] + 64 * t);
+    };
+    auto x_store = [&](int stage) {
+#pragma unroll
+        for (int p = 0; p < NB; ++p)
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                *reinterpret_cast<uint4*>(s_x + stage * XSTAGE + p * XPART + st_off[c]) = xreg[p][c];
+    };
+
+    // ---- weight fragment addressing -------------------------------------
+    const uint4* w1p = L.W1f + (size_t)(4 * w) * 64 + lane;  // + ((part*S16 + s16)*16 + rti)*64
+    half8 afr[4][NA][4];
+    auto a_load = [&](int slot, int s16) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p)
+#pragma unroll
+            for (int rti = 0; rti < 4; ++rti) {
+                const uint4 v = w1p[((size_t)(p * S16 + s16) * 16 + rti) * 64];
+                afr[slot][p][rti] = __builtin_bit_cast(half8, v);
+            }
+    };
+
+    f32x16 acc[4][CT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][c][e] = 0.f;
+
+    // in-flight LayerNorm-0 statistics (RAW only): wave w < CT owns tile w
+    float st_c = 0.f, st_s = 0.f, st_q2 = 0.f;
+    if constexpr (RAW) {
+        if (w < CT) {
+            int grow = m0 + 32 * w + r;
+            grow = grow < a.B ? grow : a.B - 1;
+            st_c = (float)a.xh[(int64_t)lrun * a.x_layer_stride + (int64_t)grow * d + 8 * hh];
+        }
+    }
+
+    // ---- prologue ---------------------------------------------------------
+    x_load(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a_load(s, s);
+    x_store(0);
+    if (T > 1) x_load(1);
+
+    // ---- fc1 main loop: one barrier per 64-wide K step ----------------------
+    for (int t = 0; t < T; ++t) {
+        __syncthreads();
+        if (t + 1 < T) x_store((t + 1) & 1);
+        if (t + 2 < T) x_load(t + 2);
+        const char* xs = s_x + (t & 1) * XSTAGE;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            half8 bfr[NB][CT];
+#pragma unroll
+            for (int p = 0; p < NB; ++p)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const int off = p * XPART + rd_row_off[c] + (((2 * sub + hh) ^ rd_sw[c]) << 4);
+                    bfr[p][c] = *reinterpret_cast<const half8*>(xs + off);
+                }
+            if constexpr (RAW) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    if (c == w) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float dv = (float)bfr[0][c][j] - st_c;
+                            st_s += dv;
+                            st_q2 = fmaf(dv, dv, st_q2);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int rti = 0; rti < 4; ++rti)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    acc[rti][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[sub][0][rti], bfr[0][c],
+                                                                         acc[rti][c], 0, 0, 0);
+                    if constexpr (NB == 2)
+                        acc[rti][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            afr[sub][0][rti], bfr[1][c], acc[rti][c], 0, 0, 0);
+                    if constexpr (NA == 2)
+                        acc[rti][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            afr[sub][1][rti], bfr[0][c], acc[rti][c], 0, 0, 0);
+                }
+            if (t + 1 < T) a_load(sub, 4 * (t + 1) + sub);
+        }
+    }
+
+    // ---- LayerNorm-0 statistics -> LDS -------------------------------------
+    if constexpr (RAW) {
+        if (w < CT) {
+            // this lane: n = d/2 elements, shift st_c; partner lane^32 the other half
+            const float n = 0.5f * (float)d;
+            const float mean_a = st_c + st_s / n;
+            const float m2_a = st_q2 - st_s * st_s / n;
+            const float mean_b = __shfl_xor(mean_a, 32, 64);
+            const float m2_b = __shfl_xor(m2_a, 32, 64);
+            const float delta = mean_b - mean_a;
+            const float mean = mean_a + 0.5f * delta;
+            const float m2 = m2_a + m2_b + delta * delta * (0.5f * n);
+            const float var = fmaxf(m2 / (float)d, 0.f);
+            if (hh == 0) {
+                s_mu0[32 * w + r] = mean;
+                s_rs0[32 * w + r] = 1.0f / sqrtf(var + kLnEps);
+            }
+        }
+    }
+    __syncthreads();  // stats visible; every wave is done with the staging ring
+
+    // ---- epilogue 1: LN0 fold, bias, SiLU ------------------------------------
+    {
+        float mu[CT], rs[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            mu[c] = RAW ? s_mu0[32 * c + r] : 0.f;
+            rs[c] = (RAW ? s_rs0[32 * c + r] : 1.f) * L.sc1;
+        }
+#pragma unroll
+        for (int rti = 0; rti < 4; ++rti)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int nb = 128 * w + 32 * rti + 8 * g4 + 4 * hh;
+                const f32x4 ws = *reinterpret_cast<const f32x4*>(L.wsum1 + nb);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(L.b1 + nb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        float v = acc[rti][c][4 * g4 + e];
+                        if constexpr (RAW) v = fmaf(-mu[c], ws[e], v);
+                        acc[rti][c][4 * g4 + e] = silu_f(fmaf(rs[c], v, bb[e]));
+                    }
+            }
+    }
+
+    // two-pass LayerNorm statistics over the 512 hidden units of every column
+    auto ln_stats = [&](auto& A, auto NT, float* mean_out, float* rstd_out) {
+        constexpr int NTc = decltype(NT)::value;
+        float* bufA = s_red;
+        float* bufB = s_red + 4 * ROWS;
+        float s[NTc];
+#pragma unroll
+        for (int c = 0; c < NTc; ++c) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) t += A[i][c][e];
+            s[c] = xor32(t);
+            if (hh == 0) bufA[w * ROWS + 32 * c + r] = s[c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NTc; ++c) {
+            const int m = 32 * c + r;
+            mean_out[c] = (bufA[m] + bufA[ROWS + m] + bufA[2 * ROWS + m] + bufA[3 * ROWS + m]) *
+                          (1.0f / kHidden);
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float dv = A[i][c][e] - mean_out[c];
+                    t = fmaf(dv, dv, t);
+                }
+            t = xor32(t);
+            if (hh == 0) bufB[w * ROWS + m] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NTc; ++c) {
+            const int m = 32 * c + r;
+            const float var =
+                (bufB[m] + bufB[ROWS + m] + bufB[2 * ROWS + m] + bufB[3 * ROWS + m]) * (1.0f / kHidden);
+            rstd_out[c] = 1.0f / sqrtf(var + kLnEps);
+        }
+    };
+
+    float mean1[CT], rstd1[CT];
+    ln_stats(acc, std::integral_constant<int, CT>{}, mean1, rstd1);
+
+    // ---- fc2 / fc3, G column tiles at a time ---------------------------------
+    const uint4* w2p = L.W2f + (size_t)(4 * w) * 64 + lane;  // + ((part*32 + ks)*16 + rti)*64
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g > 0) __syncthreads();  // previous pass finished reading the exchange area
+        // publish this wave's normalised activations as ready-made B fragments
+#pragma unroll
+        for (int rti = 0; rti < 4; ++rti)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int c2 = 0; c2 < G; ++c2) {
+                    const int c = g * G + c2;
+                    half8 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = (acc[rti][c][8 * s + j] - mean1[c]) * rstd1[c];
+                        const _Float16 h16 = (_Float16)v;
+                        hi[j] = h16;
+                        lo[j] = (_Float16)(v - (float)h16);
+                    }
+                    const int fi = (((4 * w + rti) * 2 + s) * G + c2) * 64 + lane;
+                    *reinterpret_cast<half8*>(s_ex + (size_t)fi * 16) = hi;
+                    *reinterpret_cast<half8*>(s_ex + (size_t)(16 * 2 * G * 64 + fi) * 16) = lo;
+                }
+
+        f32x16 acc2[4][G];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < G; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[i][c][e] = 0.f;
+
+        half8 a2[2][NA][4];
+        auto a2_load = [&](int slot, int ks) {
+#pragma unroll
+            for (int p = 0; p < NA; ++p)
+#pragma unroll
+                for (int rti = 0; rti < 4; ++rti) {
+                    const uint4 v = w2p[((size_t)(p * 32 + ks) * 16 + rti) * 64];
+                    a2[slot][p][rti] = __builtin_bit_cast(half8, v);
+                }
+        };
+        a2_load(0, 0);
+        a2_load(1, 1);
+        __syncthreads();  // fragments of all four waves are in LDS
+
+        for (int ks2 = 0; ks2 < 32; ks2 += 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ks = ks2 + u;
+                half8 b2h[G], b2l[G];
+#pragma unroll
+                for (int c2 = 0; c2 < G; ++c2) {
+                    const int fi = (ks * G + c2) * 64 + lane;
+                    b2h[c2] = *reinterpret_cast<const half8*>(s_ex + (size_t)fi * 16);
+                    b2l[c2] = *reinterpret_cast<const half8*>(s_ex + (size_t)(16 * 2 * G * 64 + fi) * 16);
+                }
+#pragma unroll
+                for (int rti = 0; rti < 4; ++rti)
+#pragma unroll
+                    for (int c2 = 0; c2 < G; ++c2) {
+                        acc2[rti][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            a2[u][0][rti], b2h[c2], acc2[rti][c2], 0, 0, 0);
+                        acc2[rti][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            a2[u][0][rti], b2l[c2], acc2[rti][c2], 0, 0, 0);
+                        if constexpr (NA == 2)
+                            acc2[rti][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                a2[u][1][rti], b2h[c2], acc2[rti][c2], 0, 0, 0);
+                    }
+                if (ks + 2 < 32) a2_load(u, ks + 2);
+            }
+        }
+
+        // epilogue 2: bias, SiLU, LN2, fc3
+#pragma unroll
+        for (int rti = 0; rti < 4; ++rti)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int nb = 128 * w + 32 * rti + 8 * g4 + 4 * hh;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(L.b2 + nb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int c2 = 0; c2 < G; ++c2)
+                        acc2[rti][c2][4 * g4 + e] =
+                            silu_f(fmaf(L.sc2, acc2[rti][c2][4 * g4 + e], bb[e]));
+            }
+        float mean2[G], rstd2[G];
+        ln_stats(acc2, std::integral_constant<int, G>{}, mean2, rstd2);
+
+        float p0[G], p1[G];
+#pragma unroll
+        for (int c2 = 0; c2 < G; ++c2) p0[c2] = p1[c2] = 0.f;
+#pragma unroll
+        for (int rti = 0; rti < 4; ++rti)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int nb = 128 * w + 32 * rti + 8 * g4 + 4 * hh;
+                const f32x4 w30 = *reinterpret_cast<const f32x4*>(L.W3 + nb);
+                const f32x4 w31 = *reinterpret_cast<const f32x4*>(L.W3 + kHidden + nb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int c2 = 0; c2 < G; ++c2) {
+                        const float v = (acc2[rti][c2][4 * g4 + e] - mean2[c2]) * rstd2[c2];
+                        p0[c2] = fmaf(v, w30[e], p0[c2]);
+                        p1[c2] = fmaf(v, w31[e], p1[c2]);
+                    }
+            }
+        float* bufC = s_red + 8 * ROWS;
+        float* bufD = s_red + 12 * ROWS;
+#pragma unroll
+        for (int c2 = 0; c2 < G; ++c2) {
+            const float q0 = xor32(p0[c2]);
+            const float q1 = xor32(p1[c2]);
+            if (hh == 0) {
+                bufC[w * ROWS + 32 * c2 + r] = q0;
+                bufD[w * ROWS + 32 * c2 + r] = q1;
+            }
+        }
+        __syncthreads();
+        if (tid < 32 * G) {
+            const int m_loc = 32 * g * G + tid;  // column within the workgroup tile
+            const int row = m0 + m_loc;
+            if (row < a.B) {
+                const float l0 = L.b3[0] + (bufC[tid] + bufC[ROWS + tid]) + (bufC[2 * ROWS + tid] + bufC[3 * ROWS + tid]);
+                const float l1 = L.b3[1] + (bufD[tid] + bufD[ROWS + tid]) + (bufD[2 * ROWS + tid] + bufD[3 * ROWS + tid]);
+                float2 o;
+                o.x = l0;
+                o.y = l1;
+                *reinterpret_cast<float2*>(a.logits + ((size_t)lrun * a.B + row) * 2) = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fp32 activations -> LayerNorm-0-normalised hi/lo fp16 terms (one wave per row)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prenorm_split_kernel(const float* __restrict__ x,
+                                                           int64_t x_layer_stride, int B, int d,
+                                                           int n_rows_total, _Float16* __restrict__ xh,
+                                                           _Float16* __restrict__ xl) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows_total) return;
+    const int l = row / B, b = row - l * B;
+    const float* src = x + (int64_t)l * x_layer_stride + (int64_t)b * d;
+    _Float16* dh = xh + (int64_t)row * d;
+    _Float16* dl = xl + (int64_t)row * d;
+    // pass 1: mean ; pass 2: centred second moment (rows are L2/L1 hot on re-read)
+    float s = 0.f;
+    for (int i = lane * 4; i < d; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)d;
+    float q = 0.f;
+    for (int i = lane * 4; i < d; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float dv = v[e] - mean;
+            q = fmaf(dv, dv, q);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)d + kLnEps);
+    for (int i = lane * 4; i < d; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+        half4 h, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float n = (v[e] - mean) * rstd;
+            const _Float16 h16 = (_Float16)n;
+            h[e] = h16;
+            lo[e] = (_Float16)(n - (float)h16);
+        }
+        *reinterpret_cast<half4*>(dh + i) = h;
+        *reinterpret_cast<half4*>(dl + i) = lo;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// gate: exp_rag.py:407-415 in the reference's own order (float32, layer by layer)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ logits, int L, int B,
+                                                  int ablation, float theta,
+                                                  float* __restrict__ probsum,
+                                                  int32_t* __restrict__ decision) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int n = ablation; n < L; ++n) {
+        const float2 z = *reinterpret_cast<const float2*>(logits + ((size_t)n * B + b) * 2);
+        const float m = fmaxf(z.x, z.y);
+        const float e0 = expf(z.x - m), e1 = expf(z.y - m);
+        const float inv = 1.0f / (e0 + e1);
+        s0 += e0 * inv;
+        s1 += e1 * inv;
+    }
+    if (probsum) {
+        probsum[2 * b] = s0;
+        probsum[2 * b + 1] = s1;
+    }
+    if (decision) decision[b] = (s0 + theta < s1) ? 0 : 1;
+}
+
+// ---------------------------------------------------------------------------
+// pooling: on-device replacements for the hook cache
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pool_accumulate_kernel(float* __restrict__ acc,
+                                                             const T* __restrict__ h, int64_t n,
+                                                             int assign) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        f32x4 v;
+        if constexpr (sizeof(T) == 4) {
+            v = *reinterpret_cast<const f32x4*>(h + i);
+        } else {
+            const half4 hv = *reinterpret_cast<const half4*>(h + i);
+            v = {(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(acc + i);
+        *dst = assign ? v : (*dst + v);
+    }
+}
+
+// out[b,:] = sum or mean of the last pred_lens[b] positions of acts[b] ([B,T,d])
+template <typename T>
+__global__ __launch_bounds__(256) void pool_ragged_kernel(const T* __restrict__ acts, int Tlen, int d,
+                                                         const int64_t* __restrict__ pred_lens,
+                                                         int scale_mean, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int col = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (col >= d) return;
+    int64_t n = pred_lens[b];
+    n = n < 0 ? 0 : (n > Tlen ? Tlen : n);
+    const T* base = acts + ((int64_t)b * Tlen + (Tlen - n)) * d + col;
+    // sequential accumulation in position order, like torch.sum/mean over dim 0
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t t = 0; t < n; ++t) {
+        if constexpr (sizeof(T) == 4) {
+            s += *reinterpret_cast<const f32x4*>(base + t * d);
+        } else {
+            const half4 hv = *reinterpret_cast<const half4*>(base + t * d);
+            s += f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+        }
+    }
+    if (scale_mean && n > 0) s = s / (float)n;
+    *reinterpret_cast<f32x4*>(out + (int64_t)b * d + col) = s;
+}
+
+}  // namespace prag
+
+// ===========================================================================
+// host side
+// ===========================================================================
+using namespace prag;
+
+struct HostLayer {  // kept for prag_prober_effective_weights
+    std::vector<float> W1, b1, W2, b2, W3, b3;
+};
+
+struct prag_prober {
+    int n_layers, d, na;
+    std::vector<bool> loaded;
+    std::vector<LayerDev> h_layers;
+    std::vector<HostLayer> eff;
+    std::vector<void*> allocs;
+    LayerDev* d_layers = nullptr;
+    _Float16* ws_h = nullptr;  // [L][maxB][d] hi / lo workspace for fp32 activations
+    _Float16* ws_l = nullptr;
+    int64_t ws_rows = 0;
+};
+
+static int pick_scale_exp(double maxabs) {
+    if (!(maxabs > 0.0)) return 0;
+    // bring the largest magnitude into [2^13, 2^14): no fp16 subnormal terms, no overflow
+    return 13 - (int)std::floor(std::log2(maxabs));
+}
+
+// pack an [512][K] (double, already scaled) matrix into MFMA A-fragment order
+// kmap(step, half, j) gives the source column of element j of lane-half `half` at k-step `step`
+template <typename KMap>
+static void pack_fragments(const std::vector<double>& Ws, int K, int n_steps, int na, KMap kmap,
+                           std::vector<_Float16>& out, std::vector<double>& deq) {
+    out.assign((size_t)na * n_steps * 16 * 64 * 8, (_Float16)0);
+    deq.assign((size_t)kHidden * K, 0.0);
+    for (int step = 0; step < n_steps; ++step)
+        for (int rt = 0; rt < 16; ++rt)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = 32 * rt + (lane & 31), half = lane >> 5;
+                for (int j = 0; j < 8; ++j) {
+                    const int col = kmap(step, half, j);
+                    const double v = Ws[(size_t)row * K + col];
+                    const _Float16 hi = (_Float16)v;
+                    const size_t o = ((((size_t)step) * 16 + rt) * 64 + lane) * 8 + j;
+                    out[o] = hi;
+                    double q = (double)hi;
+                    if (na == 2) {
+                        const _Float16 lo = (_Float16)(v - (double)hi);
+                        out[(size_t)n_steps * 16 * 64 * 8 + o] = lo;
+                        q += (double)lo;
+                    }
+                    deq[(size_t)row * K + col] = q;
+                }
+            }
+}
+
+template <typename T>
+static int upload(prag_prober* p, const std::vector<T>& v, const T** out) {
+    void* dptr = nullptr;
+    PRAG_HIP(hipMalloc(&dptr, v.size() * sizeof(T)));
+    p->allocs.push_back(dptr);
+    PRAG_HIP(hipMemcpy(dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<const T*>(dptr);
+    return PRAG_OK;
+}
+
+extern "C" int prag_prober_create(prag_prober_t** out, int n_layers, int d_model, int d_hidden,
+                                  int n_classes, int weight_mode) {
+    PRAG_REQUIRE(out != nullptr, PRAG_EINVAL, "prag_prober_create: out is NULL");
+    PRAG_REQUIRE(n_layers >= 1 && n_layers <= 64, PRAG_EINVAL, "n_layers=%d out of range [1,64]", n_layers);
+    PRAG_REQUIRE(d_hidden == kHidden, PRAG_EUNSUPPORTED,
+                 "d_hidden=%d: the reference prober has hidden_size=512 (utils.py:30)", d_hidden);
+    PRAG_REQUIRE(n_classes == kClasses, PRAG_EUNSUPPORTED,
+                 "n_classes=%d: the reference uses num_classes=2 (utils.py:289)", n_classes);
+    PRAG_REQUIRE(d_model >= 128 && d_model % 64 == 0, PRAG_EUNSUPPORTED,
+                 "d_model=%d must be a multiple of 64 and >= 128", d_model);
+    PRAG_REQUIRE(weight_mode == PRAG_W_F16 || weight_mode == PRAG_W_F32, PRAG_EINVAL,
+                 "weight_mode=%d", weight_mode);
+    prag_prober* p = new (std::nothrow) prag_prober();
+    PRAG_REQUIRE(p != nullptr, PRAG_ENOMEM, "out of host memory");
+    p->n_layers = n_layers;
+    p->d = d_model;
+    p->na = (weight_mode == PRAG_W_F32) ? 2 : 1;
+    p->loaded.assign(n_layers, false);
+    p->h_layers.resize(n_layers);
+    p->eff.resize(n_layers);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_layers), sizeof(LayerDev) * n_layers);
+    if (e != hipSuccess) {
+        set_error("hipMalloc failed: %s", hipGetErrorString(e));
+        delete p;
+        return PRAG_EHIP;
+    }
+    *out = p;
+    return PRAG_OK;
+}
+
+extern "C" int prag_prober_load_layer(prag_prober_t* p, int li, const float* ln0_w, const float* ln0_b,
+                                      const float* W1, const float* b1, const float* ln1_w,
+                                      const float* ln1_b, const float* W2, const float* b2,
+                                      const float* ln2_w, const float* ln2_b, const float* W3,
+                                      const float* b3) {
+    PRAG_REQUIRE(p != nullptr, PRAG_EINVAL, "prober handle is NULL");
+    PRAG_REQUIRE(li >= 0 && li < p->n_layers, PRAG_EINVAL, "layer_idx=%d out of range", li);
+    PRAG_REQUIRE(ln0_w && ln0_b && W1 && b1 && ln1_w && ln1_b && W2 && b2 && ln2_w && ln2_b && W3 && b3,
+                 PRAG_EINVAL, "prag_prober_load_layer: NULL parameter array");
+    const int d = p->d, H = kHidden;
+    LayerDev& L = p->h_layers[li];
+    HostLayer& E = p->eff[li];
+
+    // ---- fc1: fold ln0 affine, scale, pack ---------------------------------
+    std::vector<double> Wg((size_t)H * d);
+    double mx = 0.0;
+    for (int n = 0; n < H; ++n)
+        for (int k = 0; k < d; ++k) {
+            const double v = (double)W1[(size_t)n * d + k] * (double)ln0_w[k];
+            Wg[(size_t)n * d + k] = v;
+            mx = std::max(mx, std::fabs(v));
+        }
+    const int e1 = pick_scale_exp(mx);
+    for (auto& v : Wg) v = std::ldexp(v, e1);
+    std::vector<_Float16> packed;
+    std::vector<double> deq;
+    pack_fragments(Wg, d, d / 16, p->na,
+                   [](int step, int half, int j) { return 16 * step + 8 * half + j; }, packed, deq);
+    std::vector<float> wsum(H), b1e(H);
+    E.W1.resize((size_t)H * d);
+    E.b1.resize(H);
+    for (int n = 0; n < H; ++n) {
+        double s = 0.0, bb = (double)b1[n];
+        for (int k = 0; k < d; ++k) {
+            s += deq[(size_t)n * d + k];
+            bb += (double)W1[(size_t)n * d + k] * (double)ln0_b[k];
+            E.W1[(size_t)n * d + k] = (float)std::ldexp(deq[(size_t)n * d + k], -e1);
+        }
+        wsum[n] = (float)s;
+        b1e[n] = (float)bb;
+        E.b1[n] = b1e[n];
+    }
+    int rc;
+    const _Float16* dW1 = nullptr;
+    if ((rc = upload(p, packed, &dW1)) != PRAG_OK) return rc;
+    L.W1f = reinterpret_cast<const uint4*>(dW1);
+    if ((rc = upload(p, wsum, &L.wsum1)) != PRAG_OK) return rc;
+    if ((rc = upload(p, b1e, &L.b1)) != PRAG_OK) return rc;
+    L.sc1 = (float)std::ldexp(1.0, -e1);
+
+    // ---- fc2: fold ln1 affine; k order = accumulator-register order of fc1 ----
+    std::vector<double> W2g((size_t)H * H);
+    mx = 0.0;
+    for (int n = 0; n < H; ++n)
+        for (int k = 0; k < H; ++k) {
+            const double v = (double)W2[(size_t)n * H + k] * (double)ln1_w[k];
+            W2g[(size_t)n * H + k] = v;
+            mx = std::max(mx, std::fabs(v));
+        }
+    const int e2 = pick_scale_exp(mx);
+    for (auto& v : W2g) v = std::ldexp(v, e2);
+    pack_fragments(W2g, H, 32, p->na,
+                   [](int step, int half, int j) {
+                       // step = 2*row_tile + s ; element j of lane-half `half` holds hidden unit
+                       // 32*row_tile + 16*s + 8*(j>>2) + 4*half + (j&3)  (32x32 C/D layout)
+                       return 32 * (step >> 1) + 16 * (step & 1) + 8 * (j >> 2) + 4 * half + (j & 3);
+                   },
+                   packed, deq);
+    std::vector<float> b2e(H);
+    E.W2.resize((size_t)H * H);
+    E.b2.resize(H);
+    for (int n = 0; n < H; ++n) {
+        double bb = (double)b2[n];
+        for (int k = 0; k < H; ++k) {
+            bb += (double)W2[(size_t)n * H + k] * (double)ln1_b[k];
+            E.W2[(size_t)n * H + k] = (float)std::ldexp(deq[(size_t)n * H + k], -e2);
+        }
+        b2e[n] = (float)bb;
+        E.b2[n] = b2e[n];
+    }
+    const _Float16* dW2 = nullptr;
+    if ((rc = upload(p, packed, &dW2)) != PRAG_OK) return rc;
+    L.W2f = reinterpret_cast<const uint4*>(dW2);
+    if ((rc = upload(p, b2e, &L.b2)) != PRAG_OK) return rc;
+    L.sc2 = (float)std::ldexp(1.0, -e2);
+
+    // ---- fc3: fp32 VALU, fold ln2 affine --------------------------------------
+    std::vector<float> W3e((size_t)kClasses * H);
+    E.W3.resize((size_t)kClasses * H);
+    E.b3.resize(kClasses);
+    for (int c = 0; c < kClasses; ++c) {
+        double bb = (double)b3[c];
+        for (int k = 0; k < H; ++k) {
+            W3e[(size_t)c * H + k] = (float)((double)W3[(size_t)c * H + k] * (double)ln2_w[k]);
+            bb += (double)W3[(size_t)c * H + k] * (double)ln2_b[k];
+            E.W3[(size_t)c * H + k] = W3e[(size_t)c * H + k];
+        }
+        L.b3[c] = (float)bb;
+        E.b3[c] = L.b3[c];
+    }
+    if ((rc = upload(p, W3e, &L.W3)) != PRAG_OK) return rc;
+
+    PRAG_HIP(hipMemcpy(p->d_layers + li, &L, sizeof(LayerDev), hipMemcpyHostToDevice));
+    PRAG_HIP(hipDeviceSynchronize());
+    p->loaded[li] = true;
+    return PRAG_OK;
+}
+
+extern "C" int prag_prober_effective_weights(prag_prober_t* p, int li, float* W1, float* b1, float* W2,
+                                             float* b2, float* W3, float* b3) {
+    PRAG_REQUIRE(p != nullptr, PRAG_EINVAL, "prober handle is NULL");
+    PRAG_REQUIRE(li >= 0 && li < p->n_layers, PRAG_EINVAL, "layer_idx=%d out of range", li);
+    PRAG_REQUIRE(p->loaded[li], PRAG_ESTATE, "layer %d has no weights loaded", li);
+    const HostLayer& E = p->eff[li];
+    if (W1) memcpy(W1, E.W1.data(), E.W1.size() * sizeof(float));
+    if (b1) memcpy(b1, E.b1.data(), E.b1.size() * sizeof(float));
+    if (W2) memcpy(W2, E.W2.data(), E.W2.size() * sizeof(float));
+    if (b2) memcpy(b2, E.b2.data(), E.b2.size() * sizeof(float));
+    if (W3) memcpy(W3, E.W3.data(), E.W3.size() * sizeof(float));
+    if (b3) memcpy(b3, E.b3.data(), E.b3.size() * sizeof(float));
+    return PRAG_OK;
+}
+
+extern "C" int prag_prober_reserve(prag_prober_t* p, int max_B) {
+    PRAG_REQUIRE(p != nullptr, PRAG_EINVAL, "prober handle is NULL");
+    PRAG_REQUIRE(max_B >= 1, PRAG_EINVAL, "max_B=%d", max_B);
+    const int64_t rows = (int64_t)p->n_layers * max_B;
+    if (rows <= p->ws_rows) return PRAG_OK;
+    if (p->ws_h) (void)hipFree(p->ws_h);
+    if (p->ws_l) (void)hipFree(p->ws_l);
+    p->ws_h = p->ws_l = nullptr;
+    p->ws_rows = 0;
+    PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&p->ws_h), (size_t)rows * p->d * sizeof(_Float16)));
+    PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&p->ws_l), (size_t)rows * p->d * sizeof(_Float16)));
+    p->ws_rows = rows;
+    return PRAG_OK;
+}
+
+template <int NA, int NB, int CT>
+static int launch_fused(const ProberArgs& a, int n_run, hipStream_t st) {
+    constexpr int G = CT >= 2 ? 2 : 1;
+    constexpr int ROWS = 32 * CT;
+    constexpr int XSTAGE = NB * ROWS * 128;
+    constexpr int EXCH = 2 * 16 * 2 * G * 1024;
+    constexpr int REGION_A = (2 * XSTAGE > EXCH) ? 2 * XSTAGE : EXCH;
+    constexpr int LDS = REGION_A + (16 * ROWS + 2 * ROWS) * (int)sizeof(float);
+    auto kern = prober_fused_kernel<NA, NB, CT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    dim3 grid((a.B + ROWS - 1) / ROWS, n_run);
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, a);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+static int pick_ct(int B, int n_run, int max_ct) {
+    // smallest tile that still fills the chip: more workgroups pull weights in parallel
+    int ct = 1;
+    while (ct < max_ct && (int64_t)((B + 32 * ct - 1) / (32 * ct)) * n_run > 256) ct *= 2;
+    return ct;
+}
+
+extern "C" int prag_prober_forward(prag_prober_t* p, const void* x_dev, int x_dtype,
+                                   int64_t x_layer_stride, int layer0, int n_run, int B,
+                                   float* logits_dev, void* stream) {
+    PRAG_REQUIRE(p != nullptr, PRAG_EINVAL, "prober handle is NULL");
+    PRAG_REQUIRE(x_dev && logits_dev, PRAG_EINVAL, "prag_prober_forward: NULL device pointer");
+    PRAG_REQUIRE(B >= 1, PRAG_EINVAL, "B=%d must be >= 1", B);
+    PRAG_REQUIRE(layer0 >= 0 && n_run >= 1 && layer0 + n_run <= p->n_layers, PRAG_EINVAL,
+                 "layers [%d,%d) outside [0,%d)", layer0, layer0 + n_run, p->n_layers);
+    PRAG_REQUIRE(x_dtype == PRAG_F32 || x_dtype == PRAG_F16, PRAG_EINVAL, "x_dtype=%d", x_dtype);
+    PRAG_REQUIRE(n_run == 1 || x_layer_stride >= (int64_t)B * p->d, PRAG_EINVAL,
+                 "x_layer_stride=%lld smaller than B*d_model", (long long)x_layer_stride);
+    for (int l = layer0; l < layer0 + n_run; ++l)
+        PRAG_REQUIRE(p->loaded[l], PRAG_ESTATE, "layer %d has no weights loaded", l);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+    ProberArgs a;
+    a.layers = p->d_layers;
+    a.layer0 = layer0;
+    a.B = B;
+    a.d = p->d;
+    a.logits = logits_dev;
+    int nb;
+    if (x_dtype == PRAG_F16) {
+        a.xh = reinterpret_cast<const _Float16*>(x_dev);
+        a.xl = nullptr;
+        a.x_layer_stride = x_layer_stride;
+        nb = 1;
+    } else {
+        if ((int64_t)n_run * B > p->ws_rows) {
+            int rc = prag_prober_reserve(p, B);
+            if (rc != PRAG_OK) return rc;
+        }
+        const int rows = n_run * B;
+        hipLaunchKernelGGL(prenorm_split_kernel, dim3((rows + 3) / 4), dim3(256), 0, st,
+                           reinterpret_cast<const float*>(x_dev), x_layer_stride, B, p->d, rows,
+                           p->ws_h, p->ws_l);
+        PRAG_LAUNCH_CHECK();
+        a.xh = p->ws_h;
+        a.xl = p->ws_l;
+        a.x_layer_stride = (int64_t)B * p->d;
+        nb = 2;
+    }
+    const int max_ct = (p->na == 1 && nb == 1) ? 4 : 2;
+    const int ct = pick_ct(B, n_run, max_ct);
+#define PRAG_DISPATCH(NA_, NB_)                                      \
+    if (p->na == NA_ && nb == NB_) {                                 \
+        if (ct == 1) return launch_fused<NA_, NB_, 1>(a, n_run, st); \
+        if (ct == 2) return launch_fused<NA_, NB_, 2>(a, n_run, st); \
+    }
+    if (p->na == 1 && nb == 1 && ct == 4) return launch_fused<1, 1, 4>(a, n_run, st);
+    PRAG_DISPATCH(1, 1)
+    PRAG_DISPATCH(1, 2)
+    PRAG_DISPATCH(2, 1)
+    PRAG_DISPATCH(2, 2)
+#undef PRAG_DISPATCH
+    set_error("internal: no kernel for na=%d nb=%d ct=%d", p->na, nb, ct);
+    return PRAG_EUNSUPPORTED;
+}
+
+extern "C" int prag_gate_from_logits(const float* logits_dev, int L, int B, int ablation, float theta,
+                                     float* probsum_dev, int32_t* decision_dev, void* stream) {
+    PRAG_REQUIRE(logits_dev != nullptr, PRAG_EINVAL, "logits_dev is NULL");
+    PRAG_REQUIRE(L >= 1 && B >= 1, PRAG_EINVAL, "L=%d B=%d", L, B);
+    PRAG_REQUIRE(ablation >= 0 && ablation <= L, PRAG_EINVAL, "ablation=%d outside [0,%d]", ablation, L);
+    hipLaunchKernelGGL(gate_kernel, dim3((B + 255) / 256), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), logits_dev, L, B, ablation, theta,
+                       probsum_dev, decision_dev);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+extern "C" int prag_gate(prag_prober_t* p, const void* x_dev, int x_dtype, int64_t x_layer_stride, int B,
+                         int ablation, float theta, float* logits_dev, float* probsum_dev,
+                         int32_t* decision_dev, void* stream) {
+    PRAG_REQUIRE(p != nullptr, PRAG_EINVAL, "prober handle is NULL");
+    int rc = prag_prober_forward(p, x_dev, x_dtype, x_layer_stride, 0, p->n_layers, B, logits_dev, stream);
+    if (rc != PRAG_OK) return rc;
+    return prag_gate_from_logits(logits_dev, p->n_layers, B, ablation, theta, probsum_dev, decision_dev,
+                                 stream);
+}
+
+extern "C" void prag_prober_destroy(prag_prober_t* p) {
+    if (!p) return;
+    for (void* q : p->allocs) (void)hipFree(q);
+    if (p->d_layers) (void)hipFree(p->d_layers);
+    if (p->ws_h) (void)hipFree(p->ws_h);
+    if (p->ws_l) (void)hipFree(p->ws_l);
+    delete p;
+}
+
+extern "C" int prag_pool_accumulate(float* acc_dev, const void* h_dev, int h_dtype, int64_t n_elems,
+                                    int assign, void* stream) {
+    PRAG_REQUIRE(acc_dev && h_dev, PRAG_EINVAL, "prag_pool_accumulate: NULL device pointer");
+    PRAG_REQUIRE(n_elems >= 0 && n_elems % 4 == 0, PRAG_EINVAL, "n_elems=%lld must be a multiple of 4",
+                 (long long)n_elems);
+    PRAG_REQUIRE(h_dtype == PRAG_F32 || h_dtype == PRAG_F16, PRAG_EINVAL, "h_dtype=%d", h_dtype);
+    if (n_elems == 0) return PRAG_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int blocks = (int)std::min<int64_t>((n_elems / 4 + 255) / 256, 2048);
+    if (h_dtype == PRAG_F32)
+        hipLaunchKernelGGL(pool_accumulate_kernel<float>, dim3(blocks), dim3(256), 0, st, acc_dev,
+                           reinterpret_cast<const float*>(h_dev), n_elems, assign);
+    else
+        hipLaunchKernelGGL(pool_accumulate_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, acc_dev,
+                           reinterpret_cast<const _Float16*>(h_dev), n_elems, assign);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+extern "C" int prag_pool_ragged(const void* acts_dev, int dtype, int B, int T, int d,
+                                const int64_t* pred_lens_dev, int scale_mean, float* out_dev,
+                                void* stream) {
+    PRAG_REQUIRE(acts_dev && pred_lens_dev && out_dev, PRAG_EINVAL, "prag_pool_ragged: NULL device pointer");
+    PRAG_REQUIRE(B >= 1 && T >= 1 && d >= 4 && d % 4 == 0, PRAG_EINVAL, "B=%d T=%d d=%d", B, T, d);
+    PRAG_REQUIRE(dtype == PRAG_F32 || dtype == PRAG_F16, PRAG_EINVAL, "dtype=%d", dtype);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((d / 4 + 255) / 256, B);
+    if (dtype == PRAG_F32)
+        hipLaunchKernelGGL(pool_ragged_kernel<float>, grid, dim3(256), 0, st,
+                           reinterpret_cast<const float*>(acts_dev), T, d, pred_lens_dev, scale_mean, out_dev);
+    else
+        hipLaunchKernelGGL(pool_ragged_kernel<_Float16>, grid, dim3(256), 0, st,
+                           reinterpret_cast<const _Float16*>(acts_dev), T, d, pred_lens_dev, scale_mean,
+                           out_dev);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}

@@ -1,0 +1,199 @@
+"""Host-side mirror of the reference's dense-retriever interface.
+
+Reference call sites (paths relative to /root/reference):
+  * ``faiss.IndexFlatL2(768)``, ``index.add(emb)``        make_indexer.py:449-455
+  * ``faiss.write_index`` / ``faiss.read_index``          make_indexer.py:457, exp_rag.py:248
+  * ``index.search(x, k)`` -> (D, I)                       utils.py:374-380
+  * ``encode_query`` / ``find_topk_sim`` / ``batch_topk_sim``  utils.py:365-380
+
+``HipFlatIndex`` keeps the corpus in HBM and answers ``search`` with the fused
+scan/top-k kernels of libprag.so.  NumPy in -> NumPy out (like faiss); CUDA
+tensors in -> CUDA tensors out (no host round trip).
+"""
+import ctypes
+import struct
+
+import numpy as np
+
+from . import _lib
+
+_STORE = {"f32": _lib.PRAG_F32, "fp32": _lib.PRAG_F32, "f16": _lib.PRAG_F16, "fp16": _lib.PRAG_F16}
+METRIC_L2, METRIC_IP, METRIC_COS = _lib.METRIC_L2, _lib.METRIC_IP, _lib.METRIC_COS
+
+
+class HipFlatIndex:
+    """Exact brute-force index: ``IndexFlatL2`` / ``IndexFlatIP`` semantics."""
+
+    def __init__(self, d: int, metric="l2", store: str = "f32", capacity: int = 0, device=None):
+        _lib.require_gpu()
+        import torch
+        self.d = int(d)
+        self.metric = _lib.metric_id(metric)
+        self.store = store
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.is_trained = True
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().prag_index_create(ctypes.byref(h), self.d, self.metric, _STORE[store],
+                                                    int(capacity)))
+        self._h = h
+
+    @property
+    def ntotal(self) -> int:
+        return int(_lib.lib().prag_index_ntotal(self._h))
+
+    def _rows_arg(self, x):
+        """-> (pointer, n, is_device, keepalive)"""
+        import torch
+        if isinstance(x, torch.Tensor):
+            if x.dim() != 2 or x.shape[1] != self.d:
+                raise ValueError(f"expected [n,{self.d}], got {tuple(x.shape)}")
+            x = x.contiguous().float()
+            if x.is_cuda:
+                return ctypes.c_void_p(x.data_ptr()), x.shape[0], 1, x
+            x = x.numpy()
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError(f"expected [n,{self.d}], got {x.shape}")
+        return ctypes.c_void_p(x.ctypes.data), x.shape[0], 0, x
+
+    def add(self, x):
+        import torch
+        ptr, n, is_dev, keep = self._rows_arg(x)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().prag_index_add(self._h, ptr, n, is_dev))
+        del keep
+
+    def add_synthetic(self, seed: int, row0: int, n: int):
+        """Append rows [row0,row0+n) of the shared counter-based generator
+        (oracle_np.synth_rows) without touching the host."""
+        import torch
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().prag_index_add_synthetic(self._h, int(seed) & 0xFFFFFFFF, int(row0), int(n)))
+
+    def search(self, x, k: int, id_offset: int = 0):
+        """-> (D float32 [B,k], I int64 [B,k]); -1 / +-FLT_MAX padded if ntotal < k."""
+        import torch
+        k = int(k)
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            ptr, B, _, keep = self._rows_arg(x)
+            D = torch.empty((B, k), dtype=torch.float32, device=x.device)
+            I = torch.empty((B, k), dtype=torch.int64, device=x.device)
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().prag_index_search(self._h, ptr, B, k, int(id_offset),
+                                                        ctypes.c_void_p(D.data_ptr()),
+                                                        ctypes.c_void_p(I.data_ptr()), 1,
+                                                        _lib.current_stream_ptr(x.device)))
+            del keep
+            return D, I
+        ptr, B, _, keep = self._rows_arg(x)
+        D = np.empty((B, k), np.float32)
+        I = np.empty((B, k), np.int64)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().prag_index_search(self._h, ptr, B, k, int(id_offset),
+                                                    ctypes.c_void_p(D.ctypes.data), ctypes.c_void_p(I.ctypes.data),
+                                                    0, _lib.current_stream_ptr(self.device)))
+        del keep
+        return D, I
+
+    def reconstruct_n(self, row0: int = 0, n: int = None) -> np.ndarray:
+        n = self.ntotal - row0 if n is None else n
+        out = np.empty((n, self.d), np.float32)
+        import torch
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().prag_index_reconstruct(self._h, int(row0), int(n),
+                                                         ctypes.c_void_p(out.ctypes.data)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.lib().prag_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def IndexFlatL2(d: int, **kw) -> HipFlatIndex:
+    """``faiss.IndexFlatL2(d)`` (make_indexer.py:450)."""
+    return HipFlatIndex(d, "l2", kw.pop("store", "f32"), **kw)
+
+
+def IndexFlatIP(d: int, **kw) -> HipFlatIndex:
+    return HipFlatIndex(d, "ip", kw.pop("store", "f32"), **kw)
+
+
+def merge_topk(D_parts, I_parts, k: int, metric) -> tuple:
+    """Exchange step of the row-sharded index on device: D_parts/I_parts are
+    CUDA tensors [n_parts,B,k] (e.g. the output of an RCCL all-gather)."""
+    import torch
+    _lib.require_gpu()
+    D_parts = D_parts.contiguous()
+    I_parts = I_parts.contiguous()
+    P, B, kk = D_parts.shape
+    assert kk == k and I_parts.shape == D_parts.shape
+    D = torch.empty((B, k), dtype=torch.float32, device=D_parts.device)
+    I = torch.empty((B, k), dtype=torch.int64, device=D_parts.device)
+    with torch.cuda.device(D_parts.device):
+        _lib.check(_lib.lib().prag_merge_topk(ctypes.c_void_p(D_parts.data_ptr()), ctypes.c_void_p(I_parts.data_ptr()),
+                                              P, B, k, _lib.metric_id(metric), ctypes.c_void_p(D.data_ptr()),
+                                              ctypes.c_void_p(I.data_ptr()), _lib.current_stream_ptr(D_parts.device)))
+    return D, I
+
+
+# ---------------------------------------------------------------------------
+# faiss IndexFlat file format (make_indexer.py:457 write_index, exp_rag.py:248
+# read_index).  [third-party format, restated from faiss's index_write.cpp as
+# published; faiss is not installable here so this is unverified against it]:
+#   fourcc "IxF2"(L2) | "IxFI"(IP); int32 d; int64 ntotal; int64 dummy(1<<20) x2;
+#   uint8 is_trained; int32 metric_type (0 = IP, 1 = L2); uint64 n_floats; float32[]
+# ---------------------------------------------------------------------------
+def write_index(index: HipFlatIndex, path: str):
+    rows = index.reconstruct_n(0, index.ntotal)
+    l2 = index.metric == METRIC_L2
+    with open(path, "wb") as f:
+        f.write(b"IxF2" if l2 else b"IxFI")
+        f.write(struct.pack("<iqqqBi", index.d, index.ntotal, 1 << 20, 1 << 20, 1, 1 if l2 else 0))
+        f.write(struct.pack("<Q", rows.size))
+        f.write(rows.tobytes())
+
+
+def read_index(path: str, store: str = "f32", chunk_rows: int = 1 << 18) -> HipFlatIndex:
+    with open(path, "rb") as f:
+        cc = f.read(4)
+        if cc not in (b"IxF2", b"IxFI", b"IxFl"):
+            raise ValueError(f"{path}: not a flat faiss index (fourcc {cc!r})")
+        d, ntotal, _, _, _, metric_type = struct.unpack("<iqqqBi", f.read(4 + 8 * 3 + 1 + 4))
+        if metric_type > 1:
+            f.read(4)  # metric_arg
+        (n_floats,) = struct.unpack("<Q", f.read(8))
+        if n_floats != ntotal * d:
+            raise ValueError(f"{path}: header says {ntotal}x{d} but holds {n_floats} floats")
+        ix = HipFlatIndex(d, "l2" if metric_type == 1 else "ip", store, capacity=ntotal)
+        done = 0
+        while done < ntotal:
+            m = min(chunk_rows, ntotal - done)
+            ix.add(np.frombuffer(f.read(m * d * 4), dtype=np.float32).reshape(m, d))
+            done += m
+    return ix
+
+
+# ---------------------------------------------------------------------------
+# the reference's helpers, same names and argument meaning (utils.py:365-380)
+# ---------------------------------------------------------------------------
+def encode_query(model_retr, query):
+    return model_retr.encode(query)
+
+
+def find_topk_sim(model_retr, query: str, index, k: int):
+    import torch
+    D, I = index.search(np.array(torch.tensor(encode_query(model_retr, query)).unsqueeze(0)), k=k)
+    return D, I
+
+
+def batch_topk_sim(model_retr, query, index, k: int):
+    D, I = index.search(encode_query(model_retr, query), k=k)
+    return D, I

@@ -1,0 +1,126 @@
+"""The retrieve-decide loop and its input producer, restated for the HIP path.
+
+Reference (paths relative to /root/reference):
+  * hook_fn / add_layer_hook            exp_rag.py:315-329  (activations.detach().cpu() per pass)
+  * return_mean_output                  exp_rag.py:381-389  (cat(cache[1:],1).sum(1) -> prober)
+  * the per-query loop                  exp_rag.py:396-474  (<= 4 retrieval rounds)
+  * return_evidences                    exp_rag.py:369-379
+
+``HiddenStatePool`` replaces the hook cache with a running on-device
+accumulator: no D2H copy per token, no H2D before the
+gate.  ``retrieve_decide`` is the loop with the model / prompt / corpus pieces
+injected, so exp_rag.py's control flow can be driven unchanged.
+"""
+import ctypes
+
+from . import _lib
+
+
+class HiddenStatePool:
+    """acc[l] = sum over all positions of every forward pass after the first."""
+
+    def __init__(self, n_layers: int, d_model: int, batch: int = 1, device=None):
+        _lib.require_gpu()
+        import torch
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.acc = torch.zeros((n_layers, batch, d_model), dtype=torch.float32, device=self.device)
+        self.passes = [0] * n_layers
+
+    def reset(self):            # `cache = {}` exp_rag.py:397, 423
+        self.passes = [0] * len(self.passes)
+
+    def hook(self, slot: int):
+        """Returns a forward hook for layer slot `slot` (``model.add_hook(name, fn)``)."""
+        def fn(activations, hook=None):
+            self.observe(slot, activations)
+            return activations
+        return fn
+
+    def observe(self, slot: int, activations):
+        import torch
+        n = self.passes[slot]
+        self.passes[slot] = n + 1
+        if n == 0:
+            return              # element 0 = the prompt pass, skipped by cache[name][1:]
+        a = activations.detach()
+        if a.dtype not in (torch.float32, torch.float16):
+            a = a.float()
+        a = a.contiguous()
+        Bt, T, d = a.shape
+        dst = self.acc[slot]
+        dt = _lib.PRAG_F32 if a.dtype == torch.float32 else _lib.PRAG_F16
+        st = _lib.current_stream_ptr(a.device)
+        with torch.cuda.device(a.device):
+            if T == 1:
+                _lib.check(_lib.lib().prag_pool_accumulate(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(a.data_ptr()),
+                                                           dt, Bt * d, 1 if n == 1 else 0, st))
+            else:   # a pass without KV cache: sum all of its positions first
+                lens = torch.full((Bt,), T, dtype=torch.int64, device=a.device)
+                tmp = torch.empty((Bt, d), dtype=torch.float32, device=a.device)
+                _lib.check(_lib.lib().prag_pool_ragged(ctypes.c_void_p(a.data_ptr()), dt, Bt, T, d,
+                                                       ctypes.c_void_p(lens.data_ptr()), 0,
+                                                       ctypes.c_void_p(tmp.data_ptr()), st))
+                _lib.check(_lib.lib().prag_pool_accumulate(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(tmp.data_ptr()),
+                                                           _lib.PRAG_F32, Bt * d, 1 if n == 1 else 0, st))
+
+    def pooled(self):
+        if min(self.passes) < 2:   # torch.concat([]) raises in the reference
+            raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
+        return self.acc
+
+
+def pool_ragged(acts, pred_lens, mean: bool = True):
+    """train.py:153-162 + 202-205 on device: [B,T,d] -> [B,d] over the last
+    pred_lens[b] positions (mean) or their sum (inference-time pooling)."""
+    import torch
+    _lib.require_gpu()
+    acts = acts.contiguous()
+    if acts.dtype not in (torch.float32, torch.float16):
+        acts = acts.float()
+    B, T, d = acts.shape
+    lens = torch.as_tensor(pred_lens, dtype=torch.int64, device=acts.device).contiguous()
+    out = torch.empty((B, d), dtype=torch.float32, device=acts.device)
+    with torch.cuda.device(acts.device):
+        _lib.check(_lib.lib().prag_pool_ragged(ctypes.c_void_p(acts.data_ptr()),
+                                               _lib.PRAG_F32 if acts.dtype == torch.float32 else _lib.PRAG_F16,
+                                               B, T, d, ctypes.c_void_p(lens.data_ptr()), 1 if mean else 0,
+                                               ctypes.c_void_p(out.data_ptr()), _lib.current_stream_ptr(acts.device)))
+    return out
+
+
+def return_evidences(retrieved_passages) -> str:
+    """exp_rag.py:369-379 (dense branch: passages are plain strings)."""
+    return "\n".join(f"passage {n + 1}: {p}" for n, p in enumerate(retrieved_passages))
+
+
+def retrieve_decide(question: str, first_input, *, generate, gate, retrieve, lookup, make_prompt, tokenize,
+                    to_string, reset=lambda: None, k: int = 5):
+    """One query of exp_rag.py:396-474.
+
+    generate(inputs) -> output ids ; gate() -> 0 (stop) | 1 (retrieve) ;
+    retrieve(text, k) -> (D, I) ; lookup(ids) -> list[str] ;
+    make_prompt(question, evidences) -> str ; tokenize(str) -> inputs ;
+    to_string(output) -> list[str] ; reset() clears the hidden-state pool.
+    Returns (prediction text, retr_count) with the reference's cap semantics:
+    at most 4 rounds run, retr_count saturates at 3 (exp_rag.py:462-465).
+    """
+    reset()
+    output = generate(first_input)
+    retr_count = 0
+    decision = gate()
+    if decision == 0:
+        return to_string(output)[0], retr_count
+    search_input_new = None
+    while decision == 1:
+        reset()
+        query = question if retr_count == 0 else search_input_new[0]
+        _, I = retrieve(query, k)
+        ids = I[0].tolist()
+        evidences = return_evidences(lookup(ids))
+        output = generate(tokenize(make_prompt(question, evidences)))
+        decision = gate()
+        search_input_new = to_string(output)
+        if retr_count > 2:
+            break
+        retr_count += 1
+    return search_input_new[0], retr_count

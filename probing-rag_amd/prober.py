@@ -1,0 +1,290 @@
+"""Host-side mirror of the reference's prober interface on top of libprag.so.
+
+Reference call sites (paths relative to /root/reference):
+  * ``ImprovedProbe(input_size, output_size)``; ``.to(device)``,
+    ``.load_state_dict(sd)``, ``.eval()``, ``prober(x)``  utils.py:29-57, 302-329
+  * ``Config_Maker``                                       utils.py:282-290
+  * ``load_prober_cfg_gemma_2b``                           utils.py:382-383
+  * ``load_prober_models``                                 utils.py:385-387
+  * ``return_prober_logit_gemma_2b``                       utils.py:389-390
+  * gate (softmax / sum / threshold)                       exp_rag.py:393, 406-415
+
+``HipProber`` is one layer's prober (drop-in for ``ImprovedProbe`` in eval
+mode); ``HipProberEnsemble`` owns all probed layers and runs them plus the gate
+in one fused launch — ``ensemble.probers`` is a list of per-layer callables so
+the reference's ``zip(cfg_list, probers)`` loop works unchanged.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+STATE_KEYS = (
+    "layer_norm_input.weight", "layer_norm_input.bias",
+    "fc1.weight", "fc1.bias",
+    "layer_norm1.weight", "layer_norm1.bias",
+    "fc2.weight", "fc2.bias",
+    "layer_norm2.weight", "layer_norm2.bias",
+    "fc3.weight", "fc3.bias",
+)
+HIDDEN = 512
+_WEIGHT_MODES = {"f32": _lib.PRAG_W_F32, "fp32": _lib.PRAG_W_F32, "f16": _lib.PRAG_W_F16, "fp16": _lib.PRAG_W_F16}
+
+
+def _as_f32_host(v):
+    if hasattr(v, "detach"):
+        v = v.detach().to("cpu").float().numpy()
+    return np.ascontiguousarray(v, dtype=np.float32)
+
+
+def _x_dtype(x):
+    import torch
+    if x.dtype == torch.float32:
+        return _lib.PRAG_F32
+    if x.dtype == torch.float16:
+        return _lib.PRAG_F16
+    raise TypeError(f"activations must be float32 or float16, got {x.dtype}")
+
+
+class HipProberEnsemble:
+    """All probed layers' ImprovedProbe weights + the gate, on one GPU."""
+
+    def __init__(self, n_layers: int, d_model: int, num_classes: int = 2, weights: str = "f32",
+                 device=None):
+        _lib.require_gpu()
+        import torch
+        self.n_layers, self.d_model, self.num_classes = int(n_layers), int(d_model), int(num_classes)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.weights = weights
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().prag_prober_create(ctypes.byref(h), self.n_layers, self.d_model, HIDDEN,
+                                                     self.num_classes, _WEIGHT_MODES[weights]))
+        self._h = h
+        self.probers = [_LayerView(self, l) for l in range(self.n_layers)]
+
+    # -- weights ------------------------------------------------------------
+    def load_layer(self, layer_idx: int, state_dict: dict):
+        missing = [k for k in STATE_KEYS if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in STATE_KEYS]
+        if missing or unexpected:  # same contract as nn.Module.load_state_dict(strict=True)
+            raise RuntimeError(f"Error(s) in loading state_dict for ImprovedProbe: missing {missing}, "
+                               f"unexpected {unexpected}")
+        arrs = [_as_f32_host(state_dict[k]) for k in STATE_KEYS]
+        want = [(self.d_model,), (self.d_model,), (HIDDEN, self.d_model), (HIDDEN,), (HIDDEN,), (HIDDEN,),
+                (HIDDEN, HIDDEN), (HIDDEN,), (HIDDEN,), (HIDDEN,), (self.num_classes, HIDDEN), (self.num_classes,)]
+        for k, a, w in zip(STATE_KEYS, arrs, want):
+            if a.shape != w:
+                raise RuntimeError(f"size mismatch for {k}: got {a.shape}, expected {w}")
+        import torch
+        with torch.cuda.device(self.device):
+            ptrs = [a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) for a in arrs]
+            _lib.check(_lib.lib().prag_prober_load_layer(self._h, int(layer_idx), *ptrs))
+
+    def effective_state_dict(self, layer_idx: int) -> dict:
+        """The weights the kernels compute with, as an ImprovedProbe state dict
+        whose LayerNorm affines are identity (they are folded into W/b)."""
+        d, H, C = self.d_model, HIDDEN, self.num_classes
+        W1, b1 = np.empty((H, d), np.float32), np.empty((H,), np.float32)
+        W2, b2 = np.empty((H, H), np.float32), np.empty((H,), np.float32)
+        W3, b3 = np.empty((C, H), np.float32), np.empty((C,), np.float32)
+        fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+        _lib.check(_lib.lib().prag_prober_effective_weights(self._h, int(layer_idx), fp(W1), fp(b1), fp(W2),
+                                                            fp(b2), fp(W3), fp(b3)))
+        one = lambda n: np.ones((n,), np.float32)
+        zero = lambda n: np.zeros((n,), np.float32)
+        return {"layer_norm_input.weight": one(d), "layer_norm_input.bias": zero(d),
+                "fc1.weight": W1, "fc1.bias": b1,
+                "layer_norm1.weight": one(H), "layer_norm1.bias": zero(H),
+                "fc2.weight": W2, "fc2.bias": b2,
+                "layer_norm2.weight": one(H), "layer_norm2.bias": zero(H),
+                "fc3.weight": W3, "fc3.bias": b3}
+
+    def reserve(self, max_batch: int):
+        _lib.check(_lib.lib().prag_prober_reserve(self._h, int(max_batch)))
+
+    # -- compute --------------------------------------------------------------
+    def _check_x(self, x, ndim):
+        import torch
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            raise RuntimeError("Expected all tensors to be on the same device: the prober lives on "
+                               f"{self.device}, got {getattr(x, 'device', type(x))}")
+        if x.dim() != ndim or x.shape[-1] != self.d_model:
+            raise RuntimeError(f"expected activations of shape [{'L,' if ndim == 3 else ''}B,{self.d_model}], "
+                               f"got {tuple(x.shape)}")
+        return x if x.is_contiguous() else x.contiguous()
+
+    def forward_layer(self, layer_idx: int, x):
+        """``prober(input)`` for one layer: x [B,d] -> logits [B,2] float32."""
+        import torch
+        x = self._check_x(x, 2)
+        B = x.shape[0]
+        out = torch.empty((B, self.num_classes), dtype=torch.float32, device=x.device)
+        if B == 0:
+            return out
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().prag_prober_forward(self._h, ctypes.c_void_p(x.data_ptr()), _x_dtype(x),
+                                                      0, int(layer_idx), 1, B,
+                                                      ctypes.c_void_p(out.data_ptr()),
+                                                      _lib.current_stream_ptr(x.device)))
+        return out
+
+    def forward(self, x):
+        """All layers in one launch: x [L,B,d] -> logits [L,B,2]."""
+        import torch
+        x = self._check_x(x, 3)
+        L, B = x.shape[0], x.shape[1]
+        if L != self.n_layers:
+            raise RuntimeError(f"expected {self.n_layers} layers of activations, got {L}")
+        out = torch.empty((L, B, self.num_classes), dtype=torch.float32, device=x.device)
+        if B == 0:
+            return out
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().prag_prober_forward(self._h, ctypes.c_void_p(x.data_ptr()), _x_dtype(x),
+                                                      B * self.d_model, 0, L, B,
+                                                      ctypes.c_void_p(out.data_ptr()),
+                                                      _lib.current_stream_ptr(x.device)))
+        return out
+
+    __call__ = forward
+
+    def gate(self, x, ablation: int = 0, threshold: float = 0.0, out=None):
+        """exp_rag.py:406-415 for a batch: returns (logits [L,B,2], probsum [B,2],
+        decision int32 [B]); decision 1 = retrieve.  ``out`` may carry
+        preallocated (logits, probsum, decision) tensors."""
+        import torch
+        x = self._check_x(x, 3)
+        L, B = x.shape[0], x.shape[1]
+        if L != self.n_layers:
+            raise RuntimeError(f"expected {self.n_layers} layers of activations, got {L}")
+        if out is None:
+            logits = torch.empty((L, B, 2), dtype=torch.float32, device=x.device)
+            probsum = torch.empty((B, 2), dtype=torch.float32, device=x.device)
+            decision = torch.empty((B,), dtype=torch.int32, device=x.device)
+        else:
+            logits, probsum, decision = out
+        if B == 0:
+            return logits, probsum, decision
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().prag_gate(self._h, ctypes.c_void_p(x.data_ptr()), _x_dtype(x),
+                                            B * self.d_model, B, int(ablation), float(threshold),
+                                            ctypes.c_void_p(logits.data_ptr()),
+                                            ctypes.c_void_p(probsum.data_ptr()),
+                                            ctypes.c_void_p(decision.data_ptr()),
+                                            _lib.current_stream_ptr(x.device)))
+        return logits, probsum, decision
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.lib().prag_prober_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gate_from_logits(logits, ablation: int = 0, threshold: float = 0.0):
+    """The gate arithmetic alone on device logits [L,B,2] (or a list of L
+    [B,2] tensors, as return_prober_logit_gemma_2b produces)."""
+    import torch
+    if isinstance(logits, (list, tuple)):
+        logits = torch.stack([t.reshape(-1, 2) for t in logits])
+    if not logits.is_cuda:
+        raise RuntimeError("gate_from_logits needs device logits; there is no CPU path")
+    logits = logits.contiguous().float()
+    L, B = logits.shape[0], logits.shape[1]
+    probsum = torch.empty((B, 2), dtype=torch.float32, device=logits.device)
+    decision = torch.empty((B,), dtype=torch.int32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        _lib.check(_lib.lib().prag_gate_from_logits(ctypes.c_void_p(logits.data_ptr()), L, B, int(ablation),
+                                                    float(threshold), ctypes.c_void_p(probsum.data_ptr()),
+                                                    ctypes.c_void_p(decision.data_ptr()),
+                                                    _lib.current_stream_ptr(logits.device)))
+    return probsum, decision
+
+
+class _LayerView:
+    """One layer of an ensemble, callable like the reference's prober."""
+
+    def __init__(self, ens: HipProberEnsemble, layer_idx: int):
+        self._ens, self._l = ens, layer_idx
+
+    def __call__(self, x):
+        return self._ens.forward_layer(self._l, x)
+
+    def load_state_dict(self, sd, strict: bool = True):
+        self._ens.load_layer(self._l, sd)
+        return self
+
+    def state_dict(self):
+        return self._ens.effective_state_dict(self._l)
+
+    def eval(self):   # inference only: dropout is identity (utils.py:329)
+        return self
+
+    def to(self, device=None, *a, **k):
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("the HIP prober is forward-only (training is outside the hot path)")
+        return self
+
+
+class HipProber(_LayerView):
+    """Drop-in for ``ImprovedProbe(input_size, output_size)`` in eval mode."""
+
+    def __init__(self, input_size: int, output_size: int = 2, hidden_size: int = HIDDEN, weights: str = "f32",
+                 device=None):
+        if hidden_size != HIDDEN:
+            raise NotImplementedError("hidden_size is fixed at 512 (utils.py:30)")
+        super().__init__(HipProberEnsemble(1, input_size, output_size, weights=weights, device=device), 0)
+
+    forward = _LayerView.__call__
+
+
+# ---------------------------------------------------------------------------
+# the reference's module-level helpers, same names and argument meaning
+# ---------------------------------------------------------------------------
+class Config_Maker:
+    """utils.py:282-290."""
+
+    def __init__(self, model, method, layer, position, device):
+        self.method = method
+        self.layer = layer
+        self.position = position
+        self.device = device
+        self.d_model = model.cfg.d_model
+        self.model_id = model.cfg.tokenizer_name
+        self.num_classes = 2
+
+
+def load_prober_cfg_gemma_2b(model, config, position, device, start, end, step):
+    """utils.py:382-383 (exp_rag.py:311 calls it with 6, 17, 2)."""
+    return [config(model, "tokens_mean", j, position, device) for j in range(start, end, step)]
+
+
+def load_prober_models(state_dicts, cfg_list, weights: str = "f32"):
+    """utils.py:385-387.  The reference maps ``--ds`` to hard-coded checkpoint
+    paths (utils.py:303-326) that are not shipped; here ``state_dicts`` is either
+    a list of state dicts / checkpoint paths (one per cfg) or a callable
+    ``cfg -> state dict``.  Returns the list of per-layer probers, all living in
+    one ensemble (``probers[0]._ens``)."""
+    import torch
+    ens = HipProberEnsemble(len(cfg_list), cfg_list[0].d_model, cfg_list[0].num_classes, weights=weights,
+                            device=cfg_list[0].device if str(cfg_list[0].device) != "cuda" else None)
+    for i, cfg in enumerate(cfg_list):
+        sd = state_dicts(cfg) if callable(state_dicts) else state_dicts[i]
+        if isinstance(sd, (str, bytes)):
+            sd = torch.load(sd, map_location="cpu")
+        ens.load_layer(i, sd)
+    return ens.probers
+
+
+def return_prober_logit_gemma_2b(method_function, cfg_list, model_list):
+    """utils.py:389-390, verbatim semantics: one call per layer, logits to CPU."""
+    return [method_function(cfg, model).to("cpu") for cfg, model in zip(cfg_list, model_list)]

@@ -1,0 +1,65 @@
+"""CPU: libprag.so builds/loads and exports every symbol include/prag.h declares;
+argument validation works without a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import probing_rag_amd as pra
+from probing_rag_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "prag.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(prag_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = _declared_symbols()
+    assert len(names) >= 20
+    lib = pra.lib()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in prag.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == names
+    assert lib.prag_version() == 100
+
+
+def test_argument_validation_without_gpu():
+    lib = pra.lib()
+    h = ctypes.c_void_p()
+    assert lib.prag_prober_create(ctypes.byref(h), 6, 2048, 256, 2, 1) == -4   # hidden != 512
+    assert b"hidden_size=512" in lib.prag_last_error()
+    assert lib.prag_prober_create(ctypes.byref(h), 6, 2000, 512, 2, 1) == -4   # d % 64
+    assert lib.prag_prober_create(ctypes.byref(h), 0, 2048, 512, 2, 1) == -1
+    assert lib.prag_index_create(ctypes.byref(h), 770, 0, 0, 0) == -4
+    assert lib.prag_index_create(ctypes.byref(h), 768, 7, 0, 0) == -1
+    assert lib.prag_prober_forward(None, None, 0, 0, 0, 1, 1, None, None) == -1
+    assert lib.prag_index_search(None, None, 1, 5, 0, None, None, 0, None) == -1
+    assert lib.prag_merge_topk(None, None, 2, 1, 5, 0, None, None, None) == -1
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pra.HipFlatIndex(768)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pra.HipProberEnsemble(6, 2048)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pra.HipProber(2048, 2)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "probing-rag_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "prag_oracle" not in src and "oracle_np import" not in src, f

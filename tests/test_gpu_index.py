@@ -1,0 +1,163 @@
+"""GPU parity: HIP flat index (through the C ABI) vs the oracle's definition of
+faiss.IndexFlatL2 / IP search.  Bar: indices bit-exact, scores within 1e-4
+(relative for L2 — SURVEY.md §7 hard part 4)."""
+import numpy as np
+import pytest
+
+from oracle import oracle_c, oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+
+METRICS = [onp.METRIC_L2, onp.METRIC_IP, onp.METRIC_COS]
+
+
+def _stored(X, metric, store):
+    xs = onp.normalize_rows(X) if metric == onp.METRIC_COS else X
+    return onp.store_round(xs, store)
+
+
+def _check(D, I, D0, I0, metric):
+    assert np.array_equal(I, I0)
+    if metric == onp.METRIC_L2:
+        np.testing.assert_allclose(D, D0, rtol=1e-4, atol=0)
+    else:
+        np.testing.assert_allclose(D, D0, atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("store", ["f32", "f16"])
+@pytest.mark.parametrize("metric", METRICS)
+@pytest.mark.parametrize("N,B,k,d", [(10_000, 128, 5, 768),   # BASELINE config 1
+                                     (1, 1, 5, 768), (31, 3, 10, 64), (2049, 33, 10, 128),
+                                     (4097, 70, 26, 256), (777, 1, 1, 1024)])
+def test_search_matches_definition(metric, store, N, B, k, d):
+    import probing_rag_amd as pra
+    X = onp.synth_rows(42, 0, N, d)
+    if N > 40:
+        X[N // 2] = X[3]                       # exact duplicates -> tie broken by lowest id
+        X[N - 1] = X[3]
+    Q = onp.synth_rows(7, 0, B, d)
+    if N > 40:
+        Q[0] = X[3]                            # the duplicated row is query 0's best match
+    ix = pra.HipFlatIndex(d, metric, store)
+    ix.add(X[: N // 2])                        # two adds: insertion-order ids
+    ix.add(X[N // 2:])
+    assert ix.ntotal == N and ix.d == d
+    xs = _stored(X, metric, store)
+    np.testing.assert_array_equal(ix.reconstruct_n(), xs)
+    D, I = ix.search(Q, k)
+    assert D.dtype == np.float32 and I.dtype == np.int64 and D.shape == (B, k)
+    D0, I0 = onp.flat_search(xs, Q, k, metric)
+    _check(D, I, D0, I0, metric)
+    if N > 40:
+        want = [3, N // 2, N - 1][:k] if metric != onp.METRIC_IP else None
+        if want:
+            assert I[0, :len(want)].tolist() == want
+
+
+def test_empty_padding_offsets_and_device_io():
+    import torch
+    import probing_rag_amd as pra
+    ix = pra.IndexFlatL2(768)
+    Q = onp.synth_rows(7, 0, 4, 768)
+    D, I = ix.search(Q, 5)                      # empty index
+    assert (I == -1).all() and (D == np.finfo(np.float32).max).all()
+    ix.add(np.zeros((0, 768), np.float32))     # empty add is a no-op
+    X = onp.synth_rows(42, 0, 3, 768)
+    ix.add(X)
+    D, I = ix.search(Q, 5, id_offset=1000)
+    D0, I0 = onp.flat_search(X, Q, 5, onp.METRIC_L2, id_offset=1000)
+    assert np.array_equal(I, I0) and (I[:, 3:] == -1).all()
+    np.testing.assert_allclose(D[:, :3], D0[:, :3], rtol=1e-6)
+    # CUDA tensors in -> CUDA tensors out, same answer, explicit non-default stream
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        Dd, Id = ix.search(torch.from_numpy(Q).cuda(), 5, id_offset=1000)
+    s.synchronize()
+    assert Dd.is_cuda and np.array_equal(Id.cpu().numpy(), I) and np.array_equal(Dd.cpu().numpy(), D)
+    ip = pra.IndexFlatIP(768)
+    ip.add(torch.from_numpy(X).cuda())         # device rows
+    D, I = ip.search(Q, 2)
+    D0, I0 = onp.flat_search(X, Q, 2, onp.METRIC_IP)
+    assert np.array_equal(I, I0)
+    with pytest.raises(pra.PragError, match="PRAG_EUNSUPPORTED"):
+        ix.search(Q, 100)
+    with pytest.raises(ValueError):
+        ix.add(np.zeros((2, 100), np.float32))
+
+
+def test_synthetic_rows_match_oracle_generator_bit_for_bit():
+    import probing_rag_amd as pra
+    ix = pra.HipFlatIndex(768, "l2", "f32")
+    ix.add_synthetic(42, 5_000_000_000 // 768, 100)     # counter crosses 2^32
+    got = ix.reconstruct_n()
+    want = onp.synth_rows(42, 5_000_000_000 // 768, 100, 768)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_shard_simulation_equals_unsharded(metric):
+    """`world` logical shards on one device, same local-search +
+    merge code as the multi-GPU path, must equal the unsharded search."""
+    import torch
+    import probing_rag_amd as pra
+    N, d, k = 5000, 768, 10
+    X = onp.synth_rows(42, 0, N, d)
+    X[4000] = X[10]
+    Q = onp.synth_rows(7, 0, 40, d)
+    Q[1] = X[10]
+    whole = pra.HipFlatIndex(d, metric, "f16")
+    whole.add(X)
+    qd = torch.from_numpy(Q).cuda()
+    D0, I0 = whole.search(qd, k)
+    shards = []
+    for r in range(8):
+        lo, hi = pra.partition_rows(N, 8, r)
+        ix = pra.HipFlatIndex(d, metric, "f16")
+        ix.add(X[lo:hi])
+        shards.append(ix)
+    D1, I1 = pra.search_shards_on_one_gpu(shards, qd, k, metric)
+    assert torch.equal(I0, I1) and torch.equal(D0, D1)
+    xs = _stored(X, metric, "f16")
+    Dn, In = onp.flat_search(xs, Q, k, metric)
+    _check(D1.cpu().numpy(), I1.cpu().numpy(), Dn, In, metric)
+
+
+def test_write_read_index_roundtrip(tmp_path):
+    import probing_rag_amd as pra
+    X = onp.synth_rows(1, 0, 1000, 768)
+    ix = pra.IndexFlatL2(768)
+    ix.add(X)
+    path = str(tmp_path / "contriever_nq_2.bin")     # make_indexer.py:457 naming
+    pra.write_index(ix, path)
+    ix2 = pra.read_index(path)                       # exp_rag.py:248
+    Q = onp.synth_rows(2, 0, 3, 768)
+    a, b = ix.search(Q, 5), ix2.search(Q, 5)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+
+
+def test_c3_full_size_properties():
+    """BASELINE config 3: 1k queries x 1M docs x 768, cosine top-10, fp16 rows.
+    Size-independent checks: planted near-duplicates must come back first,
+    result lists are sorted, ids unique, 8-shard simulation agrees; the C oracle
+    verifies a handful of queries against the full corpus exactly."""
+    import torch
+    import probing_rag_amd as pra
+    N, d, B, k = 1_000_000, 768, 1000, 10
+    ix = pra.HipFlatIndex(d, "cos", "f16", capacity=N)
+    ix.add_synthetic(42, 0, N)
+    planted = (np.arange(B, dtype=np.int64) * 997 + 13) % N
+    Q = np.stack([onp.synth_rows(42, int(r), 1, d)[0] for r in planted[:64]])
+    Q = np.concatenate([Q, onp.synth_rows(7, 0, B - 64, d)])
+    Q[:64] += 0.05 * onp.synth_rows(9, 0, 64, d)
+    qd = torch.from_numpy(Q).cuda()
+    D, I = ix.search(qd, k)
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    assert (I[:64, 0] == planted[:64]).all()
+    assert (np.diff(D, axis=1) <= 0).all() and (I >= 0).all() and (I < N).all()
+    assert all(len(set(row)) == k for row in I.tolist())
+    # exact check of 6 queries against every row (C oracle, fp64)
+    xs = ix.reconstruct_n(0, N)
+    pick = [0, 1, 63, 64, 500, 999]
+    D0, I0 = oracle_c.flat_search(xs, Q[pick], k, onp.METRIC_COS)
+    assert np.array_equal(I[pick], I0)
+    np.testing.assert_allclose(D[pick], D0, atol=1e-4, rtol=0)

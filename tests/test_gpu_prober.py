@@ -1,0 +1,179 @@
+"""GPU parity: HIP prober ensemble + gate (through the C ABI) vs the oracle and
+the golden vectors of the reference's ImprovedProbe.  Tolerance: 1e-4 on logits
+(BASELINE.json north_star); decisions exact outside 1e-4 of the threshold."""
+import numpy as np
+import pytest
+
+from oracle import oracle_c, oracle_np as onp
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _ensemble(case, weights):
+    import probing_rag_amd as pra
+    states = [cases.synth_state(case["wseed"] + l, case["d"]) for l in range(case["L"])]
+    ens = pra.HipProberEnsemble(case["L"], case["d"], 2, weights=weights)
+    for l, st in enumerate(states):
+        ens.load_layer(l, st)
+    return ens, states
+
+
+def _oracle_effective(ens, x_np):
+    return np.stack([onp.prober_forward(ens.effective_state_dict(l), x_np[l]) for l in range(ens.n_layers)])
+
+
+@pytest.mark.parametrize("case", cases.PROBER_CASES, ids=lambda c: c["name"])
+def test_fp32_parity_against_reference_golden(torch_cuda, golden, case):
+    """The reference's own call shape: fp32 activations, fp32 weights."""
+    torch = torch_cuda
+    ens, states = _ensemble(case, "f32")
+    x = cases.case_x(case)
+    xd = torch.from_numpy(x).cuda()
+    logits = ens.forward(xd).cpu().numpy()
+    ref = golden[f"{case['name']}/logits"]
+    np.testing.assert_allclose(logits, ref, atol=TOL, rtol=0)
+    np.testing.assert_allclose(logits, onp.ensemble_forward(states, x), atol=TOL, rtol=0)
+    # per-layer `prober(input)` (exp_rag.py:387) == ensemble launch
+    for l, prober in enumerate(ens.probers):
+        one = prober(xd[l]).to("cpu").numpy()
+        np.testing.assert_allclose(one, logits[l], atol=1e-6, rtol=0)
+    # gate for every (ablation, theta) of the paper's sweep
+    for ab in cases.ABLATIONS:
+        if ab >= case["L"]:
+            continue
+        for th in cases.THETAS:
+            lg, ps, dec = ens.gate(xd, ablation=ab, threshold=th)
+            ps, dec = ps.cpu().numpy(), dec.cpu().numpy()
+            ref_ps = golden[f"{case['name']}/probsum_ab{ab}"]
+            np.testing.assert_allclose(ps, ref_ps, atol=TOL, rtol=0)
+            ref_dec = golden[f"{case['name']}/decision_ab{ab}_th{th}"]
+            margin = np.abs(ref_ps[:, 0] + np.float32(th) - ref_ps[:, 1])
+            assert not ((dec != ref_dec) & (margin > TOL)).any()
+            # bit-for-bit against the oracle's gate on OUR logits
+            ops, odec = oracle_c.gate(lg.cpu().numpy(), ab, th)
+            np.testing.assert_allclose(ps, ops, atol=1e-6, rtol=0)
+            m2 = np.abs(ops[:, 0] + np.float32(th) - ops[:, 1])
+            assert not ((dec != odec) & (m2 > 1e-6)).any()
+
+
+@pytest.mark.parametrize("weights,xdtype", [("f16", "f16"), ("f16", "f32"), ("f32", "f16")])
+@pytest.mark.parametrize("case", cases.PROBER_CASES, ids=lambda c: c["name"])
+def test_reduced_precision_modes_against_oracle_on_same_operands(torch_cuda, golden, case, weights, xdtype):
+    """fp16 weights / activations: parity is defined on identical numeric inputs —
+    the oracle consumes the fp16-rounded activations and the weights the kernel
+    actually holds (effective_state_dict), in float64."""
+    torch = torch_cuda
+    ens, _ = _ensemble(case, weights)
+    x = cases.case_x(case)
+    if xdtype == "f16":
+        if np.abs(x).max() > 6e4:
+            pytest.skip("fp16 overflow")
+        xd = torch.from_numpy(x).cuda().half()
+        x_seen = xd.float().cpu().numpy()
+    else:
+        xd = torch.from_numpy(x).cuda()
+        x_seen = x
+    logits = ens.forward(xd).cpu().numpy()
+    np.testing.assert_allclose(logits, _oracle_effective(ens, x_seen), atol=TOL, rtol=0)
+    # and it stays close to the full-precision reference (weight rounding only)
+    np.testing.assert_allclose(logits, golden[f"{case['name']}/logits"], atol=2e-2, rtol=0)
+
+
+def test_state_dict_contract(torch_cuda):
+    import probing_rag_amd as pra
+    p = pra.HipProber(2048, 2)
+    st = cases.synth_state(1, 2048)
+    bad = dict(st)
+    bad.pop("fc3.bias")
+    with pytest.raises(RuntimeError, match="missing"):
+        p.load_state_dict(bad)
+    bad = dict(st)
+    bad["fc1.weight"] = bad["fc1.weight"][:, :100]
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        p.load_state_dict(bad)
+    with pytest.raises(pra.PragError, match="PRAG_ESTATE"):
+        p(torch_cuda.zeros(1, 2048, device="cuda"))
+    p.load_state_dict({k: torch_cuda.from_numpy(v) for k, v in st.items()}).eval().to("cuda")
+    with pytest.raises(RuntimeError, match="same device"):
+        p(torch_cuda.zeros(1, 2048))
+    out = p(torch_cuda.zeros(0, 2048, device="cuda"))
+    assert tuple(out.shape) == (0, 2)
+
+
+def test_c2_full_size_properties(torch_cuda):
+    """BASELINE config 2: B=4096 x 6 layers x d=2048 fp16.  The oracle checks a
+    256-row sample; size-independent properties cover the rest: a row's logits do
+    not depend on which tile/batch it sits in, nor on a power-of-two rescale of
+    the activations (LayerNorm-first)."""
+    torch = torch_cuda
+    case = dict(name="c2", d=2048, L=6, B=4096, sigma=1.0, wseed=100, xseed=999)
+    ens, _ = _ensemble(case, "f16")
+    x = cases.case_x(case)
+    xd = torch.from_numpy(x).cuda().half()
+    logits, probsum, dec = ens.gate(xd, 0, 0.0)
+    logits = logits.cpu().numpy()
+    assert np.isfinite(logits).all()
+    rows = np.arange(0, 4096, 16)
+    want = _oracle_effective(ens, xd[:, rows].float().cpu().numpy())
+    np.testing.assert_allclose(logits[:, rows], want, atol=TOL, rtol=0)
+    # batch-composition independence (different tile shapes are used for B=37)
+    sub = np.array([3, 4095, 1027, 64, 65, 2048] + list(range(500, 531)))
+    small = ens.forward(xd[:, sub].contiguous()).cpu().numpy()
+    np.testing.assert_allclose(small, logits[:, sub], atol=2e-6, rtol=0)
+    # scale invariance: x*4 is exact in fp16
+    scaled = ens.forward(xd * 4).cpu().numpy()
+    np.testing.assert_allclose(scaled, logits, atol=TOL, rtol=0)
+    # gate consistency with the oracle on these logits
+    ops, odec = oracle_c.gate(logits, 0, 0.0)
+    np.testing.assert_allclose(probsum.cpu().numpy(), ops, atol=1e-6, rtol=0)
+    m = np.abs(ops[:, 0] - ops[:, 1])
+    assert not ((dec.cpu().numpy() != odec) & (m > 1e-6)).any()
+
+
+def test_pooling_kernels(torch_cuda, golden):
+    """exp_rag.py:385-386 (sum over decode steps, prompt pass skipped) and
+    train.py:153-162/202-205 (ragged mean) on device."""
+    torch = torch_cuda
+    import probing_rag_amd as pra
+    case = cases.POOL_CASES[0]
+    acts, pred_lens, labels = cases.synth_pool_inputs(case)
+    ad = torch.from_numpy(acts).cuda()
+    mean = pra.pool_ragged(ad, pred_lens, mean=True).cpu().numpy()
+    np.testing.assert_allclose(mean, onp.pool_ragged_mean(acts, pred_lens), atol=1e-6, rtol=1e-6)
+    st = cases.synth_state(case["wseed"], case["d"])
+    p = pra.HipProber(case["d"], 2)
+    p.load_state_dict(st)
+    probs = torch.softmax(p(torch.from_numpy(mean).cuda()), dim=-1).cpu().numpy()
+    np.testing.assert_allclose(probs, golden[f"{case['name']}/probs"], atol=TOL, rtol=0)
+    sums = pra.pool_ragged(ad, pred_lens, mean=False)
+    np.testing.assert_allclose(p(sums).cpu().numpy(), golden[f"{case['name']}/sum_logits"], atol=TOL, rtol=0)
+    # hook accumulator: pass 0 = prompt (skipped), then T decode steps
+    pool = pra.HiddenStatePool(2, 64, batch=1)
+    rng = np.random.default_rng(0)
+    passes = [rng.standard_normal((1, 9, 64)).astype(np.float32)] + \
+             [rng.standard_normal((1, 1, 64)).astype(np.float32) for _ in range(7)]
+    with pytest.raises(RuntimeError):
+        pool.pooled()
+    for layer in range(2):
+        for a in passes:
+            pool.observe(layer, torch.from_numpy(a * (layer + 1)).cuda())
+    got = pool.pooled().cpu().numpy()
+    want = onp.pool_sum_decode_steps(passes)
+    np.testing.assert_allclose(got[0], want, atol=1e-5)
+    np.testing.assert_allclose(got[1], 2 * want, atol=1e-5)
+    pool.reset()
+    pool.observe(0, torch.from_numpy(passes[0]).cuda())
+    pool.observe(0, torch.from_numpy(passes[0]).cuda())   # a multi-position later pass
+    pool.observe(1, torch.from_numpy(passes[0]).cuda())
+    pool.observe(1, torch.from_numpy(passes[1]).cuda())
+    np.testing.assert_allclose(pool.pooled()[0].cpu().numpy(), passes[0].sum(axis=1), atol=1e-5)

@@ -1,0 +1,104 @@
+"""CPU: host-side logic that needs no kernels — loop control flow, evidence
+formatting, row partitioning, faiss file header, reference-shaped helpers."""
+import struct
+
+import numpy as np
+
+import probing_rag_amd as pra
+from oracle import oracle_np as onp
+
+
+def test_partition_rows_covers_everything_contiguously():
+    for n, w in ((21_000_000, 8), (10, 3), (5, 8), (0, 4), (1000, 1)):
+        spans = [pra.partition_rows(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        for (a, b), (c, d) in zip(spans, spans[1:]):
+            assert b == c and a <= b and c <= d
+    assert pra.partition_rows(21_000_000, 8, 0) == (0, 2_625_000)
+
+
+def test_return_evidences_format():
+    # exp_rag.py:369-379
+    assert pra.return_evidences(["a", "b", "c"]) == "passage 1: a\npassage 2: b\npassage 3: c"
+    assert pra.return_evidences([]) == ""
+
+
+def _drive(decisions):
+    """Run retrieve_decide with a scripted gate; returns (pred, retr_count, log)."""
+    it = iter(decisions)
+    log = {"queries": [], "gen": 0, "resets": 0}
+
+    def generate(inp):
+        log["gen"] += 1
+        return f"out{log['gen']}"
+
+    def retrieve(text, k):
+        log["queries"].append((text, k))
+        return np.zeros((1, k), np.float32), np.arange(k, dtype=np.int64)[None, :]
+
+    pred, rc = pra.retrieve_decide(
+        "Q?", "ids0", generate=generate, gate=lambda: next(it), retrieve=retrieve,
+        lookup=lambda ids: [f"doc{i}" for i in ids], make_prompt=lambda q, ev: f"{ev}|{q}",
+        tokenize=lambda s: s, to_string=lambda o: [f"text({o})"],
+        reset=lambda: log.__setitem__("resets", log["resets"] + 1), k=5)
+    return pred, rc, log
+
+
+def test_retrieve_decide_matches_reference_cap_semantics():
+    # exp_rag.py:417-468: <= 4 rounds, retr_count saturates at 3, round >= 2 queries
+    # with the full decoded text (exp_rag.py:435, 457)
+    for decisions in ([0], [1, 0], [1, 1, 0], [1, 1, 1, 0], [1, 1, 1, 1, 0], [1, 1, 1, 1, 1, 1]):
+        pred, rc, log = _drive(decisions)
+        want_rc, want_rounds = onp.retr_count_from_decisions(decisions)
+        assert rc == want_rc and len(log["queries"]) == want_rounds
+        assert log["gen"] == 1 + want_rounds and log["resets"] == 1 + want_rounds
+        if want_rounds:
+            assert log["queries"][0] == ("Q?", 5)
+            for j, (text, _) in enumerate(log["queries"][1:], start=2):
+                assert text == f"text(out{j})"
+            assert pred == f"text(out{1 + want_rounds})"
+        else:
+            assert pred == "text(out1)"
+
+
+def test_reference_shaped_helpers():
+    class Cfg:
+        d_model, tokenizer_name = 2048, "google/gemma-2b"
+
+    class Model:
+        cfg = Cfg()
+
+    cfgs = pra.load_prober_cfg_gemma_2b(Model(), pra.Config_Maker, "resid_post", "cuda", 6, 17, 2)
+    assert [c.layer for c in cfgs] == [6, 8, 10, 12, 14, 16]       # exp_rag.py:311
+    assert all(c.method == "tokens_mean" and c.num_classes == 2 and c.d_model == 2048 for c in cfgs)
+
+    class T:
+        def __init__(self, v): self.v = v
+        def to(self, dev): return ("cpu", self.v)
+
+    got = pra.return_prober_logit_gemma_2b(lambda cfg, m: T(m(cfg)), [1, 2], [lambda c: c * 10, lambda c: c * 100])
+    assert got == [("cpu", 10), ("cpu", 200)]
+
+    class Enc:
+        def encode(self, q): return np.full((len(q), 4), 2.0, np.float32)
+
+    class Ix:
+        def search(self, x, k): return x[:, :k], np.zeros((len(x), k), np.int64)
+
+    D, I = pra.batch_topk_sim(Enc(), ["a", "b"], Ix(), k=3)             # utils.py:378-380
+    assert D.shape == (2, 3) and I.shape == (2, 3)
+
+
+def test_write_index_emits_faiss_flat_header(tmp_path):
+    class Fake:
+        d, ntotal, metric = 4, 3, pra.index.METRIC_L2
+        def reconstruct_n(self, a, n): return np.arange(12, dtype=np.float32).reshape(3, 4)
+
+    p = tmp_path / "x.bin"
+    pra.write_index(Fake(), str(p))
+    raw = p.read_bytes()
+    assert raw[:4] == b"IxF2"
+    d, nt, _, _, trained, metric = struct.unpack("<iqqqBi", raw[4:4 + 33])
+    assert (d, nt, trained, metric) == (4, 3, 1, 1)
+    (nf,) = struct.unpack("<Q", raw[37:45])
+    assert nf == 12 and np.frombuffer(raw[45:], np.float32).tolist() == list(range(12))
