@@ -114,6 +114,14 @@ int prag_prober_effective_weights(prag_prober_t* p, int layer_idx, float* W1, fl
  * that later forward calls never allocate (stream-capture safe). */
 int prag_prober_reserve(prag_prober_t* p, int max_B);
 
+/* Measurement hook (no reference counterpart): record a HIP-event pair on the
+ * launch stream around every fused prober kernel (slots > 0 enables and sizes
+ * the ring, 0 disables).  prag_prober_profile_read waits for the recorded
+ * events, writes up to `cap` durations in ms, returns their count in *n_out and
+ * rewinds the ring. */
+int prag_prober_profile(prag_prober_t* p, int slots);
+int prag_prober_profile_read(prag_prober_t* p, float* ms, int cap, int* n_out);
+
 void prag_prober_destroy(prag_prober_t* p);
 
 /* Replaces `torch.sum(torch.concat(cache[name][1:], dim=1), dim=1)`
@@ -171,6 +179,10 @@ int prag_merge_topk(const float* D_parts_dev, const int64_t* I_parts_dev, int n_
 
 /* Read back stored rows [row0,row0+n) as float32 (what the scan sees). */
 int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n, float* out_host);
+
+/* Measurement hook: as prag_prober_profile, around every scan_topk launch. */
+int prag_index_profile(prag_index_t* ix, int slots);
+int prag_index_profile_read(prag_index_t* ix, float* ms, int cap, int* n_out);
 
 void prag_index_destroy(prag_index_t* ix);
 

@@ -57,6 +57,8 @@ SIGNATURES = {
     "prag_gate_from_logits": (_I, [_P, _I, _I, _I, _F, _P, _P, _P]),
     "prag_prober_effective_weights": (_I, [_P, _I] + [_FP] * 6),
     "prag_prober_reserve": (_I, [_P, _I]),
+    "prag_prober_profile": (_I, [_P, _I]),
+    "prag_prober_profile_read": (_I, [_P, _FP, _I, ctypes.POINTER(_I)]),
     "prag_prober_destroy": (None, [_P]),
     "prag_pool_accumulate": (_I, [_P, _P, _I, _L, _I, _P]),
     "prag_pool_ragged": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
@@ -68,6 +70,8 @@ SIGNATURES = {
     "prag_index_search": (_I, [_P, _P, _I, _I, _L, _P, _P, _I, _P]),
     "prag_merge_topk": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "prag_index_reconstruct": (_I, [_P, _L, _L, _P]),
+    "prag_index_profile": (_I, [_P, _I]),
+    "prag_index_profile_read": (_I, [_P, _FP, _I, ctypes.POINTER(_I)]),
     "prag_index_destroy": (None, [_P]),
 }
 

@@ -534,6 +534,7 @@ struct prag_index {
     int64_t* io_I = nullptr;
     int io_B = 0, io_k = 0;
     int n_cu = 256;
+    EventRing prof;
 };
 
 static size_t elt(const prag_index* ix) { return ix->store == PRAG_F32 ? 4 : 2; }
@@ -669,7 +670,7 @@ static int pick_kc(int k) {
 }
 
 template <int QT, int KC, bool F32>
-static int launch_scan(const ScanArgs& a, int grid, hipStream_t st) {
+static int launch_scan(const ScanArgs& a, int grid, hipStream_t st, EventRing& prof) {
     const int lds = QT * a.qstride + 8 * 4096;
     auto kern = scan_topk_kernel<QT, KC, F32>;
     static bool attr_set = false;
@@ -678,17 +679,19 @@ static int launch_scan(const ScanArgs& a, int grid, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    prof.begin(st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    prof.end(st);
     PRAG_LAUNCH_CHECK();
     return PRAG_OK;
 }
 
 template <int QT, bool F32>
-static int dispatch_scan_kc(int kc, const ScanArgs& a, int grid, hipStream_t st) {
+static int dispatch_scan_kc(int kc, const ScanArgs& a, int grid, hipStream_t st, EventRing& prof) {
     switch (kc) {
-        case 8: return launch_scan<QT, 8, F32>(a, grid, st);
-        case 16: return launch_scan<QT, 16, F32>(a, grid, st);
-        case 32: return launch_scan<QT, 32, F32>(a, grid, st);
+        case 8: return launch_scan<QT, 8, F32>(a, grid, st, prof);
+        case 16: return launch_scan<QT, 16, F32>(a, grid, st, prof);
+        case 32: return launch_scan<QT, 32, F32>(a, grid, st, prof);
     }
     set_error("internal: KC=%d", kc);
     return PRAG_EUNSUPPORTED;
@@ -794,11 +797,11 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
             a.q16 = ix->q16 + (size_t)p0 * ix->d;
             int rc;
             if (QT == 32)
-                rc = ix->store == PRAG_F32 ? dispatch_scan_kc<32, true>(kc, a, grid, st)
-                                           : dispatch_scan_kc<32, false>(kc, a, grid, st);
+                rc = ix->store == PRAG_F32 ? dispatch_scan_kc<32, true>(kc, a, grid, st, ix->prof)
+                                           : dispatch_scan_kc<32, false>(kc, a, grid, st, ix->prof);
             else
-                rc = ix->store == PRAG_F32 ? dispatch_scan_kc<64, true>(kc, a, grid, st)
-                                           : dispatch_scan_kc<64, false>(kc, a, grid, st);
+                rc = ix->store == PRAG_F32 ? dispatch_scan_kc<64, true>(kc, a, grid, st, ix->prof)
+                                           : dispatch_scan_kc<64, false>(kc, a, grid, st, ix->prof);
             if (rc != PRAG_OK) return rc;
             const int nq = std::min(QT, B - p0);
             rc = launch_merge(kc, ix->part_key, ix->part_idx, n_lists, QT, nq, ix->cand + (size_t)p0 * kc, st);
@@ -853,8 +856,23 @@ extern "C" int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n,
     return PRAG_OK;
 }
 
+extern "C" int prag_index_profile(prag_index_t* ix, int slots) {
+    PRAG_REQUIRE(ix != nullptr && slots >= 0 && slots <= 4096, PRAG_EINVAL, "prag_index_profile: bad argument");
+    if (slots == 0) {
+        ix->prof.disable();
+        return PRAG_OK;
+    }
+    return ix->prof.enable(slots);
+}
+
+extern "C" int prag_index_profile_read(prag_index_t* ix, float* ms, int cap, int* n_out) {
+    PRAG_REQUIRE(ix != nullptr && ms != nullptr && cap >= 0, PRAG_EINVAL, "prag_index_profile_read: bad argument");
+    return ix->prof.read(ms, cap, n_out);
+}
+
 extern "C" void prag_index_destroy(prag_index_t* ix) {
     if (!ix) return;
+    ix->prof.disable();
     void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->part_key, ix->part_idx, ix->cand,
                     ix->io_q, ix->io_D, ix->io_I};
     for (void* p : ptrs)

@@ -6,6 +6,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <vector>
+
 #include "prag.h"
 
 namespace prag {
@@ -33,6 +35,52 @@ void set_error(const char* fmt, ...);
 
 // Launch check that does not synchronise.
 #define PRAG_LAUNCH_CHECK() PRAG_HIP(hipGetLastError())
+
+// Optional per-kernel timing: pairs of HIP events recorded on the launch stream
+// around the dominant kernel of a call (bench.py's roofline uses these).
+struct EventRing {
+    std::vector<hipEvent_t> a, b;
+    int n = 0;
+    bool on = false;
+    int enable(int slots) {
+        disable();
+        a.resize(slots);
+        b.resize(slots);
+        for (int i = 0; i < slots; ++i) {
+            if (hipEventCreate(&a[i]) != hipSuccess || hipEventCreate(&b[i]) != hipSuccess) return PRAG_EHIP;
+        }
+        n = 0;
+        on = slots > 0;
+        return PRAG_OK;
+    }
+    void disable() {
+        for (auto e : a) (void)hipEventDestroy(e);
+        for (auto e : b) (void)hipEventDestroy(e);
+        a.clear();
+        b.clear();
+        n = 0;
+        on = false;
+    }
+    void begin(hipStream_t st) {
+        if (on && n < (int)a.size()) (void)hipEventRecord(a[n], st);
+    }
+    void end(hipStream_t st) {
+        if (on && n < (int)a.size()) {
+            (void)hipEventRecord(b[n], st);
+            ++n;
+        }
+    }
+    int read(float* ms, int cap, int* n_out) {
+        int m = n < cap ? n : cap;
+        for (int i = 0; i < m; ++i) {
+            if (hipEventSynchronize(b[i]) != hipSuccess) return PRAG_EHIP;
+            if (hipEventElapsedTime(&ms[i], a[i], b[i]) != hipSuccess) return PRAG_EHIP;
+        }
+        if (n_out) *n_out = m;
+        n = 0;
+        return PRAG_OK;
+    }
+};
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));

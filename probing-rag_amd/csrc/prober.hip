@@ -604,6 +604,7 @@ struct prag_prober {
     _Float16* ws_h = nullptr;  // [L][maxB][d] hi / lo workspace for fp32 activations
     _Float16* ws_l = nullptr;
     int64_t ws_rows = 0;
+    EventRing prof;
 };
 
 static int pick_scale_exp(double maxabs) {
@@ -819,7 +820,7 @@ extern "C" int prag_prober_reserve(prag_prober_t* p, int max_B) {
 }
 
 template <int NA, int NB, int CT>
-static int launch_fused(const ProberArgs& a, int n_run, hipStream_t st) {
+static int launch_fused(const ProberArgs& a, int n_run, hipStream_t st, EventRing& prof) {
     constexpr int G = CT >= 2 ? 2 : 1;
     constexpr int ROWS = 32 * CT;
     constexpr int XSTAGE = NB * ROWS * 128;
@@ -834,7 +835,9 @@ static int launch_fused(const ProberArgs& a, int n_run, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid((a.B + ROWS - 1) / ROWS, n_run);
+    prof.begin(st);
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, a);
+    prof.end(st);
     PRAG_LAUNCH_CHECK();
     return PRAG_OK;
 }
@@ -892,10 +895,10 @@ extern "C" int prag_prober_forward(prag_prober_t* p, const void* x_dev, int x_dt
     const int ct = pick_ct(B, n_run, max_ct);
 #define PRAG_DISPATCH(NA_, NB_)                                      \
     if (p->na == NA_ && nb == NB_) {                                 \
-        if (ct == 1) return launch_fused<NA_, NB_, 1>(a, n_run, st); \
-        if (ct == 2) return launch_fused<NA_, NB_, 2>(a, n_run, st); \
+        if (ct == 1) return launch_fused<NA_, NB_, 1>(a, n_run, st, p->prof); \
+        if (ct == 2) return launch_fused<NA_, NB_, 2>(a, n_run, st, p->prof); \
     }
-    if (p->na == 1 && nb == 1 && ct == 4) return launch_fused<1, 1, 4>(a, n_run, st);
+    if (p->na == 1 && nb == 1 && ct == 4) return launch_fused<1, 1, 4>(a, n_run, st, p->prof);
     PRAG_DISPATCH(1, 1)
     PRAG_DISPATCH(1, 2)
     PRAG_DISPATCH(2, 1)
@@ -927,8 +930,23 @@ extern "C" int prag_gate(prag_prober_t* p, const void* x_dev, int x_dtype, int64
                                  stream);
 }
 
+extern "C" int prag_prober_profile(prag_prober_t* p, int slots) {
+    PRAG_REQUIRE(p != nullptr && slots >= 0 && slots <= 4096, PRAG_EINVAL, "prag_prober_profile: bad argument");
+    if (slots == 0) {
+        p->prof.disable();
+        return PRAG_OK;
+    }
+    return p->prof.enable(slots);
+}
+
+extern "C" int prag_prober_profile_read(prag_prober_t* p, float* ms, int cap, int* n_out) {
+    PRAG_REQUIRE(p != nullptr && ms != nullptr && cap >= 0, PRAG_EINVAL, "prag_prober_profile_read: bad argument");
+    return p->prof.read(ms, cap, n_out);
+}
+
 extern "C" void prag_prober_destroy(prag_prober_t* p) {
     if (!p) return;
+    p->prof.disable();
     for (void* q : p->allocs) (void)hipFree(q);
     if (p->d_layers) (void)hipFree(p->d_layers);
     if (p->ws_h) (void)hipFree(p->ws_h);

@@ -197,3 +197,17 @@ def find_topk_sim(model_retr, query: str, index, k: int):
 def batch_topk_sim(model_retr, query, index, k: int):
     D, I = index.search(encode_query(model_retr, query), k=k)
     return D, I
+
+
+def _ix_profile(self, slots: int):
+    """Record HIP events around every scan_topk launch (0 disables)."""
+    _lib.check(_lib.lib().prag_index_profile(self._h, int(slots)))
+
+
+def _ix_profile_read(self):
+    from .prober import _profile_read
+    return _profile_read(_lib.lib().prag_index_profile_read, self._h)
+
+
+HipFlatIndex.profile = _ix_profile
+HipFlatIndex.profile_read = _ix_profile_read

@@ -288,3 +288,24 @@ def load_prober_models(state_dicts, cfg_list, weights: str = "f32"):
 def return_prober_logit_gemma_2b(method_function, cfg_list, model_list):
     """utils.py:389-390, verbatim semantics: one call per layer, logits to CPU."""
     return [method_function(cfg, model).to("cpu") for cfg, model in zip(cfg_list, model_list)]
+
+
+def _profile_read(fn, handle, cap=4096):
+    ms = (ctypes.c_float * cap)()
+    n = ctypes.c_int(0)
+    _lib.check(fn(handle, ms, cap, ctypes.byref(n)))
+    return [float(ms[i]) for i in range(n.value)]
+
+
+def _ens_profile(self, slots: int):
+    """Record HIP events around every fused prober kernel (0 disables)."""
+    _lib.check(_lib.lib().prag_prober_profile(self._h, int(slots)))
+
+
+def _ens_profile_read(self):
+    """Durations (ms) of the fused prober kernels recorded since the last read."""
+    return _profile_read(_lib.lib().prag_prober_profile_read, self._h)
+
+
+HipProberEnsemble.profile = _ens_profile
+HipProberEnsemble.profile_read = _ens_profile_read
