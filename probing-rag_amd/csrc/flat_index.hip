@@ -238,8 +238,12 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
     const int chunk_bytes = F32 ? 256 : 128;
     const char* rows = reinterpret_cast<const char*>(a.rows);
 
-    uint4 ld[NLD];
-    auto issue = [&](int tile, int c) {
+    // Two chunks of every lane's 16-B pieces are kept in flight (ldA / ldB).  The
+    // refill is unconditional and branch-free - past the last tile it re-reads the
+    // (clamped) last row - so the registers never merge across control flow and
+    // the compiler keeps counted vmcnt waits instead of draining the queue.
+    uint4 ldA[NLD], ldB[NLD];
+    auto issue = [&](uint4 (&ld)[NLD], int tile, int c) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             int64_t row = (int64_t)tile * 32 + st_doc[i];
@@ -257,56 +261,85 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-    if (n_my > 0) issue(gw, 0);
-    for (int ti = 0; ti < n_my; ++ti) {
-        const int tile = gw + ti * nW;
-        for (int c = 0; c < NCH; ++c) {
-            // stage the chunk that is in registers, then immediately refill them
+    // (tile, chunk) cursors: cur = being consumed, nx = next to be requested
+    int tile_cur = gw, c_cur = 0;
+    int tile_nx = gw, c_nx = 0;
+    auto advance = [&](int& t, int& c) {
+        const bool wrap = (c + 1 == NCH);
+        c = wrap ? 0 : c + 1;
+        t = wrap ? t + nW : t;
+    };
+    f32x4 xn[4];
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                if constexpr (F32) {
-                    const f32x4 f = __builtin_bit_cast(f32x4, ld[i]);
-                    half4 h;
+    for (int g = 0; g < 4; ++g) xn[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto body = [&](uint4 (&ld)[NLD]) {
+        // norms of this tile's rows: requested at its first chunk, i.e. OLDER than
+        // every prefetch issued below, so waiting for them does not drain the queue
+        if (a.use_norm && c_cur == 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = (_Float16)f[e];
-                    *reinterpret_cast<half4*>(s_st + st_dst[i]) = h;
-                } else {
-                    *reinterpret_cast<uint4*>(s_st + st_dst[i]) = ld[i];
-                }
-            }
-            if (c + 1 < NCH) issue(tile, c + 1);
-            else if (ti + 1 < n_my) issue(tile + nW, 0);
+            for (int g = 0; g < 4; ++g)
+                xn[g] = *reinterpret_cast<const f32x4*>(a.xnorm + (int64_t)tile_cur * 32 + 8 * g + 4 * hh);
+        }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const half8 av = *reinterpret_cast<const half8*>(s_st + a_off + (((2 * s + hh) ^ a_sw) << 4));
-                const int P = c * 8 + 2 * s + hh;
+        for (int i = 0; i < NLD; ++i) {
+            const uint4 v = ld[i];
+            if constexpr (F32) {
+                const f32x4 f = __builtin_bit_cast(f32x4, v);
+                half4 h;
 #pragma unroll
-                for (int t = 0; t < NQ; ++t) {
-                    const int qrow = 32 * t + r;
-                    const half8 bv = *reinterpret_cast<const half8*>(
-                        s_q + qrow * qstride + (((P & ~15) | ((P ^ qrow) & 15)) << 4));
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[t], 0, 0, 0);
-                }
+                for (int e = 0; e < 4; ++e) h[e] = (_Float16)f[e];
+                *reinterpret_cast<half4*>(s_st + st_dst[i]) = h;
+            } else {
+                *reinterpret_cast<uint4*>(s_st + st_dst[i]) = v;
             }
         }
-        // ---- epilogue: 16 rows x this lane's query -> running top-KC ---------
-        const int64_t doc0 = (int64_t)tile * 32;
+        issue(ld, tile_nx, c_nx);
+        advance(tile_nx, c_nx);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 xn = {0.f, 0.f, 0.f, 0.f};
-            if (a.use_norm) xn = *reinterpret_cast<const f32x4*>(a.xnorm + doc0 + 8 * g + 4 * hh);
+        for (int s = 0; s < 4; ++s) {
+            const half8 av = *reinterpret_cast<const half8*>(s_st + a_off + (((2 * s + hh) ^ a_sw) << 4));
+            const int P = c_cur * 8 + 2 * s + hh;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t doc = doc0 + 8 * g + 4 * hh + e;
-                const bool valid = doc < a.N;
-#pragma unroll
-                for (int t = 0; t < NQ; ++t) {
-                    const float key = valid ? fmaf(a.alpha, acc[t][4 * g + e], xn[e]) : INFINITY;
-                    top[t].push(key, (int)doc);
-                    acc[t][4 * g + e] = 0.f;
-                }
+            for (int t = 0; t < NQ; ++t) {
+                const int qrow = 32 * t + r;
+                const half8 bv = *reinterpret_cast<const half8*>(
+                    s_q + qrow * qstride + (((P & ~15) | ((P ^ qrow) & 15)) << 4));
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[t], 0, 0, 0);
             }
         }
+        if (c_cur == NCH - 1) {
+            // ---- epilogue: 16 rows x this lane's queries -> running top-KC -------
+            const int64_t doc0 = (int64_t)tile_cur * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int64_t doc = doc0 + 8 * g + 4 * hh + e;
+                    const bool valid = doc < a.N;
+#pragma unroll
+                    for (int t = 0; t < NQ; ++t) {
+                        const float key = valid ? fmaf(a.alpha, acc[t][4 * g + e], xn[g][e]) : INFINITY;
+                        top[t].push(key, (int)doc);
+                        acc[t][4 * g + e] = 0.f;
+                    }
+                }
+        }
+        advance(tile_cur, c_cur);
+    };
+
+    const int n_it = n_my * NCH;
+    if (n_it > 0) {
+        issue(ldA, tile_nx, c_nx);
+        advance(tile_nx, c_nx);
+        issue(ldB, tile_nx, c_nx);
+        advance(tile_nx, c_nx);
+        int it = 0;
+        for (; it + 1 < n_it; it += 2) {
+            body(ldA);
+            body(ldB);
+        }
+        if (it < n_it) body(ldA);
     }
 
     // ---- per-lane lists -> global: list id = (wave_global*2 + hh) ------------
