@@ -204,8 +204,8 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
         const int ppr = d >> 3;  // pieces per row
         for (int e = tid; e < QT * ppr; e += 512) {
             const int row = e / ppr, p = e - row * ppr;
-            const uint4 v = *reinterpret_cast<const uint4*>(a.q16 + (int64_t)row * d + 8 * p);
-            *reinterpret_cast<uint4*>(s_q + row * qstride + (((p & ~15) | ((p ^ row) & 15)) << 4)) = v;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(a.q16 + (int64_t)row * d + 8 * p);
+            *reinterpret_cast<u32x4*>(s_q + row * qstride + (((p & ~15) | ((p ^ row) & 15)) << 4)) = v;
         }
     }
     __syncthreads();
@@ -242,13 +242,13 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
     // refill is unconditional and branch-free - past the last tile it re-reads the
     // (clamped) last row - so the registers never merge across control flow and
     // the compiler keeps counted vmcnt waits instead of draining the queue.
-    uint4 ldA[NLD], ldB[NLD];
-    auto issue = [&](uint4 (&ld)[NLD], int tile, int c) {
+    u32x4 ldA[NLD], ldB[NLD];
+    auto issue = [&](u32x4 (&ld)[NLD], int tile, int c) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             int64_t row = (int64_t)tile * 32 + st_doc[i];
             row = row < a.N ? row : a.N - 1;
-            ld[i] = *reinterpret_cast<const uint4*>(rows + row * row_bytes + c * chunk_bytes + col_b);
+            ld[i] = *reinterpret_cast<const u32x4*>(rows + row * row_bytes + c * chunk_bytes + col_b);
         }
     };
 
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) xn[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto body = [&](uint4 (&ld)[NLD]) {
+    auto body = [&](u32x4 (&ld)[NLD]) {
         // norms of this tile's rows: requested at its first chunk, i.e. OLDER than
         // every prefetch issued below, so waiting for them does not drain the queue
         if (a.use_norm && c_cur == 0) {
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const uint4 v = ld[i];
+            const u32x4 v = ld[i];
             if constexpr (F32) {
                 const f32x4 f = __builtin_bit_cast(f32x4, v);
                 half4 h;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
                 for (int e = 0; e < 4; ++e) h[e] = (_Float16)f[e];
                 *reinterpret_cast<half4*>(s_st + st_dst[i]) = h;
             } else {
-                *reinterpret_cast<uint4*>(s_st + st_dst[i]) = v;
+                *reinterpret_cast<u32x4*>(s_st + st_dst[i]) = v;
             }
         }
         issue(ld, tile_nx, c_nx);

@@ -49,8 +49,8 @@ constexpr int kClasses = 2;
 constexpr float kLnEps = 1e-5f;
 
 struct LayerDev {
-    const uint4* W1f;    // [NA][d/16][16 row tiles][64 lanes] x 16 B
-    const uint4* W2f;    // [NA][32 k steps][16 row tiles][64 lanes] x 16 B
+    const u32x4* W1f;    // [NA][d/16][16 row tiles][64 lanes] x 16 B
+    const u32x4* W2f;    // [NA][32 k steps][16 row tiles][64 lanes] x 16 B
     const float* wsum1;  // [512] row sums of the packed (scaled) W1
     const float* b1;     // [512] b1 + W1 . ln0_b
     const float* b2;     // [512] b2 + W2 . ln1_b
@@ -75,25 +75,37 @@ __device__ __forceinline__ float silu_f(float h) {
     return h * __frcp_rn(1.0f + __expf(-h));
 }
 
+// Pointers fetched from a struct in memory have no provable address space and
+// compile to flat_load (which counts on lgkmcnt too and forces full drains at
+// every barrier); these helpers pin them to global memory.
+typedef const __attribute__((address_space(1))) u32x4* gptr_u32x4;
+typedef const __attribute__((address_space(1))) float* gptr_f32;
+__device__ __forceinline__ gptr_u32x4 as_global(const u32x4* p) { return (gptr_u32x4)p; }
+__device__ __forceinline__ gptr_f32 as_global(const float* p) { return (gptr_f32)p; }
+
 __device__ __forceinline__ float xor32(float v) { return v + __shfl_xor(v, 32, 64); }
 
-template <int NA, int NB, int CT>
-__global__ __launch_bounds__(256, 1) void prober_fused_kernel(ProberArgs a) {
+template <int NA, int NB, int CT, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberArgs a) {
+    constexpr int NT = 64 * NWV;        // threads
+    constexpr int RT = 16 / NWV;        // 32-row hidden tiles per wave
     constexpr int G = CT >= 2 ? 2 : 1;  // column tiles per fc2 pass
     constexpr int NG = CT / G;
     constexpr bool RAW = (NB == 1);
     constexpr int ROWS = 32 * CT;
-    constexpr int XPART = ROWS * 128;          // bytes of one staged part (64 halves per row)
+    constexpr int XPART = ROWS * 128;            // bytes of one staged part (64 halves per row)
     constexpr int XSTAGE = NB * XPART;
     constexpr int EXCH = 2 * 16 * 2 * G * 1024;  // hi/lo x 16 row tiles x 2 k-steps x G tiles
     constexpr int REGION_A = (2 * XSTAGE > EXCH) ? 2 * XSTAGE : EXCH;
+    constexpr int NPASS = (256 * CT + NT - 1) / NT;  // 16-B pieces per thread per staged part
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_x = smem;                                   // staging ring (fc1)
-    char* s_ex = smem;                                  // exchange fragments (fc2), same bytes
-    float* s_red = reinterpret_cast<float*>(smem + REGION_A);  // [4 bufs][4 waves][ROWS]
-    float* s_mu0 = s_red + 4 * 4 * ROWS;                // [ROWS]
-    float* s_rs0 = s_mu0 + ROWS;                        // [ROWS]
+    char* s_x = smem;                                          // staging ring (fc1)
+    char* s_ex = smem;                                         // exchange fragments (fc2), same bytes
+    float* s_red = reinterpret_cast<float*>(smem + REGION_A);  // [4 bufs][NWV waves][ROWS]
+    float* s_mu0 = s_red + 4 * NWV * ROWS;                     // [ROWS]
+    float* s_rs0 = s_mu0 + ROWS;                               // [ROWS]
+    float* s_cst = s_rs0 + ROWS;  // [5][512]: wsum1, b1, b2, W3[0], W3[1] (epilogue constants)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -107,22 +119,30 @@ __global__ __launch_bounds__(256, 1) void prober_fused_kernel(ProberArgs a) {
     const int S16 = d >> 4;
     const int T = d >> 6;
 
-    // ---- activation staging addresses (thread -> 16-B piece of a row) -----
-    const int st_row = tid >> 3;  // + 32*c per pass
-    const int st_q = tid & 7;
-    const _Float16* xsrc[NB][CT];
-    int st_off[CT];
+    // epilogue constants -> LDS once, so no epilogue ever waits on a global load
+    for (int i = tid; i < 5 * kHidden / 4; i += NT) {
+        const int arr = i / (kHidden / 4), o = (i % (kHidden / 4)) * 4;
+        const gptr_f32 src = as_global(arr == 0 ? L.wsum1 : arr == 1 ? L.b1 : arr == 2 ? L.b2 : (L.W3 + (arr - 3) * kHidden));
+        typedef const __attribute__((address_space(1))) f32x4* gptr_f32x4;
+        *reinterpret_cast<f32x4*>(s_cst + arr * kHidden + o) = *(gptr_f32x4)(src + o);
+    }
+
+    // ---- activation staging: thread -> 16-B piece(s) of the [ROWS x 64] tile ----
+    // (threads beyond the tile duplicate an in-range piece: no divergent loads)
+    const _Float16* xsrc[NB][NPASS];
+    int st_off[NPASS];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        const int row = 32 * c + st_row;
+    for (int c = 0; c < NPASS; ++c) {
+        const int e = (tid + c * NT) % (256 * CT);
+        const int row = e >> 3, q = e & 7;
         int grow = m0 + row;
         grow = grow < a.B ? grow : a.B - 1;
-        const int64_t base = (int64_t)lrun * a.x_layer_stride + (int64_t)grow * d + 8 * st_q;
+        const int64_t base = (int64_t)lrun * a.x_layer_stride + (int64_t)grow * d + 8 * q;
         xsrc[0][c] = a.xh + base;
         if constexpr (NB == 2) xsrc[1][c] = a.xl + base;
-        st_off[c] = row * 128 + ((st_q ^ ((row >> 1) & 7)) << 4);
+        st_off[c] = row * 128 + ((q ^ ((row >> 1) & 7)) << 4);
     }
-    // fragment read offsets: lane (r,hh), tile ct, sub-step s16 -> piece 2*s16+hh
+    // fragment read offsets: lane (r,hh), tile c, sub-step -> piece 2*sub+hh of row 32c+r
     int rd_row_off[CT], rd_sw[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -131,66 +151,80 @@ __global__ __launch_bounds__(256, 1) void prober_fused_kernel(ProberArgs a) {
         rd_sw[c] = (row >> 1) & 7;
     }
 
-    uint4 xreg[NB][CT];
+    u32x4 xreg[NB][NPASS];
     auto x_load = [&](int t) {
 #pragma unroll
         for (int p = 0; p < NB; ++p)
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
-                xreg[p][c] = *reinterpret_cast<const uint4*>(xsrc[p][c] + 64 * t);
+            for (int c = 0; c < NPASS; ++c)
+                xreg[p][c] = *reinterpret_cast<const u32x4*>(xsrc[p][c] + 64 * t);
     };
     auto x_store = [&](int stage) {
 #pragma unroll
         for (int p = 0; p < NB; ++p)
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
-                *reinterpret_cast<uint4*>(s_x + stage * XSTAGE + p * XPART + st_off[c]) = xreg[p][c];
+            for (int c = 0; c < NPASS; ++c)
+                *reinterpret_cast<u32x4*>(s_x + stage * XSTAGE + p * XPART + st_off[c]) = xreg[p][c];
     };
 
-    // ---- weight fragment addressing -------------------------------------
-    const uint4* w1p = L.W1f + (size_t)(4 * w) * 64 + lane;  // + ((part*S16 + s16)*16 + rti)*64
-    half8 afr[4][NA][4];
+    // ---- weight fragments: straight from global, 1 KiB per wave-load --------------
+    const gptr_u32x4 w1p = as_global(L.W1f) + (size_t)(RT * w) * 64 + lane;  // + ((part*S16 + s16)*16 + rti)*64
+    half8 afr[4][NA][RT];
     auto a_load = [&](int slot, int s16) {
 #pragma unroll
         for (int p = 0; p < NA; ++p)
 #pragma unroll
-            for (int rti = 0; rti < 4; ++rti) {
-                const uint4 v = w1p[((size_t)(p * S16 + s16) * 16 + rti) * 64];
+            for (int rti = 0; rti < RT; ++rti) {
+                const u32x4 v = w1p[((size_t)(p * S16 + s16) * 16 + rti) * 64];
                 afr[slot][p][rti] = __builtin_bit_cast(half8, v);
             }
     };
 
-    f32x16 acc[4][CT];
+    f32x16 acc[RT][CT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int c = 0; c < CT; ++c)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][c][e] = 0.f;
 
-    // in-flight LayerNorm-0 statistics (RAW only): wave w < CT owns tile w
+    // in-flight LayerNorm-0 statistics (RAW only): wave w accumulates column tile
+    // (w % CT) from its own extra fragment read - no wave-dependent branch in the loop
+    const int stat_c = w % CT;
+    const int stat_row = 32 * stat_c + r;
+    const int stat_off = stat_row * 128;
+    const int stat_sw = (stat_row >> 1) & 7;
     float st_c = 0.f, st_s = 0.f, st_q2 = 0.f;
     if constexpr (RAW) {
-        if (w < CT) {
-            int grow = m0 + 32 * w + r;
-            grow = grow < a.B ? grow : a.B - 1;
-            st_c = (float)a.xh[(int64_t)lrun * a.x_layer_stride + (int64_t)grow * d + 8 * hh];
-        }
+        int grow = m0 + stat_row;
+        grow = grow < a.B ? grow : a.B - 1;
+        st_c = (float)a.xh[(int64_t)lrun * a.x_layer_stride + (int64_t)grow * d + 8 * hh];
     }
 
-    // ---- prologue ---------------------------------------------------------
+    // ---- prologue ---------------------------------------------------------------
+    // (issue order mirrors the loop body - activations first, then the four weight
+    // slots - so the counted vmcnt waits at the loop head hold on entry too)
     x_load(0);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) a_load(s, s);
     x_store(0);
-    if (T > 1) x_load(1);
+    x_load(1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        __builtin_amdgcn_sched_barrier(0);  // pin the issue order (see above)
+        a_load(s, s);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
-    // ---- fc1 main loop: one barrier per 64-wide K step ----------------------
+    // ---- fc1 main loop: one barrier per 64-wide K step, no other control flow -----
     for (int t = 0; t < T; ++t) {
-        __syncthreads();
-        if (t + 1 < T) x_store((t + 1) & 1);
-        if (t + 2 < T) x_load(t + 2);
+        // LDS-only hand-off: drain this wave's LDS ops and meet at a raw barrier.
+        // (__syncthreads() also carries a fence that makes hipcc drain vmcnt to 0,
+        // which would serialise the weight prefetch every K step.)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        x_store((t + 1) & 1);                  // tile t+1 (loaded one step ago)
+        x_load(t + 2 < T ? t + 2 : T - 1);     // clamped: the tail re-reads the last tile
         const char* xs = s_x + (t & 1) * XSTAGE;
+        const int s16n = 4 * (t + 1 < T ? t + 1 : T - 1);
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
             half8 bfr[NB][CT];
@@ -202,19 +236,16 @@ __global__ __launch_bounds__(256, 1) void prober_fused_kernel(ProberArgs a) {
                     bfr[p][c] = *reinterpret_cast<const half8*>(xs + off);
                 }
             if constexpr (RAW) {
+                const half8 sf = *reinterpret_cast<const half8*>(xs + stat_off + (((2 * sub + hh) ^ stat_sw) << 4));
 #pragma unroll
-                for (int c = 0; c < CT; ++c)
-                    if (c == w) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float dv = (float)bfr[0][c][j] - st_c;
-                            st_s += dv;
-                            st_q2 = fmaf(dv, dv, st_q2);
-                        }
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    const float dv = (float)sf[j] - st_c;
+                    st_s += dv;
+                    st_q2 = fmaf(dv, dv, st_q2);
+                }
             }
 #pragma unroll
-            for (int rti = 0; rti < 4; ++rti)
+            for (int rti = 0; rti < RT; ++rti)
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
                     acc[rti][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[sub][0][rti], bfr[0][c],
@@ -226,32 +257,31 @@ __global__ __launch_bounds__(256, 1) void prober_fused_kernel(ProberArgs a) {
                         acc[rti][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
                             afr[sub][1][rti], bfr[0][c], acc[rti][c], 0, 0, 0);
                 }
-            if (t + 1 < T) a_load(sub, 4 * (t + 1) + sub);
+            a_load(sub, s16n + sub);  // refill this slot for the next K step
+            __builtin_amdgcn_sched_barrier(0);  // keep sub-steps apart: caps live fragments (no spills)
         }
     }
 
-    // ---- LayerNorm-0 statistics -> LDS -------------------------------------
+    // ---- LayerNorm-0 statistics -> LDS -------------------------------------------
     if constexpr (RAW) {
-        if (w < CT) {
-            // this lane: n = d/2 elements, shift st_c; partner lane^32 the other half
-            const float n = 0.5f * (float)d;
-            const float mean_a = st_c + st_s / n;
-            const float m2_a = st_q2 - st_s * st_s / n;
-            const float mean_b = __shfl_xor(mean_a, 32, 64);
-            const float m2_b = __shfl_xor(m2_a, 32, 64);
-            const float delta = mean_b - mean_a;
-            const float mean = mean_a + 0.5f * delta;
-            const float m2 = m2_a + m2_b + delta * delta * (0.5f * n);
-            const float var = fmaxf(m2 / (float)d, 0.f);
-            if (hh == 0) {
-                s_mu0[32 * w + r] = mean;
-                s_rs0[32 * w + r] = 1.0f / sqrtf(var + kLnEps);
-            }
+        // this lane: n = d/2 elements around shift st_c; partner lane^32 the other half
+        const float n = 0.5f * (float)d;
+        const float mean_a = st_c + st_s / n;
+        const float m2_a = st_q2 - st_s * st_s / n;
+        const float mean_b = __shfl_xor(mean_a, 32, 64);
+        const float m2_b = __shfl_xor(m2_a, 32, 64);
+        const float delta = mean_b - mean_a;
+        const float mean = mean_a + 0.5f * delta;
+        const float m2 = m2_a + m2_b + delta * delta * (0.5f * n);
+        const float var = fmaxf(m2 / (float)d, 0.f);
+        if (hh == 0 && w < CT) {
+            s_mu0[stat_row] = mean;
+            s_rs0[stat_row] = 1.0f / sqrtf(var + kLnEps);
         }
     }
     __syncthreads();  // stats visible; every wave is done with the staging ring
 
-    // ---- epilogue 1: LN0 fold, bias, SiLU ------------------------------------
+    // ---- epilogue 1: LN0 fold, bias, SiLU --------------------------------------------
     {
         float mu[CT], rs[CT];
 #pragma unroll
@@ -260,12 +290,12 @@ __global__ __launch_bounds__(256, 1) void prober_fused_kernel(ProberArgs a) {
             rs[c] = (RAW ? s_rs0[32 * c + r] : 1.f) * L.sc1;
         }
 #pragma unroll
-        for (int rti = 0; rti < 4; ++rti)
+        for (int rti = 0; rti < RT; ++rti)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const int nb = 128 * w + 32 * rti + 8 * g4 + 4 * hh;
-                const f32x4 ws = *reinterpret_cast<const f32x4*>(L.wsum1 + nb);
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(L.b1 + nb);
+                const int nb = 32 * (RT * w + rti) + 8 * g4 + 4 * hh;
+                const f32x4 ws = *reinterpret_cast<const f32x4*>(s_cst + nb);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(s_cst + kHidden + nb);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -278,30 +308,31 @@ __global__ __launch_bounds__(256, 1) void prober_fused_kernel(ProberArgs a) {
     }
 
     // two-pass LayerNorm statistics over the 512 hidden units of every column
-    auto ln_stats = [&](auto& A, auto NT, float* mean_out, float* rstd_out) {
-        constexpr int NTc = decltype(NT)::value;
+    auto ln_stats = [&](auto& A, auto NT_, float* mean_out, float* rstd_out) {
+        constexpr int NTc = decltype(NT_)::value;
         float* bufA = s_red;
-        float* bufB = s_red + 4 * ROWS;
-        float s[NTc];
+        float* bufB = s_red + NWV * ROWS;
 #pragma unroll
         for (int c = 0; c < NTc; ++c) {
             float t = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) t += A[i][c][e];
-            s[c] = xor32(t);
-            if (hh == 0) bufA[w * ROWS + 32 * c + r] = s[c];
+            t = xor32(t);
+            if (hh == 0) bufA[w * ROWS + 32 * c + r] = t;
         }
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < NTc; ++c) {
             const int m = 32 * c + r;
-            mean_out[c] = (bufA[m] + bufA[ROWS + m] + bufA[2 * ROWS + m] + bufA[3 * ROWS + m]) *
-                          (1.0f / kHidden);
+            float sm = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NWV; ++ww) sm += bufA[ww * ROWS + m];
+            mean_out[c] = sm * (1.0f / kHidden);
             float t = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const float dv = A[i][c][e] - mean_out[c];
@@ -314,23 +345,24 @@ __global__ __launch_bounds__(256, 1) void prober_fused_kernel(ProberArgs a) {
 #pragma unroll
         for (int c = 0; c < NTc; ++c) {
             const int m = 32 * c + r;
-            const float var =
-                (bufB[m] + bufB[ROWS + m] + bufB[2 * ROWS + m] + bufB[3 * ROWS + m]) * (1.0f / kHidden);
-            rstd_out[c] = 1.0f / sqrtf(var + kLnEps);
+            float sv = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NWV; ++ww) sv += bufB[ww * ROWS + m];
+            rstd_out[c] = 1.0f / sqrtf(sv * (1.0f / kHidden) + kLnEps);
         }
     };
 
     float mean1[CT], rstd1[CT];
     ln_stats(acc, std::integral_constant<int, CT>{}, mean1, rstd1);
 
-    // ---- fc2 / fc3, G column tiles at a time ---------------------------------
-    const uint4* w2p = L.W2f + (size_t)(4 * w) * 64 + lane;  // + ((part*32 + ks)*16 + rti)*64
+    // ---- fc2 / fc3, G column tiles at a time ---------------------------------------
+    const gptr_u32x4 w2p = as_global(L.W2f) + (size_t)(RT * w) * 64 + lane;  // + ((part*32 + ks)*16 + rti)*64
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         if (g > 0) __syncthreads();  // previous pass finished reading the exchange area
         // publish this wave's normalised activations as ready-made B fragments
 #pragma unroll
-        for (int rti = 0; rti < 4; ++rti)
+        for (int rti = 0; rti < RT; ++rti)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -344,33 +376,34 @@ __global__ __launch_bounds__(256, 1) void prober_fused_kernel(ProberArgs a) {
                         hi[j] = h16;
                         lo[j] = (_Float16)(v - (float)h16);
                     }
-                    const int fi = (((4 * w + rti) * 2 + s) * G + c2) * 64 + lane;
+                    const int fi = (((RT * w + rti) * 2 + s) * G + c2) * 64 + lane;
                     *reinterpret_cast<half8*>(s_ex + (size_t)fi * 16) = hi;
                     *reinterpret_cast<half8*>(s_ex + (size_t)(16 * 2 * G * 64 + fi) * 16) = lo;
                 }
 
-        f32x16 acc2[4][G];
+        f32x16 acc2[RT][G];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int c = 0; c < G; ++c)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc2[i][c][e] = 0.f;
 
-        half8 a2[2][NA][4];
+        half8 a2[2][NA][RT];
         auto a2_load = [&](int slot, int ks) {
 #pragma unroll
             for (int p = 0; p < NA; ++p)
 #pragma unroll
-                for (int rti = 0; rti < 4; ++rti) {
-                    const uint4 v = w2p[((size_t)(p * 32 + ks) * 16 + rti) * 64];
+                for (int rti = 0; rti < RT; ++rti) {
+                    const u32x4 v = w2p[((size_t)(p * 32 + ks) * 16 + rti) * 64];
                     a2[slot][p][rti] = __builtin_bit_cast(half8, v);
                 }
         };
         a2_load(0, 0);
         a2_load(1, 1);
-        __syncthreads();  // fragments of all four waves are in LDS
+        __syncthreads();  // fragments of all waves are in LDS
 
+#pragma unroll 1
         for (int ks2 = 0; ks2 < 32; ks2 += 2) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -383,7 +416,7 @@ __global__ __launch_bounds__(256, 1) void prober_fused_kernel(ProberArgs a) {
                     b2l[c2] = *reinterpret_cast<const half8*>(s_ex + (size_t)(16 * 2 * G * 64 + fi) * 16);
                 }
 #pragma unroll
-                for (int rti = 0; rti < 4; ++rti)
+                for (int rti = 0; rti < RT; ++rti)
 #pragma unroll
                     for (int c2 = 0; c2 < G; ++c2) {
                         acc2[rti][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
@@ -394,17 +427,18 @@ __global__ __launch_bounds__(256, 1) void prober_fused_kernel(ProberArgs a) {
                             acc2[rti][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
                                 a2[u][1][rti], b2h[c2], acc2[rti][c2], 0, 0, 0);
                     }
-                if (ks + 2 < 32) a2_load(u, ks + 2);
+                a2_load(u, ks + 2 < 32 ? ks + 2 : 31);  // clamped refill, no branch
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 
         // epilogue 2: bias, SiLU, LN2, fc3
 #pragma unroll
-        for (int rti = 0; rti < 4; ++rti)
+        for (int rti = 0; rti < RT; ++rti)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const int nb = 128 * w + 32 * rti + 8 * g4 + 4 * hh;
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(L.b2 + nb);
+                const int nb = 32 * (RT * w + rti) + 8 * g4 + 4 * hh;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(s_cst + 2 * kHidden + nb);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -419,12 +453,12 @@ __global__ __launch_bounds__(256, 1) void prober_fused_kernel(ProberArgs a) {
 #pragma unroll
         for (int c2 = 0; c2 < G; ++c2) p0[c2] = p1[c2] = 0.f;
 #pragma unroll
-        for (int rti = 0; rti < 4; ++rti)
+        for (int rti = 0; rti < RT; ++rti)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const int nb = 128 * w + 32 * rti + 8 * g4 + 4 * hh;
-                const f32x4 w30 = *reinterpret_cast<const f32x4*>(L.W3 + nb);
-                const f32x4 w31 = *reinterpret_cast<const f32x4*>(L.W3 + kHidden + nb);
+                const int nb = 32 * (RT * w + rti) + 8 * g4 + 4 * hh;
+                const f32x4 w30 = *reinterpret_cast<const f32x4*>(s_cst + 3 * kHidden + nb);
+                const f32x4 w31 = *reinterpret_cast<const f32x4*>(s_cst + 4 * kHidden + nb);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -434,8 +468,8 @@ __global__ __launch_bounds__(256, 1) void prober_fused_kernel(ProberArgs a) {
                         p1[c2] = fmaf(v, w31[e], p1[c2]);
                     }
             }
-        float* bufC = s_red + 8 * ROWS;
-        float* bufD = s_red + 12 * ROWS;
+        float* bufC = s_red + 2 * NWV * ROWS;
+        float* bufD = s_red + 3 * NWV * ROWS;
 #pragma unroll
         for (int c2 = 0; c2 < G; ++c2) {
             const float q0 = xor32(p0[c2]);
@@ -450,8 +484,12 @@ __global__ __launch_bounds__(256, 1) void prober_fused_kernel(ProberArgs a) {
             const int m_loc = 32 * g * G + tid;  // column within the workgroup tile
             const int row = m0 + m_loc;
             if (row < a.B) {
-                const float l0 = L.b3[0] + (bufC[tid] + bufC[ROWS + tid]) + (bufC[2 * ROWS + tid] + bufC[3 * ROWS + tid]);
-                const float l1 = L.b3[1] + (bufD[tid] + bufD[ROWS + tid]) + (bufD[2 * ROWS + tid] + bufD[3 * ROWS + tid]);
+                float l0 = L.b3[0], l1 = L.b3[1];
+#pragma unroll
+                for (int ww = 0; ww < NWV; ++ww) {
+                    l0 += bufC[ww * ROWS + tid];
+                    l1 += bufD[ww * ROWS + tid];
+                }
                 float2 o;
                 o.x = l0;
                 o.y = l1;
@@ -726,7 +764,7 @@ extern "C" int prag_prober_load_layer(prag_prober_t* p, int li, const float* ln0
     int rc;
     const _Float16* dW1 = nullptr;
     if ((rc = upload(p, packed, &dW1)) != PRAG_OK) return rc;
-    L.W1f = reinterpret_cast<const uint4*>(dW1);
+    L.W1f = reinterpret_cast<const u32x4*>(dW1);
     if ((rc = upload(p, wsum, &L.wsum1)) != PRAG_OK) return rc;
     if ((rc = upload(p, b1e, &L.b1)) != PRAG_OK) return rc;
     L.sc1 = (float)std::ldexp(1.0, -e1);
@@ -763,7 +801,7 @@ extern "C" int prag_prober_load_layer(prag_prober_t* p, int li, const float* ln0
     }
     const _Float16* dW2 = nullptr;
     if ((rc = upload(p, packed, &dW2)) != PRAG_OK) return rc;
-    L.W2f = reinterpret_cast<const uint4*>(dW2);
+    L.W2f = reinterpret_cast<const u32x4*>(dW2);
     if ((rc = upload(p, b2e, &L.b2)) != PRAG_OK) return rc;
     L.sc2 = (float)std::ldexp(1.0, -e2);
 
@@ -819,15 +857,15 @@ extern "C" int prag_prober_reserve(prag_prober_t* p, int max_B) {
     return PRAG_OK;
 }
 
-template <int NA, int NB, int CT>
+template <int NA, int NB, int CT, int NWV>
 static int launch_fused(const ProberArgs& a, int n_run, hipStream_t st, EventRing& prof) {
     constexpr int G = CT >= 2 ? 2 : 1;
     constexpr int ROWS = 32 * CT;
     constexpr int XSTAGE = NB * ROWS * 128;
     constexpr int EXCH = 2 * 16 * 2 * G * 1024;
     constexpr int REGION_A = (2 * XSTAGE > EXCH) ? 2 * XSTAGE : EXCH;
-    constexpr int LDS = REGION_A + (16 * ROWS + 2 * ROWS) * (int)sizeof(float);
-    auto kern = prober_fused_kernel<NA, NB, CT>;
+    constexpr int LDS = REGION_A + (4 * NWV * ROWS + 2 * ROWS + 5 * kHidden) * (int)sizeof(float);
+    auto kern = prober_fused_kernel<NA, NB, CT, NWV>;
     static bool attr_set = false;
     if (!attr_set) {
         PRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -836,7 +874,7 @@ static int launch_fused(const ProberArgs& a, int n_run, hipStream_t st, EventRin
     }
     dim3 grid((a.B + ROWS - 1) / ROWS, n_run);
     prof.begin(st);
-    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, a);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), LDS, st, a);
     prof.end(st);
     PRAG_LAUNCH_CHECK();
     return PRAG_OK;
@@ -893,12 +931,12 @@ extern "C" int prag_prober_forward(prag_prober_t* p, const void* x_dev, int x_dt
     }
     const int max_ct = (p->na == 1 && nb == 1) ? 4 : 2;
     const int ct = pick_ct(B, n_run, max_ct);
-#define PRAG_DISPATCH(NA_, NB_)                                      \
-    if (p->na == NA_ && nb == NB_) {                                 \
-        if (ct == 1) return launch_fused<NA_, NB_, 1>(a, n_run, st, p->prof); \
-        if (ct == 2) return launch_fused<NA_, NB_, 2>(a, n_run, st, p->prof); \
+#define PRAG_DISPATCH(NA_, NB_)                                                      \
+    if (p->na == NA_ && nb == NB_) {                                                 \
+        if (ct == 1) return launch_fused<NA_, NB_, 1, 4>(a, n_run, st, p->prof);     \
+        if (ct == 2) return launch_fused<NA_, NB_, 2, 8>(a, n_run, st, p->prof);     \
     }
-    if (p->na == 1 && nb == 1 && ct == 4) return launch_fused<1, 1, 4>(a, n_run, st, p->prof);
+    if (p->na == 1 && nb == 1 && ct == 4) return launch_fused<1, 1, 4, 8>(a, n_run, st, p->prof);
     PRAG_DISPATCH(1, 1)
     PRAG_DISPATCH(1, 2)
     PRAG_DISPATCH(2, 1)
