@@ -35,6 +35,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <type_traits>
@@ -936,7 +937,11 @@ extern "C" int prag_prober_forward(prag_prober_t* p, const void* x_dev, int x_dt
         if (ct == 1) return launch_fused<NA_, NB_, 1, 4>(a, n_run, st, p->prof);     \
         if (ct == 2) return launch_fused<NA_, NB_, 2, 8>(a, n_run, st, p->prof);     \
     }
-    if (p->na == 1 && nb == 1 && ct == 4) return launch_fused<1, 1, 4, 8>(a, n_run, st, p->prof);
+    if (p->na == 1 && nb == 1 && ct == 4) {
+        static const int nwv = getenv("PRAG_PROBER_NWV") ? atoi(getenv("PRAG_PROBER_NWV")) : 8;  // tuning knob
+        if (nwv == 4) return launch_fused<1, 1, 4, 4>(a, n_run, st, p->prof);
+        return launch_fused<1, 1, 4, 8>(a, n_run, st, p->prof);
+    }
     PRAG_DISPATCH(1, 1)
     PRAG_DISPATCH(1, 2)
     PRAG_DISPATCH(2, 1)
