@@ -153,6 +153,17 @@ struct ScanArgs {
     int* out_idx;
 };
 
+__device__ __forceinline__ uint32_t sortable_u32(float key) {
+    const uint32_t u = __float_as_uint(key);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);  // monotone float -> uint
+}
+__device__ __forceinline__ float unsortable_f32(uint32_t u) {
+    return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+__device__ __forceinline__ unsigned long long pack_key(float key, int idx) {
+    return ((unsigned long long)sortable_u32(key) << 32) | (uint32_t)idx;
+}
+
 template <int KC>
 struct TopList {
     float k[KC];
@@ -165,8 +176,10 @@ struct TopList {
         }
     }
     // strict '<': among equal keys the earlier (lower row id) entry stays in front
-    __device__ __forceinline__ void push(float key, int idx) {
-        if (key < k[KC - 1]) {
+    // `tau` is a workgroup-wide upper bound on the KC-th best key of this query
+    // (some lane already holds KC keys <= tau): anything above it cannot survive.
+    __device__ __forceinline__ void push(float key, int idx, float tau) {
+        if (key < k[KC - 1] && key <= tau) {
             bool prev = false;  // c_{j-1}: key < old[j-1]
             float ok = 0.f;
             int oi = 0;  // old[j-1]
@@ -198,6 +211,8 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
     const int qstride = a.qstride;
     char* s_q = smem;
     char* s_st = smem + QT * qstride + w * 4096;
+    uint32_t* s_tau = reinterpret_cast<uint32_t*>(smem + QT * qstride + 8 * 4096);  // [QT] sortable keys
+    if (tid < QT) s_tau[tid] = 0xFF800000u;  // sortable(+inf)
 
     // ---- query tile -> LDS (swizzled 16-B pieces) --------------------------
     {
@@ -311,6 +326,9 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
         if (c_cur == NCH - 1) {
             // ---- epilogue: 16 rows x this lane's queries -> running top-KC -------
             const int64_t doc0 = (int64_t)tile_cur * 32;
+            float tau[NQ];
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) tau[t] = unsortable_f32(s_tau[32 * t + r]);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -320,10 +338,14 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
 #pragma unroll
                     for (int t = 0; t < NQ; ++t) {
                         const float key = valid ? fmaf(a.alpha, acc[t][4 * g + e], xn[g][e]) : INFINITY;
-                        top[t].push(key, (int)doc);
+                        top[t].push(key, (int)doc, tau[t]);
                         acc[t][4 * g + e] = 0.f;
                     }
                 }
+            // publish this lane's KC-th best when it tightened the workgroup bound
+#pragma unroll
+            for (int t = 0; t < NQ; ++t)
+                if (top[t].k[KC - 1] < tau[t]) atomicMin(&s_tau[32 * t + r], sortable_u32(top[t].k[KC - 1]));
         }
         advance(tile_cur, c_cur);
     };
@@ -342,15 +364,40 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
         if (it < n_it) body(ldA);
     }
 
-    // ---- per-lane lists -> global: list id = (wave_global*2 + hh) ------------
-    const int64_t list = (int64_t)gw * 2 + hh;
+    // ---- merge the 16 per-lane lists of every query inside the workgroup -----------
+    // (LDS is free now: one query tile at a time, 16 lists x 32 queries x KC x 8 B)
+    unsigned long long* s_m = reinterpret_cast<unsigned long long*>(smem);
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
-        const int64_t o = (list * QT + 32 * t + r) * KC;
+        __syncthreads();
+        {
+            unsigned long long* dst = s_m + ((size_t)(w * 2 + hh) * 32 + r) * KC;
 #pragma unroll
-        for (int j = 0; j < KC; ++j) {
-            a.out_key[o + j] = top[t].k[j];
-            a.out_idx[o + j] = top[t].i[j];
+            for (int j = 0; j < KC; ++j) dst[j] = pack_key(top[t].k[j], top[t].i[j]);
+        }
+        __syncthreads();
+        // 16 consecutive lanes = the 16 source lists of one query; KC rounds of 16-way min
+        const int q = tid >> 4, src = tid & 15;
+        const unsigned long long* mine = s_m + ((size_t)src * 32 + q) * KC;
+        int head = 0;
+        unsigned long long cur = mine[0];
+        const int64_t o = ((int64_t)blockIdx.x * QT + 32 * t + q) * KC;
+        for (int round = 0; round < KC; ++round) {
+            unsigned long long m = cur;
+#pragma unroll
+            for (int sft = 1; sft < 16; sft <<= 1) {
+                const unsigned long long other = __shfl_xor(m, sft, 64);
+                m = other < m ? other : m;
+            }
+            if (cur == m && (uint32_t)m != (uint32_t)kIdxSentinel) {  // unique owner pops
+                ++head;
+                cur = head < KC ? mine[head] : ~0ull;
+            }
+            if (src == 0) {
+                a.out_idx[o + round] = (int)(uint32_t)m;
+                // undo the monotone mapping for the key
+                a.out_key[o + round] = unsortable_f32((uint32_t)(m >> 32));
+            }
         }
     }
 }
@@ -358,11 +405,6 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
 // ---------------------------------------------------------------------------
 // merge the per-lane lists of one query tile: grid = queries, 256 threads
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long pack_key(float key, int idx) {
-    uint32_t u = __float_as_uint(key);
-    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;  // monotone float -> uint
-    return ((unsigned long long)u << 32) | (uint32_t)idx;
-}
 
 template <int KC>
 __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restrict__ part_key,
@@ -704,7 +746,9 @@ static int pick_kc(int k) {
 
 template <int QT, int KC, bool F32>
 static int launch_scan(const ScanArgs& a, int grid, hipStream_t st, EventRing& prof) {
-    const int lds = QT * a.qstride + 8 * 4096;
+    const int lds_loop = QT * a.qstride + 8 * 4096 + QT * 4;   // queries + stages + thresholds
+    const int lds_merge = 16 * 32 * KC * 8;                     // in-workgroup list merge
+    const int lds = lds_loop > lds_merge ? lds_loop : lds_merge;
     auto kern = scan_topk_kernel<QT, KC, F32>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -777,7 +821,9 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
 
     // ---- workspace --------------------------------------------------------------
     const int qstride = (ix->d * 2 + 255) / 256 * 256;
-    const int QT = (B > 32 && 64 * qstride + 8 * 4096 <= 160 * 1024) ? 64 : 32;
+    // 64-query tiles when they fit LDS; fp32 rows with 32-deep lists stay at 32 (VGPR budget)
+    const bool wide_ok = 64 * qstride + 8 * 4096 + 64 * 4 <= 160 * 1024 && !(ix->store == PRAG_F32 && kc == 32);
+    const int QT = (B > 32 && wide_ok) ? 64 : 32;
     const int Bpad = (B + QT - 1) / QT * QT;
     if (Bpad > ix->q_cap) {
         if (ix->q32) (void)hipFree(ix->q32);
@@ -789,7 +835,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     }
     const int n_tiles = (int)((ix->ntotal + 31) / 32);
     const int grid = std::max(1, std::min(ix->n_cu, (n_tiles + 7) / 8));
-    const int n_lists = grid * 16;
+    const int n_lists = grid;  // one merged list per workgroup and query
     const size_t part_need = (size_t)n_lists * QT * kc;
     if (part_need > ix->part_cap) {
         if (ix->part_key) (void)hipFree(ix->part_key);
