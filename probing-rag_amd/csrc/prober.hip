@@ -55,8 +55,10 @@ struct LayerDev {
     const float* wsum1;  // [512] row sums of the packed (scaled) W1
     const float* b1;     // [512] b1 + W1 . ln0_b
     const float* b2;     // [512] b2 + W2 . ln1_b
+    const float* w2sum;  // [512] row sums of the packed (scaled) W2
     const float* W3;     // [2][512] W3 * ln2_w
     float b3[2];         // b3 + W3 . ln2_b
+    float w3sum[2];      // row sums of W3 * ln2_w
     float sc1, sc2;      // 2^-e of the packed fc1 / fc2 weights
 };
 
@@ -79,6 +81,7 @@ __device__ __forceinline__ float silu_f(float h) {
 // Pointers fetched from a struct in memory have no provable address space and
 // compile to flat_load (which counts on lgkmcnt too and forces full drains at
 // every barrier); these helpers pin them to global memory.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) u32x4* gptr_u32x4;
 typedef const __attribute__((address_space(1))) float* gptr_f32;
 __device__ __forceinline__ gptr_u32x4 as_global(const u32x4* p) { return (gptr_u32x4)p; }
@@ -103,10 +106,10 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_x = smem;                                          // staging ring (fc1)
     char* s_ex = smem;                                         // exchange fragments (fc2), same bytes
-    float* s_red = reinterpret_cast<float*>(smem + REGION_A);  // [4 bufs][NWV waves][ROWS]
-    float* s_mu0 = s_red + 4 * NWV * ROWS;                     // [ROWS]
+    float* s_red = reinterpret_cast<float*>(smem + REGION_A);  // [2][NWV][ROWS] LN1 sums, then [4][NWV][64]
+    float* s_mu0 = s_red + 2 * NWV * ROWS + 4 * NWV * 64;      // [ROWS]
     float* s_rs0 = s_mu0 + ROWS;                               // [ROWS]
-    float* s_cst = s_rs0 + ROWS;  // [5][512]: wsum1, b1, b2, W3[0], W3[1] (epilogue constants)
+    float* s_cst = s_rs0 + ROWS;  // [6][512]: wsum1, b1, b2, W3[0], W3[1], w2sum (epilogue constants)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -121,9 +124,10 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     const int T = d >> 6;
 
     // epilogue constants -> LDS once, so no epilogue ever waits on a global load
-    for (int i = tid; i < 5 * kHidden / 4; i += NT) {
+    for (int i = tid; i < 6 * kHidden / 4; i += NT) {
         const int arr = i / (kHidden / 4), o = (i % (kHidden / 4)) * 4;
-        const gptr_f32 src = as_global(arr == 0 ? L.wsum1 : arr == 1 ? L.b1 : arr == 2 ? L.b2 : (L.W3 + (arr - 3) * kHidden));
+        const gptr_f32 src = as_global(arr == 0 ? L.wsum1 : arr == 1 ? L.b1 : arr == 2 ? L.b2
+                                       : arr == 5 ? L.w2sum : (L.W3 + (arr - 3) * kHidden));
         typedef const __attribute__((address_space(1))) f32x4* gptr_f32x4;
         *reinterpret_cast<f32x4*>(s_cst + arr * kHidden + o) = *(gptr_f32x4)(src + o);
     }
@@ -195,12 +199,8 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     const int stat_row = 32 * stat_c + r;
     const int stat_off = stat_row * 128;
     const int stat_sw = (stat_row >> 1) & 7;
-    float st_c = 0.f, st_s = 0.f, st_q2 = 0.f;
-    if constexpr (RAW) {
-        int grow = m0 + stat_row;
-        grow = grow < a.B ? grow : a.B - 1;
-        st_c = (float)a.xh[(int64_t)lrun * a.x_layer_stride + (int64_t)grow * d + 8 * hh];
-    }
+    float st_s = 0.f, st_q2 = 0.f;
+    const half2_t kOnes2 = {(_Float16)1.f, (_Float16)1.f};
 
     // ---- prologue ---------------------------------------------------------------
     // (issue order mirrors the loop body - activations first, then the four weight
@@ -237,12 +237,14 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                     bfr[p][c] = *reinterpret_cast<const half8*>(xs + off);
                 }
             if constexpr (RAW) {
+                // LayerNorm-0 sums with v_dot2_f32_f16: products of halves are exact in f32,
+                // accumulation is f32 (error ~1e-6 * (1 + mean^2/var) on the variance)
                 const half8 sf = *reinterpret_cast<const half8*>(xs + stat_off + (((2 * sub + hh) ^ stat_sw) << 4));
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float dv = (float)sf[j] - st_c;
-                    st_s += dv;
-                    st_q2 = fmaf(dv, dv, st_q2);
+                for (int j = 0; j < 4; ++j) {
+                    const half2_t xv = half2_t{sf[2 * j], sf[2 * j + 1]};
+                    st_s = __builtin_amdgcn_fdot2(xv, kOnes2, st_s, false);
+                    st_q2 = __builtin_amdgcn_fdot2(xv, xv, st_q2, false);
                 }
             }
 #pragma unroll
@@ -265,16 +267,11 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
 
     // ---- LayerNorm-0 statistics -> LDS -------------------------------------------
     if constexpr (RAW) {
-        // this lane: n = d/2 elements around shift st_c; partner lane^32 the other half
-        const float n = 0.5f * (float)d;
-        const float mean_a = st_c + st_s / n;
-        const float m2_a = st_q2 - st_s * st_s / n;
-        const float mean_b = __shfl_xor(mean_a, 32, 64);
-        const float m2_b = __shfl_xor(m2_a, 32, 64);
-        const float delta = mean_b - mean_a;
-        const float mean = mean_a + 0.5f * delta;
-        const float m2 = m2_a + m2_b + delta * delta * (0.5f * n);
-        const float var = fmaxf(m2 / (float)d, 0.f);
+        // this lane summed half of the row (k = 16s + 8hh + j); partner lane^32 the other half
+        const float s1 = st_s + __shfl_xor(st_s, 32, 64);
+        const float s2 = st_q2 + __shfl_xor(st_q2, 32, 64);
+        const float mean = s1 / (float)d;
+        const float var = fmaxf(s2 / (float)d - mean * mean, 0.f);
         if (hh == 0 && w < CT) {
             s_mu0[stat_row] = mean;
             s_rs0[stat_row] = 1.0f / sqrtf(var + kLnEps);
@@ -282,13 +279,18 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     }
     __syncthreads();  // stats visible; every wave is done with the staging ring
 
-    // ---- epilogue 1: LN0 fold, bias, SiLU --------------------------------------------
+    // ---- epilogue 1: LN0 fold, bias, SiLU, one-pass LN1 sums ---------------------------
+    // LayerNorm-1 is NOT applied element-wise: fc2 consumes the raw SiLU outputs and
+    // its epilogue applies  rstd1*(W2~ s - mean1*rowsum(W2~)) + b2~  (same algebra as LN0).
+    float* bufS1 = s_red;               // [NWV][ROWS] partial sums of s
+    float* bufS2 = s_red + NWV * ROWS;  // [NWV][ROWS] partial sums of s*s
     {
-        float mu[CT], rs[CT];
+        float mu[CT], rs[CT], S1[CT], S2[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             mu[c] = RAW ? s_mu0[32 * c + r] : 0.f;
             rs[c] = (RAW ? s_rs0[32 * c + r] : 1.f) * L.sc1;
+            S1[c] = S2[c] = 0.f;
         }
 #pragma unroll
         for (int rti = 0; rti < RT; ++rti)
@@ -303,83 +305,54 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                     for (int c = 0; c < CT; ++c) {
                         float v = acc[rti][c][4 * g4 + e];
                         if constexpr (RAW) v = fmaf(-mu[c], ws[e], v);
-                        acc[rti][c][4 * g4 + e] = silu_f(fmaf(rs[c], v, bb[e]));
+                        const float sv = silu_f(fmaf(rs[c], v, bb[e]));
+                        acc[rti][c][4 * g4 + e] = sv;
+                        S1[c] += sv;
+                        S2[c] = fmaf(sv, sv, S2[c]);
                     }
+                __builtin_amdgcn_sched_barrier(0);  // bound live ranges: 16 SiLU chains at a time
             }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float t1 = xor32(S1[c]), t2 = xor32(S2[c]);
+            if (hh == 0) {
+                bufS1[w * ROWS + 32 * c + r] = t1;
+                bufS2[w * ROWS + 32 * c + r] = t2;
+            }
+        }
     }
 
-    // two-pass LayerNorm statistics over the 512 hidden units of every column
-    auto ln_stats = [&](auto& A, auto NT_, float* mean_out, float* rstd_out) {
-        constexpr int NTc = decltype(NT_)::value;
-        float* bufA = s_red;
-        float* bufB = s_red + NWV * ROWS;
-#pragma unroll
-        for (int c = 0; c < NTc; ++c) {
-            float t = 0.f;
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) t += A[i][c][e];
-            t = xor32(t);
-            if (hh == 0) bufA[w * ROWS + 32 * c + r] = t;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < NTc; ++c) {
-            const int m = 32 * c + r;
-            float sm = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < NWV; ++ww) sm += bufA[ww * ROWS + m];
-            mean_out[c] = sm * (1.0f / kHidden);
-            float t = 0.f;
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float dv = A[i][c][e] - mean_out[c];
-                    t = fmaf(dv, dv, t);
-                }
-            t = xor32(t);
-            if (hh == 0) bufB[w * ROWS + m] = t;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < NTc; ++c) {
-            const int m = 32 * c + r;
-            float sv = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < NWV; ++ww) sv += bufB[ww * ROWS + m];
-            rstd_out[c] = 1.0f / sqrtf(sv * (1.0f / kHidden) + kLnEps);
-        }
-    };
-
-    float mean1[CT], rstd1[CT];
-    ln_stats(acc, std::integral_constant<int, CT>{}, mean1, rstd1);
-
     // ---- fc2 / fc3, G column tiles at a time ---------------------------------------
+    float* bufT1 = s_red + 2 * NWV * ROWS;  // [NWV][64] x4: sum s2, sum s2^2, fc3 class 0 / 1 partials
+    float* bufT2 = bufT1 + NWV * 64;
+    float* bufP0 = bufT2 + NWV * 64;
+    float* bufP1 = bufP0 + NWV * 64;
     const gptr_u32x4 w2p = as_global(L.W2f) + (size_t)(RT * w) * 64 + lane;  // + ((part*32 + ks)*16 + rti)*64
+    float mean1[CT], rstd1[CT];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        if (g > 0) __syncthreads();  // previous pass finished reading the exchange area
-        // publish this wave's normalised activations as ready-made B fragments
+        if (g > 0) __syncthreads();  // previous pass finished reading the exchange area / T buffers
+        // publish this wave's SiLU outputs as ready-made B fragments (hi + lo halves, RTZ split)
 #pragma unroll
         for (int rti = 0; rti < RT; ++rti)
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int s2i = 0; s2i < 2; ++s2i)
 #pragma unroll
                 for (int c2 = 0; c2 < G; ++c2) {
                     const int c = g * G + c2;
-                    half8 hi, lo;
+                    u32x4 hi, lo;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float v = (acc[rti][c][8 * s + j] - mean1[c]) * rstd1[c];
-                        const _Float16 h16 = (_Float16)v;
-                        hi[j] = h16;
-                        lo[j] = (_Float16)(v - (float)h16);
+                    for (int j = 0; j < 4; ++j) {
+                        const float v0 = acc[rti][c][8 * s2i + 2 * j], v1 = acc[rti][c][8 * s2i + 2 * j + 1];
+                        const auto h01 = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+                        const auto l01 = __builtin_amdgcn_cvt_pkrtz(v0 - (float)h01[0], v1 - (float)h01[1]);
+                        hi[j] = __builtin_bit_cast(unsigned int, h01);
+                        lo[j] = __builtin_bit_cast(unsigned int, l01);
                     }
-                    const int fi = (((RT * w + rti) * 2 + s) * G + c2) * 64 + lane;
-                    *reinterpret_cast<half8*>(s_ex + (size_t)fi * 16) = hi;
-                    *reinterpret_cast<half8*>(s_ex + (size_t)(16 * 2 * G * 64 + fi) * 16) = lo;
+                    const int fi = (((RT * w + rti) * 2 + s2i) * G + c2) * 64 + lane;
+                    *reinterpret_cast<u32x4*>(s_ex + (size_t)fi * 16) = hi;
+                    *reinterpret_cast<u32x4*>(s_ex + (size_t)(16 * 2 * G * 64 + fi) * 16) = lo;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 
         f32x16 acc2[RT][G];
@@ -401,8 +374,26 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                 }
         };
         a2_load(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         a2_load(1, 1);
-        __syncthreads();  // fragments of all waves are in LDS
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();  // fragments (and, first time, the LN1 partial sums) of all waves are in LDS
+
+        if (g == 0) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const int m = 32 * c + r;
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < NWV; ++ww) {
+                    t1 += bufS1[ww * ROWS + m];
+                    t2 += bufS2[ww * ROWS + m];
+                }
+                mean1[c] = t1 * (1.0f / kHidden);
+                const float var = fmaxf(t2 * (1.0f / kHidden) - mean1[c] * mean1[c], 0.f);
+                rstd1[c] = 1.0f / sqrtf(var + kLnEps);
+            }
+        }
 
 #pragma unroll 1
         for (int ks2 = 0; ks2 < 32; ks2 += 2) {
@@ -433,67 +424,65 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
             }
         }
 
-        // epilogue 2: bias, SiLU, LN2, fc3
+        // epilogue 2: LN1 fold, bias, SiLU, one-pass LN2 sums, fc3 partial dot products
+        float T1[G], T2[G], P0[G], P1[G], m1[G], r1[G];
+#pragma unroll
+        for (int c2 = 0; c2 < G; ++c2) {
+            T1[c2] = T2[c2] = P0[c2] = P1[c2] = 0.f;
+            m1[c2] = mean1[g * G + c2];
+            r1[c2] = rstd1[g * G + c2] * L.sc2;
+        }
 #pragma unroll
         for (int rti = 0; rti < RT; ++rti)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int nb = 32 * (RT * w + rti) + 8 * g4 + 4 * hh;
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(s_cst + 2 * kHidden + nb);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int c2 = 0; c2 < G; ++c2)
-                        acc2[rti][c2][4 * g4 + e] =
-                            silu_f(fmaf(L.sc2, acc2[rti][c2][4 * g4 + e], bb[e]));
-            }
-        float mean2[G], rstd2[G];
-        ln_stats(acc2, std::integral_constant<int, G>{}, mean2, rstd2);
-
-        float p0[G], p1[G];
-#pragma unroll
-        for (int c2 = 0; c2 < G; ++c2) p0[c2] = p1[c2] = 0.f;
-#pragma unroll
-        for (int rti = 0; rti < RT; ++rti)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int nb = 32 * (RT * w + rti) + 8 * g4 + 4 * hh;
+                const f32x4 w2s = *reinterpret_cast<const f32x4*>(s_cst + 5 * kHidden + nb);
                 const f32x4 w30 = *reinterpret_cast<const f32x4*>(s_cst + 3 * kHidden + nb);
                 const f32x4 w31 = *reinterpret_cast<const f32x4*>(s_cst + 4 * kHidden + nb);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int c2 = 0; c2 < G; ++c2) {
-                        const float v = (acc2[rti][c2][4 * g4 + e] - mean2[c2]) * rstd2[c2];
-                        p0[c2] = fmaf(v, w30[e], p0[c2]);
-                        p1[c2] = fmaf(v, w31[e], p1[c2]);
+                        const float v = fmaf(-m1[c2], w2s[e], acc2[rti][c2][4 * g4 + e]);
+                        const float sv = silu_f(fmaf(r1[c2], v, bb[e]));
+                        T1[c2] += sv;
+                        T2[c2] = fmaf(sv, sv, T2[c2]);
+                        P0[c2] = fmaf(sv, w30[e], P0[c2]);
+                        P1[c2] = fmaf(sv, w31[e], P1[c2]);
                     }
+                __builtin_amdgcn_sched_barrier(0);
             }
-        float* bufC = s_red + 2 * NWV * ROWS;
-        float* bufD = s_red + 3 * NWV * ROWS;
 #pragma unroll
         for (int c2 = 0; c2 < G; ++c2) {
-            const float q0 = xor32(p0[c2]);
-            const float q1 = xor32(p1[c2]);
+            const float t1 = xor32(T1[c2]), t2 = xor32(T2[c2]), q0 = xor32(P0[c2]), q1 = xor32(P1[c2]);
             if (hh == 0) {
-                bufC[w * ROWS + 32 * c2 + r] = q0;
-                bufD[w * ROWS + 32 * c2 + r] = q1;
+                bufT1[w * 64 + 32 * c2 + r] = t1;
+                bufT2[w * 64 + 32 * c2 + r] = t2;
+                bufP0[w * 64 + 32 * c2 + r] = q0;
+                bufP1[w * 64 + 32 * c2 + r] = q1;
             }
         }
         __syncthreads();
         if (tid < 32 * G) {
-            const int m_loc = 32 * g * G + tid;  // column within the workgroup tile
-            const int row = m0 + m_loc;
+            const int row = m0 + 32 * g * G + tid;
             if (row < a.B) {
-                float l0 = L.b3[0], l1 = L.b3[1];
+                float t1 = 0.f, t2 = 0.f, q0 = 0.f, q1 = 0.f;
 #pragma unroll
                 for (int ww = 0; ww < NWV; ++ww) {
-                    l0 += bufC[ww * ROWS + tid];
-                    l1 += bufD[ww * ROWS + tid];
+                    t1 += bufT1[ww * 64 + tid];
+                    t2 += bufT2[ww * 64 + tid];
+                    q0 += bufP0[ww * 64 + tid];
+                    q1 += bufP1[ww * 64 + tid];
                 }
+                // logits = W3~ . LN2(s2) + b3~ = rstd2 * (W3~.s2 - mean2 * rowsum(W3~)) + b3~
+                const float mean2 = t1 * (1.0f / kHidden);
+                const float var2 = fmaxf(t2 * (1.0f / kHidden) - mean2 * mean2, 0.f);
+                const float rstd2 = 1.0f / sqrtf(var2 + kLnEps);
                 float2 o;
-                o.x = l0;
-                o.y = l1;
+                o.x = fmaf(rstd2, q0 - mean2 * L.w3sum[0], L.b3[0]);
+                o.y = fmaf(rstd2, q1 - mean2 * L.w3sum[1], L.b3[1]);
                 *reinterpret_cast<float2*>(a.logits + ((size_t)lrun * a.B + row) * 2) = o;
             }
         }
@@ -788,18 +777,21 @@ extern "C" int prag_prober_load_layer(prag_prober_t* p, int li, const float* ln0
                        return 32 * (step >> 1) + 16 * (step & 1) + 8 * (j >> 2) + 4 * half + (j & 3);
                    },
                    packed, deq);
-    std::vector<float> b2e(H);
+    std::vector<float> b2e(H), w2sum(H);
     E.W2.resize((size_t)H * H);
     E.b2.resize(H);
     for (int n = 0; n < H; ++n) {
-        double bb = (double)b2[n];
+        double bb = (double)b2[n], sm = 0.0;
         for (int k = 0; k < H; ++k) {
             bb += (double)W2[(size_t)n * H + k] * (double)ln1_b[k];
+            sm += deq[(size_t)n * H + k];
             E.W2[(size_t)n * H + k] = (float)std::ldexp(deq[(size_t)n * H + k], -e2);
         }
         b2e[n] = (float)bb;
+        w2sum[n] = (float)sm;
         E.b2[n] = b2e[n];
     }
+    if ((rc = upload(p, w2sum, &L.w2sum)) != PRAG_OK) return rc;
     const _Float16* dW2 = nullptr;
     if ((rc = upload(p, packed, &dW2)) != PRAG_OK) return rc;
     L.W2f = reinterpret_cast<const u32x4*>(dW2);
@@ -811,13 +803,15 @@ extern "C" int prag_prober_load_layer(prag_prober_t* p, int li, const float* ln0
     E.W3.resize((size_t)kClasses * H);
     E.b3.resize(kClasses);
     for (int c = 0; c < kClasses; ++c) {
-        double bb = (double)b3[c];
+        double bb = (double)b3[c], sm = 0.0;
         for (int k = 0; k < H; ++k) {
             W3e[(size_t)c * H + k] = (float)((double)W3[(size_t)c * H + k] * (double)ln2_w[k]);
             bb += (double)W3[(size_t)c * H + k] * (double)ln2_b[k];
+            sm += (double)W3e[(size_t)c * H + k];
             E.W3[(size_t)c * H + k] = W3e[(size_t)c * H + k];
         }
         L.b3[c] = (float)bb;
+        L.w3sum[c] = (float)sm;
         E.b3[c] = L.b3[c];
     }
     if ((rc = upload(p, W3e, &L.W3)) != PRAG_OK) return rc;
@@ -865,7 +859,7 @@ static int launch_fused(const ProberArgs& a, int n_run, hipStream_t st, EventRin
     constexpr int XSTAGE = NB * ROWS * 128;
     constexpr int EXCH = 2 * 16 * 2 * G * 1024;
     constexpr int REGION_A = (2 * XSTAGE > EXCH) ? 2 * XSTAGE : EXCH;
-    constexpr int LDS = REGION_A + (4 * NWV * ROWS + 2 * ROWS + 5 * kHidden) * (int)sizeof(float);
+    constexpr int LDS = REGION_A + (2 * NWV * ROWS + 4 * NWV * 64 + 2 * ROWS + 6 * kHidden) * (int)sizeof(float);
     auto kern = prober_fused_kernel<NA, NB, CT, NWV>;
     static bool attr_set = false;
     if (!attr_set) {
