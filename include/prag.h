@@ -177,6 +177,14 @@ int prag_index_search(prag_index_t* ix, const float* q, int B, int k, int64_t id
 int prag_merge_topk(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts, int B,
                     int k, int metric, float* D_dev, int64_t* I_dev, void* stream);
 
+/* Same merge for results that were exchanged as ONE buffer per shard: part p
+ * starts at parts_dev + p * part_stride_bytes and holds D float32 [B,k] followed
+ * (at the next multiple of 8 bytes) by I int64 [B,k] - what prag_index_search
+ * writes when D/I point into such a buffer - so the exchange is a single
+ * all-gather. */
+int prag_merge_topk_packed(const void* parts_dev, int64_t part_stride_bytes, int n_parts, int B, int k,
+                           int metric, float* D_dev, int64_t* I_dev, void* stream);
+
 /* Read back stored rows [row0,row0+n) as float32 (what the scan sees). */
 int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n, float* out_host);
 

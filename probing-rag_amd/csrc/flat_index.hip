@@ -459,33 +459,49 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------
-// exact rerank: grid = queries, 256 threads (4 waves take candidates round-robin)
+// exact rerank: grid = queries, one wave per candidate (KC waves), 16-B row loads
 // ---------------------------------------------------------------------------
 template <bool F32>
-__global__ __launch_bounds__(256) void rerank_kernel(const void* __restrict__ rows, int d, int metric_l2,
-                                                    const float* __restrict__ q32,
-                                                    const int* __restrict__ cand_idx, int KC, int k,
-                                                    int64_t id_offset, float* __restrict__ D,
-                                                    int64_t* __restrict__ I) {
+__global__ __launch_bounds__(1024) void rerank_kernel(const void* __restrict__ rows, int d, int metric_l2,
+                                                     const float* __restrict__ q32,
+                                                     const int* __restrict__ cand_idx, int KC, int k,
+                                                     int64_t id_offset, float* __restrict__ D,
+                                                     int64_t* __restrict__ I) {
     __shared__ double s_score[64];
     __shared__ int s_idx[64];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6;
     const float* q = q32 + (int64_t)b * d;
-    for (int c = w; c < KC; c += 4) {
+    for (int c = w; c < KC; c += nw) {
         const int idx = cand_idx[(int64_t)b * KC + c];
         double s = 0.0;
         if (idx >= 0) {
-            for (int e = lane; e < d; e += 64) {
-                double x;
-                if constexpr (F32) x = (double)reinterpret_cast<const float*>(rows)[(int64_t)idx * d + e];
-                else x = (double)reinterpret_cast<const _Float16*>(rows)[(int64_t)idx * d + e];
-                const double qv = (double)q[e];
-                if (metric_l2) {
-                    const double t = qv - x;
-                    s = fma(t, t, s);
+            // 8 consecutive elements per lane per step (d is a multiple of 64)
+            for (int e = lane * 8; e < d; e += 512) {
+                float xv[8];
+                if constexpr (F32) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(rows) + (int64_t)idx * d + e);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(rows) + (int64_t)idx * d + e + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { xv[j] = a0[j]; xv[4 + j] = a1[j]; }
                 } else {
-                    s = fma(qv, x, s);
+                    const half8 h = *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(rows) + (int64_t)idx * d + e);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[j] = (float)h[j];
+                }
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(q + e);
+                const f32x4 q1 = *reinterpret_cast<const f32x4*>(q + e + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double qv = (double)(j < 4 ? q0[j] : q1[j - 4]);
+                    const double x = (double)xv[j];
+                    if (metric_l2) {
+                        const double t = qv - x;
+                        s = fma(t, t, s);
+                    } else {
+                        s = fma(qv, x, s);
+                    }
                 }
             }
 #pragma unroll
@@ -531,7 +547,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(const void* __restrict__ ro
 // cross-shard merge: one thread per query, n_parts sorted lists of k
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void merge_shards_kernel(const float* __restrict__ Dp,
-                                                         const int64_t* __restrict__ Ip, int n_parts, int B,
+                                                         const int64_t* __restrict__ Ip, int64_t d_stride,
+                                                         int64_t i_stride, int n_parts, int B,
                                                          int k, int metric_l2, float* __restrict__ D,
                                                          int64_t* __restrict__ I) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -546,10 +563,10 @@ __global__ __launch_bounds__(64) void merge_shards_kernel(const float* __restric
         int64_t bi = 0;
         for (int p = 0; p < n_parts; ++p) {
             if (head[p] >= k) continue;
-            const int64_t o = ((int64_t)p * B + b) * k + head[p];
-            const int64_t id = Ip[o];
+            const int64_t o = (int64_t)b * k + head[p];
+            const int64_t id = Ip[p * i_stride + o];
             if (id < 0) continue;  // padding sorts last
-            const float dv = Dp[o];
+            const float dv = Dp[p * d_stride + o];
             bool take;
             if (best < 0) take = true;
             else if (dv != bd) take = metric_l2 ? (dv < bd) : (dv > bd);
@@ -888,10 +905,10 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         }
     }
     if (ix->store == PRAG_F32)
-        hipLaunchKernelGGL(rerank_kernel<true>, dim3(B), dim3(256), 0, st, ix->rows, ix->d, metric_l2, ix->q32,
+        hipLaunchKernelGGL(rerank_kernel<true>, dim3(B), dim3(64 * std::min(kc, 16)), 0, st, ix->rows, ix->d, metric_l2, ix->q32,
                            ix->cand, kc, k, id_offset, D_dev, I_dev);
     else
-        hipLaunchKernelGGL(rerank_kernel<false>, dim3(B), dim3(256), 0, st, ix->rows, ix->d, metric_l2, ix->q32,
+        hipLaunchKernelGGL(rerank_kernel<false>, dim3(B), dim3(64 * std::min(kc, 16)), 0, st, ix->rows, ix->d, metric_l2, ix->q32,
                            ix->cand, kc, k, id_offset, D_dev, I_dev);
     PRAG_LAUNCH_CHECK();
 
@@ -903,16 +920,33 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     return PRAG_OK;
 }
 
-extern "C" int prag_merge_topk(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts, int B, int k,
-                               int metric, float* D_dev, int64_t* I_dev, void* stream) {
-    PRAG_REQUIRE(D_parts_dev && I_parts_dev && D_dev && I_dev, PRAG_EINVAL, "prag_merge_topk: NULL pointer");
+static int merge_topk_impl(const float* Dp, const int64_t* Ip, int64_t d_stride, int64_t i_stride, int n_parts,
+                           int B, int k, int metric, float* D_dev, int64_t* I_dev, void* stream) {
+    PRAG_REQUIRE(Dp && Ip && D_dev && I_dev, PRAG_EINVAL, "prag_merge_topk: NULL pointer");
     PRAG_REQUIRE(n_parts >= 1 && n_parts <= 64, PRAG_EINVAL, "n_parts=%d outside [1,64]", n_parts);
     PRAG_REQUIRE(B >= 0 && k >= 1, PRAG_EINVAL, "B=%d k=%d", B, k);
     if (B == 0) return PRAG_OK;
     hipLaunchKernelGGL(merge_shards_kernel, dim3((B + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
-                       D_parts_dev, I_parts_dev, n_parts, B, k, metric == PRAG_METRIC_L2 ? 1 : 0, D_dev, I_dev);
+                       Dp, Ip, d_stride, i_stride, n_parts, B, k, metric == PRAG_METRIC_L2 ? 1 : 0, D_dev, I_dev);
     PRAG_LAUNCH_CHECK();
     return PRAG_OK;
+}
+
+extern "C" int prag_merge_topk(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts, int B, int k,
+                               int metric, float* D_dev, int64_t* I_dev, void* stream) {
+    return merge_topk_impl(D_parts_dev, I_parts_dev, (int64_t)B * k, (int64_t)B * k, n_parts, B, k, metric, D_dev,
+                           I_dev, stream);
+}
+
+extern "C" int prag_merge_topk_packed(const void* parts_dev, int64_t part_stride_bytes, int n_parts, int B, int k,
+                                      int metric, float* D_dev, int64_t* I_dev, void* stream) {
+    PRAG_REQUIRE(parts_dev != nullptr, PRAG_EINVAL, "prag_merge_topk_packed: NULL pointer");
+    const int64_t i_off = ((int64_t)B * k * 4 + 7) / 8 * 8;  // I block starts 8-byte aligned after the D block
+    PRAG_REQUIRE(part_stride_bytes >= i_off + (int64_t)B * k * 8 && part_stride_bytes % 8 == 0, PRAG_EINVAL,
+                 "part_stride_bytes=%lld too small or not a multiple of 8", (long long)part_stride_bytes);
+    const char* base = reinterpret_cast<const char*>(parts_dev);
+    return merge_topk_impl(reinterpret_cast<const float*>(base), reinterpret_cast<const int64_t*>(base + i_off),
+                           part_stride_bytes / 4, part_stride_bytes / 8, n_parts, B, k, metric, D_dev, I_dev, stream);
 }
 
 extern "C" int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n, float* out_host) {

@@ -71,14 +71,18 @@ class HipFlatIndex:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().prag_index_add_synthetic(self._h, int(seed) & 0xFFFFFFFF, int(row0), int(n)))
 
-    def search(self, x, k: int, id_offset: int = 0):
-        """-> (D float32 [B,k], I int64 [B,k]); -1 / +-FLT_MAX padded if ntotal < k."""
+    def search(self, x, k: int, id_offset: int = 0, out=None):
+        """-> (D float32 [B,k], I int64 [B,k]); -1 / +-FLT_MAX padded if ntotal < k.
+        ``out=(D, I)`` lets device callers supply the result tensors."""
         import torch
         k = int(k)
         if isinstance(x, torch.Tensor) and x.is_cuda:
             ptr, B, _, keep = self._rows_arg(x)
-            D = torch.empty((B, k), dtype=torch.float32, device=x.device)
-            I = torch.empty((B, k), dtype=torch.int64, device=x.device)
+            if out is None:
+                D = torch.empty((B, k), dtype=torch.float32, device=x.device)
+                I = torch.empty((B, k), dtype=torch.int64, device=x.device)
+            else:
+                D, I = out
             with torch.cuda.device(self.device):
                 _lib.check(_lib.lib().prag_index_search(self._h, ptr, B, k, int(id_offset),
                                                         ctypes.c_void_p(D.data_ptr()),
@@ -124,6 +128,37 @@ def IndexFlatL2(d: int, **kw) -> HipFlatIndex:
 
 def IndexFlatIP(d: int, **kw) -> HipFlatIndex:
     return HipFlatIndex(d, "ip", kw.pop("store", "f32"), **kw)
+
+
+def packed_result_buffer(B: int, k: int, device, n_parts: int = 1):
+    """One byte buffer per shard holding D f32 [B,k] then (8-byte aligned) I i64
+    [B,k]; returns (buf uint8 [n_parts, stride], stride, i_offset)."""
+    import torch
+    i_off = (B * k * 4 + 7) // 8 * 8
+    stride = i_off + B * k * 8
+    return torch.empty((n_parts, stride), dtype=torch.uint8, device=device), stride, i_off
+
+
+def packed_views(buf_row, B: int, k: int, i_off: int):
+    """(D, I) views into one row of a packed buffer."""
+    import torch
+    D = buf_row[:B * k * 4].view(torch.float32).view(B, k)
+    I = buf_row[i_off:i_off + B * k * 8].view(torch.int64).view(B, k)
+    return D, I
+
+
+def merge_topk_packed(buf, B: int, k: int, metric) -> tuple:
+    """Merge the shards of a packed buffer [n_parts, stride] (after ONE all-gather)."""
+    import torch
+    _lib.require_gpu()
+    P, stride = buf.shape
+    D = torch.empty((B, k), dtype=torch.float32, device=buf.device)
+    I = torch.empty((B, k), dtype=torch.int64, device=buf.device)
+    with torch.cuda.device(buf.device):
+        _lib.check(_lib.lib().prag_merge_topk_packed(ctypes.c_void_p(buf.data_ptr()), stride, P, B, k,
+                                                     _lib.metric_id(metric), ctypes.c_void_p(D.data_ptr()),
+                                                     ctypes.c_void_p(I.data_ptr()), _lib.current_stream_ptr(buf.device)))
+    return D, I
 
 
 def merge_topk(D_parts, I_parts, k: int, metric) -> tuple:

@@ -48,6 +48,23 @@ class HipEngine:
         from .index import merge_topk
         return merge_topk(D_parts, I_parts, k, metric)
 
+    # single-collective exchange: results are written straight into one packed
+    # buffer per shard (D then I), all-gathered once, merged from the packed form
+    def search_packed(self, q, k, id_offset):
+        from .index import packed_result_buffer, packed_views
+        q = torch.as_tensor(q)
+        if not q.is_cuda:
+            q = q.to(self.device)
+        B = q.shape[0]
+        buf, stride, i_off = packed_result_buffer(B, k, q.device)
+        D, I = packed_views(buf[0], B, k, i_off)
+        self.index.search(q, k, id_offset=id_offset, out=(D, I))
+        return buf, D, I
+
+    def merge_packed(self, gathered, B, k, metric):
+        from .index import merge_topk_packed
+        return merge_topk_packed(gathered, B, k, metric)
+
 
 class ShardedFlatIndex:
     def __init__(self, d: int, metric="l2", store: str = "f16", capacity: int = 0, group=None, engine=None):
@@ -102,6 +119,13 @@ class ShardedFlatIndex:
         """q replicated on every rank -> identical (D [B,k], I [B,k]) on every rank."""
         if not self._synced:
             raise RuntimeError("ShardedFlatIndex.sync() must run (on every rank) after adding rows")
+        if hasattr(self.engine, "search_packed"):
+            buf, D_loc, I_loc = self.engine.search_packed(q, k, self.id_offset)
+            if self.world == 1:
+                return D_loc, I_loc
+            gathered = torch.empty((self.world, buf.shape[1]), dtype=torch.uint8, device=buf.device)
+            self.dist.all_gather_into_tensor(gathered, buf, group=self.group)
+            return self.engine.merge_packed(gathered, D_loc.shape[0], k, self.metric)
         D_loc, I_loc = self.engine.search(q, k, self.id_offset)
         if self.world == 1:
             return D_loc, I_loc
@@ -114,12 +138,20 @@ class ShardedFlatIndex:
         return self.engine.merge(D_all.view(self.world, B, k), I_all.view(self.world, B, k), k, self.metric)
 
 
-def search_shards_on_one_gpu(shards, q, k: int, metric):
+def search_shards_on_one_gpu(shards, q, k: int, metric, packed: bool = True):
     """1-GPU shard simulation (gpurun gives one GPU): `shards` is a list of
     HipFlatIndex holding consecutive row ranges; runs the same local-search +
-    merge code the multi-GPU path runs, without the collective."""
-    from .index import merge_topk
-    Ds, Is, off = [], [], 0
+    merge code the multi-GPU path runs (packed single-buffer exchange format by
+    default), without the collective."""
+    from .index import merge_topk, merge_topk_packed, packed_result_buffer, packed_views
+    B, off = q.shape[0], 0
+    if packed:
+        buf, stride, i_off = packed_result_buffer(B, k, q.device, n_parts=len(shards))
+        for p, ix in enumerate(shards):
+            ix.search(q, k, id_offset=off, out=packed_views(buf[p], B, k, i_off))
+            off += ix.ntotal
+        return merge_topk_packed(buf, B, k, metric)
+    Ds, Is = [], []
     for ix in shards:
         D, I = ix.search(q, k, id_offset=off)
         Ds.append(D)

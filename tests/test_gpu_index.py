@@ -115,8 +115,10 @@ def test_shard_simulation_equals_unsharded(metric):
         ix = pra.HipFlatIndex(d, metric, "f16")
         ix.add(X[lo:hi])
         shards.append(ix)
-    D1, I1 = pra.search_shards_on_one_gpu(shards, qd, k, metric)
+    D1, I1 = pra.search_shards_on_one_gpu(shards, qd, k, metric)                  # packed exchange format
     assert torch.equal(I0, I1) and torch.equal(D0, D1)
+    D2, I2 = pra.search_shards_on_one_gpu(shards, qd, k, metric, packed=False)    # two-tensor format
+    assert torch.equal(I0, I2) and torch.equal(D0, D2)
     xs = _stored(X, metric, "f16")
     Dn, In = onp.flat_search(xs, Q, k, metric)
     _check(D1.cpu().numpy(), I1.cpu().numpy(), Dn, In, metric)
