@@ -403,6 +403,185 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// query-stationary scan for large query batches (fp16 rows): 128 queries per pass.
+// Eight waves (two per SIMD, so one wave's LDS/barrier latency hides under the
+// other's MFMAs) each keep 16 queries as v_mfma_f32_16x16x32_f16 B fragments in
+// registers (d/32 x 4 VGPRs); the workgroup stages 128-row x 64-element chunks of
+// the corpus ONCE through a double-buffered LDS tile that all waves read, so one
+// HBM pass serves 128 queries.  Loads run 4 chunks ahead in four named register
+// sets (static rotation: d/64 is a multiple of 4), one raw barrier per chunk.
+// ---------------------------------------------------------------------------
+template <int NKS /* d/32 */, int KC>
+__global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
+    constexpr int NCH = NKS / 2;  // 64-element chunks per row
+    static_assert(NCH % 4 == 0, "register-set rotation needs d % 256 == 0");
+    constexpr int DG = 128;       // rows per workgroup step
+    constexpr int STAGE = DG * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g4 = lane >> 4;
+    // xnorm loads in the epilogue are the only ordinary VMEM loads inside the scan loop;
+    // everything else is LDS-DMA counted by hand (see the vmcnt(4) below).
+    const int d = NKS * 32;
+
+    // ---- this wave's 16 queries -> registers (B operand: k = 32s + 8*g4 + j) --------
+    half8 qf[NKS];
+    {
+        const _Float16* qrow = a.q16 + (int64_t)(16 * w + r16) * d + 8 * g4;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) qf[s] = *reinterpret_cast<const half8*>(qrow + 32 * s);
+    }
+
+    const int n_groups = (int)((a.N + DG - 1) / DG);
+    const int nWG = gridDim.x;
+    const int n_my = (int)blockIdx.x < n_groups ? (n_groups - (int)blockIdx.x + nWG - 1) / nWG : 0;
+
+    // LDS-DMA staging (no staging registers): one wave-instruction writes 1 KiB of LDS
+    // linearly (lane x 16 B), so the XOR swizzle is applied to the per-lane SOURCE address:
+    // wave w, piece j covers rows 8*(2w+j) .. +8 of the [128 rows x 128 B] chunk; lane l
+    // fills slot l&7 of row 8*(2w+j) + (l>>3) with global piece (slot ^ ((row>>1)&7)).
+    typedef const __attribute__((address_space(1))) char* gcptr;
+    const gcptr rows = (gcptr) reinterpret_cast<const char*>(a.rows);
+    const int64_t row_bytes = (int64_t)d * 2;
+    int st_doc[2], st_col[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int doc = 8 * (2 * w + j) + (lane >> 3);
+        st_doc[j] = doc;
+        st_col[j] = (((lane & 7) ^ ((doc >> 1) & 7)) << 4);
+    }
+    gcptr p_cur[2];
+    gcptr p_nxt[2];
+    auto group_ptrs = [&](gcptr (&ptr)[2], int group) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int64_t row = (int64_t)group * DG + st_doc[j];
+            row = row < a.N ? row : a.N - 1;
+            ptr[j] = rows + row * row_bytes + st_col[j];
+        }
+    };
+    typedef __attribute__((address_space(3))) char* lptr;
+    const lptr lds0 = (lptr)smem;
+    // chunk c of the group behind `ptr` -> ring stage `stg` (c, stg compile-time)
+#define PRAG_DMA(ptr, c_, stg_)                                                                          \
+    {                                                                                                   \
+        __builtin_amdgcn_global_load_lds(ptr[0] + (c_) * 128, lds0 + (stg_) * STAGE + (2 * w) * 1024, 16, 0, 0);     \
+        __builtin_amdgcn_global_load_lds(ptr[1] + (c_) * 128, lds0 + (stg_) * STAGE + (2 * w + 1) * 1024, 16, 0, 0); \
+    }
+
+    TopList<KC> top;
+    top.init();
+    f32x4 acc[8];  // 8 tiles of 16 rows; C layout: query = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // swizzled fragment offsets of k-step 0 (tile t): constant for the whole scan; k-step 1
+    // is the same address with byte-bit 6 flipped ((4 | g4) ^ sw == 4 ^ (g4 ^ sw))
+    int a_rd[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int row = 16 * t + r16;
+        a_rd[t] = row * 128 + ((g4 ^ ((row >> 1) & 7)) << 4);
+    }
+
+    if (n_my > 0) {
+        const int g0 = blockIdx.x;
+        group_ptrs(p_cur, g0);
+        group_ptrs(p_nxt, g0 + nWG);
+        // prologue: chunks 0..2 in flight into ring stages 0..2
+        PRAG_DMA(p_cur, 0, 0)
+        PRAG_DMA(p_cur, 1, 1)
+        PRAG_DMA(p_cur, 2, 2)
+
+        for (int gi = 0; gi < n_my; ++gi) {
+            const int g = g0 + gi * nWG;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                // chunk `c` has landed once all but the 2 younger chunks (4 DMAs) are done; the
+                // barrier makes every wave's part visible and frees stage (c+3)%4 (read last step)
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (c + 3 < NCH) PRAG_DMA(p_cur, (c + 3) % NCH, (c + 3) % 4)
+                else PRAG_DMA(p_nxt, (c + 3) % NCH, (c + 3) % 4)
+                const char* xs = smem + (c % 4) * STAGE;
+                // four fragment reads in flight at a time (LDS latency would otherwise be paid per MFMA)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int tb = 0; tb < 8; tb += 4) {
+                        half8 av[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            av[u] = *reinterpret_cast<const half8*>(xs + (a_rd[tb + u] ^ (s2 << 6)));
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            acc[tb + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[u], qf[2 * c + s2], acc[tb + u], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
+            // next group's pointers become current; compute the one after
+            p_cur[0] = p_nxt[0];
+            p_cur[1] = p_nxt[1];
+            group_ptrs(p_nxt, g + 2 * nWG);
+            // ---- epilogue: 8 x 4 rows against this lane's query -----------------------
+            const int64_t doc0 = (int64_t)g * DG;
+            float tau = top.k[KC - 1];
+            tau = fminf(tau, __shfl_xor(tau, 16, 64));
+            tau = fminf(tau, __shfl_xor(tau, 32, 64));
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                f32x4 nv = {0.f, 0.f, 0.f, 0.f};
+                if (a.use_norm) nv = *reinterpret_cast<const f32x4*>(a.xnorm + doc0 + 16 * t + 4 * g4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int64_t doc = doc0 + 16 * t + 4 * g4 + e;
+                    const float key = doc < a.N ? fmaf(a.alpha, acc[t][e], nv[e]) : INFINITY;
+                    top.push(key, (int)doc, tau);
+                }
+                acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail DMAs before LDS is reused
+    }
+#undef PRAG_DMA
+
+    // ---- merge the four row-quarter lists of every query: one list per (wg, query) ------
+    __syncthreads();
+    unsigned long long* s_m = reinterpret_cast<unsigned long long*>(smem);
+    {
+        unsigned long long* dst = s_m + ((size_t)(16 * w + r16) * 4 + g4) * KC;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) dst[j] = pack_key(top.k[j], top.i[j]);
+    }
+    __syncthreads();
+    {
+        const int q = tid >> 2, src = tid & 3;
+        const unsigned long long* mine = s_m + ((size_t)q * 4 + src) * KC;
+        int head = 0;
+        unsigned long long cur = mine[0];
+        const int64_t o = ((int64_t)blockIdx.x * 128 + q) * KC;
+        for (int round = 0; round < KC; ++round) {
+            unsigned long long m = cur;
+#pragma unroll
+            for (int sft = 1; sft < 4; sft <<= 1) {
+                const unsigned long long other = __shfl_xor(m, sft, 64);
+                m = other < m ? other : m;
+            }
+            if (cur == m && (uint32_t)m != (uint32_t)kIdxSentinel) {
+                ++head;
+                cur = head < KC ? mine[head] : ~0ull;
+            }
+            if (src == 0) {
+                a.out_idx[o + round] = (int)(uint32_t)m;
+                a.out_key[o + round] = unsortable_f32((uint32_t)(m >> 32));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // merge the per-lane lists of one query tile: grid = queries, 256 threads
 // ---------------------------------------------------------------------------
 
@@ -791,6 +970,40 @@ static int dispatch_scan_kc(int kc, const ScanArgs& a, int grid, hipStream_t st,
     return PRAG_EUNSUPPORTED;
 }
 
+template <int NKS, int KC>
+static int launch_qs(const ScanArgs& a, int grid, hipStream_t st, EventRing& prof) {
+    const int lds = 4 * 128 * 128 > 128 * 4 * KC * 8 ? 4 * 128 * 128 : 128 * 4 * KC * 8;  // 4-stage ring
+    auto kern = scan_qs_kernel<NKS, KC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    prof.begin(st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    prof.end(st);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+// query-stationary kernel: fp16 rows, d in {256,512,768,1024}, lists up to 16 deep
+static bool qs_supported(int d, int store, int kc) {
+    return store == PRAG_F16 && kc <= 16 && (d == 256 || d == 512 || d == 768 || d == 1024);
+}
+
+static int dispatch_qs(int d, int kc, const ScanArgs& a, int grid, hipStream_t st, EventRing& prof) {
+#define PRAG_QS(D_)                                                          \
+    if (d == D_) {                                                           \
+        if (kc == 8) return launch_qs<D_ / 32, 8>(a, grid, st, prof);        \
+        return launch_qs<D_ / 32, 16>(a, grid, st, prof);                    \
+    }
+    PRAG_QS(256) PRAG_QS(512) PRAG_QS(768) PRAG_QS(1024)
+#undef PRAG_QS
+    set_error("internal: query-stationary scan does not cover d=%d", d);
+    return PRAG_EUNSUPPORTED;
+}
+
 static int launch_merge(int kc, const float* pk, const int* pi, int n_lists, int QT, int nq, int* cand,
                         hipStream_t st) {
     switch (kc) {
@@ -840,7 +1053,8 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     const int qstride = (ix->d * 2 + 255) / 256 * 256;
     // 64-query tiles when they fit LDS; fp32 rows with 32-deep lists stay at 32 (VGPR budget)
     const bool wide_ok = 64 * qstride + 8 * 4096 + 64 * 4 <= 160 * 1024 && !(ix->store == PRAG_F32 && kc == 32);
-    const int QT = (B > 32 && wide_ok) ? 64 : 32;
+    const bool use_qs = B > 64 && qs_supported(ix->d, ix->store, kc);  // 128 queries per corpus pass
+    const int QT = use_qs ? 128 : ((B > 32 && wide_ok) ? 64 : 32);
     const int Bpad = (B + QT - 1) / QT * QT;
     if (Bpad > ix->q_cap) {
         if (ix->q32) (void)hipFree(ix->q32);
@@ -851,7 +1065,8 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         ix->q_cap = Bpad;
     }
     const int n_tiles = (int)((ix->ntotal + 31) / 32);
-    const int grid = std::max(1, std::min(ix->n_cu, (n_tiles + 7) / 8));
+    const int grid = use_qs ? std::max(1, std::min(ix->n_cu, (n_tiles + 3) / 4))
+                            : std::max(1, std::min(ix->n_cu, (n_tiles + 7) / 8));
     const int n_lists = grid;  // one merged list per workgroup and query
     const size_t part_need = (size_t)n_lists * QT * kc;
     if (part_need > ix->part_cap) {
@@ -892,7 +1107,9 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         for (int p0 = 0; p0 < Bpad; p0 += QT) {
             a.q16 = ix->q16 + (size_t)p0 * ix->d;
             int rc;
-            if (QT == 32)
+            if (use_qs)
+                rc = dispatch_qs(ix->d, kc, a, grid, st, ix->prof);
+            else if (QT == 32)
                 rc = ix->store == PRAG_F32 ? dispatch_scan_kc<32, true>(kc, a, grid, st, ix->prof)
                                            : dispatch_scan_kc<32, false>(kc, a, grid, st, ix->prof);
             else

@@ -28,7 +28,9 @@ def _check(D, I, D0, I0, metric):
 @pytest.mark.parametrize("metric", METRICS)
 @pytest.mark.parametrize("N,B,k,d", [(10_000, 128, 5, 768),   # BASELINE config 1
                                      (1, 1, 5, 768), (31, 3, 10, 64), (2049, 33, 10, 128),
-                                     (4097, 70, 26, 256), (777, 1, 1, 1024)])
+                                     (4097, 70, 26, 256), (777, 1, 1, 1024),
+                                     # > 64 queries: query-stationary kernel (fp16 rows, d % 256 == 0)
+                                     (5000, 130, 10, 768), (3001, 200, 5, 256), (1500, 65, 12, 1024)])
 def test_search_matches_definition(metric, store, N, B, k, d):
     import probing_rag_amd as pra
     X = onp.synth_rows(42, 0, N, d)
