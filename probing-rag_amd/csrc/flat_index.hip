@@ -108,10 +108,11 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, int B, int Bpad, int d,
                                                           int normalise, float* __restrict__ q32,
-                                                          _Float16* __restrict__ q16) {
+                                                          _Float16* __restrict__ q16, uint32_t* __restrict__ g_tau) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= Bpad) return;
+    if (lane == 0) g_tau[b] = 0xFF800000u;  // sortable(+inf): the scan's chip-wide pruning bound
     if (b >= B) {
         for (int c = lane; c < d; c += 64) q16[(int64_t)b * d + c] = (_Float16)0.f;
         return;
@@ -151,6 +152,7 @@ struct ScanArgs {
     int use_norm;            // L2: bias = ||x||^2
     float* out_key;          // [n_lists][QT][KC]
     int* out_idx;
+    uint32_t* g_tau;         // [QT] chip-wide pruning bound per query (sortable-uint keys, +inf at start)
 };
 
 __device__ __forceinline__ uint32_t sortable_u32(float key) {
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
     f32x4 xn[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) xn[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int tiles_done = 0;
 
     auto body = [&](u32x4 (&ld)[NLD]) {
         // norms of this tile's rows: requested at its first chunk, i.e. OLDER than
@@ -296,6 +299,7 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
             for (int g = 0; g < 4; ++g)
                 xn[g] = *reinterpret_cast<const f32x4*>(a.xnorm + (int64_t)tile_cur * 32 + 8 * g + 4 * hh);
         }
+
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const u32x4 v = ld[i];
@@ -346,6 +350,21 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
 #pragma unroll
             for (int t = 0; t < NQ; ++t)
                 if (top[t].k[KC - 1] < tau[t]) atomicMin(&s_tau[32 * t + r], sortable_u32(top[t].k[KC - 1]));
+            // chip-wide pruning bound: wave 0 of every workgroup trades its LDS bound with the
+            // global one every 8th tile (any lane's KC-th best anywhere is a valid upper bound;
+            // a stale value is only looser).  Kept rare: 2048 waves on 64 hot words serialise.
+            ++tiles_done;
+            if (w == 0 && (tiles_done & 7) == 0 && hh == 0) {
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) {
+                    const uint32_t loc = s_tau[32 * t + r];
+                    const uint32_t glob = __hip_atomic_load(a.g_tau + 32 * t + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (loc < glob)
+                        __hip_atomic_fetch_min(a.g_tau + 32 * t + r, loc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else if (glob < loc)
+                        atomicMin(&s_tau[32 * t + r], glob);
+                }
+            }
         }
         advance(tile_cur, c_cur);
     };
@@ -473,6 +492,7 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
 
     TopList<KC> top;
     top.init();
+    uint32_t gtau = 0xFF800000u;
     f32x4 acc[8];  // 8 tiles of 16 rows; C layout: query = lane&15, row = 4*(lane>>4) + reg
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -505,6 +525,7 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
                 __builtin_amdgcn_s_barrier();
                 if (c + 3 < NCH) PRAG_DMA(p_cur, (c + 3) % NCH, (c + 3) % 4)
                 else PRAG_DMA(p_nxt, (c + 3) % NCH, (c + 3) % 4)
+
                 const char* xs = smem + (c % 4) * STAGE;
                 // four fragment reads in flight at a time (LDS latency would otherwise be paid per MFMA)
 #pragma unroll
@@ -530,6 +551,7 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
             float tau = top.k[KC - 1];
             tau = fminf(tau, __shfl_xor(tau, 16, 64));
             tau = fminf(tau, __shfl_xor(tau, 32, 64));
+            tau = fminf(tau, unsortable_f32(gtau));
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 f32x4 nv = {0.f, 0.f, 0.f, 0.f};
@@ -541,6 +563,19 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
                     top.push(key, (int)doc, tau);
                 }
                 acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if ((gi & 3) == 3) {  // every 4th group: trade this query's bound with the chip-wide one
+                float mine_f = top.k[KC - 1];
+                mine_f = fminf(mine_f, __shfl_xor(mine_f, 16, 64));
+                mine_f = fminf(mine_f, __shfl_xor(mine_f, 32, 64));
+                const uint32_t mine = sortable_u32(mine_f);
+                if (g4 == 0) {
+                    const uint32_t glob = __hip_atomic_load(a.g_tau + 16 * w + r16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (mine < glob)
+                        __hip_atomic_fetch_min(a.g_tau + 16 * w + r16, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gtau = glob < mine ? glob : mine;
+                }
+                gtau = __shfl(gtau, r16, 64);  // lanes of quarter 0 hold the fresh value
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail DMAs before LDS is reused
@@ -799,6 +834,7 @@ struct prag_index {
     size_t part_cap = 0;  // entries
     int* cand = nullptr;
     size_t cand_cap = 0;
+    uint32_t* g_tau = nullptr;  // [q_cap]
     // host-io staging
     float* io_q = nullptr;
     float* io_D = nullptr;
@@ -1059,9 +1095,11 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     if (Bpad > ix->q_cap) {
         if (ix->q32) (void)hipFree(ix->q32);
         if (ix->q16) (void)hipFree(ix->q16);
-        ix->q32 = nullptr; ix->q16 = nullptr; ix->q_cap = 0;
+        if (ix->g_tau) (void)hipFree(ix->g_tau);
+        ix->q32 = nullptr; ix->q16 = nullptr; ix->g_tau = nullptr; ix->q_cap = 0;
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->q32), (size_t)Bpad * ix->d * sizeof(float)));
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->q16), (size_t)Bpad * ix->d * sizeof(_Float16)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->g_tau), (size_t)Bpad * sizeof(uint32_t)));
         ix->q_cap = Bpad;
     }
     const int n_tiles = (int)((ix->ntotal + 31) / 32);
@@ -1087,7 +1125,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
 
     const int metric_l2 = ix->metric == PRAG_METRIC_L2;
     hipLaunchKernelGGL(prep_queries_kernel, dim3((Bpad + 3) / 4), dim3(256), 0, st, q_dev, B, Bpad, ix->d,
-                       ix->metric == PRAG_METRIC_COS ? 1 : 0, ix->q32, ix->q16);
+                       ix->metric == PRAG_METRIC_COS ? 1 : 0, ix->q32, ix->q16, ix->g_tau);
     PRAG_LAUNCH_CHECK();
 
     if (ix->ntotal == 0) {
@@ -1106,6 +1144,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         a.out_idx = ix->part_idx;
         for (int p0 = 0; p0 < Bpad; p0 += QT) {
             a.q16 = ix->q16 + (size_t)p0 * ix->d;
+            a.g_tau = ix->g_tau + p0;
             int rc;
             if (use_qs)
                 rc = dispatch_qs(ix->d, kc, a, grid, st, ix->prof);
@@ -1203,7 +1242,7 @@ extern "C" int prag_index_profile_read(prag_index_t* ix, float* ms, int cap, int
 extern "C" void prag_index_destroy(prag_index_t* ix) {
     if (!ix) return;
     ix->prof.disable();
-    void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->part_key, ix->part_idx, ix->cand,
+    void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->g_tau, ix->part_key, ix->part_idx, ix->cand,
                     ix->io_q, ix->io_D, ix->io_I};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
