@@ -70,6 +70,8 @@ struct ProberArgs {
     int layer0;
     int B;
     int d;
+    int n_tiles;    // row tiles per layer (set by the launcher)
+    int n_run;      // layers in this launch
     float* logits;  // [n_run][B][2]
 };
 
@@ -116,9 +118,15 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31;
     const int hh = lane >> 5;
-    const int lrun = blockIdx.y;
+    // XCD-aware placement (speed only): blocks b and b+8 share an XCD, so give every XCD a
+    // contiguous chunk of the layer-major work list - its 4 MiB L2 then holds one or two
+    // layers' weights instead of all of them.  Blocks past the list exit.
+    const int per_xcd = (a.n_tiles * a.n_run + 7) / 8;
+    const int vidx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (vidx >= a.n_tiles * a.n_run) return;
+    const int lrun = vidx / a.n_tiles;
     const LayerDev& L = a.layers[a.layer0 + lrun];
-    const int m0 = blockIdx.x * ROWS;
+    const int m0 = (vidx - lrun * a.n_tiles) * ROWS;
     const int d = a.d;
     const int S16 = d >> 4;
     const int T = d >> 6;
@@ -226,23 +234,32 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
         x_load(t + 2 < T ? t + 2 : T - 1);     // clamped: the tail re-reads the last tile
         const char* xs = s_x + (t & 1) * XSTAGE;
         const int s16n = 4 * (t + 1 < T ? t + 1 : T - 1);
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-            half8 bfr[NB][CT];
+        // B fragments (and the statistics fragment) of sub-step s+1 are read while the
+        // MFMAs of sub-step s run: only the first read of a K step is exposed
+        half8 bfr[2][NB][CT];
+        half8 sfr[2];
+        auto b_read = [&](int buf, int sub) {
 #pragma unroll
             for (int p = 0; p < NB; ++p)
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
                     const int off = p * XPART + rd_row_off[c] + (((2 * sub + hh) ^ rd_sw[c]) << 4);
-                    bfr[p][c] = *reinterpret_cast<const half8*>(xs + off);
+                    bfr[buf][p][c] = *reinterpret_cast<const half8*>(xs + off);
                 }
+            if constexpr (RAW)
+                sfr[buf] = *reinterpret_cast<const half8*>(xs + stat_off + (((2 * sub + hh) ^ stat_sw) << 4));
+        };
+        b_read(0, 0);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            const int cb = sub & 1;
+            if (sub < 3) b_read(cb ^ 1, sub + 1);
             if constexpr (RAW) {
                 // LayerNorm-0 sums with v_dot2_f32_f16: products of halves are exact in f32,
                 // accumulation is f32 (error ~1e-6 * (1 + mean^2/var) on the variance)
-                const half8 sf = *reinterpret_cast<const half8*>(xs + stat_off + (((2 * sub + hh) ^ stat_sw) << 4));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const half2_t xv = half2_t{sf[2 * j], sf[2 * j + 1]};
+                    const half2_t xv = half2_t{sfr[cb][2 * j], sfr[cb][2 * j + 1]};
                     st_s = __builtin_amdgcn_fdot2(xv, kOnes2, st_s, false);
                     st_q2 = __builtin_amdgcn_fdot2(xv, xv, st_q2, false);
                 }
@@ -251,14 +268,14 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
             for (int rti = 0; rti < RT; ++rti)
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
-                    acc[rti][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[sub][0][rti], bfr[0][c],
+                    acc[rti][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[sub][0][rti], bfr[cb][0][c],
                                                                          acc[rti][c], 0, 0, 0);
                     if constexpr (NB == 2)
                         acc[rti][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                            afr[sub][0][rti], bfr[1][c], acc[rti][c], 0, 0, 0);
+                            afr[sub][0][rti], bfr[cb][1][c], acc[rti][c], 0, 0, 0);
                     if constexpr (NA == 2)
                         acc[rti][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                            afr[sub][1][rti], bfr[0][c], acc[rti][c], 0, 0, 0);
+                            afr[sub][1][rti], bfr[cb][0][c], acc[rti][c], 0, 0, 0);
                 }
             a_load(sub, s16n + sub);  // refill this slot for the next K step
             __builtin_amdgcn_sched_barrier(0);  // keep sub-steps apart: caps live fragments (no spills)
@@ -867,9 +884,12 @@ static int launch_fused(const ProberArgs& a, int n_run, hipStream_t st, EventRin
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
-    dim3 grid((a.B + ROWS - 1) / ROWS, n_run);
+    ProberArgs b = a;
+    b.n_tiles = (a.B + ROWS - 1) / ROWS;
+    b.n_run = n_run;
+    const int per_xcd = (b.n_tiles * n_run + 7) / 8;
     prof.begin(st);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), LDS, st, a);
+    hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(64 * NWV), LDS, st, b);
     prof.end(st);
     PRAG_LAUNCH_CHECK();
     return PRAG_OK;
