@@ -76,8 +76,10 @@ struct ProberArgs {
 };
 
 __device__ __forceinline__ float silu_f(float h) {
-    // h * sigmoid(h); v_exp_f32 / v_rcp_f32 are ~1 ulp, far inside the 1e-4 budget
-    return h * __frcp_rn(1.0f + __expf(-h));
+    // h * sigmoid(h) as v_mul + v_exp_f32 + v_add + v_rcp_f32 + v_mul; the two transcendentals
+    // are ~1 ulp, far inside the 1e-4 budget.  (__frcp_rn / "1.0f / x" expand to the full IEEE
+    // division sequence - v_div_scale, v_div_fmas, v_div_fixup: ~10 extra VALU per element.)
+    return h * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * h));
 }
 
 // Pointers fetched from a struct in memory have no provable address space and
