@@ -182,15 +182,17 @@ struct TopList {
     // (some lane already holds KC keys <= tau): anything above it cannot survive.
     __device__ __forceinline__ void push(float key, int idx, float tau) {
         if (key < k[KC - 1] && key <= tau) {
-            bool prev = false;  // c_{j-1}: key < old[j-1]
-            float ok = 0.f;
-            int oi = 0;  // old[j-1]
+            // sorted insertion, dropping the last entry: new_k[j] = clamp(key, old[j-1], old[j])
+            // = v_med3_f32; the id follows the same choice via the two compares
+            bool prev = false;       // key < old[j-1]
+            float ok = -INFINITY;    // old[j-1]
+            int oi = 0;
 #pragma unroll
             for (int j = 0; j < KC; ++j) {
                 const float cur_k = k[j];
                 const int cur_i = i[j];
                 const bool c = key < cur_k;
-                k[j] = prev ? ok : (c ? key : cur_k);
+                k[j] = __builtin_amdgcn_fmed3f(ok, cur_k, key);
                 i[j] = prev ? oi : (c ? idx : cur_i);
                 prev = c;
                 ok = cur_k;
