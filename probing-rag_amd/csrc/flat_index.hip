@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
     char* s_q = smem;
     char* s_st = smem + QT * qstride + w * 4096;
     uint32_t* s_tau = reinterpret_cast<uint32_t*>(smem + QT * qstride + 8 * 4096);  // [QT] sortable keys
-    if (tid < QT) s_tau[tid] = 0xFF800000u;  // sortable(+inf)
+    if (tid < QT) s_tau[tid] = a.g_tau[tid];  // +inf, or the pre-pass bound (valid: subset of the shard)
 
     // ---- query tile -> LDS (swizzled 16-B pieces) --------------------------
     {
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
 
     TopList<KC> top;
     top.init();
-    uint32_t gtau = 0xFF800000u;
+    uint32_t gtau = a.g_tau[16 * w + r16];  // +inf, or the pre-pass bound
     f32x4 acc[8];  // 8 tiles of 16 rows; C layout: query = lane&15, row = 4*(lane>>4) + reg
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -625,7 +625,8 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
 template <int KC>
 __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restrict__ part_key,
                                                          const int* __restrict__ part_idx, int n_lists,
-                                                         int QT, int* __restrict__ cand_idx /*[q][KC]*/) {
+                                                         int QT, int* __restrict__ cand_idx /*[q][KC]*/,
+                                                         uint32_t* __restrict__ tau_out /*[q] or null*/) {
     __shared__ unsigned long long s_min[4];
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
@@ -670,7 +671,12 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
             for (int i = 0; i + 1 < KC; ++i) loc[i] = loc[i + 1];
             loc[KC - 1] = kInf;
         }
-        if (tid == 0) cand_idx[(int64_t)q * KC + round] = (g == kInf) ? -1 : (int)(uint32_t)g;
+        if (tid == 0) {
+            cand_idx[(int64_t)q * KC + round] = (g == kInf) ? -1 : (int)(uint32_t)g;
+            // pre-pass use: the KC-th best key of the rows seen = a valid pruning bound for the
+            // full scan (those rows are a subset of the shard)
+            if (tau_out && round == KC - 1 && g != kInf) tau_out[q] = (uint32_t)(g >> 32);
+        }
     }
 }
 
@@ -1043,11 +1049,11 @@ static int dispatch_qs(int d, int kc, const ScanArgs& a, int grid, hipStream_t s
 }
 
 static int launch_merge(int kc, const float* pk, const int* pi, int n_lists, int QT, int nq, int* cand,
-                        hipStream_t st) {
+                        uint32_t* tau_out, hipStream_t st) {
     switch (kc) {
-        case 8: hipLaunchKernelGGL(merge_lists_kernel<8>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand); break;
-        case 16: hipLaunchKernelGGL(merge_lists_kernel<16>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand); break;
-        case 32: hipLaunchKernelGGL(merge_lists_kernel<32>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand); break;
+        case 8: hipLaunchKernelGGL(merge_lists_kernel<8>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out); break;
+        case 16: hipLaunchKernelGGL(merge_lists_kernel<16>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out); break;
+        case 32: hipLaunchKernelGGL(merge_lists_kernel<32>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out); break;
         default: set_error("internal: KC=%d", kc); return PRAG_EUNSUPPORTED;
     }
     PRAG_LAUNCH_CHECK();
@@ -1144,21 +1150,40 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         a.use_norm = metric_l2;
         a.out_key = ix->part_key;
         a.out_idx = ix->part_idx;
+        auto run_scan = [&](const ScanArgs& sa, int g, EventRing& ring) -> int {
+            if (use_qs) return dispatch_qs(ix->d, kc, sa, g, st, ring);
+            if (QT == 32)
+                return ix->store == PRAG_F32 ? dispatch_scan_kc<32, true>(kc, sa, g, st, ring)
+                                             : dispatch_scan_kc<32, false>(kc, sa, g, st, ring);
+            return ix->store == PRAG_F32 ? dispatch_scan_kc<64, true>(kc, sa, g, st, ring)
+                                         : dispatch_scan_kc<64, false>(kc, sa, g, st, ring);
+        };
+        // Pre-pass over the first kSample rows (same kernels, a few workgroups): per query, the
+        // KC-th best key of that SUBSET is a valid upper bound on the shard's KC-th best, so the
+        // full scan starts pruned (~0.2 % quantile) instead of inserting at every slot while its
+        // per-lane lists warm up.  Only worth it when the shard is much larger than the sample.
+        constexpr int64_t kSample = 8192;
+        const bool prepass = ix->ntotal >= 16 * kSample;
+        static EventRing no_prof;  // the pre-pass is not part of the profiled scan launches
         for (int p0 = 0; p0 < Bpad; p0 += QT) {
             a.q16 = ix->q16 + (size_t)p0 * ix->d;
             a.g_tau = ix->g_tau + p0;
-            int rc;
-            if (use_qs)
-                rc = dispatch_qs(ix->d, kc, a, grid, st, ix->prof);
-            else if (QT == 32)
-                rc = ix->store == PRAG_F32 ? dispatch_scan_kc<32, true>(kc, a, grid, st, ix->prof)
-                                           : dispatch_scan_kc<32, false>(kc, a, grid, st, ix->prof);
-            else
-                rc = ix->store == PRAG_F32 ? dispatch_scan_kc<64, true>(kc, a, grid, st, ix->prof)
-                                           : dispatch_scan_kc<64, false>(kc, a, grid, st, ix->prof);
-            if (rc != PRAG_OK) return rc;
             const int nq = std::min(QT, B - p0);
-            rc = launch_merge(kc, ix->part_key, ix->part_idx, n_lists, QT, nq, ix->cand + (size_t)p0 * kc, st);
+            int rc;
+            if (prepass) {
+                ScanArgs pre = a;
+                pre.N = kSample;
+                pre.n_tiles = (int)(kSample / 32);
+                const int pre_grid = use_qs ? (int)(kSample / 128) : (int)(kSample / 256);
+                rc = run_scan(pre, pre_grid, no_prof);
+                if (rc != PRAG_OK) return rc;
+                rc = launch_merge(kc, ix->part_key, ix->part_idx, pre_grid, QT, nq, ix->cand + (size_t)p0 * kc,
+                                  ix->g_tau + p0, st);
+                if (rc != PRAG_OK) return rc;
+            }
+            rc = run_scan(a, grid, ix->prof);
+            if (rc != PRAG_OK) return rc;
+            rc = launch_merge(kc, ix->part_key, ix->part_idx, n_lists, QT, nq, ix->cand + (size_t)p0 * kc, nullptr, st);
             if (rc != PRAG_OK) return rc;
         }
     }

@@ -56,6 +56,31 @@ def test_search_matches_definition(metric, store, N, B, k, d):
             assert I[0, :len(want)].tolist() == want
 
 
+@pytest.mark.parametrize("B", [3, 40, 100])
+@pytest.mark.parametrize("metric", [onp.METRIC_L2, onp.METRIC_COS])
+def test_prepass_bound_keeps_ties_and_planted_rows(metric, B):
+    """Shards >= 128k rows start the scan from a pre-pass bound (KC-th best key of the
+    first 8192 rows).  The bound is compared with <=, so exact duplicates of the best
+    row - inside and outside the sampled prefix - must still come back lowest-id first."""
+    import probing_rag_amd as pra
+    N, d, k = 150_000, 256, 10
+    X = onp.synth_rows(11, 0, N, d)
+    dups = [5, 17, 4000, 8191, 8192, 9000, 50_000, 77_777, 120_000, 149_999, 149_000, 64, 65, 100_001]
+    for j in dups[1:]:
+        X[j] = X[5]
+    Q = onp.synth_rows(12, 0, B, d)
+    Q[0] = X[5]
+    Q[1] = X[140_000]                     # best match far outside the sampled prefix
+    ix = pra.HipFlatIndex(d, metric, "f16")
+    ix.add(X)
+    D, I = ix.search(Q, k)
+    xs = _stored(X, metric, "f16")
+    D0, I0 = onp.flat_search(xs, Q, k, metric)
+    _check(D, I, D0, I0, metric)
+    assert I[0].tolist() == sorted(dups)[:k]
+    assert I[1, 0] == 140_000
+
+
 def test_empty_padding_offsets_and_device_io():
     import torch
     import probing_rag_amd as pra
