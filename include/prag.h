@@ -44,6 +44,7 @@ extern "C" {
 /* element types of caller-provided activations / stored corpus rows */
 #define PRAG_F32 0
 #define PRAG_F16 1
+#define PRAG_BF16 2   /* activations only (hidden states of a bf16 LM); handled like PRAG_F32 */
 
 /* weight precision of a prober handle */
 #define PRAG_W_F16 1   /* weights rounded to 11 significant bits (one fp16 MFMA term)   */
@@ -83,7 +84,7 @@ int prag_prober_load_layer(prag_prober_t* p, int layer_idx,
 
 /* Replaces `logit = prober(input)` (exp_rag.py:387, utils.py:45-57) for
  * `n_run` consecutive layers starting at `layer0`, in ONE launch.
- *   x_dev: activations, element type x_dtype (PRAG_F32 | PRAG_F16); row b of
+ *   x_dev: activations, element type x_dtype (PRAG_F32 | PRAG_F16 | PRAG_BF16); row b of
  *          layer l starts at element (l - layer0) * x_layer_stride + b * d_model
  *   logits_dev: float32 [n_run, B, 2]                                        */
 int prag_prober_forward(prag_prober_t* p, const void* x_dev, int x_dtype,
@@ -138,6 +139,15 @@ int prag_pool_accumulate(float* acc_dev, const void* h_dev, int h_dtype, int64_t
  * pred_lens_dev int64 [B].  scale_mean=0 gives the inference-time sum pool. */
 int prag_pool_ragged(const void* acts_dev, int dtype, int B, int T, int d,
                      const int64_t* pred_lens_dev, int scale_mean, float* out_dev, void* stream);
+
+/* Replaces the attention-masked mean pooling at the end of
+ * `SentenceTransformer('facebook/contriever-msmarco').encode` (utils.py:365-366,
+ * make_indexer.py:447-455; third-party code, restated from its published
+ * definition): out[b,:] = sum_t mask[b,t] * h[b,t,:] / max(sum_t mask[b,t], 1).
+ * hidden_dev [B,T,d] (PRAG_F32 | PRAG_F16 | PRAG_BF16), mask_dev int64 [B,T],
+ * out_dev float32 [B,d] - ready to hand to prag_index_search on the device. */
+int prag_pool_masked_mean(const void* hidden_dev, int dtype, const int64_t* mask_dev, int B, int T, int d,
+                          float* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------
  * Flat (exact, brute-force) index

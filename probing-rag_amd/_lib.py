@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "lib", "libprag.so")
 
 PRAG_OK = 0
-PRAG_F32, PRAG_F16 = 0, 1
+PRAG_F32, PRAG_F16, PRAG_BF16 = 0, 1, 2
 PRAG_W_F32, PRAG_W_F16 = 0, 1
 METRIC_L2, METRIC_IP, METRIC_COS = 0, 1, 2
 _METRICS = {"l2": METRIC_L2, "ip": METRIC_IP, "cos": METRIC_COS, "cosine": METRIC_COS}
@@ -62,6 +62,7 @@ SIGNATURES = {
     "prag_prober_destroy": (None, [_P]),
     "prag_pool_accumulate": (_I, [_P, _P, _I, _L, _I, _P]),
     "prag_pool_ragged": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "prag_pool_masked_mean": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
     "prag_index_create": (_I, [ctypes.POINTER(_P), _I, _I, _I, _L]),
     "prag_index_add": (_I, [_P, _P, _L, _I]),
     "prag_index_add_synthetic": (_I, [_P, ctypes.c_uint32, _L, _L]),

@@ -511,7 +511,20 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
 // ---------------------------------------------------------------------------
 // fp32 activations -> LayerNorm-0-normalised hi/lo fp16 terms (one wave per row)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prenorm_split_kernel(const float* __restrict__ x,
+// T = float or bf16 bits (unsigned short)
+template <typename T>
+__device__ __forceinline__ f32x4 load4_as_f32(const T* p) {
+    if constexpr (sizeof(T) == 4) {
+        return *reinterpret_cast<const f32x4*>(p);
+    } else {  // bf16: the upper half of an f32
+        const ushort4 u = *reinterpret_cast<const ushort4*>(p);
+        return f32x4{__uint_as_float((uint32_t)u.x << 16), __uint_as_float((uint32_t)u.y << 16),
+                     __uint_as_float((uint32_t)u.z << 16), __uint_as_float((uint32_t)u.w << 16)};
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void prenorm_split_kernel(const T* __restrict__ x,
                                                            int64_t x_layer_stride, int B, int d,
                                                            int n_rows_total, _Float16* __restrict__ xh,
                                                            _Float16* __restrict__ xl) {
@@ -519,13 +532,13 @@ __global__ __launch_bounds__(256) void prenorm_split_kernel(const float* __restr
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows_total) return;
     const int l = row / B, b = row - l * B;
-    const float* src = x + (int64_t)l * x_layer_stride + (int64_t)b * d;
+    const T* src = x + (int64_t)l * x_layer_stride + (int64_t)b * d;
     _Float16* dh = xh + (int64_t)row * d;
     _Float16* dl = xl + (int64_t)row * d;
     // pass 1: mean ; pass 2: centred second moment (rows are L2/L1 hot on re-read)
     float s = 0.f;
     for (int i = lane * 4; i < d; i += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+        const f32x4 v = load4_as_f32(src + i);
         s += (v[0] + v[1]) + (v[2] + v[3]);
     }
 #pragma unroll
@@ -533,7 +546,7 @@ __global__ __launch_bounds__(256) void prenorm_split_kernel(const float* __restr
     const float mean = s / (float)d;
     float q = 0.f;
     for (int i = lane * 4; i < d; i += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+        const f32x4 v = load4_as_f32(src + i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float dv = v[e] - mean;
@@ -544,7 +557,7 @@ __global__ __launch_bounds__(256) void prenorm_split_kernel(const float* __restr
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
     const float rstd = 1.0f / sqrtf(q / (float)d + kLnEps);
     for (int i = lane * 4; i < d; i += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+        const f32x4 v = load4_as_f32(src + i);
         half4 h, lo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -556,6 +569,33 @@ __global__ __launch_bounds__(256) void prenorm_split_kernel(const float* __restr
         *reinterpret_cast<half4*>(dh + i) = h;
         *reinterpret_cast<half4*>(dl + i) = lo;
     }
+}
+
+// attention-masked mean over the sequence: one block column per 4 features
+template <typename T>
+__global__ __launch_bounds__(256) void pool_masked_mean_kernel(const T* __restrict__ h,
+                                                              const int64_t* __restrict__ mask, int Tlen, int d,
+                                                              float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int col = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (col >= d) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    float cnt = 0.f;
+    for (int t = 0; t < Tlen; ++t) {
+        const float m = (float)mask[(int64_t)b * Tlen + t];
+        if (m != 0.f) {
+            const T* p = h + ((int64_t)b * Tlen + t) * d + col;
+            f32x4 v;
+            if constexpr (sizeof(T) == 4) v = *reinterpret_cast<const f32x4*>(p);
+            else if constexpr (std::is_same<T, _Float16>::value) {
+                const half4 hv = *reinterpret_cast<const half4*>(p);
+                v = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+            } else v = load4_as_f32(p);
+            s += v * m;
+            cnt += m;
+        }
+    }
+    *reinterpret_cast<f32x4*>(out + (int64_t)b * d + col) = s / fmaxf(cnt, 1.0f);   // clamp(min=1e-9) ~ no-op for int masks
 }
 
 // ---------------------------------------------------------------------------
@@ -912,7 +952,8 @@ extern "C" int prag_prober_forward(prag_prober_t* p, const void* x_dev, int x_dt
     PRAG_REQUIRE(B >= 1, PRAG_EINVAL, "B=%d must be >= 1", B);
     PRAG_REQUIRE(layer0 >= 0 && n_run >= 1 && layer0 + n_run <= p->n_layers, PRAG_EINVAL,
                  "layers [%d,%d) outside [0,%d)", layer0, layer0 + n_run, p->n_layers);
-    PRAG_REQUIRE(x_dtype == PRAG_F32 || x_dtype == PRAG_F16, PRAG_EINVAL, "x_dtype=%d", x_dtype);
+    PRAG_REQUIRE(x_dtype == PRAG_F32 || x_dtype == PRAG_F16 || x_dtype == PRAG_BF16, PRAG_EINVAL, "x_dtype=%d",
+                 x_dtype);
     PRAG_REQUIRE(n_run == 1 || x_layer_stride >= (int64_t)B * p->d, PRAG_EINVAL,
                  "x_layer_stride=%lld smaller than B*d_model", (long long)x_layer_stride);
     for (int l = layer0; l < layer0 + n_run; ++l)
@@ -937,9 +978,13 @@ extern "C" int prag_prober_forward(prag_prober_t* p, const void* x_dev, int x_dt
             if (rc != PRAG_OK) return rc;
         }
         const int rows = n_run * B;
-        hipLaunchKernelGGL(prenorm_split_kernel, dim3((rows + 3) / 4), dim3(256), 0, st,
-                           reinterpret_cast<const float*>(x_dev), x_layer_stride, B, p->d, rows,
-                           p->ws_h, p->ws_l);
+        if (x_dtype == PRAG_F32)
+            hipLaunchKernelGGL(prenorm_split_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, st,
+                               reinterpret_cast<const float*>(x_dev), x_layer_stride, B, p->d, rows, p->ws_h, p->ws_l);
+        else
+            hipLaunchKernelGGL(prenorm_split_kernel<unsigned short>, dim3((rows + 3) / 4), dim3(256), 0, st,
+                               reinterpret_cast<const unsigned short*>(x_dev), x_layer_stride, B, p->d, rows,
+                               p->ws_h, p->ws_l);
         PRAG_LAUNCH_CHECK();
         a.xh = p->ws_h;
         a.xl = p->ws_l;
@@ -1028,6 +1073,26 @@ extern "C" int prag_pool_accumulate(float* acc_dev, const void* h_dev, int h_dty
     else
         hipLaunchKernelGGL(pool_accumulate_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, acc_dev,
                            reinterpret_cast<const _Float16*>(h_dev), n_elems, assign);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+extern "C" int prag_pool_masked_mean(const void* hidden_dev, int dtype, const int64_t* mask_dev, int B, int T, int d,
+                                     float* out_dev, void* stream) {
+    PRAG_REQUIRE(hidden_dev && mask_dev && out_dev, PRAG_EINVAL, "prag_pool_masked_mean: NULL device pointer");
+    PRAG_REQUIRE(B >= 1 && T >= 1 && d >= 4 && d % 4 == 0, PRAG_EINVAL, "B=%d T=%d d=%d", B, T, d);
+    PRAG_REQUIRE(dtype == PRAG_F32 || dtype == PRAG_F16 || dtype == PRAG_BF16, PRAG_EINVAL, "dtype=%d", dtype);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((d / 4 + 255) / 256, B);
+    if (dtype == PRAG_F32)
+        hipLaunchKernelGGL(pool_masked_mean_kernel<float>, grid, dim3(256), 0, st,
+                           reinterpret_cast<const float*>(hidden_dev), mask_dev, T, d, out_dev);
+    else if (dtype == PRAG_F16)
+        hipLaunchKernelGGL(pool_masked_mean_kernel<_Float16>, grid, dim3(256), 0, st,
+                           reinterpret_cast<const _Float16*>(hidden_dev), mask_dev, T, d, out_dev);
+    else
+        hipLaunchKernelGGL(pool_masked_mean_kernel<unsigned short>, grid, dim3(256), 0, st,
+                           reinterpret_cast<const unsigned short*>(hidden_dev), mask_dev, T, d, out_dev);
     PRAG_LAUNCH_CHECK();
     return PRAG_OK;
 }

@@ -88,6 +88,26 @@ def pool_ragged(acts, pred_lens, mean: bool = True):
     return out
 
 
+def masked_mean_pool(hidden, attention_mask):
+    """Contriever / sentence-transformers mean pooling (utils.py:365-366 ->
+    SentenceTransformer.encode, third-party) on device: hidden [B,T,d] (f32/f16/bf16),
+    attention_mask [B,T] -> float32 [B,d] embeddings, ready for HipFlatIndex.search."""
+    import torch
+    _lib.require_gpu()
+    hidden = hidden.contiguous()
+    dt = {torch.float32: _lib.PRAG_F32, torch.float16: _lib.PRAG_F16, torch.bfloat16: _lib.PRAG_BF16}.get(hidden.dtype)
+    if dt is None:
+        hidden, dt = hidden.float(), _lib.PRAG_F32
+    B, T, d = hidden.shape
+    mask = attention_mask.to(device=hidden.device, dtype=torch.int64).contiguous()
+    out = torch.empty((B, d), dtype=torch.float32, device=hidden.device)
+    with torch.cuda.device(hidden.device):
+        _lib.check(_lib.lib().prag_pool_masked_mean(ctypes.c_void_p(hidden.data_ptr()), dt, ctypes.c_void_p(mask.data_ptr()),
+                                                    B, T, d, ctypes.c_void_p(out.data_ptr()),
+                                                    _lib.current_stream_ptr(hidden.device)))
+    return out
+
+
 def return_evidences(retrieved_passages) -> str:
     """exp_rag.py:369-379 (dense branch: passages are plain strings)."""
     return "\n".join(f"passage {n + 1}: {p}" for n, p in enumerate(retrieved_passages))

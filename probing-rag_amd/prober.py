@@ -44,7 +44,9 @@ def _x_dtype(x):
         return _lib.PRAG_F32
     if x.dtype == torch.float16:
         return _lib.PRAG_F16
-    raise TypeError(f"activations must be float32 or float16, got {x.dtype}")
+    if x.dtype == torch.bfloat16:
+        return _lib.PRAG_BF16
+    raise TypeError(f"activations must be float32, float16 or bfloat16, got {x.dtype}")
 
 
 class HipProberEnsemble:

@@ -177,3 +177,25 @@ def test_pooling_kernels(torch_cuda, golden):
     pool.observe(1, torch.from_numpy(passes[0]).cuda())
     pool.observe(1, torch.from_numpy(passes[1]).cuda())
     np.testing.assert_allclose(pool.pooled()[0].cpu().numpy(), passes[0].sum(axis=1), atol=1e-5)
+
+
+def test_bf16_activations_and_masked_mean_pool(torch_cuda):
+    """bf16 hidden states (the usual HF dtype) go through the fp32 pre-normalise path; the
+    encoder-side masked mean pool matches its definition."""
+    torch = torch_cuda
+    import probing_rag_amd as pra
+    case = cases.PROBER_CASES[2]
+    ens, _ = _ensemble(case, "f32")
+    x = cases.case_x(case)
+    xb = torch.from_numpy(x).cuda().bfloat16()
+    got = ens.forward(xb).cpu().numpy()
+    want = _oracle_effective(ens, xb.float().cpu().numpy())
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+    rng = np.random.default_rng(3)
+    h = rng.standard_normal((5, 17, 768)).astype(np.float32)
+    lens = [17, 1, 9, 4, 12]
+    mask = np.array([[1] * n + [0] * (17 - n) for n in lens], np.int64)
+    want = (h * mask[:, :, None]).sum(1) / mask.sum(1, keepdims=True)
+    for dt, tol in ((torch.float32, 1e-6), (torch.float16, 2e-3), (torch.bfloat16, 2e-2)):
+        got = pra.masked_mean_pool(torch.from_numpy(h).cuda().to(dt), torch.from_numpy(mask).cuda()).cpu().numpy()
+        np.testing.assert_allclose(got, want, atol=tol, rtol=0)
