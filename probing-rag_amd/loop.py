@@ -88,6 +88,22 @@ def pool_ragged(acts, pred_lens, mean: bool = True):
     return out
 
 
+def method_2_eval(prober, activations, labels, pred_lens):
+    """train.py:199-208, 222-225 / utils.py:181-203 (`_method_2_util` + `return_acc`), forward
+    only: ragged last-`pred_len` MEAN pool (HIP) -> prober (HIP) -> softmax(-1) ->
+    CrossEntropyLoss applied to the probabilities (the reference's double softmax,
+    train.py:149-150) -> argmax accuracy.  activations [B,T,d] on the GPU.
+    Returns (accuracy rounded to 4 places, n, loss, probs) - the reference returns the first
+    three."""
+    import torch
+    pooled = pool_ragged(activations, pred_lens, mean=True)
+    probs = torch.softmax(prober(pooled), dim=-1)
+    labels = torch.as_tensor(labels, device=probs.device).long()
+    loss = torch.nn.functional.cross_entropy(probs, labels)
+    correct = (torch.argmax(probs, dim=-1) == labels).sum().item()
+    return round(correct / labels.size(0), 4), len(labels), loss, probs
+
+
 def masked_mean_pool(hidden, attention_mask):
     """Contriever / sentence-transformers mean pooling (utils.py:365-366 ->
     SentenceTransformer.encode, third-party) on device: hidden [B,T,d] (f32/f16/bf16),

@@ -199,3 +199,17 @@ def test_bf16_activations_and_masked_mean_pool(torch_cuda):
     for dt, tol in ((torch.float32, 1e-6), (torch.float16, 2e-3), (torch.bfloat16, 2e-2)):
         got = pra.masked_mean_pool(torch.from_numpy(h).cuda().to(dt), torch.from_numpy(mask).cuda()).cpu().numpy()
         np.testing.assert_allclose(got, want, atol=tol, rtol=0)
+
+
+def test_method_2_eval_matches_reference_golden(torch_cuda, golden):
+    """train.py's evaluation forward (ragged mean pool -> prober -> double-softmax CE -> acc)."""
+    torch = torch_cuda
+    import probing_rag_amd as pra
+    case = cases.POOL_CASES[0]
+    acts, pred_lens, labels = cases.synth_pool_inputs(case)
+    p = pra.HipProber(case["d"], 2)
+    p.load_state_dict(cases.synth_state(case["wseed"], case["d"]))
+    acc, n, loss, probs = pra.method_2_eval(p, torch.from_numpy(acts).cuda(), labels, pred_lens)
+    np.testing.assert_allclose(probs.cpu().numpy(), golden[f"{case['name']}/probs"], atol=TOL, rtol=0)
+    assert abs(float(loss) - float(golden[f"{case['name']}/loss"])) < 1e-4
+    assert acc == round(float(golden[f"{case['name']}/acc"]), 4) and n == case["B"]
