@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--metric", default="cos", choices=["cos", "l2", "ip"])
     ap.add_argument("--store", default="f16", choices=["f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap-gate", type=int, default=1,
+                    help="1: run the gate on a second stream beside the HBM-bound scan (scan capped at "
+                         "n_cu-16 workgroups); 0: one stream")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -140,9 +143,26 @@ def main():
         q_np[i] = onp.synth_rows(42, r, 1, d_emb)[0] + 0.05 * q_np[i]
     q = torch.from_numpy(q_np).cuda()
 
+    main_stream = torch.cuda.current_stream()
+    side_stream = torch.cuda.Stream()
+    if args.overlap_gate:
+        n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        index.engine.index.set_scan_workgroups(n_cu - 16)
+
     def step():
-        ens.gate(x, 0, 0.0, out=gate_out)
-        return index.search(q, args.k)
+        if not args.overlap_gate:
+            ens.gate(x, 0, 0.0, out=gate_out)
+            return index.search(q, args.k)
+        # the search goes first so the scan's persistent workgroups settle on their CUs; the gate
+        # (independent work: the decisions of the NEXT batch) fills the CUs left free
+        start = torch.cuda.Event()
+        start.record(main_stream)                 # everything before this step
+        out = index.search(q, args.k)
+        side_stream.wait_event(start)             # NOT the search just enqueued
+        with torch.cuda.stream(side_stream):
+            ens.gate(x, 0, 0.0, out=gate_out)
+        main_stream.wait_stream(side_stream)      # the step ends when both are done
+        return out
 
     def fence():
         if world > 1:
@@ -222,7 +242,8 @@ def main():
                                f"top-{args.k} of {args.queries} queries over {args.docs} x 768 {args.store} docs",
                    "docs_total": args.docs, "docs_per_gpu": n_local, "d_emb": d_emb, "queries": args.queries,
                    "k": args.k, "gate_batch": args.gate_batch, "gate_batch_per_gpu": Bg, "d_model": d_model,
-                   "parallelism": f"corpus rows sharded x{world}; gate rows split x{world}"},
+                   "parallelism": f"corpus rows sharded x{world}; gate rows split x{world}",
+                   "gate_overlapped_with_scan": bool(args.overlap_gate)},
         "probe_decisions_per_s": args.gate_batch / (gate_avg_ms * 1e-3) if gate_ms else None,
         "scores_per_s_per_gpu": value / world,
         "planted_top1_recall": 1.0 if planted_ok else 0.0,

@@ -198,6 +198,11 @@ int prag_merge_topk_packed(const void* parts_dev, int64_t part_stride_bytes, int
 /* Read back stored rows [row0,row0+n) as float32 (what the scan sees). */
 int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n, float* out_host);
 
+/* Cap the number of workgroups (= CUs) the scan kernels occupy; 0 = all CUs.  The scan is
+ * HBM-bound, so leaving a few CUs free lets an independent kernel on another stream (e.g. the
+ * prober gate of the next batch) run concurrently instead of queueing behind it. */
+int prag_index_set_scan_workgroups(prag_index_t* ix, int n_workgroups);
+
 /* Measurement hook: as prag_prober_profile, around every scan_topk launch. */
 int prag_index_profile(prag_index_t* ix, int slots);
 int prag_index_profile_read(prag_index_t* ix, float* ms, int cap, int* n_out);

@@ -849,6 +849,7 @@ struct prag_index {
     int64_t* io_I = nullptr;
     int io_B = 0, io_k = 0;
     int n_cu = 256;
+    int wg_cap = 0;  // 0 = use every CU
     EventRing prof;
 };
 
@@ -1111,9 +1112,10 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         ix->q_cap = Bpad;
     }
     const int n_tiles = (int)((ix->ntotal + 31) / 32);
-    const int grid = use_qs ? std::max(1, std::min(ix->n_cu, (n_tiles + 3) / 4))
-                            : std::max(1, std::min(ix->n_cu, (n_tiles + 7) / 8));
-    const int n_lists = grid;  // one merged list per workgroup and query
+    const int cu_budget = ix->wg_cap > 0 ? std::min(ix->wg_cap, ix->n_cu) : ix->n_cu;
+    const int grid = use_qs ? std::max(1, std::min(cu_budget, (n_tiles + 3) / 4))
+                            : std::max(1, std::min(cu_budget, (n_tiles + 7) / 8));
+    const int n_lists = std::max(grid, 64);  // one merged list per workgroup and query (>= pre-pass grid)
     const size_t part_need = (size_t)n_lists * QT * kc;
     if (part_need > ix->part_cap) {
         if (ix->part_key) (void)hipFree(ix->part_key);
@@ -1249,6 +1251,12 @@ extern "C" int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n,
     hipError_t e = hipMemcpy(out_host, tmp, (size_t)ne * sizeof(float), hipMemcpyDeviceToHost);
     (void)hipFree(tmp);
     PRAG_HIP(e);
+    return PRAG_OK;
+}
+
+extern "C" int prag_index_set_scan_workgroups(prag_index_t* ix, int n_workgroups) {
+    PRAG_REQUIRE(ix != nullptr && n_workgroups >= 0, PRAG_EINVAL, "prag_index_set_scan_workgroups: bad argument");
+    ix->wg_cap = n_workgroups;
     return PRAG_OK;
 }
 

@@ -234,6 +234,14 @@ def batch_topk_sim(model_retr, query, index, k: int):
     return D, I
 
 
+def _ix_set_scan_workgroups(self, n: int):
+    """Cap the CUs the (HBM-bound) scan occupies so another stream's kernel can run beside it."""
+    _lib.check(_lib.lib().prag_index_set_scan_workgroups(self._h, int(n)))
+
+
+HipFlatIndex.set_scan_workgroups = _ix_set_scan_workgroups
+
+
 def _ix_profile(self, slots: int):
     """Record HIP events around every scan_topk launch (0 disables)."""
     _lib.check(_lib.lib().prag_index_profile(self._h, int(slots)))
