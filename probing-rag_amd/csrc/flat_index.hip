@@ -114,26 +114,41 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
     if (b >= Bpad) return;
     if (lane == 0) g_tau[b] = 0xFF800000u;  // sortable(+inf): the scan's chip-wide pruning bound
     if (b >= B) {
-        for (int c = lane; c < d; c += 64) q16[(int64_t)b * d + c] = (_Float16)0.f;
+        for (int c = lane * 4; c < d; c += 256) *reinterpret_cast<half4*>(q16 + (int64_t)b * d + c) = half4{0, 0, 0, 0};
         return;
     }
     const float* s = q + (int64_t)b * d;
+    // d is a multiple of 64: 4 consecutive elements per lane per step, at most 6 steps (d <= 1536)
+    f32x4 v[6];
+    double ss = 0.0;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int c = lane * 4 + it * 256;
+        v[it] = c < d ? *reinterpret_cast<const f32x4*>(s + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss = fma((double)v[it][e], (double)v[it][e], ss);
+    }
     double nrm = 1.0;
     if (normalise) {
-        double ss = 0.0;
-        for (int c = lane; c < d; c += 64) {
-            const double v = (double)s[c];
-            ss = fma(v, v, ss);
-        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
         nrm = sqrt(ss);
         if (!(nrm > 0.0)) nrm = 1.0;
     }
-    for (int c = lane; c < d; c += 64) {
-        const float v = normalise ? (float)((double)s[c] / nrm) : s[c];
-        q32[(int64_t)b * d + c] = v;
-        q16[(int64_t)b * d + c] = (_Float16)v;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < d) {
+            f32x4 o;
+            half4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = normalise ? (float)((double)v[it][e] / nrm) : v[it][e];
+                h[e] = (_Float16)o[e];
+            }
+            *reinterpret_cast<f32x4*>(q32 + (int64_t)b * d + c) = o;
+            *reinterpret_cast<half4*>(q16 + (int64_t)b * d + c) = h;
+        }
     }
 }
 
@@ -218,13 +233,28 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
     uint32_t* s_tau = reinterpret_cast<uint32_t*>(smem + QT * qstride + 8 * 4096);  // [QT] sortable keys
     if (tid < QT) s_tau[tid] = a.g_tau[tid];  // +inf, or the pre-pass bound (valid: subset of the shard)
 
-    // ---- query tile -> LDS (swizzled 16-B pieces) --------------------------
+    // ---- query tile -> LDS (swizzled 16-B pieces); loads issued in batches of 8 so their
+    //      latencies overlap (a one-load-at-a-time loop costs ~25 us per launch) -----------
     {
         const int ppr = d >> 3;  // pieces per row
-        for (int e = tid; e < QT * ppr; e += 512) {
-            const int row = e / ppr, p = e - row * ppr;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(a.q16 + (int64_t)row * d + 8 * p);
-            *reinterpret_cast<u32x4*>(s_q + row * qstride + (((p & ~15) | ((p ^ row) & 15)) << 4)) = v;
+        const int total = QT * ppr;
+        for (int e0 = tid; e0 < total; e0 += 512 * 8) {
+            u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 512;
+                const int ec = e < total ? e : total - 1;
+                const int row = ec / ppr, pc = ec - row * ppr;
+                v[u] = *reinterpret_cast<const u32x4*>(a.q16 + (int64_t)row * d + 8 * pc);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 512;
+                if (e < total) {
+                    const int row = e / ppr, pc = e - row * ppr;
+                    *reinterpret_cast<u32x4*>(s_q + row * qstride + (((pc & ~15) | ((pc ^ row) & 15)) << 4)) = v[u];
+                }
+            }
         }
     }
     __syncthreads();
@@ -622,20 +652,32 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
 // merge the per-lane lists of one query tile: grid = queries, 256 threads
 // ---------------------------------------------------------------------------
 
+// KC smallest (key,id) pairs of one query: every thread folds its share of the per-workgroup
+// lists into a sorted register list, each wave selects its KC best with shuffles only, the four
+// wave results are ranked by counting (ids are unique, so ranks are unique).
 template <int KC>
 __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restrict__ part_key,
                                                          const int* __restrict__ part_idx, int n_lists,
                                                          int QT, int* __restrict__ cand_idx /*[q][KC]*/,
                                                          uint32_t* __restrict__ tau_out /*[q] or null*/) {
-    __shared__ unsigned long long s_min[4];
+    __shared__ unsigned long long s_w[4 * KC];
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
     const unsigned long long kInf = ~0ull;
     unsigned long long loc[KC];
 #pragma unroll
     for (int j = 0; j < KC; ++j) loc[j] = kInf;
     for (int l = tid; l < n_lists; l += 256) {
         const int64_t o = ((int64_t)l * QT + q) * KC;
+        if (loc[0] == kInf) {  // first list of this thread: already sorted, take it whole
+#pragma unroll
+            for (int j = 0; j < KC; ++j) {
+                const int idx = part_idx[o + j];
+                loc[j] = idx == kIdxSentinel ? kInf : pack_key(part_key[o + j], idx);
+            }
+            continue;
+        }
         for (int j = 0; j < KC; ++j) {
             const int idx = part_idx[o + j];
             if (idx == kIdxSentinel) break;  // lists are sorted, sentinels last
@@ -653,6 +695,7 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
             }
         }
     }
+    // wave-level selection: KC rounds of a 64-lane min, the owner pops (no barriers)
     for (int round = 0; round < KC; ++round) {
         unsigned long long m = loc[0];
 #pragma unroll
@@ -660,22 +703,27 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
             const unsigned long long other = __shfl_xor(m, o, 64);
             m = other < m ? other : m;
         }
-        if ((tid & 63) == 0) s_min[tid >> 6] = m;
-        __syncthreads();
-        unsigned long long g = s_min[0];
-#pragma unroll
-        for (int i = 1; i < 4; ++i) g = s_min[i] < g ? s_min[i] : g;
-        __syncthreads();
-        if (loc[0] == g && g != kInf) {  // unique owner: every row id appears once
+        if (loc[0] == m && m != kInf) {  // unique owner: every row id appears once
 #pragma unroll
             for (int i = 0; i + 1 < KC; ++i) loc[i] = loc[i + 1];
             loc[KC - 1] = kInf;
         }
-        if (tid == 0) {
-            cand_idx[(int64_t)q * KC + round] = (g == kInf) ? -1 : (int)(uint32_t)g;
+        if (lane == 0) s_w[w * KC + round] = m;
+    }
+    __syncthreads();
+    // rank the 4*KC survivors by counting; rank < KC goes out
+    for (int e = tid; e < 4 * KC; e += 256) {
+        const unsigned long long v = s_w[e];
+        int rank = 0;
+        for (int j = 0; j < 4 * KC; ++j) {
+            const unsigned long long u = s_w[j];
+            rank += (u < v) || (u == v && j < e);   // sentinels tie: order by position
+        }
+        if (rank < KC) {
+            cand_idx[(int64_t)q * KC + rank] = (v == kInf) ? -1 : (int)(uint32_t)v;
             // pre-pass use: the KC-th best key of the rows seen = a valid pruning bound for the
             // full scan (those rows are a subset of the shard)
-            if (tau_out && round == KC - 1 && g != kInf) tau_out[q] = (uint32_t)(g >> 32);
+            if (tau_out && rank == KC - 1 && v != kInf) tau_out[q] = (uint32_t)(v >> 32);
         }
     }
 }
@@ -1115,8 +1163,8 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     const int cu_budget = ix->wg_cap > 0 ? std::min(ix->wg_cap, ix->n_cu) : ix->n_cu;
     const int grid = use_qs ? std::max(1, std::min(cu_budget, (n_tiles + 3) / 4))
                             : std::max(1, std::min(cu_budget, (n_tiles + 7) / 8));
-    const int n_lists = std::max(grid, 64);  // one merged list per workgroup and query (>= pre-pass grid)
-    const size_t part_need = (size_t)n_lists * QT * kc;
+    const int n_lists = grid;  // one merged list per workgroup and query
+    const size_t part_need = (size_t)std::max(grid, 64) * QT * kc;  // the pre-pass may use up to 64 workgroups
     if (part_need > ix->part_cap) {
         if (ix->part_key) (void)hipFree(ix->part_key);
         if (ix->part_idx) (void)hipFree(ix->part_idx);
