@@ -528,14 +528,11 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
     f32x4 acc[8];  // 8 tiles of 16 rows; C layout: query = lane&15, row = 4*(lane>>4) + reg
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // swizzled fragment offsets of k-step 0 (tile t): constant for the whole scan; k-step 1
-    // is the same address with byte-bit 6 flipped ((4 | g4) ^ sw == 4 ^ (g4 ^ sw))
-    int a_rd[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int row = 16 * t + r16;
-        a_rd[t] = row * 128 + ((g4 ^ ((row >> 1) & 7)) << 4);
-    }
+    // swizzled fragment offsets: row = 16t + r16, so the swizzle term ((row>>1)&7) does not depend
+    // on the tile t: address = base[s2] + t*2048 (+ stage offset), both folded into ds_read immediates.
+    // k-step 1 is k-step 0 with byte-bit 6 flipped ((4 | g4) ^ sw == 4 ^ (g4 ^ sw)).
+    const int a_base0 = r16 * 128 + ((g4 ^ ((r16 >> 1) & 7)) << 4);
+    const int a_base1 = a_base0 ^ 64;
 
     if (n_my > 0) {
         const int g0 = blockIdx.x;
@@ -567,10 +564,13 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
                         half8 av[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            av[u] = *reinterpret_cast<const half8*>(xs + (a_rd[tb + u] ^ (s2 << 6)));
+                            av[u] = *reinterpret_cast<const half8*>(xs + (s2 ? a_base1 : a_base0) + (tb + u) * 2048);
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
                             acc[tb + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[u], qf[2 * c + s2], acc[tb + u], 0, 0, 0);
+                        // pin the order: all four LDS reads first (their latencies overlap), then the MFMAs
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
             }
