@@ -108,10 +108,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(1, n_dev)   # (several ranks per GPU only in the gloo smoke mode below)
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL ("nccl") is the product path.  PRAG_BENCH_BACKEND=gloo exists only to exercise the
+        # multi-rank control flow on a box with fewer GPUs than ranks (collectives staged via host).
+        backend = os.environ.get("PRAG_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     import probing_rag_amd as pra
     from oracle import oracle_np as onp
@@ -146,7 +154,7 @@ def main():
     main_stream = torch.cuda.current_stream()
     side_stream = torch.cuda.Stream()
     if args.overlap_gate:
-        n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        n_cu = torch.cuda.get_device_properties(dev_index).multi_processor_count
         index.engine.index.set_scan_workgroups(n_cu - 16)
 
     def step():

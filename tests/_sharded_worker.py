@@ -1,0 +1,47 @@
+"""Worker for tests/test_gpu_sharded_ranks.py: run under torch.distributed.run with 2 ranks on ONE
+GPU (gloo for the exchange, since RCCL refuses two ranks per device) - the real HIP local search,
+packed result buffers, all-gather and packed merge of ShardedFlatIndex."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    import probing_rag_amd as pra
+    from oracle import oracle_np as onp
+    N, d, k = 200_001, 768, 10                      # ragged split: 100001 + 100000 rows
+    X = onp.synth_rows(42, 0, N, d)
+    X[150_000] = X[7]                                # tie across shards -> lowest id
+    Q = onp.synth_rows(7, 0, 70, d)                  # > 64 queries: query-stationary kernel
+    Q[0] = X[7]
+    for metric in ("l2", "cos"):
+        ix = pra.ShardedFlatIndex(d, metric, "f16")
+        lo, hi = pra.partition_rows(N, world, rank)
+        ix.add_local(X[lo:hi])
+        ix.sync()
+        assert ix.ntotal == N and ix.id_offset == lo
+        D, I = ix.search(torch.from_numpy(Q).cuda(), k)
+        whole = pra.HipFlatIndex(d, metric, "f16")
+        whole.add(X)
+        D0, I0 = whole.search(torch.from_numpy(Q).cuda(), k)
+        assert torch.equal(I, I0), (rank, metric)
+        assert torch.equal(D, D0), (rank, metric)
+        if metric == "l2":
+            assert I[0, :2].tolist() == [7, 150_000]
+    dist.barrier()
+    if rank == 0:
+        print("SHARDED_OK")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
