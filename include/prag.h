@@ -198,6 +198,12 @@ int prag_merge_topk_packed(const void* parts_dev, int64_t part_stride_bytes, int
 /* Read back stored rows [row0,row0+n) as float32 (what the scan sees). */
 int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n, float* out_host);
 
+/* Robustness knob for near-duplicate-dense corpora: the fused scan keeps KC >= k candidates per
+ * query on fp16 operands and the float64 rerank orders them; the returned ids are exact unless more
+ * than KC-k rows lie within the fp16 scoring error of the k-th result.  depth = 0 picks the default
+ * (8 for k<=5, 16 for k<=12, 32 for k<=26); 16 or 32 force a deeper candidate list. */
+int prag_index_set_candidate_depth(prag_index_t* ix, int depth);
+
 /* Cap the number of workgroups (= CUs) the scan kernels occupy; 0 = all CUs.  The scan is
  * HBM-bound, so leaving a few CUs free lets an independent kernel on another stream (e.g. the
  * prober gate of the next batch) run concurrently instead of queueing behind it. */

@@ -72,6 +72,7 @@ SIGNATURES = {
     "prag_merge_topk": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "prag_merge_topk_packed": (_I, [_P, _L, _I, _I, _I, _I, _P, _P, _P]),
     "prag_index_reconstruct": (_I, [_P, _L, _L, _P]),
+    "prag_index_set_candidate_depth": (_I, [_P, _I]),
     "prag_index_set_scan_workgroups": (_I, [_P, _I]),
     "prag_index_profile": (_I, [_P, _I]),
     "prag_index_profile_read": (_I, [_P, _FP, _I, ctypes.POINTER(_I)]),

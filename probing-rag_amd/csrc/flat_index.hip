@@ -898,6 +898,7 @@ struct prag_index {
     int io_B = 0, io_k = 0;
     int n_cu = 256;
     int wg_cap = 0;  // 0 = use every CU
+    int kc_min = 0;  // 0 = default candidate depth for k
     EventRing prof;
 };
 
@@ -1115,7 +1116,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     PRAG_REQUIRE(B >= 0 && k >= 1, PRAG_EINVAL, "B=%d k=%d", B, k);
     if (B == 0) return PRAG_OK;
     PRAG_REQUIRE(q && D && I, PRAG_EINVAL, "prag_index_search: NULL pointer");
-    const int kc = pick_kc(k);
+    const int kc = std::max(pick_kc(k), pick_kc(k) ? ix->kc_min : 0);
     PRAG_REQUIRE(kc != 0, PRAG_EUNSUPPORTED, "k=%d: the fused top-k keeps at most 26 results per query", k);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
@@ -1299,6 +1300,14 @@ extern "C" int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n,
     hipError_t e = hipMemcpy(out_host, tmp, (size_t)ne * sizeof(float), hipMemcpyDeviceToHost);
     (void)hipFree(tmp);
     PRAG_HIP(e);
+    return PRAG_OK;
+}
+
+extern "C" int prag_index_set_candidate_depth(prag_index_t* ix, int depth) {
+    PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
+    PRAG_REQUIRE(depth == 0 || depth == 8 || depth == 16 || depth == 32, PRAG_EINVAL,
+                 "candidate depth %d: use 0 (default), 8, 16 or 32", depth);
+    ix->kc_min = depth;
     return PRAG_OK;
 }
 

@@ -234,6 +234,15 @@ def batch_topk_sim(model_retr, query, index, k: int):
     return D, I
 
 
+def _ix_set_candidate_depth(self, depth: int):
+    """Keep `depth` (0=default, 8, 16, 32) candidates per query through the fp16 scan before the
+    float64 rerank - deeper lists tolerate more near-ties at the k-th result."""
+    _lib.check(_lib.lib().prag_index_set_candidate_depth(self._h, int(depth)))
+
+
+HipFlatIndex.set_candidate_depth = _ix_set_candidate_depth
+
+
 def _ix_set_scan_workgroups(self, n: int):
     """Cap the CUs the (HBM-bound) scan occupies so another stream's kernel can run beside it."""
     _lib.check(_lib.lib().prag_index_set_scan_workgroups(self._h, int(n)))

@@ -190,3 +190,27 @@ def test_c3_full_size_properties():
     D0, I0 = oracle_c.flat_search(xs, Q[pick], k, onp.METRIC_COS)
     assert np.array_equal(I[pick], I0)
     np.testing.assert_allclose(D[pick], D0, atol=1e-4, rtol=0)
+
+
+def test_candidate_depth_knob_resolves_dense_near_ties():
+    """30 rows within ~1e-4 of each other around the query: the default 8-deep list for k=5 may
+    pick a different near-tie than the float64 definition; a 32-deep list must be exact."""
+    import probing_rag_amd as pra
+    N, d, k = 20_000, 256, 5
+    X = onp.synth_rows(21, 0, N, d)
+    q = onp.synth_rows(22, 0, 1, d)
+    rng = np.random.default_rng(5)
+    near = rng.choice(N, 30, replace=False)
+    X[near] = q[0] + 3e-4 * rng.standard_normal((30, d)).astype(np.float32)
+    ix = pra.HipFlatIndex(d, "l2", "f32")
+    ix.add(X)
+    D0, I0 = onp.flat_search(X, q, k, onp.METRIC_L2)
+    ix.set_candidate_depth(32)
+    D, I = ix.search(q, k)
+    assert np.array_equal(I, I0)
+    np.testing.assert_allclose(D, D0, rtol=1e-4)
+    ix.set_candidate_depth(0)
+    D1, I1 = ix.search(q, k)
+    assert set(I1[0].tolist()) <= set(near.tolist())          # still the right neighbourhood
+    with pytest.raises(pra.PragError, match="PRAG_EINVAL"):
+        ix.set_candidate_depth(5)
