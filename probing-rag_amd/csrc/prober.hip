@@ -7,30 +7,29 @@
 //   sum over layers and the threshold compare.
 //
 // How (DESIGN.md "Kernel 1"):
-//   * One workgroup = 4 waves (one per SIMD) = one tile of 32*CT batch rows of
-//     one layer.  The GEMMs are computed TRANSPOSED, H^T[n, m] = W[n, :] . x[m, :]
-//     on v_mfma_f32_32x32x16_f16: the weight rows sit on the MFMA A operand, the
-//     batch rows on the B operand, so every wave owns 128 of the 512 hidden units
-//     for all of the tile's rows.
-//   * Weights are pre-packed at load time in MFMA-fragment-major order (one
-//     fully coalesced 1 KiB global_load_dwordx4 per fragment per wave, straight
-//     to VGPRs - a wave's weight rows are not shared with the other waves, so
-//     an LDS round trip would be pure overhead).  LayerNorm affines are folded
-//     into the following Linear at load time.
-//   * Activations (shared by the 4 waves) are staged through LDS in full 128-B
-//     lines with an XOR swizzle that makes the ds_read_b128 fragment reads
-//     conflict-free; double-buffered, one barrier per 64-wide K step.
-//   * fp16 activations are fed to the MFMA *raw* (exact); LayerNorm-0 is
-//     applied in the epilogue:  rstd*(W~x - mu*rowsum(W~)) + b~ , with mu/rstd
-//     computed in-flight from the staged fragments (shifted sums + Chan merge).
-//   * The fc1 accumulator tile has the hidden index in its registers and the
-//     batch row on its lane - exactly the B-operand layout of the next MFMA
-//     (k order permuted; W2 is pre-permuted to match), so LN1/SiLU run
-//     lane-locally and fc2's operand crosses waves through LDS as ready-made
-//     1 KiB fragments (hi + lo fp16 terms: ~22 bits).
-//   * fc3 (512->2), the cross-wave reductions and the logits store finish the
-//     launch; a second tiny kernel does softmax / sum over layers / threshold in
-//     the reference's own order (deterministic, no float atomics).
+//   * One workgroup = NWV waves (8 = two per SIMD for 64/128-row tiles, 4 for 32-row tiles) =
+//     one tile of 32*CT batch rows of one layer; XCD-aware block -> (layer, tile) placement.
+//     The GEMMs are computed TRANSPOSED, H^T[n, m] = W[n, :] . x[m, :] on
+//     v_mfma_f32_32x32x16_f16: the weight rows sit on the MFMA A operand, the batch rows on
+//     the B operand, so every wave owns 512/NWV hidden units for all of the tile's rows.
+//   * Weights are pre-packed at load time in MFMA-fragment-major order (one fully coalesced
+//     1 KiB global_load_dwordx4 per fragment per wave, straight to VGPRs - a wave's weight rows
+//     are not shared with the other waves, so an LDS round trip would be pure overhead).
+//     LayerNorm affines are folded into the following Linear at load time.
+//   * Activations (shared by all waves) are staged through LDS in full 128-B lines with an
+//     XOR swizzle that makes the ds_read_b128 fragment reads conflict-free; double-buffered,
+//     one raw s_barrier per 64-wide K step, fragments of the next sub-step prefetched.
+//   * No LayerNorm is applied element-wise.  fp16 activations are fed to the MFMA *raw*
+//     (exact) and LN0 becomes  rstd*(W~x - mu*rowsum(W~)) + b~  in the epilogue, with
+//     sum x / sum x^2 from v_dot2_f32_f16 on the staged fragments; LN1 and LN2 are folded the
+//     same way into the fc2 / fc3 epilogues from one-pass sums of the SiLU outputs.
+//   * The fc1 accumulator tile has the hidden index in its registers and the batch row on its
+//     lane - exactly the B-operand layout of the next MFMA (k order permuted; W2 is
+//     pre-permuted to match), so SiLU runs lane-locally and fc2's operand crosses waves
+//     through LDS as ready-made 1 KiB fragments (hi + lo fp16 terms: ~22 bits).
+//   * fc3 (512->2) partial dot products, the cross-wave reductions and the logits store finish
+//     the launch; a second tiny kernel does softmax / sum over layers / threshold in the
+//     reference's own order (deterministic, no float atomics).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
