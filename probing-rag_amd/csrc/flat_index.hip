@@ -108,13 +108,17 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, int B, int Bpad, int d,
                                                           int normalise, float* __restrict__ q32,
-                                                          _Float16* __restrict__ q16, uint32_t* __restrict__ g_tau) {
+                                                          _Float16* __restrict__ q16, _Float16* __restrict__ q16lo,
+                                                          uint32_t* __restrict__ g_tau) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= Bpad) return;
     if (lane == 0) g_tau[b] = 0xFF800000u;  // sortable(+inf): the scan's chip-wide pruning bound
     if (b >= B) {
-        for (int c = lane * 4; c < d; c += 256) *reinterpret_cast<half4*>(q16 + (int64_t)b * d + c) = half4{0, 0, 0, 0};
+        for (int c = lane * 4; c < d; c += 256) {
+            *reinterpret_cast<half4*>(q16 + (int64_t)b * d + c) = half4{0, 0, 0, 0};
+            *reinterpret_cast<half4*>(q16lo + (int64_t)b * d + c) = half4{0, 0, 0, 0};
+        }
         return;
     }
     const float* s = q + (int64_t)b * d;
@@ -140,14 +144,16 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
         const int c = lane * 4 + it * 256;
         if (c < d) {
             f32x4 o;
-            half4 h;
+            half4 h, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 o[e] = normalise ? (float)((double)v[it][e] / nrm) : v[it][e];
                 h[e] = (_Float16)o[e];
+                lo[e] = (_Float16)(o[e] - (float)h[e]);
             }
             *reinterpret_cast<f32x4*>(q32 + (int64_t)b * d + c) = o;
             *reinterpret_cast<half4*>(q16 + (int64_t)b * d + c) = h;
+            *reinterpret_cast<half4*>(q16lo + (int64_t)b * d + c) = lo;
         }
     }
 }
@@ -158,7 +164,8 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
 struct ScanArgs {
     const void* rows;        // [N][d] f16 or f32
     const float* xnorm;      // [roundup(N,32)]
-    const _Float16* q16;     // [QT][d] this pass's query tile
+    const _Float16* q16;     // [QT][d] this pass's query tile (fp16 rounding of the f32 query)
+    const _Float16* q16lo;   // [QT][d] fp16(q32 - q16): second term of the high-precision selection
     int64_t N;
     int d;
     int qstride;             // LDS bytes per query row (multiple of 256)
@@ -217,42 +224,60 @@ struct TopList {
     }
 };
 
-template <int QT, int KC, bool F32>
+// HP ("high-precision selection", QT == 32 only): the query is carried as q16 + q16lo and fp32
+// rows as hi + lo halves, 2 (fp16 rows) or 3 (fp32 rows) MFMAs per k-step - the matrix pipe is
+// mostly idle in this HBM-bound kernel - so the selection keys are accurate to f32 accumulation
+// (~1e-7 relative) instead of the fp16 rounding of the operands (~3e-5): the reference's own call
+// shape (a handful of queries, fp32 rows) no longer depends on how many near-ties surround the
+// k-th result.
+template <int QT, int KC, bool F32, bool HP>
 __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
+    static_assert(!HP || QT == 32, "high-precision selection is built for one 32-query tile");
     constexpr int NQ = QT / 32;
+    constexpr bool SPLIT_ROWS = HP && F32;          // rows staged as hi + lo halves
+    constexpr int CHK = SPLIT_ROWS ? 32 : 64;       // elements per staged chunk (4 KiB of LDS per wave either way)
+    constexpr int KS = CHK / 16;                    // MFMA k-steps per chunk
+    constexpr int RSB = CHK * 2;                    // bytes per staged row (fp16)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int d = a.d;
-    const int NCH = d >> 6;  // 64-element chunks per row
+    const int NCH = d / CHK;
     const int qstride = a.qstride;
+    constexpr int NQT = HP ? 2 : 1;                 // query tiles in LDS: q16 (+ q16lo)
     char* s_q = smem;
-    char* s_st = smem + QT * qstride + w * 4096;
-    uint32_t* s_tau = reinterpret_cast<uint32_t*>(smem + QT * qstride + 8 * 4096);  // [QT] sortable keys
+    char* s_ql = smem + QT * qstride;               // HP only
+    char* s_st = smem + NQT * QT * qstride + w * 4096;
+    uint32_t* s_tau = reinterpret_cast<uint32_t*>(smem + NQT * QT * qstride + 8 * 4096);  // [QT] sortable keys
     if (tid < QT) s_tau[tid] = a.g_tau[tid];  // +inf, or the pre-pass bound (valid: subset of the shard)
 
-    // ---- query tile -> LDS (swizzled 16-B pieces); loads issued in batches of 8 so their
+    // ---- query tile(s) -> LDS (swizzled 16-B pieces); loads issued in batches of 8 so their
     //      latencies overlap (a one-load-at-a-time loop costs ~25 us per launch) -----------
     {
         const int ppr = d >> 3;  // pieces per row
         const int total = QT * ppr;
-        for (int e0 = tid; e0 < total; e0 += 512 * 8) {
-            u32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * 512;
-                const int ec = e < total ? e : total - 1;
-                const int row = ec / ppr, pc = ec - row * ppr;
-                v[u] = *reinterpret_cast<const u32x4*>(a.q16 + (int64_t)row * d + 8 * pc);
-            }
+        for (int plane = 0; plane < NQT; ++plane) {
+            const _Float16* qsrc = plane == 0 ? a.q16 : a.q16lo;
+            char* qdst = plane == 0 ? s_q : s_ql;
+            for (int e0 = tid; e0 < total; e0 += 512 * 8) {
+                u32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * 512;
-                if (e < total) {
-                    const int row = e / ppr, pc = e - row * ppr;
-                    *reinterpret_cast<u32x4*>(s_q + row * qstride + (((pc & ~15) | ((pc ^ row) & 15)) << 4)) = v[u];
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * 512;
+                    const int ec = e < total ? e : total - 1;
+                    const int row = ec / ppr, pc = ec - row * ppr;
+                    v[u] = *reinterpret_cast<const u32x4*>(qsrc + (int64_t)row * d + 8 * pc);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * 512;
+                    if (e < total) {
+                        const int row = e / ppr, pc = e - row * ppr;
+                        *reinterpret_cast<u32x4*>(qdst + row * qstride + (((pc & ~15) | ((pc ^ row) & 15)) << 4)) = v[u];
+                    }
                 }
             }
         }
@@ -267,12 +292,19 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
 #pragma unroll
     for (int t = 0; t < NQ; ++t) top[t].init();
 
-    // staging geometry
-    constexpr int NLD = F32 ? 8 : 4;  // 16-B loads per lane per chunk
+    // staging geometry: NLD 16-B loads per lane per chunk; a staged row is RSB bytes of fp16 and
+    // its 16-B pieces are XOR-swizzled so that the fragment reads below are conflict-free
+    //   64-element chunks (128-B rows): slot = piece ^ ((row>>1)&7)
+    //   32-element chunks ( 64-B rows): slot = piece ^ ((row>>2)&3)
+    constexpr int NLD = SPLIT_ROWS ? 4 : (F32 ? 8 : 4);
     int st_doc[NLD], st_dst[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        if constexpr (F32) {
+        if constexpr (SPLIT_ROWS) {   // 32 rows x 128 B of f32 per chunk: lane -> 4 floats -> 8 B of hi, 8 B of lo
+            const int doc = 8 * i + (lane >> 3), q4 = lane & 7;
+            st_doc[i] = doc;
+            st_dst[i] = doc * 64 + (((q4 >> 1) ^ ((doc >> 2) & 3)) << 4) + (q4 & 1) * 8;
+        } else if constexpr (F32) {
             const int doc = 4 * i + (lane >> 4), q4 = lane & 15;
             st_doc[i] = doc;
             st_dst[i] = doc * 128 + (((q4 >> 1) ^ ((doc >> 1) & 7)) << 4) + (q4 & 1) * 8;
@@ -282,9 +314,9 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
             st_dst[i] = doc * 128 + ((q ^ ((doc >> 1) & 7)) << 4);
         }
     }
-    const int col_b = F32 ? (lane & 15) * 16 : (lane & 7) * 16;  // byte offset inside the chunk
+    const int col_b = SPLIT_ROWS ? (lane & 7) * 16 : (F32 ? (lane & 15) * 16 : (lane & 7) * 16);  // byte offset inside the chunk
     const int64_t row_bytes = (int64_t)d * (F32 ? 4 : 2);
-    const int chunk_bytes = F32 ? 256 : 128;
+    const int chunk_bytes = CHK * (F32 ? 4 : 2);
     const char* rows = reinterpret_cast<const char*>(a.rows);
 
     // Two chunks of every lane's 16-B pieces are kept in flight (ldA / ldB).  The
@@ -335,7 +367,17 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const u32x4 v = ld[i];
-            if constexpr (F32) {
+            if constexpr (SPLIT_ROWS) {
+                const f32x4 f = __builtin_bit_cast(f32x4, v);
+                half4 h, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = (_Float16)f[e];
+                    lo[e] = (_Float16)(f[e] - (float)h[e]);
+                }
+                *reinterpret_cast<half4*>(s_st + st_dst[i]) = h;
+                *reinterpret_cast<half4*>(s_st + 2048 + st_dst[i]) = lo;
+            } else if constexpr (F32) {
                 const f32x4 f = __builtin_bit_cast(f32x4, v);
                 half4 h;
 #pragma unroll
@@ -348,15 +390,25 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
         issue(ld, tile_nx, c_nx);
         advance(tile_nx, c_nx);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const half8 av = *reinterpret_cast<const half8*>(s_st + a_off + (((2 * s + hh) ^ a_sw) << 4));
-            const int P = c_cur * 8 + 2 * s + hh;
+        for (int s = 0; s < KS; ++s) {
+            const int a_addr = SPLIT_ROWS ? (r * 64 + (((2 * s + hh) ^ ((r >> 2) & 3)) << 4))
+                                          : (a_off + (((2 * s + hh) ^ a_sw) << 4));
+            const half8 av = *reinterpret_cast<const half8*>(s_st + a_addr);
+            const int P = c_cur * (CHK / 8) + 2 * s + hh;
 #pragma unroll
             for (int t = 0; t < NQ; ++t) {
                 const int qrow = 32 * t + r;
-                const half8 bv = *reinterpret_cast<const half8*>(
-                    s_q + qrow * qstride + (((P & ~15) | ((P ^ qrow) & 15)) << 4));
+                const int q_addr = qrow * qstride + (((P & ~15) | ((P ^ qrow) & 15)) << 4);
+                const half8 bv = *reinterpret_cast<const half8*>(s_q + q_addr);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[t], 0, 0, 0);
+                if constexpr (HP) {
+                    const half8 bl = *reinterpret_cast<const half8*>(s_ql + q_addr);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bl, acc[t], 0, 0, 0);
+                    if constexpr (SPLIT_ROWS) {
+                        const half8 al = *reinterpret_cast<const half8*>(s_st + 2048 + a_addr);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bv, acc[t], 0, 0, 0);
+                    }
+                }
             }
         }
         if (c_cur == NCH - 1) {
@@ -884,7 +936,9 @@ struct prag_index {
     // search workspace
     float* q32 = nullptr;
     _Float16* q16 = nullptr;
+    _Float16* q16lo = nullptr;
     int q_cap = 0;
+    int hp_mode = 1;   // high-precision selection for <= 32 queries (0 = off)
     float* part_key = nullptr;
     int* part_idx = nullptr;
     size_t part_cap = 0;  // entries
@@ -1034,12 +1088,12 @@ static int pick_kc(int k) {
     return 0;  // a 64-deep per-lane list does not fit the 256-VGPR budget of 2 waves/SIMD
 }
 
-template <int QT, int KC, bool F32>
+template <int QT, int KC, bool F32, bool HP = false>
 static int launch_scan(const ScanArgs& a, int grid, hipStream_t st, EventRing& prof) {
-    const int lds_loop = QT * a.qstride + 8 * 4096 + QT * 4;   // queries + stages + thresholds
+    const int lds_loop = (HP ? 2 : 1) * QT * a.qstride + 8 * 4096 + QT * 4;   // queries + stages + thresholds
     const int lds_merge = 16 * 32 * KC * 8;                     // in-workgroup list merge
     const int lds = lds_loop > lds_merge ? lds_loop : lds_merge;
-    auto kern = scan_topk_kernel<QT, KC, F32>;
+    auto kern = scan_topk_kernel<QT, KC, F32, HP>;
     static bool attr_set = false;
     if (!attr_set) {
         PRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1053,12 +1107,12 @@ static int launch_scan(const ScanArgs& a, int grid, hipStream_t st, EventRing& p
     return PRAG_OK;
 }
 
-template <int QT, bool F32>
+template <int QT, bool F32, bool HP = false>
 static int dispatch_scan_kc(int kc, const ScanArgs& a, int grid, hipStream_t st, EventRing& prof) {
     switch (kc) {
-        case 8: return launch_scan<QT, 8, F32>(a, grid, st, prof);
-        case 16: return launch_scan<QT, 16, F32>(a, grid, st, prof);
-        case 32: return launch_scan<QT, 32, F32>(a, grid, st, prof);
+        case 8: return launch_scan<QT, 8, F32, HP>(a, grid, st, prof);
+        case 16: return launch_scan<QT, 16, F32, HP>(a, grid, st, prof);
+        case 32: return launch_scan<QT, 32, F32, HP>(a, grid, st, prof);
     }
     set_error("internal: KC=%d", kc);
     return PRAG_EUNSUPPORTED;
@@ -1149,14 +1203,18 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     const bool wide_ok = 64 * qstride + 8 * 4096 + 64 * 4 <= 160 * 1024 && !(ix->store == PRAG_F32 && kc == 32);
     const bool use_qs = B > 64 && qs_supported(ix->d, ix->store, kc);  // 128 queries per corpus pass
     const int QT = use_qs ? 128 : ((B > 32 && wide_ok) ? 64 : 32);
+    // <= 32 queries (the reference's call shape): high-precision selection, if two query tiles fit LDS
+    const bool use_hp = ix->hp_mode && QT == 32 && 2 * 32 * qstride + 8 * 4096 + 32 * 4 <= 160 * 1024;
     const int Bpad = (B + QT - 1) / QT * QT;
     if (Bpad > ix->q_cap) {
         if (ix->q32) (void)hipFree(ix->q32);
         if (ix->q16) (void)hipFree(ix->q16);
+        if (ix->q16lo) (void)hipFree(ix->q16lo);
         if (ix->g_tau) (void)hipFree(ix->g_tau);
-        ix->q32 = nullptr; ix->q16 = nullptr; ix->g_tau = nullptr; ix->q_cap = 0;
+        ix->q32 = nullptr; ix->q16 = nullptr; ix->q16lo = nullptr; ix->g_tau = nullptr; ix->q_cap = 0;
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->q32), (size_t)Bpad * ix->d * sizeof(float)));
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->q16), (size_t)Bpad * ix->d * sizeof(_Float16)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->q16lo), (size_t)Bpad * ix->d * sizeof(_Float16)));
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->g_tau), (size_t)Bpad * sizeof(uint32_t)));
         ix->q_cap = Bpad;
     }
@@ -1184,7 +1242,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
 
     const int metric_l2 = ix->metric == PRAG_METRIC_L2;
     hipLaunchKernelGGL(prep_queries_kernel, dim3((Bpad + 3) / 4), dim3(256), 0, st, q_dev, B, Bpad, ix->d,
-                       ix->metric == PRAG_METRIC_COS ? 1 : 0, ix->q32, ix->q16, ix->g_tau);
+                       ix->metric == PRAG_METRIC_COS ? 1 : 0, ix->q32, ix->q16, ix->q16lo, ix->g_tau);
     PRAG_LAUNCH_CHECK();
 
     if (ix->ntotal == 0) {
@@ -1203,6 +1261,9 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         a.out_idx = ix->part_idx;
         auto run_scan = [&](const ScanArgs& sa, int g, EventRing& ring) -> int {
             if (use_qs) return dispatch_qs(ix->d, kc, sa, g, st, ring);
+            if (QT == 32 && use_hp)
+                return ix->store == PRAG_F32 ? dispatch_scan_kc<32, true, true>(kc, sa, g, st, ring)
+                                             : dispatch_scan_kc<32, false, true>(kc, sa, g, st, ring);
             if (QT == 32)
                 return ix->store == PRAG_F32 ? dispatch_scan_kc<32, true>(kc, sa, g, st, ring)
                                              : dispatch_scan_kc<32, false>(kc, sa, g, st, ring);
@@ -1218,6 +1279,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         static EventRing no_prof;  // the pre-pass is not part of the profiled scan launches
         for (int p0 = 0; p0 < Bpad; p0 += QT) {
             a.q16 = ix->q16 + (size_t)p0 * ix->d;
+            a.q16lo = ix->q16lo + (size_t)p0 * ix->d;
             a.g_tau = ix->g_tau + p0;
             const int nq = std::min(QT, B - p0);
             int rc;
@@ -1334,7 +1396,7 @@ extern "C" int prag_index_profile_read(prag_index_t* ix, float* ms, int cap, int
 extern "C" void prag_index_destroy(prag_index_t* ix) {
     if (!ix) return;
     ix->prof.disable();
-    void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->g_tau, ix->part_key, ix->part_idx, ix->cand,
+    void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->q16lo, ix->g_tau, ix->part_key, ix->part_idx, ix->cand,
                     ix->io_q, ix->io_D, ix->io_I};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

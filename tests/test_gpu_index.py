@@ -212,5 +212,34 @@ def test_candidate_depth_knob_resolves_dense_near_ties():
     ix.set_candidate_depth(0)
     D1, I1 = ix.search(q, k)
     assert set(I1[0].tolist()) <= set(near.tolist())          # still the right neighbourhood
+    # (squared-L2 keys of rows this close to the query cancel catastrophically in the
+    # ||x||^2 - 2 q.x form at f32, so only the deep list guarantees the exact ids here)
+
+
+def test_high_precision_selection_resolves_close_inner_products():
+    """<= 32 queries take the high-precision selection (query and fp32 rows as hi+lo fp16 terms,
+    f32 accumulation): 30 rows whose inner products with the query differ by 2e-5 relative -
+    below the fp16-operand scoring error - must come back in exact order at the default depth."""
+    import probing_rag_amd as pra
+    N, d, k = 20_000, 256, 5
+    X = onp.synth_rows(31, 0, N, d)
+    q = onp.synth_rows(32, 0, 1, d)
+    rng = np.random.default_rng(6)
+    near = rng.choice(N, 30, replace=False)
+    for j, row in enumerate(near):
+        X[row] = q[0] * np.float32(1.0 + 2e-5 * j)
+    D0, I0 = onp.flat_search(X, q, k, onp.METRIC_IP)
+    assert set(I0[0].tolist()) == set(near[-5:].tolist())
+    ix = pra.HipFlatIndex(d, "ip", "f32")
+    ix.add(X)
+    D, I = ix.search(q, k)                                     # 1 query: high-precision path
+    assert np.array_equal(I, I0)
+    np.testing.assert_allclose(D, D0, rtol=1e-6)
+    Q40 = np.concatenate([q, onp.synth_rows(33, 0, 39, d)])    # 40 queries: fp16-operand kernels
+    _, I2 = ix.search(Q40, k)
+    assert set(I2[0].tolist()) <= set(near.tolist())           # right neighbourhood; order may differ
+    ix.set_candidate_depth(32)
+    _, I3 = ix.search(Q40, k)
+    assert np.array_equal(I3[:1], I0)                          # 30 near-ties fit a 32-deep list
     with pytest.raises(pra.PragError, match="PRAG_EINVAL"):
         ix.set_candidate_depth(5)
