@@ -22,15 +22,14 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
 
-#include "prag_common.h"
+#include "flat_internal.h"
 
 namespace prag {
-
-constexpr int kIdxSentinel = 0x7fffffff;
 
 // ---------------------------------------------------------------------------
 // counter-based synthetic rows: bit-identical to oracle_np.synth_rows
@@ -113,7 +112,8 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= Bpad) return;
-    if (lane == 0) g_tau[b] = 0xFF800000u;  // sortable(+inf): the scan's chip-wide pruning bound
+    // the scan's chip-wide pruning bound: +inf for real queries; padding rows never collect anything
+    if (lane == 0) g_tau[b] = b < B ? kSortablePosInf : kSortableNegInf;
     if (b >= B) {
         for (int c = lane * 4; c < d; c += 256) {
             *reinterpret_cast<half4*>(q16 + (int64_t)b * d + c) = half4{0, 0, 0, 0};
@@ -176,17 +176,6 @@ struct ScanArgs {
     int* out_idx;
     uint32_t* g_tau;         // [QT] chip-wide pruning bound per query (sortable-uint keys, +inf at start)
 };
-
-__device__ __forceinline__ uint32_t sortable_u32(float key) {
-    const uint32_t u = __float_as_uint(key);
-    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);  // monotone float -> uint
-}
-__device__ __forceinline__ float unsortable_f32(uint32_t u) {
-    return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
-}
-__device__ __forceinline__ unsigned long long pack_key(float key, int idx) {
-    return ((unsigned long long)sortable_u32(key) << 32) | (uint32_t)idx;
-}
 
 template <int KC>
 struct TopList {
@@ -945,6 +934,13 @@ struct prag_index {
     int* cand = nullptr;
     size_t cand_cap = 0;
     uint32_t* g_tau = nullptr;  // [q_cap]
+    // MFMA-tiled scan (> 128 queries): per-query candidate buffers
+    uint32_t* mm_cnt = nullptr;
+    uint32_t* mm_ovf = nullptr;
+    float* mm_ckey = nullptr;
+    int* mm_cidx = nullptr;
+    int mm_q_cap = 0;
+    int mm_mode = 1;   // 0 = never take the MFMA-tiled path (PRAG_SCAN_MM=0)
     // host-io staging
     float* io_q = nullptr;
     float* io_D = nullptr;
@@ -961,7 +957,7 @@ static size_t elt(const prag_index* ix) { return ix->store == PRAG_F32 ? 4 : 2; 
 static int ensure_capacity(prag_index* ix, int64_t want) {
     if (want <= ix->cap) return PRAG_OK;
     int64_t ncap = std::max<int64_t>(want, ix->cap + ix->cap / 2);
-    ncap = (ncap + 31) / 32 * 32;
+    ncap = (ncap + 255) / 256 * 256;  // the MFMA-tiled scan reads whole 256-row tiles
     void* nrows = nullptr;
     float* nnorm = nullptr;
     PRAG_HIP(hipMalloc(&nrows, (size_t)ncap * ix->d * elt(ix)));
@@ -998,6 +994,7 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
         ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e);
     if (capacity_rows > 0) {
         int rc = ensure_capacity(ix, capacity_rows);
         if (rc != PRAG_OK) {
@@ -1201,8 +1198,10 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     const int qstride = (ix->d * 2 + 255) / 256 * 256;
     // 64-query tiles when they fit LDS; fp32 rows with 32-deep lists stay at 32 (VGPR budget)
     const bool wide_ok = 64 * qstride + 8 * 4096 + 64 * 4 <= 160 * 1024 && !(ix->store == PRAG_F32 && kc == 32);
-    const bool use_qs = B > 64 && qs_supported(ix->d, ix->store, kc);  // 128 queries per corpus pass
-    const int QT = use_qs ? 128 : ((B > 32 && wide_ok) ? 64 : 32);
+    // > 128 queries: the contraction bounds the search -> MFMA-tiled scan, 256 queries per tile
+    const bool use_mm = B > 128 && ix->mm_mode && ix->ntotal > 0 && mm_supported(ix->d, ix->store, kc);
+    const bool use_qs = !use_mm && B > 64 && qs_supported(ix->d, ix->store, kc);  // 128 queries per corpus pass
+    const int QT = use_mm ? 256 : use_qs ? 128 : ((B > 32 && wide_ok) ? 64 : 32);
     // <= 32 queries (the reference's call shape): high-precision selection, if two query tiles fit LDS
     const bool use_hp = ix->hp_mode && QT == 32 && 2 * 32 * qstride + 8 * 4096 + 32 * 4 <= 160 * 1024;
     const int Bpad = (B + QT - 1) / QT * QT;
@@ -1240,6 +1239,19 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         ix->cand_cap = cand_need;
     }
 
+    if (use_mm && Bpad > ix->mm_q_cap) {
+        if (ix->mm_cnt) (void)hipFree(ix->mm_cnt);
+        if (ix->mm_ovf) (void)hipFree(ix->mm_ovf);
+        if (ix->mm_ckey) (void)hipFree(ix->mm_ckey);
+        if (ix->mm_cidx) (void)hipFree(ix->mm_cidx);
+        ix->mm_cnt = nullptr; ix->mm_ovf = nullptr; ix->mm_ckey = nullptr; ix->mm_cidx = nullptr; ix->mm_q_cap = 0;
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_cnt), (size_t)Bpad * sizeof(uint32_t)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_ovf), (size_t)Bpad * sizeof(uint32_t)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_ckey), (size_t)Bpad * kMmCapQ * sizeof(float)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_cidx), (size_t)Bpad * kMmCapQ * sizeof(int)));
+        ix->mm_q_cap = Bpad;
+    }
+
     const int metric_l2 = ix->metric == PRAG_METRIC_L2;
     hipLaunchKernelGGL(prep_queries_kernel, dim3((Bpad + 3) / 4), dim3(256), 0, st, q_dev, B, Bpad, ix->d,
                        ix->metric == PRAG_METRIC_COS ? 1 : 0, ix->q32, ix->q16, ix->q16lo, ix->g_tau);
@@ -1247,6 +1259,28 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
 
     if (ix->ntotal == 0) {
         PRAG_HIP(hipMemsetAsync(ix->cand, 0xFF, cand_need * sizeof(int), st));  // all -1
+    } else if (use_mm) {
+        MmSearch m;
+        m.rows = reinterpret_cast<const _Float16*>(ix->rows);
+        m.xnorm = ix->xnorm;
+        m.N = ix->ntotal;
+        m.d = ix->d;
+        m.q16 = ix->q16;
+        m.B = B;
+        m.Bpad = Bpad;
+        m.alpha = metric_l2 ? -2.0f : -1.0f;
+        m.use_norm = metric_l2;
+        m.kc = kc;
+        m.tau = ix->g_tau;
+        m.cand = ix->cand;
+        m.cnt = ix->mm_cnt;
+        m.ckey = ix->mm_ckey;
+        m.cidx = ix->mm_cidx;
+        m.ovf = ix->mm_ovf;
+        m.cap_q = kMmCapQ;
+        m.max_wg = cu_budget;
+        const int rc = mm_run(m, st, ix->prof);
+        if (rc != PRAG_OK) return rc;
     } else {
         ScanArgs a;
         a.rows = ix->rows;
@@ -1397,7 +1431,7 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
     if (!ix) return;
     ix->prof.disable();
     void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->q16lo, ix->g_tau, ix->part_key, ix->part_idx, ix->cand,
-                    ix->io_q, ix->io_D, ix->io_I};
+                    ix->io_q, ix->io_D, ix->io_I, ix->mm_cnt, ix->mm_ovf, ix->mm_ckey, ix->mm_cidx};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete ix;

@@ -1,0 +1,58 @@
+// Internal pieces shared by the flat-index translation units (flat_index.hip, flat_mm.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "prag_common.h"
+
+namespace prag {
+
+constexpr int kIdxSentinel = 0x7fffffff;
+
+// monotone float <-> uint maps: selection keys are compared / atomically min-ed as integers
+__device__ __forceinline__ uint32_t sortable_u32(float key) {
+    const uint32_t u = __float_as_uint(key);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float unsortable_f32(uint32_t u) {
+    return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+__device__ __forceinline__ unsigned long long pack_key(float key, int idx) {
+    return ((unsigned long long)sortable_u32(key) << 32) | (uint32_t)idx;
+}
+constexpr uint32_t kSortablePosInf = 0xFF800000u;  // sortable_u32(+inf)
+constexpr uint32_t kSortableNegInf = 0x007FFFFFu;  // sortable_u32(-inf)
+
+// ---------------------------------------------------------------------------
+// MFMA-tiled scan for large query batches (flat_mm.hip): 256 queries x 256 rows per
+// workgroup tile, candidates collected by threshold filtering.
+// ---------------------------------------------------------------------------
+struct MmSearch {
+    const _Float16* rows;   // [cap][d] fp16, cap a multiple of 256
+    const float* xnorm;     // [cap]
+    int64_t N;              // rows in the shard
+    int d;
+    const _Float16* q16;    // [Bpad][d], Bpad a multiple of 256, zero rows past B
+    int B, Bpad;
+    float alpha;            // key = (use_norm ? ||x||^2 : 0) + alpha * dot
+    int use_norm;
+    int kc;                 // candidates kept per query (8, 16 or 32)
+    uint32_t* tau;          // [Bpad] sortable pruning bound per query: +inf for real queries, -inf for padding
+    int* cand;              // [Bpad][kc] out: candidate row ids (-1 = none), ordered by (key, id)
+    // workspace
+    uint32_t* cnt;          // [Bpad]
+    float* ckey;            // [Bpad][cap_q]
+    int* cidx;              // [Bpad][cap_q]
+    uint32_t* ovf;          // [Bpad] set when a query's candidate buffer overflowed in some segment
+    int cap_q;              // candidate slots per query (>= first segment)
+    int max_wg;             // workgroups the scan may occupy
+};
+
+constexpr int kMmCapQ = 2048;        // candidate slots per query = rows of the first segment
+bool mm_supported(int d, int store_dtype, int kc);
+// Enqueue the segmented scan on `st`; returns PRAG_OK or a negative status.  `prof` brackets
+// the launch over the largest segment.
+int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof);
+
+}  // namespace prag

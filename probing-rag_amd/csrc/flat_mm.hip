@@ -1,0 +1,437 @@
+// MFMA-tiled flat scan for large query batches (> 128 queries) on MI355X (gfx950):
+// BASELINE config 3 (1k queries x 1M rows x 768, "MFMA tile") - the regime where the
+// [queries x d] x [d x rows] contraction, not the HBM stream, bounds index.search
+// (reference call site: utils.py:378-380 batch_topk_sim -> faiss IndexFlat.search).
+//
+// scan_mm_kernel: persistent workgroups (8 waves = 2 per SIMD, 1 workgroup per CU) walk
+// 256-row x 256-query tiles in an XCD-aware order (the workgroups of one XCD take the query
+// blocks of the same row tile at the same time, so the rows come from HBM once and from that
+// XCD's L2 afterwards).  Both operands stream through LDS by LDS-DMA (global_load_lds_dwordx4,
+// source-side XOR swizzle, no staging registers) in 64-wide K tiles, double buffered; every
+// wave owns a 128-row x 64-query block of accumulators (8 x v_mfma_f32_32x32x16_f16 tiles).
+// A K tile is four phases {fragment reads for one 64x32 quadrant | 16 KiB of DMA for a K tile
+// two ahead | counted vmcnt | barrier | 8 MFMAs | barrier}; the two wave groups (row halves)
+// run one barrier apart, so one group's MFMAs cover the other group's LDS reads.  Every LDS
+// region is read in exactly one phase, restaged two phases later and waited for one phase
+// before its next read: five phases of flight time per DMA with a uniform vmcnt(8).
+//
+// [B,N] never exists: after the last K tile each lane compares its 128 scores with the
+// per-query pruning bound and appends the rare survivors (key, row) to a per-query candidate
+// buffer (one global atomic per survivor).  The corpus is scanned in segments of geometrically
+// growing size (2048 rows, then x16): mm_compact_kernel reduces every query's buffer to its
+// KC best after each segment and tightens the bound to the KC-th best key seen so far, so a
+// segment contributes ~16*KC candidates per query when rows are exchangeable.  A buffer that
+// overflows anyway (rows sorted by decreasing distance, say) raises a per-query flag and the
+// caller re-runs those queries through the per-lane-list kernels, which cannot overflow.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "flat_internal.h"
+
+namespace prag {
+
+struct MmArgs {
+    const _Float16* rows;
+    const float* xnorm;
+    const _Float16* q16;
+    int64_t row0, row1;   // this segment: rows [row0,row1), row0 % 256 == 0
+    int n_qb;             // query blocks of 256
+    int n_tiles;          // row tiles x query blocks
+    float alpha;
+    int use_norm;
+    const uint32_t* tau;  // [n_qb*256]
+    uint32_t* cnt;
+    float* ckey;
+    int* cidx;
+    int cap_q;
+};
+
+// LDS map (bytes): A even/odd K tile at 0 / 32 KiB, B even/odd at 64 / 96 KiB ([256 rows][128 B],
+// 16-B pieces XOR-swizzled with (row>>1)&7), then 1 KiB of row norms and 1 KiB of bounds.
+constexpr int kMmLdsXn = 131072;
+constexpr int kMmLdsTau = 131072 + 1024;
+constexpr int kMmLdsBytes = 131072 + 2048;
+
+template <int NKT /* d / 64, even */>
+__global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
+    static_assert(NKT % 2 == 0 && NKT >= 4, "K tiles are consumed in even/odd pairs");
+    constexpr int64_t RB = (int64_t)NKT * 128;  // bytes per fp16 row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef const __attribute__((address_space(1))) char* gcptr;
+    typedef __attribute__((address_space(3))) char* lptr;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;  // row half / 64-query strip of this wave
+    const int r = lane & 31, h = lane >> 5;
+
+    // blocks b, b+8, b+16, ... share an XCD: give each XCD a contiguous run of tiles so the
+    // workgroups that run together on it work on the same rows (bijective for any grid size)
+    const int nwg = gridDim.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = (int)blockIdx.x & 7;
+    const int v = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + ((int)blockIdx.x >> 3);
+    const int n_my = v < a.n_tiles ? (a.n_tiles - v + nwg - 1) / nwg : 0;
+    if (n_my == 0) return;  // whole workgroup (grid <= tiles, so this does not happen)
+
+    // ---- fragment read offsets: A row = 128*wr + 32*mt + r, B row = 64*wc + 32*nt + r; the
+    //      swizzle term (row>>1)&7 only depends on r, k-step ks flips byte bits 5..6 ---------
+    const int swz = (r >> 1) & 7;
+    int a_off[4], b_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int piece = ((2 * ks + h) ^ swz) << 4;
+        a_off[ks] = (128 * wr + r) * 128 + piece;
+        b_off[ks] = 65536 + (64 * wc + r) * 128 + piece;
+    }
+
+    // ---- LDS-DMA geometry: one wave instruction fills 8 rows x 128 B linearly, so lane l
+    //      fetches global piece (l&7) ^ swizzle(row) of row 8*chunk + (l>>3) ------------------
+    const int l8 = lane >> 3;
+    const int colb = (((lane & 7) ^ ((4 * (w & 1) + (lane >> 4)) & 7)) << 4);
+    const int a_thr = 8 * w + l8;                              // A rows 8w.. (+128: second instruction)
+    const int b_thr = 64 * (w >> 2) + 8 * (w & 3) + l8;        // B strips (w>>2) and (w>>2)+2, first 32 rows
+    const gcptr rows_g = (gcptr) reinterpret_cast<const char*>(a.rows);
+    const gcptr q_g = (gcptr) reinterpret_cast<const char*>(a.q16);
+    const lptr lds0 = (lptr)smem;
+    const lptr dA = lds0 + w * 1024;
+    const lptr dB = lds0 + 65536 + (64 * (w >> 2) + 8 * (w & 3)) * 128;
+
+    struct TilePtr {
+        gcptr pa, pb;
+        int64_t row0;
+        int q0;
+    };
+    auto tile_ptr = [&](int t) {
+        t = t < a.n_tiles ? t : a.n_tiles - 1;  // past the end: re-stage the last tile (never read)
+        const int rt = t / a.n_qb, qb = t - rt * a.n_qb;
+        TilePtr p;
+        p.row0 = a.row0 + (int64_t)rt * 256;
+        p.q0 = qb * 256;
+        p.pa = rows_g + (p.row0 + a_thr) * RB + colb;
+        p.pb = q_g + (int64_t)(p.q0 + b_thr) * RB + colb;
+        return p;
+    };
+
+#define MM_GLDS(gp_, lp_) __builtin_amdgcn_global_load_lds((gp_), (lp_), 16, 0, 0)
+    // the four 16-KiB staging steps of one K tile (kt_) into buffer buf_ (0 even, 1 odd)
+#define MM_SA0(tp_, kt_, buf_)                                    \
+    {                                                             \
+        const gcptr g0_ = (tp_).pa + (kt_) * 128;                 \
+        const gcptr g1_ = g0_ + 128 * RB;                         \
+        const lptr l0_ = dA + (buf_) * 32768;                     \
+        const lptr l1_ = l0_ + 16384;                             \
+        MM_GLDS(g0_, l0_);                                        \
+        MM_GLDS(g1_, l1_);                                        \
+    }
+#define MM_SA1(tp_, kt_, buf_)                                    \
+    {                                                             \
+        const gcptr g0_ = (tp_).pa + 64 * RB + (kt_) * 128;       \
+        const gcptr g1_ = g0_ + 128 * RB;                         \
+        const lptr l0_ = dA + (buf_) * 32768 + 8192;              \
+        const lptr l1_ = l0_ + 16384;                             \
+        MM_GLDS(g0_, l0_);                                        \
+        MM_GLDS(g1_, l1_);                                        \
+    }
+#define MM_SB0(tp_, kt_, buf_)                                    \
+    {                                                             \
+        const gcptr g0_ = (tp_).pb + (kt_) * 128;                 \
+        const gcptr g1_ = g0_ + 128 * RB;                         \
+        const lptr l0_ = dB + (buf_) * 32768;                     \
+        const lptr l1_ = l0_ + 16384;                             \
+        MM_GLDS(g0_, l0_);                                        \
+        MM_GLDS(g1_, l1_);                                        \
+    }
+#define MM_SB1(tp_, kt_, buf_)                                    \
+    {                                                             \
+        const gcptr g0_ = (tp_).pb + 32 * RB + (kt_) * 128;       \
+        const gcptr g1_ = g0_ + 128 * RB;                         \
+        const lptr l0_ = dB + (buf_) * 32768 + 4096;              \
+        const lptr l1_ = l0_ + 16384;                             \
+        MM_GLDS(g0_, l0_);                                        \
+        MM_GLDS(g1_, l1_);                                        \
+    }
+#define MM_LDSR(off_) (*reinterpret_cast<const half8*>(smem + (off_)))
+    // everything staged four or more phases ago has landed; the barrier publishes it
+#define MM_WAIT_BAR()                                     \
+    {                                                     \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  \
+        __builtin_amdgcn_s_barrier();                     \
+        __builtin_amdgcn_sched_barrier(0);                \
+    }
+#define MM_MFMA8(c0_, c1_, AF_, BF_, first_)                                                          \
+    {                                                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                                                \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                            \
+            c0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF_[0][ks], BF_[ks], ((first_) && ks == 0) ? zero16 : c0_, 0, 0, 0); \
+            c1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF_[1][ks], BF_[ks], ((first_) && ks == 0) ? zero16 : c1_, 0, 0, 0); \
+        }                                                                                             \
+        __builtin_amdgcn_s_setprio(0);                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        __builtin_amdgcn_s_barrier();                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc[4][2];
+    half8 A[2][4], B0[4], B1[4];
+
+    TilePtr cur = tile_ptr(v), nxt = tile_ptr(v + nwg);
+
+    // ---- prologue: K tile 0 complete in the even buffer, first half of K tile 1 in the odd one
+    MM_SA0(cur, 0, 0)
+    MM_SB0(cur, 0, 0)
+    MM_SB1(cur, 0, 0)
+    MM_SA1(cur, 0, 0)
+    MM_SA0(cur, 1, 1)
+    MM_SB0(cur, 1, 1)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs one barrier behind
+
+    for (int ti = 0; ti < n_my; ++ti) {
+#pragma unroll
+        for (int it = 0; it < NKT / 2; ++it) {
+            const int ke = 2 * it, ko = 2 * it + 1;             // K tiles in the even / odd buffer
+            const bool wrap = ke + 2 >= NKT;                    // staging moves on to the next tile
+            const int ke2 = wrap ? ke + 2 - NKT : ke + 2;
+            const int ko2 = wrap ? ko + 2 - NKT : ko + 2;
+            const TilePtr& tn = wrap ? nxt : cur;
+            // ===== even K tile =====
+            // phase 1: quadrant (rows 0-63, queries 0-31)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) B0[ks] = MM_LDSR(b_off[ks]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) A[m][ks] = MM_LDSR(a_off[ks] + m * 4096);
+            MM_SB1(cur, ko, 1)
+            MM_WAIT_BAR()
+            MM_MFMA8(acc[0][0], acc[1][0], A, B0, it == 0)
+            // phase 2: (rows 0-63, queries 32-63)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) B1[ks] = MM_LDSR(b_off[ks] + 4096);
+            MM_SA1(cur, ko, 1)
+            if (it == NKT / 2 - 2) {
+                // row norms and bounds of this tile, well ahead of the filter.  Not in phase 1: at
+                // d = 256 this is the tile's first K-tile pair and the lagging wave group may still
+                // be reading the previous tile's copy until it passes the barrier that ends phase 1.
+                if (w < 2) {
+                    // (the lane offset is rebuilt here on purpose: hoisted out of the tile loop it costs
+                    // a VGPR pair the loop does not have, and a spilled pointer reloads behind vmcnt(0))
+                    int l16;
+                    asm volatile("v_lshlrev_b32 %0, 4, %1" : "=v"(l16) : "v"(lane));
+                    const gcptr src = w == 0 ? (gcptr) reinterpret_cast<const char*>(a.xnorm + cur.row0)
+                                             : (gcptr) reinterpret_cast<const char*>(a.tau + cur.q0);
+                    const gcptr gx = src + l16;
+                    const lptr lx = lds0 + (w == 0 ? kMmLdsXn : kMmLdsTau);
+                    MM_GLDS(gx, lx);
+                }
+            }
+            MM_WAIT_BAR()
+            MM_MFMA8(acc[0][1], acc[1][1], A, B1, it == 0)
+            // phase 3: (rows 64-127, queries 32-63)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) A[m][ks] = MM_LDSR(a_off[ks] + (2 + m) * 4096);
+            MM_SA0(tn, ke2, 0)
+            MM_WAIT_BAR()
+            MM_MFMA8(acc[2][1], acc[3][1], A, B1, it == 0)
+            // phase 4: (rows 64-127, queries 0-31), operands already in registers
+            MM_SB0(tn, ke2, 0)
+            MM_WAIT_BAR()
+            MM_MFMA8(acc[2][0], acc[3][0], A, B0, it == 0)
+            // ===== odd K tile =====
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) B0[ks] = MM_LDSR(b_off[ks] + 32768);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) A[m][ks] = MM_LDSR(a_off[ks] + 32768 + m * 4096);
+            MM_SB1(tn, ke2, 0)
+            MM_WAIT_BAR()
+            MM_MFMA8(acc[0][0], acc[1][0], A, B0, false)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) B1[ks] = MM_LDSR(b_off[ks] + 32768 + 4096);
+            MM_SA1(tn, ke2, 0)
+            MM_WAIT_BAR()
+            MM_MFMA8(acc[0][1], acc[1][1], A, B1, false)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) A[m][ks] = MM_LDSR(a_off[ks] + 32768 + (2 + m) * 4096);
+            MM_SA0(tn, ko2, 1)
+            MM_WAIT_BAR()
+            MM_MFMA8(acc[2][1], acc[3][1], A, B1, false)
+            MM_SB0(tn, ko2, 1)
+            MM_WAIT_BAR()
+            MM_MFMA8(acc[2][0], acc[3][0], A, B0, false)
+        }
+
+        // ---- filter: 128 scores per lane against the bound of their query ----------------
+        {
+            const int64_t rbase = cur.row0 + 128 * wr + 4 * h;
+            const int qbase = cur.q0 + 64 * wc + r;
+            float tauf[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                tauf[nt] = unsortable_f32(*reinterpret_cast<const uint32_t*>(smem + kMmLdsTau + (64 * wc + 32 * nt + r) * 4));
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                f32x4 xn[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    xn[g] = a.use_norm ? *reinterpret_cast<const f32x4*>(smem + kMmLdsXn + (128 * wr + 32 * mt + 8 * g + 4 * h) * 4)
+                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    float key[16];
+                    float m = INFINITY;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        key[e] = fmaf(a.alpha, acc[mt][nt][e], xn[e >> 2][e & 3]);
+                        m = fminf(m, key[e]);
+                    }
+                    if (__builtin_amdgcn_ballot_w64(m <= tauf[nt]) != 0) {  // rare once the bound is warm
+                        const int q = qbase + 32 * nt;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int64_t row = rbase + 32 * mt + 8 * (e >> 2) + (e & 3);
+                            if (key[e] <= tauf[nt] && row < a.row1) {
+                                const uint32_t slot = atomicAdd(a.cnt + q, 1u);
+                                if (slot < (uint32_t)a.cap_q) {
+                                    a.ckey[(int64_t)q * a.cap_q + slot] = key[e];
+                                    a.cidx[(int64_t)q * a.cap_q + slot] = (int)row;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        cur = nxt;
+        nxt = tile_ptr(v + (ti + 2) * nwg);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail DMAs must not outlive the workgroup's LDS
+    if (wr == 0) __builtin_amdgcn_s_barrier();         // pair the second group's extra barrier
+#undef MM_GLDS
+#undef MM_SA0
+#undef MM_SA1
+#undef MM_SB0
+#undef MM_SB1
+#undef MM_LDSR
+#undef MM_WAIT_BAR
+#undef MM_MFMA8
+}
+
+// ---------------------------------------------------------------------------
+// after each segment: a query's candidate buffer -> its KC best by (key, id), in place;
+// bound <- KC-th best key; cand[q][0..KC) <- row ids.  One wave per query.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mm_compact_kernel(uint32_t* __restrict__ cnt, float* __restrict__ ckey,
+                                                       int* __restrict__ cidx, int cap_q, int KC,
+                                                       uint32_t* __restrict__ tau, int* __restrict__ cand,
+                                                       uint32_t* __restrict__ ovf) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* s_v = reinterpret_cast<unsigned long long*>(smem);
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const uint32_t c = cnt[q];
+    const int n = c < (uint32_t)cap_q ? (int)c : cap_q;
+    const int64_t o = (int64_t)q * cap_q;
+    for (int i = lane; i < n; i += 64) s_v[i] = pack_key(ckey[o + i], cidx[o + i]);
+    __syncthreads();
+    unsigned long long prev = 0;
+    for (int round = 0; round < KC; ++round) {
+        // smallest packed value above the previous pick (row ids are unique, so values are)
+        unsigned long long m = ~0ull;
+        for (int i = lane; i < n; i += 64) {
+            const unsigned long long x = s_v[i];
+            if ((round == 0 || x > prev) && x < m) m = x;
+        }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            const unsigned long long other = __shfl_xor(m, sft, 64);
+            m = other < m ? other : m;
+        }
+        if (lane == 0) {
+            const bool ok = m != ~0ull;
+            cand[(int64_t)q * KC + round] = ok ? (int)(uint32_t)m : -1;
+            if (ok) {
+                ckey[o + round] = unsortable_f32((uint32_t)(m >> 32));
+                cidx[o + round] = (int)(uint32_t)m;
+                if (round == KC - 1) tau[q] = (uint32_t)(m >> 32);
+            }
+        }
+        prev = m;  // once exhausted (m == ~0) nothing is above it: the remaining rounds write -1
+    }
+    if (lane == 0) {
+        cnt[q] = n < KC ? n : KC;
+        if (c > (uint32_t)cap_q) ovf[q] = 1u;
+    }
+}
+
+bool mm_supported(int d, int store_dtype, int kc) {
+    return store_dtype == PRAG_F16 && (d == 256 || d == 512 || d == 768 || d == 1024) && kc >= 8 && kc <= 32;
+}
+
+template <int NKT>
+static int launch_mm(const MmArgs& a, int grid, hipStream_t st) {
+    auto kern = scan_mm_kernel<NKT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kMmLdsBytes, st, a);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
+    PRAG_REQUIRE(mm_supported(s.d, PRAG_F16, s.kc) && s.Bpad % 256 == 0 && s.cap_q >= kMmCapQ, PRAG_EUNSUPPORTED,
+                 "internal: MFMA-tiled scan called outside its envelope");
+    PRAG_HIP(hipMemsetAsync(s.cnt, 0, (size_t)s.Bpad * sizeof(uint32_t), st));
+    PRAG_HIP(hipMemsetAsync(s.ovf, 0, (size_t)s.Bpad * sizeof(uint32_t), st));
+    MmArgs a;
+    a.rows = s.rows;
+    a.xnorm = s.xnorm;
+    a.q16 = s.q16;
+    a.n_qb = s.Bpad / 256;
+    a.alpha = s.alpha;
+    a.use_norm = s.use_norm;
+    a.tau = s.tau;
+    a.cnt = s.cnt;
+    a.ckey = s.ckey;
+    a.cidx = s.cidx;
+    a.cap_q = s.cap_q;
+    int64_t lo = 0;
+    int64_t hi = std::min<int64_t>(s.N, kMmCapQ);  // first segment: every row is a candidate
+    while (lo < s.N) {
+        a.row0 = lo;
+        a.row1 = hi;
+        const int64_t n_rt = (hi - lo + 255) / 256;
+        a.n_tiles = (int)(n_rt * a.n_qb);
+        const int grid = (int)std::min<int64_t>(a.n_tiles, std::max(1, s.max_wg));
+        const bool biggest = hi == s.N;  // segments grow x16: the last one dominates
+        if (biggest) prof.begin(st);
+        int rc;
+        switch (s.d) {
+            case 256: rc = launch_mm<4>(a, grid, st); break;
+            case 512: rc = launch_mm<8>(a, grid, st); break;
+            case 768: rc = launch_mm<12>(a, grid, st); break;
+            default: rc = launch_mm<16>(a, grid, st); break;
+        }
+        if (biggest) prof.end(st);
+        if (rc != PRAG_OK) return rc;
+        hipLaunchKernelGGL(mm_compact_kernel, dim3(s.B), dim3(64), (size_t)s.cap_q * 8, st, s.cnt, s.ckey, s.cidx,
+                           s.cap_q, s.kc, s.tau, s.cand, s.ovf);
+        PRAG_LAUNCH_CHECK();
+        lo = hi;
+        hi = std::min<int64_t>(s.N, hi * 16);
+    }
+    return PRAG_OK;
+}
+
+}  // namespace prag
