@@ -220,14 +220,13 @@ struct TopList {
 // shape (a handful of queries, fp32 rows) no longer depends on how many near-ties surround the
 // k-th result.
 template <int QT, int KC, bool F32, bool HP>
-__global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
+__device__ __forceinline__ void scan_topk_body(const ScanArgs& a, char* smem) {
     static_assert(!HP || QT == 32, "high-precision selection is built for one 32-query tile");
     constexpr int NQ = QT / 32;
     constexpr bool SPLIT_ROWS = HP && F32;          // rows staged as hi + lo halves
     constexpr int CHK = SPLIT_ROWS ? 32 : 64;       // elements per staged chunk (4 KiB of LDS per wave either way)
     constexpr int KS = CHK / 16;                    // MFMA k-steps per chunk
     constexpr int RSB = CHK * 2;                    // bytes per staged row (fp16)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -494,6 +493,39 @@ __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
     }
 }
 
+template <int QT, int KC, bool F32, bool HP>
+__global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    scan_topk_body<QT, KC, F32, HP>(a, smem);
+}
+
+// Re-run of the query groups (QT queries each) whose candidate buffers overflowed in the
+// MFMA-tiled scan (flat_mm.hip): per-lane lists cannot overflow.  One launch walks all groups
+// and skips the clean ones, so the common case costs one empty kernel.  Group g writes its
+// lists at out_* + g * part_stride.
+template <int QT, int KC>
+__global__ __launch_bounds__(512, 1) void scan_topk_flagged_kernel(ScanArgs a, const uint32_t* __restrict__ q_flag,
+                                                                   int n_groups, int64_t part_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_any;
+    for (int g = 0; g < n_groups; ++g) {
+        if (threadIdx.x == 0) s_any = 0;
+        __syncthreads();
+        if (threadIdx.x < QT && q_flag[g * QT + threadIdx.x] != 0) s_any = 1;
+        __syncthreads();
+        const int any = s_any;
+        __syncthreads();
+        if (!any) continue;
+        ScanArgs b = a;
+        b.q16 = a.q16 + (int64_t)g * QT * a.d;
+        b.g_tau = a.g_tau + g * QT;
+        b.out_key = a.out_key + g * part_stride;
+        b.out_idx = a.out_idx + g * part_stride;
+        scan_topk_body<QT, KC, false, false>(b, smem);
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------
 // query-stationary scan for large query batches (fp16 rows): 128 queries per pass.
 // Eight waves (two per SIMD, so one wave's LDS/barrier latency hides under the
@@ -700,9 +732,23 @@ template <int KC>
 __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restrict__ part_key,
                                                          const int* __restrict__ part_idx, int n_lists,
                                                          int QT, int* __restrict__ cand_idx /*[q][KC]*/,
-                                                         uint32_t* __restrict__ tau_out /*[q] or null*/) {
+                                                         uint32_t* __restrict__ tau_out /*[q] or null*/,
+                                                         const uint32_t* __restrict__ q_flag /*or null*/,
+                                                         int64_t part_stride) {
     __shared__ unsigned long long s_w[4 * KC];
-    const int q = blockIdx.x;
+    // flagged mode (fallback of the MFMA-tiled scan): block = global query, lists of its group of QT
+    // queries start at part_stride * group; groups without a flagged query keep their candidates
+    int q = blockIdx.x;
+    const int64_t qglob = blockIdx.x;
+    if (q_flag) {
+        const int grp = q / QT;
+        bool any = false;
+        for (int j = 0; j < QT; ++j) any |= q_flag[grp * QT + j] != 0;
+        if (!any) return;
+        part_key += grp * part_stride;
+        part_idx += grp * part_stride;
+        q -= grp * QT;
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const unsigned long long kInf = ~0ull;
@@ -761,10 +807,10 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
             rank += (u < v) || (u == v && j < e);   // sentinels tie: order by position
         }
         if (rank < KC) {
-            cand_idx[(int64_t)q * KC + rank] = (v == kInf) ? -1 : (int)(uint32_t)v;
+            cand_idx[qglob * KC + rank] = (v == kInf) ? -1 : (int)(uint32_t)v;
             // pre-pass use: the KC-th best key of the rows seen = a valid pruning bound for the
             // full scan (those rows are a subset of the shard)
-            if (tau_out && rank == KC - 1 && v != kInf) tau_out[q] = (uint32_t)(v >> 32);
+            if (tau_out && rank == KC - 1 && v != kInf) tau_out[qglob] = (uint32_t)(v >> 32);
         }
     }
 }
@@ -1115,6 +1161,36 @@ static int dispatch_scan_kc(int kc, const ScanArgs& a, int grid, hipStream_t st,
     return PRAG_EUNSUPPORTED;
 }
 
+template <int QT, int KC>
+static int launch_flagged(const ScanArgs& a, int grid, const uint32_t* q_flag, int n_groups, int64_t part_stride,
+                          hipStream_t st) {
+    const int lds_loop = QT * a.qstride + 8 * 4096 + QT * 4;
+    const int lds_merge = 16 * 32 * KC * 8;
+    const int lds = lds_loop > lds_merge ? lds_loop : lds_merge;
+    auto kern = scan_topk_flagged_kernel<QT, KC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, q_flag, n_groups, part_stride);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+template <int QT>
+static int dispatch_flagged(int kc, const ScanArgs& a, int grid, const uint32_t* q_flag, int n_groups,
+                            int64_t part_stride, hipStream_t st) {
+    switch (kc) {
+        case 8: return launch_flagged<QT, 8>(a, grid, q_flag, n_groups, part_stride, st);
+        case 16: return launch_flagged<QT, 16>(a, grid, q_flag, n_groups, part_stride, st);
+        case 32: return launch_flagged<QT, 32>(a, grid, q_flag, n_groups, part_stride, st);
+    }
+    set_error("internal: KC=%d", kc);
+    return PRAG_EUNSUPPORTED;
+}
+
 template <int NKS, int KC>
 static int launch_qs(const ScanArgs& a, int grid, hipStream_t st, EventRing& prof) {
     const int lds = 4 * 128 * 128 > 128 * 4 * KC * 8 ? 4 * 128 * 128 : 128 * 4 * KC * 8;  // 4-stage ring
@@ -1150,11 +1226,12 @@ static int dispatch_qs(int d, int kc, const ScanArgs& a, int grid, hipStream_t s
 }
 
 static int launch_merge(int kc, const float* pk, const int* pi, int n_lists, int QT, int nq, int* cand,
-                        uint32_t* tau_out, hipStream_t st) {
+                        uint32_t* tau_out, hipStream_t st, const uint32_t* q_flag = nullptr,
+                        int64_t part_stride = 0) {
     switch (kc) {
-        case 8: hipLaunchKernelGGL(merge_lists_kernel<8>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out); break;
-        case 16: hipLaunchKernelGGL(merge_lists_kernel<16>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out); break;
-        case 32: hipLaunchKernelGGL(merge_lists_kernel<32>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out); break;
+        case 8: hipLaunchKernelGGL(merge_lists_kernel<8>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out, q_flag, part_stride); break;
+        case 16: hipLaunchKernelGGL(merge_lists_kernel<16>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out, q_flag, part_stride); break;
+        case 32: hipLaunchKernelGGL(merge_lists_kernel<32>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out, q_flag, part_stride); break;
         default: set_error("internal: KC=%d", kc); return PRAG_EUNSUPPORTED;
     }
     PRAG_LAUNCH_CHECK();
@@ -1279,7 +1356,43 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         m.ovf = ix->mm_ovf;
         m.cap_q = kMmCapQ;
         m.max_wg = cu_budget;
-        const int rc = mm_run(m, st, ix->prof);
+        int rc = mm_run(m, st, ix->prof);
+        if (rc != PRAG_OK) return rc;
+        // Queries whose candidate buffer overflowed (flag set on the device): their groups go
+        // through the per-lane-list kernel again; with no flag set this is two empty launches.
+        const bool fb64 = 64 * qstride + 8 * 4096 + 64 * 4 + 64 <= 160 * 1024 - 64;
+        const int fq = fb64 ? 64 : 32;
+        const int fb_grid = std::max(1, std::min(cu_budget, (n_tiles + 7) / 8));
+        const int n_groups = Bpad / fq;
+        const int64_t part_stride = (int64_t)fb_grid * fq * kc;
+        const size_t fb_need = (size_t)n_groups * part_stride;
+        if (fb_need > ix->part_cap) {
+            if (ix->part_key) (void)hipFree(ix->part_key);
+            if (ix->part_idx) (void)hipFree(ix->part_idx);
+            ix->part_key = nullptr; ix->part_idx = nullptr; ix->part_cap = 0;
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->part_key), fb_need * sizeof(float)));
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->part_idx), fb_need * sizeof(int)));
+            ix->part_cap = fb_need;
+        }
+        ScanArgs a;
+        a.rows = ix->rows;
+        a.xnorm = ix->xnorm;
+        a.q16 = ix->q16;
+        a.q16lo = ix->q16lo;
+        a.N = ix->ntotal;
+        a.d = ix->d;
+        a.qstride = qstride;
+        a.n_tiles = n_tiles;
+        a.alpha = m.alpha;
+        a.use_norm = metric_l2;
+        a.out_key = ix->part_key;
+        a.out_idx = ix->part_idx;
+        a.g_tau = ix->g_tau;
+        rc = fb64 ? dispatch_flagged<64>(kc, a, fb_grid, ix->mm_ovf, n_groups, part_stride, st)
+                  : dispatch_flagged<32>(kc, a, fb_grid, ix->mm_ovf, n_groups, part_stride, st);
+        if (rc != PRAG_OK) return rc;
+        rc = launch_merge(kc, ix->part_key, ix->part_idx, fb_grid, fq, B, ix->cand, nullptr, st, ix->mm_ovf,
+                          part_stride);
         if (rc != PRAG_OK) return rc;
     } else {
         ScanArgs a;

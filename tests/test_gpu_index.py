@@ -30,7 +30,9 @@ def _check(D, I, D0, I0, metric):
                                      (1, 1, 5, 768), (31, 3, 10, 64), (2049, 33, 10, 128),
                                      (4097, 70, 26, 256), (777, 1, 1, 1024),
                                      # > 64 queries: query-stationary kernel (fp16 rows, d % 256 == 0)
-                                     (5000, 130, 10, 768), (3001, 200, 5, 256), (1500, 65, 12, 1024)])
+                                     # (fp16 rows and > 128 queries: MFMA-tiled scan, 256-query tiles)
+                                     (5000, 130, 10, 768), (3001, 200, 5, 256), (1500, 65, 12, 1024),
+                                     (2500, 100, 10, 512), (40_000, 520, 10, 512), (2047, 129, 26, 1024)])
 def test_search_matches_definition(metric, store, N, B, k, d):
     import probing_rag_amd as pra
     X = onp.synth_rows(42, 0, N, d)
@@ -56,7 +58,7 @@ def test_search_matches_definition(metric, store, N, B, k, d):
             assert I[0, :len(want)].tolist() == want
 
 
-@pytest.mark.parametrize("B", [3, 40, 100])
+@pytest.mark.parametrize("B", [3, 40, 100, 300])
 @pytest.mark.parametrize("metric", [onp.METRIC_L2, onp.METRIC_COS])
 def test_prepass_bound_keeps_ties_and_planted_rows(metric, B):
     """Shards >= 128k rows start the scan from a pre-pass bound (KC-th best key of the
@@ -79,6 +81,28 @@ def test_prepass_bound_keeps_ties_and_planted_rows(metric, B):
     _check(D, I, D0, I0, metric)
     assert I[0].tolist() == sorted(dups)[:k]
     assert I[1, 0] == 140_000
+
+
+@pytest.mark.parametrize("metric", [onp.METRIC_IP, onp.METRIC_L2])
+def test_tiled_scan_candidate_overflow_falls_back(metric):
+    """The MFMA-tiled scan (> 128 queries) filters scores against a bound tightened after every
+    corpus segment into 2048 candidate slots per query.  Rows ordered so that each one beats all
+    earlier ones overflow those slots; the flagged queries must then come out of the per-lane-list
+    kernels, still exact.  Half of the queries are unrelated and stay on the tiled path."""
+    import probing_rag_amd as pra
+    N, d, B, k = 60_000, 256, 260, 10
+    X = onp.synth_rows(51, 0, N, d)
+    q0 = onp.synth_rows(52, 0, 1, d)[0]
+    s = X @ q0 if metric == onp.METRIC_IP else -((X - q0) ** 2).sum(1)
+    X = np.ascontiguousarray(X[np.argsort(s, kind="stable")])       # later rows are better matches
+    Q = onp.synth_rows(53, 0, B, d)
+    Q[: B // 2] = q0 + 0.02 * Q[: B // 2]
+    ix = pra.HipFlatIndex(d, metric, "f16")
+    ix.add(X)
+    D, I = ix.search(Q, k)
+    D0, I0 = onp.flat_search(_stored(X, metric, "f16"), Q, k, metric)
+    _check(D, I, D0, I0, metric)
+    assert (I[: B // 2] > N - 2000).all()                            # the sorted tail wins for the near-q0 half
 
 
 def test_empty_padding_offsets_and_device_io():
