@@ -202,7 +202,24 @@ def flat_search(xs: np.ndarray, q: np.ndarray, k: int, metric: int = METRIC_L2,
     sc = flat_scores(xs, q, metric)
     B, N = sc.shape
     key = sc if metric == METRIC_L2 else -sc
-    order = np.argsort(key, axis=1, kind="stable")[:, :k]
+    if metric == METRIC_L2:
+        order = np.argsort(key, axis=1, kind="stable")[:, :k]
+    else:
+        # flat_scores uses a BLAS matmul for inner products, whose rounding depends on where a
+        # row sits in the blocked GEMM: exact duplicates can differ in the last bit and would
+        # then be ordered by that noise instead of by id.  Preselect generously with the BLAS
+        # scores, rescore the preselection row by row (same summation order for every row, so
+        # identical rows get identical scores) and order by (score, id).
+        m = min(N, k + 64)
+        pre = np.argsort(key, axis=1, kind="stable")[:, :m]
+        x64 = xs.astype(np.float64)
+        q64 = (normalize_rows(q) if metric == METRIC_COS else np.asarray(q)).astype(np.float64)
+        order = np.empty((B, min(N, k)), dtype=np.int64)
+        for b in range(B):
+            ids = np.sort(pre[b])
+            exact = np.einsum("nd,d->n", x64[ids], q64[b])
+            sc[b, ids] = exact
+            order[b] = ids[np.argsort(-exact, kind="stable")[:k]]
     D = np.take_along_axis(sc, order, axis=1).astype(np.float32)
     I = order.astype(np.int64) + id_offset
     if N < k:

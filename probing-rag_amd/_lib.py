@@ -11,7 +11,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "lib", "libprag.so")
+# PRAG_LIB: load another build of the library (the timing-only `make diag` build of the tools)
+LIB_PATH = os.environ.get("PRAG_LIB") or os.path.join(_HERE, "lib", "libprag.so")
 
 PRAG_OK = 0
 PRAG_F32, PRAG_F16, PRAG_BF16 = 0, 1, 2

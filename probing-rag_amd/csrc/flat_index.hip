@@ -985,6 +985,9 @@ struct prag_index {
     uint32_t* mm_ovf = nullptr;
     float* mm_ckey = nullptr;
     int* mm_cidx = nullptr;
+    uint32_t* mm_wcnt = nullptr;
+    float* mm_wkey = nullptr;
+    int* mm_widx = nullptr;
     int mm_q_cap = 0;
     int mm_mode = 1;   // 0 = never take the MFMA-tiled path (PRAG_SCAN_MM=0)
     // host-io staging
@@ -1316,16 +1319,25 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         ix->cand_cap = cand_need;
     }
 
+    const int mm_chunk = std::min(Bpad, kMmMaxQueries);  // queries per mm_run call
     if (use_mm && Bpad > ix->mm_q_cap) {
-        if (ix->mm_cnt) (void)hipFree(ix->mm_cnt);
-        if (ix->mm_ovf) (void)hipFree(ix->mm_ovf);
-        if (ix->mm_ckey) (void)hipFree(ix->mm_ckey);
-        if (ix->mm_cidx) (void)hipFree(ix->mm_cidx);
-        ix->mm_cnt = nullptr; ix->mm_ovf = nullptr; ix->mm_ckey = nullptr; ix->mm_cidx = nullptr; ix->mm_q_cap = 0;
+        void** ws[] = {reinterpret_cast<void**>(&ix->mm_cnt), reinterpret_cast<void**>(&ix->mm_ovf),
+                       reinterpret_cast<void**>(&ix->mm_ckey), reinterpret_cast<void**>(&ix->mm_cidx),
+                       reinterpret_cast<void**>(&ix->mm_wcnt), reinterpret_cast<void**>(&ix->mm_wkey),
+                       reinterpret_cast<void**>(&ix->mm_widx)};
+        for (void** w : ws) {
+            if (*w) (void)hipFree(*w);
+            *w = nullptr;
+        }
+        ix->mm_q_cap = 0;
+        const size_t per_wg = (size_t)ix->n_cu * mm_chunk;
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_cnt), (size_t)Bpad * sizeof(uint32_t)));
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_ovf), (size_t)Bpad * sizeof(uint32_t)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_ckey), (size_t)Bpad * kMmCapQ * sizeof(float)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_cidx), (size_t)Bpad * kMmCapQ * sizeof(int)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_ckey), (size_t)mm_chunk * kMmCapQ * sizeof(float)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_cidx), (size_t)mm_chunk * kMmCapQ * sizeof(int)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_wcnt), per_wg * sizeof(uint32_t)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_wkey), per_wg * kMmCapWg * sizeof(float)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_widx), per_wg * kMmCapWg * sizeof(int)));
         ix->mm_q_cap = Bpad;
     }
 
@@ -1342,24 +1354,34 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         m.xnorm = ix->xnorm;
         m.N = ix->ntotal;
         m.d = ix->d;
-        m.q16 = ix->q16;
-        m.B = B;
-        m.Bpad = Bpad;
         m.alpha = metric_l2 ? -2.0f : -1.0f;
         m.use_norm = metric_l2;
         m.kc = kc;
-        m.tau = ix->g_tau;
-        m.cand = ix->cand;
-        m.cnt = ix->mm_cnt;
         m.ckey = ix->mm_ckey;
         m.cidx = ix->mm_cidx;
-        m.ovf = ix->mm_ovf;
         m.cap_q = kMmCapQ;
+        m.wcnt = ix->mm_wcnt;
+        m.wkey = ix->mm_wkey;
+        m.widx = ix->mm_widx;
+        m.cap_wg = kMmCapWg;
+        m.wg_slots = ix->n_cu;
         m.max_wg = cu_budget;
-        int rc = mm_run(m, st, ix->prof);
-        if (rc != PRAG_OK) return rc;
+        int rc = PRAG_OK;
+        for (int c0 = 0; c0 < B; c0 += kMmMaxQueries) {  // chunks of 4096 queries (LDS counters)
+            m.B = std::min(B - c0, kMmMaxQueries);
+            m.Bpad = std::min(Bpad - c0, kMmMaxQueries);
+            m.q16 = ix->q16 + (size_t)c0 * ix->d;
+            m.tau = ix->g_tau + c0;
+            m.cand = ix->cand + (size_t)c0 * kc;
+            m.cnt = ix->mm_cnt + c0;
+            m.ovf = ix->mm_ovf + c0;
+            rc = mm_run(m, st, ix->prof);
+            if (rc != PRAG_OK) return rc;
+        }
         // Queries whose candidate buffer overflowed (flag set on the device): their groups go
         // through the per-lane-list kernel again; with no flag set this is two empty launches.
+        if (ix->mm_mode == 2) goto mm_done;  // PRAG_SCAN_MM=2 (tests of the tests): overflow goes unrepaired
+        {
         const bool fb64 = 64 * qstride + 8 * 4096 + 64 * 4 + 64 <= 160 * 1024 - 64;
         const int fq = fb64 ? 64 : 32;
         const int fb_grid = std::max(1, std::min(cu_budget, (n_tiles + 7) / 8));
@@ -1394,6 +1416,8 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         rc = launch_merge(kc, ix->part_key, ix->part_idx, fb_grid, fq, B, ix->cand, nullptr, st, ix->mm_ovf,
                           part_stride);
         if (rc != PRAG_OK) return rc;
+        }
+    mm_done:;
     } else {
         ScanArgs a;
         a.rows = ix->rows;
@@ -1544,7 +1568,8 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
     if (!ix) return;
     ix->prof.disable();
     void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->q16lo, ix->g_tau, ix->part_key, ix->part_idx, ix->cand,
-                    ix->io_q, ix->io_D, ix->io_I, ix->mm_cnt, ix->mm_ovf, ix->mm_ckey, ix->mm_cidx};
+                    ix->io_q, ix->io_D, ix->io_I, ix->mm_cnt, ix->mm_ovf, ix->mm_ckey, ix->mm_cidx,
+                    ix->mm_wcnt, ix->mm_wkey, ix->mm_widx};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete ix;

@@ -41,15 +41,23 @@ struct MmSearch {
     uint32_t* tau;          // [Bpad] sortable pruning bound per query: +inf for real queries, -inf for padding
     int* cand;              // [Bpad][kc] out: candidate row ids (-1 = none), ordered by (key, id)
     // workspace
-    uint32_t* cnt;          // [Bpad]
-    float* ckey;            // [Bpad][cap_q]
-    int* cidx;              // [Bpad][cap_q]
-    uint32_t* ovf;          // [Bpad] set when a query's candidate buffer overflowed in some segment
-    int cap_q;              // candidate slots per query (>= first segment)
-    int max_wg;             // workgroups the scan may occupy
+    uint32_t* cnt;          // [Bpad]               candidates held in ckey/cidx[q][0..cnt)
+    float* ckey;            // [Bpad][cap_q]        first segment (slot = row), afterwards the KC best so far
+    int* cidx;
+    uint32_t* ovf;          // [Bpad] set when a query lost candidates to a full region in some segment
+    int cap_q;              // >= kMmFirstSeg
+    uint32_t* wcnt;         // [wg_slots][Bpad]          per-workgroup survivors of the running segment
+    float* wkey;            // [wg_slots][Bpad][cap_wg]
+    int* widx;
+    int cap_wg;
+    int wg_slots;           // workgroups the workspace was sized for
+    int max_wg;             // workgroups the scan may occupy (<= wg_slots)
 };
 
-constexpr int kMmCapQ = 2048;        // candidate slots per query = rows of the first segment
+constexpr int kMmFirstSeg = 2048;    // rows of the first segment (all of them become candidates); segments grow x16
+constexpr int kMmCapQ = kMmFirstSeg; // candidate slots per query in ckey/cidx
+constexpr int kMmCapWg = 64;         // survivors one workgroup can hold per query and segment
+constexpr int kMmMaxQueries = 4096;  // queries per mm_run call (LDS counters); larger batches go in chunks
 bool mm_supported(int d, int store_dtype, int kc);
 // Enqueue the segmented scan on `st`; returns PRAG_OK or a negative status.  `prof` brackets
 // the launch over the largest segment.

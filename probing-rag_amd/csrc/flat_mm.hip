@@ -12,20 +12,23 @@
 // A K tile is four phases {fragment reads for one 64x32 quadrant | 16 KiB of DMA for a K tile
 // two ahead | counted vmcnt | barrier | 8 MFMAs | barrier}; the two wave groups (row halves)
 // run one barrier apart, so one group's MFMAs cover the other group's LDS reads.  Every LDS
-// region is read in exactly one phase, restaged two phases later and waited for one phase
-// before its next read: five phases of flight time per DMA with a uniform vmcnt(8).
+// region is read in exactly one phase, restaged two or three phases later and waited for one
+// phase before its next read: four to five phases of flight time per DMA, uniform vmcnt(8).
 //
 // [B,N] never exists: after the last K tile each lane compares its 128 scores with the
-// per-query pruning bound and appends the rare survivors (key, row) to a per-query candidate
-// buffer (one global atomic per survivor).  The corpus is scanned in segments of geometrically
-// growing size (2048 rows, then x16): mm_compact_kernel reduces every query's buffer to its
-// KC best after each segment and tightens the bound to the KC-th best key seen so far, so a
-// segment contributes ~16*KC candidates per query when rows are exchangeable.  A buffer that
-// overflows anyway (rows sorted by decreasing distance, say) raises a per-query flag and the
-// caller re-runs those queries through the per-lane-list kernels, which cannot overflow.
+// per-query pruning bound and appends the rare survivors (key, row) to its workgroup's own
+// region of a candidate store: the slot comes from a counter in LDS, the stores are
+// fire-and-forget, so a survivor costs no global round trip.  The corpus is scanned in segments
+// of geometrically growing size (2048 rows - all of them candidates - then x16):
+// mm_compact_kernel reduces every query's candidates to its KC best after each segment and
+// tightens the bound to the KC-th best key seen so far, so a segment contributes ~15*KC
+// candidates per query when rows are exchangeable.  A region that overflows anyway (rows sorted
+// by decreasing distance, say) raises a per-query flag and the caller re-runs those queries
+// through the per-lane-list kernels, which cannot overflow.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "flat_internal.h"
 
@@ -41,19 +44,28 @@ struct MmArgs {
     float alpha;
     int use_norm;
     const uint32_t* tau;  // [n_qb*256]
-    uint32_t* cnt;
-    float* ckey;
+    int first;            // first segment: no bound yet, row (row0 + i) of every query goes to slot i of ckey/cidx
+    float* ckey;          // [Bpad][cap_q]
     int* cidx;
     int cap_q;
+    int Bpad;             // n_qb * 256
+    uint32_t* wcnt;       // [grid][Bpad]          survivors per (workgroup, query) of this launch
+    float* wkey;          // [grid][Bpad][cap_wg]  their keys / rows
+    int* widx;
+    int cap_wg;
+    unsigned long long* dbg;  // diagnostic builds: {core-clock ticks, 100 MHz ticks} of block 0; else null
 };
 
 // LDS map (bytes): A even/odd K tile at 0 / 32 KiB, B even/odd at 64 / 96 KiB ([256 rows][128 B],
 // 16-B pieces XOR-swizzled with (row>>1)&7), then 1 KiB of row norms and 1 KiB of bounds.
 constexpr int kMmLdsXn = 131072;
 constexpr int kMmLdsTau = 131072 + 1024;
-constexpr int kMmLdsBytes = 131072 + 2048;
+constexpr int kMmLdsCnt = 131072 + 2048;   // [Bpad] survivor counters of this workgroup
 
-template <int NKT /* d / 64, even */>
+// ABL != 0: timing-only ablations (wrong results) for tools/mm_ablate.py, built with -DPRAG_MM_DIAG;
+// bit 0 no MFMAs, bit 1 no LDS-DMA, bit 2 no fragment reads, bit 3 no filter, bit 4 vmcnt(14)
+// instead of vmcnt(8) (reads may race the DMA), bit 5 no barrier after the MFMA block
+template <int NKT /* d / 64, even */, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     static_assert(NKT % 2 == 0 && NKT >= 4, "K tiles are consumed in even/odd pairs");
     constexpr int64_t RB = (int64_t)NKT * 128;  // bytes per fp16 row
@@ -73,6 +85,9 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     const int v = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + ((int)blockIdx.x >> 3);
     const int n_my = v < a.n_tiles ? (a.n_tiles - v + nwg - 1) / nwg : 0;
     if (n_my == 0) return;  // whole workgroup (grid <= tiles, so this does not happen)
+#ifdef PRAG_MM_DIAG
+    const unsigned long long dbg_c0 = clock64(), dbg_w0 = wall_clock64();
+#endif
 
     // ---- fragment read offsets: A row = 128*wr + 32*mt + r, B row = 64*wc + 32*nt + r; the
     //      swizzle term (row>>1)&7 only depends on r, k-step ks flips byte bits 5..6 ---------
@@ -113,7 +128,8 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
         return p;
     };
 
-#define MM_GLDS(gp_, lp_) __builtin_amdgcn_global_load_lds((gp_), (lp_), 16, 0, 0)
+#define MM_GLDS(gp_, lp_)                                                              \
+    if constexpr (!(ABL & 2)) __builtin_amdgcn_global_load_lds((gp_), (lp_), 16, 0, 0)
     // the four 16-KiB staging steps of one K tile (kt_) into buffer buf_ (0 even, 1 odd)
 #define MM_SA0(tp_, kt_, buf_)                                    \
     {                                                             \
@@ -151,11 +167,12 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
         MM_GLDS(g0_, l0_);                                        \
         MM_GLDS(g1_, l1_);                                        \
     }
-#define MM_LDSR(off_) (*reinterpret_cast<const half8*>(smem + (off_)))
+#define MM_LDSR(off_) ((ABL & 4) ? hz : *reinterpret_cast<const half8*>(smem + (off_)))
     // everything staged four or more phases ago has landed; the barrier publishes it
 #define MM_WAIT_BAR()                                     \
     {                                                     \
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  \
+        if constexpr (ABL & 16) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");  \
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                        \
         __builtin_amdgcn_s_barrier();                     \
         __builtin_amdgcn_sched_barrier(0);                \
     }
@@ -163,18 +180,31 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     {                                                                                                 \
         __builtin_amdgcn_s_setprio(1);                                                                \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                            \
-            c0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF_[0][ks], BF_[ks], ((first_) && ks == 0) ? zero16 : c0_, 0, 0, 0); \
-            c1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF_[1][ks], BF_[ks], ((first_) && ks == 0) ? zero16 : c1_, 0, 0, 0); \
+            if constexpr (ABL & 1) {                                                                  \
+                asm volatile("" ::"v"(AF_[0][ks]), "v"(AF_[1][ks]), "v"(BF_[ks]));                    \
+            } else {                                                                                  \
+                c0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF_[0][ks], BF_[ks], ((first_) && ks == 0) ? zero16 : c0_, 0, 0, 0); \
+                c1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF_[1][ks], BF_[ks], ((first_) && ks == 0) ? zero16 : c1_, 0, 0, 0); \
+            }                                                                                         \
         }                                                                                             \
         __builtin_amdgcn_s_setprio(0);                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                            \
-        __builtin_amdgcn_s_barrier();                                                                 \
+        if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();                                      \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     }
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 acc[4][2];
-    half8 A[2][4], B0[4], B1[4];
+    half8 A[2][4], Bx[4], By[4];
+    half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};  // ablation 3 only: an opaque constant in place of the fragment reads
+    if constexpr (ABL & 4) asm volatile("" : "+v"(hz));
+    if constexpr (ABL & 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i >> 1][i & 1] = zero16;
+    }
+
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem + kMmLdsCnt);
+    for (int i = tid; i < a.Bpad; i += 512) s_cnt[i] = 0;  // published by the prologue's barrier
 
     TilePtr cur = tile_ptr(v), nxt = tile_ptr(v + nwg);
 
@@ -183,10 +213,12 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     MM_SB0(cur, 0, 0)
     MM_SB1(cur, 0, 0)
     MM_SA1(cur, 0, 0)
-    MM_SA0(cur, 1, 1)
     MM_SB0(cur, 1, 1)
+    MM_SA0(cur, 1, 1)
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) Bx[ks] = MM_LDSR(b_off[ks]);
     if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs one barrier behind
 
     for (int ti = 0; ti < n_my; ++ti) {
@@ -197,20 +229,22 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
             const int ke2 = wrap ? ke + 2 - NKT : ke + 2;
             const int ko2 = wrap ? ko + 2 - NKT : ko + 2;
             const TilePtr& tn = wrap ? nxt : cur;
-            // ===== even K tile =====
+            // Fragment reads are spread 8/4/8/4 over the phases (a 12-read phase does not fit the
+            // other group's 8-MFMA window): the first query tile of the NEXT K tile is fetched in
+            // phase 4 into the register set the second query tile no longer needs, so the two sets
+            // Bx/By swap roles every K tile.
+            // ===== even K tile: queries 0-31 in Bx (read one phase ago), 32-63 in By =====
             // phase 1: quadrant (rows 0-63, queries 0-31)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) B0[ks] = MM_LDSR(b_off[ks]);
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) A[m][ks] = MM_LDSR(a_off[ks] + m * 4096);
             MM_SB1(cur, ko, 1)
             MM_WAIT_BAR()
-            MM_MFMA8(acc[0][0], acc[1][0], A, B0, it == 0)
+            MM_MFMA8(acc[0][0], acc[1][0], A, Bx, it == 0)
             // phase 2: (rows 0-63, queries 32-63)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) B1[ks] = MM_LDSR(b_off[ks] + 4096);
+            for (int ks = 0; ks < 4; ++ks) By[ks] = MM_LDSR(b_off[ks] + 4096);
             MM_SA1(cur, ko, 1)
             if (it == NKT / 2 - 2) {
                 // row norms and bounds of this tile, well ahead of the filter.  Not in phase 1: at
@@ -229,48 +263,54 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
                 }
             }
             MM_WAIT_BAR()
-            MM_MFMA8(acc[0][1], acc[1][1], A, B1, it == 0)
+            MM_MFMA8(acc[0][1], acc[1][1], A, By, it == 0)
             // phase 3: (rows 64-127, queries 32-63)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) A[m][ks] = MM_LDSR(a_off[ks] + (2 + m) * 4096);
-            MM_SA0(tn, ke2, 0)
-            MM_WAIT_BAR()
-            MM_MFMA8(acc[2][1], acc[3][1], A, B1, it == 0)
-            // phase 4: (rows 64-127, queries 0-31), operands already in registers
             MM_SB0(tn, ke2, 0)
             MM_WAIT_BAR()
-            MM_MFMA8(acc[2][0], acc[3][0], A, B0, it == 0)
-            // ===== odd K tile =====
+            MM_MFMA8(acc[2][1], acc[3][1], A, By, it == 0)
+            // phase 4: (rows 64-127, queries 0-31); By <- queries 0-31 of the odd K tile
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) B0[ks] = MM_LDSR(b_off[ks] + 32768);
+            for (int ks = 0; ks < 4; ++ks) By[ks] = MM_LDSR(b_off[ks] + 32768);
+            MM_SA0(tn, ke2, 0)
+            MM_WAIT_BAR()
+            MM_MFMA8(acc[2][0], acc[3][0], A, Bx, it == 0)
+            // ===== odd K tile: queries 0-31 in By, 32-63 in Bx =====
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) A[m][ks] = MM_LDSR(a_off[ks] + 32768 + m * 4096);
             MM_SB1(tn, ke2, 0)
             MM_WAIT_BAR()
-            MM_MFMA8(acc[0][0], acc[1][0], A, B0, false)
+            MM_MFMA8(acc[0][0], acc[1][0], A, By, false)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) B1[ks] = MM_LDSR(b_off[ks] + 32768 + 4096);
+            for (int ks = 0; ks < 4; ++ks) Bx[ks] = MM_LDSR(b_off[ks] + 32768 + 4096);
             MM_SA1(tn, ke2, 0)
             MM_WAIT_BAR()
-            MM_MFMA8(acc[0][1], acc[1][1], A, B1, false)
+            MM_MFMA8(acc[0][1], acc[1][1], A, Bx, false)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) A[m][ks] = MM_LDSR(a_off[ks] + 32768 + (2 + m) * 4096);
-            MM_SA0(tn, ko2, 1)
-            MM_WAIT_BAR()
-            MM_MFMA8(acc[2][1], acc[3][1], A, B1, false)
             MM_SB0(tn, ko2, 1)
             MM_WAIT_BAR()
-            MM_MFMA8(acc[2][0], acc[3][0], A, B0, false)
+            MM_MFMA8(acc[2][1], acc[3][1], A, Bx, false)
+            // phase 8: Bx <- queries 0-31 of the next even K tile (next tile's first one at the end)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) Bx[ks] = MM_LDSR(b_off[ks]);
+            MM_SA0(tn, ko2, 1)
+            MM_WAIT_BAR()
+            MM_MFMA8(acc[2][0], acc[3][0], A, By, false)
         }
 
         // ---- filter: 128 scores per lane against the bound of their query ----------------
-        {
+        if constexpr (ABL & 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(acc[i >> 1][i & 1]));
+        } else {
             const int64_t rbase = cur.row0 + 128 * wr + 4 * h;
             const int qbase = cur.q0 + 64 * wc + r;
             float tauf[2];
@@ -293,16 +333,38 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
                         key[e] = fmaf(a.alpha, acc[mt][nt][e], xn[e >> 2][e & 3]);
                         m = fminf(m, key[e]);
                     }
-                    if (__builtin_amdgcn_ballot_w64(m <= tauf[nt]) != 0) {  // rare once the bound is warm
-                        const int q = qbase + 32 * nt;
+                    const int q = qbase + 32 * nt;
+                    if (a.first) {
+                        // no bound yet: everything is a candidate, slot = row - row0 (no counters)
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
                             const int64_t row = rbase + 32 * mt + 8 * (e >> 2) + (e & 3);
-                            if (key[e] <= tauf[nt] && row < a.row1) {
-                                const uint32_t slot = atomicAdd(a.cnt + q, 1u);
-                                if (slot < (uint32_t)a.cap_q) {
-                                    a.ckey[(int64_t)q * a.cap_q + slot] = key[e];
-                                    a.cidx[(int64_t)q * a.cap_q + slot] = (int)row;
+                            if (row < a.row1) {
+                                a.ckey[(int64_t)q * a.cap_q + (row - a.row0)] = key[e];
+                                a.cidx[(int64_t)q * a.cap_q + (row - a.row0)] = (int)row;
+                            }
+                        }
+                    } else if (__builtin_amdgcn_ballot_w64(m <= tauf[nt]) != 0) {  // rare once the bound is warm
+                        // survivors go to this workgroup's own region of the candidate store: the slot
+                        // comes from an LDS counter (no global round trip), the stores are fire-and-forget
+                        int np = 0;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int64_t row = rbase + 32 * mt + 8 * (e >> 2) + (e & 3);
+                            np += (key[e] <= tauf[nt] && row < a.row1) ? 1 : 0;
+                        }
+                        if (np > 0) {
+                            uint32_t slot = atomicAdd(s_cnt + q, (uint32_t)np);
+                            const int64_t o = ((int64_t)blockIdx.x * a.Bpad + q) * a.cap_wg;
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const int64_t row = rbase + 32 * mt + 8 * (e >> 2) + (e & 3);
+                                if (key[e] <= tauf[nt] && row < a.row1) {
+                                    if (slot < (uint32_t)a.cap_wg) {
+                                        a.wkey[o + slot] = key[e];
+                                        a.widx[o + slot] = (int)row;
+                                    }
+                                    ++slot;
                                 }
                             }
                         }
@@ -315,6 +377,15 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail DMAs must not outlive the workgroup's LDS
     if (wr == 0) __builtin_amdgcn_s_barrier();         // pair the second group's extra barrier
+    __syncthreads();                                   // both groups are through their last filter
+#ifdef PRAG_MM_DIAG
+    if (a.dbg && blockIdx.x == 0 && tid == 0) {
+        a.dbg[0] = clock64() - dbg_c0;
+        a.dbg[1] = wall_clock64() - dbg_w0;
+    }
+#endif
+    if (!a.first)
+        for (int i = tid; i < a.Bpad; i += 512) a.wcnt[(int64_t)blockIdx.x * a.Bpad + i] = s_cnt[i];
 #undef MM_GLDS
 #undef MM_SA0
 #undef MM_SA1
@@ -326,20 +397,47 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// after each segment: a query's candidate buffer -> its KC best by (key, id), in place;
+// after each segment: the query's KC best so far (ckey/cidx[q][0..cnt)) + the survivors every
+// workgroup collected for it in this segment -> its KC best by (key, id), in place;
 // bound <- KC-th best key; cand[q][0..KC) <- row ids.  One wave per query.
 // ---------------------------------------------------------------------------
+constexpr int kMmCompactCap = 4096;  // entries staged in LDS; a query with more is flagged as overflowed
+
 __global__ __launch_bounds__(64) void mm_compact_kernel(uint32_t* __restrict__ cnt, float* __restrict__ ckey,
                                                        int* __restrict__ cidx, int cap_q, int KC,
                                                        uint32_t* __restrict__ tau, int* __restrict__ cand,
-                                                       uint32_t* __restrict__ ovf) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long* s_v = reinterpret_cast<unsigned long long*>(smem);
+                                                       uint32_t* __restrict__ ovf, const uint32_t* __restrict__ wcnt,
+                                                       const float* __restrict__ wkey, const int* __restrict__ widx,
+                                                       int cap_wg, int n_wg, int Bpad) {
+    __shared__ unsigned long long s_v[kMmCompactCap];
     const int q = blockIdx.x, lane = threadIdx.x;
     const uint32_t c = cnt[q];
-    const int n = c < (uint32_t)cap_q ? (int)c : cap_q;
+    int n = c < (uint32_t)cap_q ? (int)c : cap_q;
+    bool over = c > (uint32_t)cap_q || n > kMmCompactCap;
+    n = n < kMmCompactCap ? n : kMmCompactCap;
     const int64_t o = (int64_t)q * cap_q;
     for (int i = lane; i < n; i += 64) s_v[i] = pack_key(ckey[o + i], cidx[o + i]);
+    // this segment's survivors: 64 workgroups per step, offsets by a wave prefix sum
+    for (int w0 = 0; w0 < n_wg; w0 += 64) {
+        const int wg = w0 + lane;
+        uint32_t cw = wg < n_wg ? wcnt[(int64_t)wg * Bpad + q] : 0u;
+        over |= cw > (uint32_t)cap_wg;
+        int mine = cw < (uint32_t)cap_wg ? (int)cw : cap_wg;
+        int incl = mine;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const int up = __shfl_up(incl, sft, 64);
+            if (lane >= sft) incl += up;
+        }
+        const int total = __shfl(incl, 63, 64);
+        const int at = n + incl - mine;
+        const int64_t wo = ((int64_t)wg * Bpad + q) * cap_wg;
+        for (int j = 0; j < mine; ++j) {
+            if (at + j < kMmCompactCap) s_v[at + j] = pack_key(wkey[wo + j], widx[wo + j]);
+            else over = true;
+        }
+        n = n + total < kMmCompactCap ? n + total : kMmCompactCap;
+    }
     __syncthreads();
     unsigned long long prev = 0;
     for (int round = 0; round < KC; ++round) {
@@ -365,9 +463,10 @@ __global__ __launch_bounds__(64) void mm_compact_kernel(uint32_t* __restrict__ c
         }
         prev = m;  // once exhausted (m == ~0) nothing is above it: the remaining rounds write -1
     }
+    const bool any_over = __builtin_amdgcn_ballot_w64(over) != 0;
     if (lane == 0) {
         cnt[q] = n < KC ? n : KC;
-        if (c > (uint32_t)cap_q) ovf[q] = 1u;
+        if (any_over) ovf[q] = 1u;
     }
 }
 
@@ -375,24 +474,26 @@ bool mm_supported(int d, int store_dtype, int kc) {
     return store_dtype == PRAG_F16 && (d == 256 || d == 512 || d == 768 || d == 1024) && kc >= 8 && kc <= 32;
 }
 
-template <int NKT>
+template <int NKT, int ABL = 0>
 static int launch_mm(const MmArgs& a, int grid, hipStream_t st) {
-    auto kern = scan_mm_kernel<NKT>;
+    auto kern = scan_mm_kernel<NKT, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
         PRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kMmLdsBytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kMmLdsCnt + 4 * a.Bpad, st, a);
     PRAG_LAUNCH_CHECK();
     return PRAG_OK;
 }
 
 int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
-    PRAG_REQUIRE(mm_supported(s.d, PRAG_F16, s.kc) && s.Bpad % 256 == 0 && s.cap_q >= kMmCapQ, PRAG_EUNSUPPORTED,
-                 "internal: MFMA-tiled scan called outside its envelope");
-    PRAG_HIP(hipMemsetAsync(s.cnt, 0, (size_t)s.Bpad * sizeof(uint32_t), st));
+    PRAG_REQUIRE(mm_supported(s.d, PRAG_F16, s.kc) && s.Bpad % 256 == 0 && s.Bpad <= kMmMaxQueries &&
+                     s.cap_q >= kMmFirstSeg && s.max_wg >= 1 && s.max_wg <= s.wg_slots,
+                 PRAG_EUNSUPPORTED, "internal: MFMA-tiled scan called outside its envelope");
+    const int64_t first_rows = std::min<int64_t>(s.N, kMmFirstSeg);
+    PRAG_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s.cnt), (int)first_rows, (size_t)s.Bpad, st));
     PRAG_HIP(hipMemsetAsync(s.ovf, 0, (size_t)s.Bpad * sizeof(uint32_t), st));
     MmArgs a;
     a.rows = s.rows;
@@ -402,15 +503,28 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
     a.alpha = s.alpha;
     a.use_norm = s.use_norm;
     a.tau = s.tau;
-    a.cnt = s.cnt;
     a.ckey = s.ckey;
     a.cidx = s.cidx;
     a.cap_q = s.cap_q;
+    a.Bpad = s.Bpad;
+    a.wcnt = s.wcnt;
+    a.wkey = s.wkey;
+    a.widx = s.widx;
+    a.cap_wg = s.cap_wg;
+    a.dbg = nullptr;
+#ifdef PRAG_MM_DIAG
+    static unsigned long long* dbg_dev = nullptr;
+    if (getenv("PRAG_MM_CLOCK")) {
+        if (!dbg_dev) PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&dbg_dev), 16));
+        a.dbg = dbg_dev;
+    }
+#endif
     int64_t lo = 0;
-    int64_t hi = std::min<int64_t>(s.N, kMmCapQ);  // first segment: every row is a candidate
+    int64_t hi = first_rows;  // first segment: every row is a candidate
     while (lo < s.N) {
         a.row0 = lo;
         a.row1 = hi;
+        a.first = lo == 0;
         const int64_t n_rt = (hi - lo + 255) / 256;
         a.n_tiles = (int)(n_rt * a.n_qb);
         const int grid = (int)std::min<int64_t>(a.n_tiles, std::max(1, s.max_wg));
@@ -420,13 +534,42 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
         switch (s.d) {
             case 256: rc = launch_mm<4>(a, grid, st); break;
             case 512: rc = launch_mm<8>(a, grid, st); break;
-            case 768: rc = launch_mm<12>(a, grid, st); break;
+            case 768:
+#ifdef PRAG_MM_DIAG
+            {
+                const char* e = getenv("PRAG_MM_ABLATE");
+                switch (e ? atoi(e) : 0) {
+                    case 8: rc = launch_mm<12, 8>(a, grid, st); break;
+                    case 9: rc = launch_mm<12, 9>(a, grid, st); break;
+                    case 10: rc = launch_mm<12, 10>(a, grid, st); break;
+                    case 12: rc = launch_mm<12, 12>(a, grid, st); break;
+                    case 14: rc = launch_mm<12, 14>(a, grid, st); break;
+                    case 15: rc = launch_mm<12, 15>(a, grid, st); break;
+                    case 24: rc = launch_mm<12, 24>(a, grid, st); break;
+                    case 40: rc = launch_mm<12, 40>(a, grid, st); break;
+                    case 56: rc = launch_mm<12, 56>(a, grid, st); break;
+                    default: rc = launch_mm<12>(a, grid, st); break;
+                }
+                break;
+            }
+#else
+                rc = launch_mm<12>(a, grid, st);
+                break;
+#endif
             default: rc = launch_mm<16>(a, grid, st); break;
         }
         if (biggest) prof.end(st);
         if (rc != PRAG_OK) return rc;
-        hipLaunchKernelGGL(mm_compact_kernel, dim3(s.B), dim3(64), (size_t)s.cap_q * 8, st, s.cnt, s.ckey, s.cidx,
-                           s.cap_q, s.kc, s.tau, s.cand, s.ovf);
+#ifdef PRAG_MM_DIAG
+        if (a.dbg && biggest) {
+            unsigned long long h[2];
+            PRAG_HIP(hipMemcpy(h, a.dbg, 16, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[mm diag] block 0: %llu core ticks in %.1f us -> %.0f MHz\n", h[0], h[1] / 100.0,
+                    h[1] ? h[0] / (h[1] / 100.0) : 0.0);
+        }
+#endif
+        hipLaunchKernelGGL(mm_compact_kernel, dim3(s.B), dim3(64), 0, st, s.cnt, s.ckey, s.cidx, s.cap_q, s.kc, s.tau,
+                           s.cand, s.ovf, s.wcnt, s.wkey, s.widx, s.cap_wg, a.first ? 0 : grid, s.Bpad);
         PRAG_LAUNCH_CHECK();
         lo = hi;
         hi = std::min<int64_t>(s.N, hi * 16);
