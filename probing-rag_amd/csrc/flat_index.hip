@@ -108,10 +108,17 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, int B, int Bpad, int d,
                                                           int normalise, float* __restrict__ q32,
                                                           _Float16* __restrict__ q16, _Float16* __restrict__ q16lo,
-                                                          uint32_t* __restrict__ g_tau) {
+                                                          uint32_t* __restrict__ g_tau,
+                                                          uint32_t* __restrict__ mm_cnt, uint32_t* __restrict__ mm_ovf,
+                                                          uint32_t mm_first_rows) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= Bpad) return;
+    if (mm_cnt && lane == 0) {  // MFMA-tiled scan: candidate counts / overflow flags (word Bpad: "any")
+        mm_cnt[b] = mm_first_rows;
+        mm_ovf[b] = 0u;
+        if (b == 0) mm_ovf[Bpad] = 0u;
+    }
     // the scan's chip-wide pruning bound: +inf for real queries; padding rows never collect anything
     if (lane == 0) g_tau[b] = b < B ? kSortablePosInf : kSortableNegInf;
     if (b >= B) {
@@ -508,6 +515,7 @@ __global__ __launch_bounds__(512, 1) void scan_topk_flagged_kernel(ScanArgs a, c
                                                                    int n_groups, int64_t part_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_any;
+    if (q_flag[(int64_t)n_groups * QT] == 0) return;  // the "any query flagged" word: the common case
     for (int g = 0; g < n_groups; ++g) {
         if (threadIdx.x == 0) s_any = 0;
         __syncthreads();
@@ -734,13 +742,14 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
                                                          int QT, int* __restrict__ cand_idx /*[q][KC]*/,
                                                          uint32_t* __restrict__ tau_out /*[q] or null*/,
                                                          const uint32_t* __restrict__ q_flag /*or null*/,
-                                                         int64_t part_stride) {
+                                                         int64_t part_stride, int any_idx) {
     __shared__ unsigned long long s_w[4 * KC];
     // flagged mode (fallback of the MFMA-tiled scan): block = global query, lists of its group of QT
     // queries start at part_stride * group; groups without a flagged query keep their candidates
     int q = blockIdx.x;
     const int64_t qglob = blockIdx.x;
     if (q_flag) {
+        if (q_flag[any_idx] == 0) return;  // nothing was flagged in this search
         const int grp = q / QT;
         bool any = false;
         for (int j = 0; j < QT; ++j) any |= q_flag[grp * QT + j] != 0;
@@ -1230,11 +1239,11 @@ static int dispatch_qs(int d, int kc, const ScanArgs& a, int grid, hipStream_t s
 
 static int launch_merge(int kc, const float* pk, const int* pi, int n_lists, int QT, int nq, int* cand,
                         uint32_t* tau_out, hipStream_t st, const uint32_t* q_flag = nullptr,
-                        int64_t part_stride = 0) {
+                        int64_t part_stride = 0, int any_idx = 0) {
     switch (kc) {
-        case 8: hipLaunchKernelGGL(merge_lists_kernel<8>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out, q_flag, part_stride); break;
-        case 16: hipLaunchKernelGGL(merge_lists_kernel<16>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out, q_flag, part_stride); break;
-        case 32: hipLaunchKernelGGL(merge_lists_kernel<32>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out, q_flag, part_stride); break;
+        case 8: hipLaunchKernelGGL(merge_lists_kernel<8>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out, q_flag, part_stride, any_idx); break;
+        case 16: hipLaunchKernelGGL(merge_lists_kernel<16>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out, q_flag, part_stride, any_idx); break;
+        case 32: hipLaunchKernelGGL(merge_lists_kernel<32>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out, q_flag, part_stride, any_idx); break;
         default: set_error("internal: KC=%d", kc); return PRAG_EUNSUPPORTED;
     }
     PRAG_LAUNCH_CHECK();
@@ -1332,7 +1341,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         ix->mm_q_cap = 0;
         const size_t per_wg = (size_t)ix->n_cu * mm_chunk;
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_cnt), (size_t)Bpad * sizeof(uint32_t)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_ovf), (size_t)Bpad * sizeof(uint32_t)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_ovf), ((size_t)Bpad + 1) * sizeof(uint32_t)));
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_ckey), (size_t)mm_chunk * kMmCapQ * sizeof(float)));
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_cidx), (size_t)mm_chunk * kMmCapQ * sizeof(int)));
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_wcnt), per_wg * sizeof(uint32_t)));
@@ -1343,7 +1352,9 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
 
     const int metric_l2 = ix->metric == PRAG_METRIC_L2;
     hipLaunchKernelGGL(prep_queries_kernel, dim3((Bpad + 3) / 4), dim3(256), 0, st, q_dev, B, Bpad, ix->d,
-                       ix->metric == PRAG_METRIC_COS ? 1 : 0, ix->q32, ix->q16, ix->q16lo, ix->g_tau);
+                       ix->metric == PRAG_METRIC_COS ? 1 : 0, ix->q32, ix->q16, ix->q16lo, ix->g_tau,
+                       use_mm ? ix->mm_cnt : nullptr, ix->mm_ovf,
+                       (uint32_t)std::min<int64_t>(ix->ntotal, kMmFirstSeg));
     PRAG_LAUNCH_CHECK();
 
     if (ix->ntotal == 0) {
@@ -1375,6 +1386,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
             m.cand = ix->cand + (size_t)c0 * kc;
             m.cnt = ix->mm_cnt + c0;
             m.ovf = ix->mm_ovf + c0;
+            m.ovf_any = ix->mm_ovf + Bpad;
             rc = mm_run(m, st, ix->prof);
             if (rc != PRAG_OK) return rc;
         }
@@ -1414,7 +1426,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
                   : dispatch_flagged<32>(kc, a, fb_grid, ix->mm_ovf, n_groups, part_stride, st);
         if (rc != PRAG_OK) return rc;
         rc = launch_merge(kc, ix->part_key, ix->part_idx, fb_grid, fq, B, ix->cand, nullptr, st, ix->mm_ovf,
-                          part_stride);
+                          part_stride, Bpad);
         if (rc != PRAG_OK) return rc;
         }
     mm_done:;

@@ -45,8 +45,10 @@ struct MmSearch {
     float* ckey;            // [Bpad][cap_q]        first segment (slot = row), afterwards the KC best so far
     int* cidx;
     uint32_t* ovf;          // [Bpad] set when a query lost candidates to a full region in some segment
+    uint32_t* ovf_any;      // one word: set when any query of the search was flagged
+    // (the caller presets cnt[q] = min(N, kMmFirstSeg), ovf[q] = 0, *ovf_any = 0 on the stream)
     int cap_q;              // >= kMmFirstSeg
-    uint32_t* wcnt;         // [wg_slots][Bpad]          per-workgroup survivors of the running segment
+    uint32_t* wcnt;         // [Bpad][wg_slots]          per-workgroup survivors of the running segment
     float* wkey;            // [wg_slots][Bpad][cap_wg]
     int* widx;
     int cap_wg;

@@ -44,12 +44,13 @@ struct MmArgs {
     float alpha;
     int use_norm;
     const uint32_t* tau;  // [n_qb*256]
-    int first;            // first segment: no bound yet, row (row0 + i) of every query goes to slot i of ckey/cidx
+    float inv_alpha;      // 1 / alpha (exact: alpha is -1 or -2)
     float* ckey;          // [Bpad][cap_q]
     int* cidx;
     int cap_q;
     int Bpad;             // n_qb * 256
-    uint32_t* wcnt;       // [grid][Bpad]          survivors per (workgroup, query) of this launch
+    int wg_stride;        // workgroup slots per query in wcnt
+    uint32_t* wcnt;       // [Bpad][wg_stride]     survivors per (query, workgroup) of this launch
     float* wkey;          // [grid][Bpad][cap_wg]  their keys / rows
     int* widx;
     int cap_wg;
@@ -65,8 +66,11 @@ constexpr int kMmLdsCnt = 131072 + 2048;   // [Bpad] survivor counters of this w
 // ABL != 0: timing-only ablations (wrong results) for tools/mm_ablate.py, built with -DPRAG_MM_DIAG;
 // bit 0 no MFMAs, bit 1 no LDS-DMA, bit 2 no fragment reads, bit 3 no filter, bit 4 vmcnt(14)
 // instead of vmcnt(8) (reads may race the DMA), bit 5 no barrier after the MFMA block
-template <int NKT /* d / 64, even */, int ABL = 0>
+// MODE 0: the launch over the first segment (no bound yet; every row becomes a candidate);
+// MODE 1: inner product / cosine (key = -score); MODE 2: squared L2 (key = ||x||^2 - 2 score).
+template <int NKT /* d / 64, even */, int MODE = 1, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
+    constexpr bool FIRST = MODE == 0;
     static_assert(NKT % 2 == 0 && NKT >= 4, "K tiles are consumed in even/odd pairs");
     constexpr int64_t RB = (int64_t)NKT * 128;  // bytes per fp16 row
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,10 +106,9 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
 
     // ---- LDS-DMA geometry: one wave instruction fills 8 rows x 128 B linearly, so lane l
     //      fetches global piece (l&7) ^ swizzle(row) of row 8*chunk + (l>>3) ------------------
-    const int l8 = lane >> 3;
-    const int colb = (((lane & 7) ^ ((4 * (w & 1) + (lane >> 4)) & 7)) << 4);
-    const int a_thr = 8 * w + l8;                              // A rows 8w.. (+128: second instruction)
-    const int b_thr = 64 * (w >> 2) + 8 * (w & 3) + l8;        // B strips (w>>2) and (w>>2)+2, first 32 rows
+    //      (the per-lane parts are rebuilt inside tile_ptr, once per tile, from an opaque copy of
+    //      the lane id: kept live across the main loop they get spilled, and a reload waits
+    //      behind s_waitcnt vmcnt(0))
     const gcptr rows_g = (gcptr) reinterpret_cast<const char*>(a.rows);
     const gcptr q_g = (gcptr) reinterpret_cast<const char*>(a.q16);
     const lptr lds0 = (lptr)smem;
@@ -120,6 +123,12 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     auto tile_ptr = [&](int t) {
         t = t < a.n_tiles ? t : a.n_tiles - 1;  // past the end: re-stage the last tile (never read)
         const int rt = t / a.n_qb, qb = t - rt * a.n_qb;
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        const int l8 = le >> 3;
+        const int colb = (((le & 7) ^ ((4 * (w & 1) + (le >> 4)) & 7)) << 4);
+        const int a_thr = 8 * w + l8;                        // A rows 8w.. (+128: second instruction)
+        const int b_thr = 64 * (w >> 2) + 8 * (w & 3) + l8;  // B strips (w>>2) and (w>>2)+2, first 32 rows
         TilePtr p;
         p.row0 = a.row0 + (int64_t)rt * 256;
         p.q0 = qb * 256;
@@ -311,66 +320,135 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(acc[i >> 1][i & 1]));
         } else {
+            // (everything per-lane below is rebuilt from an opaque copy of the lane id: hoisted out of
+            // the tile loop these values would sit in VGPRs the main loop does not have, and a spilled
+            // value reloads behind s_waitcnt vmcnt(0), i.e. drains the DMA pipeline once per tile)
+            int le = lane;
+            asm volatile("" : "+v"(le));
+            const int r = le & 31, h = le >> 5;
             const int64_t rbase = cur.row0 + 128 * wr + 4 * h;
             const int qbase = cur.q0 + 64 * wc + r;
-            float tauf[2];
+            float tauf[2], thr[2];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt) {
                 tauf[nt] = unsortable_f32(*reinterpret_cast<const uint32_t*>(smem + kMmLdsTau + (64 * wc + 32 * nt + r) * 4));
+                thr[nt] = tauf[nt] * a.inv_alpha;  // key <= tau  <=>  score >= tau / alpha  (alpha < 0)
+            }
+            // The other wave group waits at the next barrier while this one filters, so every
+            // instruction here is exposed twice per tile: the common case is kept to ~12 (inner
+            // product) / ~26 (L2) VALU operations per 16 scores.  v_max3/v_min3 by hand: fmaxf()
+            // adds a canonicalising v_max per operand in IEEE mode.  The s_nops cover the MFMA ->
+            // VALU read hazard the compiler cannot see through inline asm.
+            asm volatile("s_nop 15\n\ts_nop 15");
+#define MM_MAX3(d_, x_, y_, z_) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d_) : "v"(x_), "v"(y_), "v"(z_))
+#define MM_MIN3(d_, x_, y_, z_) asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d_) : "v"(x_), "v"(y_), "v"(z_))
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 f32x4 xn[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    xn[g] = a.use_norm ? *reinterpret_cast<const f32x4*>(smem + kMmLdsXn + (128 * wr + 32 * mt + 8 * g + 4 * h) * 4)
-                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int g = 0; g < 4; ++g) {
+                    if ((FIRST && a.use_norm) || MODE == 2)
+                        xn[g] = *reinterpret_cast<const f32x4*>(smem + kMmLdsXn + (128 * wr + 32 * mt + 8 * g + 4 * h) * 4);
+                    else
+                        xn[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    float key[16];
-                    float m = INFINITY;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        key[e] = fmaf(a.alpha, acc[mt][nt][e], xn[e >> 2][e & 3]);
-                        m = fminf(m, key[e]);
-                    }
+                    const f32x16& c = acc[mt][nt];
                     const int q = qbase + 32 * nt;
-                    if (a.first) {
-                        // no bound yet: everything is a candidate, slot = row - row0 (no counters)
+                    const int64_t rb = rbase + 32 * mt;
+                    if constexpr (FIRST) {
+                        // no bound yet: every row is a candidate, slot = row - row0 (no counters);
+                        // the four rows of a register quad are consecutive slots -> 16-B stores
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int64_t row = rbase + 32 * mt + 8 * (e >> 2) + (e & 3);
-                            if (row < a.row1) {
-                                a.ckey[(int64_t)q * a.cap_q + (row - a.row0)] = key[e];
-                                a.cidx[(int64_t)q * a.cap_q + (row - a.row0)] = (int)row;
+                        for (int g = 0; g < 4; ++g) {
+                            const int64_t row = rb + 8 * g;
+                            const int64_t o = (int64_t)q * a.cap_q + (row - a.row0);
+                            f32x4 kv;
+                            i32x4 iv;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                kv[e] = fmaf(a.alpha, c[4 * g + e], xn[g][e]);
+                                iv[e] = (int)row + e;
+                            }
+                            if (row + 3 < a.row1) {
+                                *reinterpret_cast<f32x4*>(a.ckey + o) = kv;
+                                *reinterpret_cast<i32x4*>(a.cidx + o) = iv;
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (row + e < a.row1) {
+                                        a.ckey[o + e] = kv[e];
+                                        a.cidx[o + e] = iv[e];
+                                    }
                             }
                         }
-                    } else if (__builtin_amdgcn_ballot_w64(m <= tauf[nt]) != 0) {  // rare once the bound is warm
-                        // survivors go to this workgroup's own region of the candidate store: the slot
-                        // comes from an LDS counter (no global round trip), the stores are fire-and-forget
-                        int np = 0;
+                    } else {
+                        // does any of the 16 scores reach the bound?
+                        bool any;
+                        if constexpr (MODE == 1) {
+                            float m;
+                            MM_MAX3(m, c[0], c[1], c[2]);
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int64_t row = rbase + 32 * mt + 8 * (e >> 2) + (e & 3);
-                            np += (key[e] <= tauf[nt] && row < a.row1) ? 1 : 0;
+                            for (int e = 3; e < 15; e += 2) MM_MAX3(m, m, c[e], c[e + 1]);
+                            any = fmaxf(m, c[15]) >= thr[nt];
+                        } else {
+                            float kk[16];
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) kk[e] = fmaf(a.alpha, c[e], xn[e >> 2][e & 3]);
+                            float m;
+                            MM_MIN3(m, kk[0], kk[1], kk[2]);
+#pragma unroll
+                            for (int e = 3; e < 15; e += 2) MM_MIN3(m, m, kk[e], kk[e + 1]);
+                            any = fminf(m, kk[15]) <= tauf[nt];
                         }
-                        if (np > 0) {
-                            uint32_t slot = atomicAdd(s_cnt + q, (uint32_t)np);
-                            const int64_t o = ((int64_t)blockIdx.x * a.Bpad + q) * a.cap_wg;
+                        if (__builtin_amdgcn_ballot_w64(any) != 0) {  // rare once the bound is warm
+                            // survivors go to this workgroup's own region of the candidate store: the
+                            // slot comes from an LDS counter (no global round trip), the stores are
+                            // fire-and-forget.  Only the register quads that hold one are expanded.
 #pragma unroll
-                            for (int e = 0; e < 16; ++e) {
-                                const int64_t row = rbase + 32 * mt + 8 * (e >> 2) + (e & 3);
-                                if (key[e] <= tauf[nt] && row < a.row1) {
-                                    if (slot < (uint32_t)a.cap_wg) {
-                                        a.wkey[o + slot] = key[e];
-                                        a.widx[o + slot] = (int)row;
+                            for (int g = 0; g < 4; ++g) {
+                                float key[4];
+                                bool hit = false;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    key[e] = fmaf(a.alpha, c[4 * g + e], xn[g][e]);
+                                    hit |= key[e] <= tauf[nt];
+                                }
+                                if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
+                                const int64_t row0q = rb + 8 * g;
+                                int np = 0;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) np += (key[e] <= tauf[nt] && row0q + e < a.row1) ? 1 : 0;
+                                if (np > 0) {
+                                    // (inline asm on purpose: in front of a compiler-visible LDS atomic hipcc
+                                    // puts s_waitcnt vmcnt(0) - the LDS-DMA in flight might alias it - which
+                                    // drains the DMA pipeline on every survivor; the counters are no DMA target)
+                                    uint32_t slot;
+                                    const uint32_t cnt_addr = (uint32_t)(uintptr_t)(lptr)(reinterpret_cast<char*>(s_cnt + q));
+                                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                                                 : "=v"(slot)
+                                                 : "v"(cnt_addr), "v"((uint32_t)np)
+                                                 : "memory");
+                                    const int64_t o = ((int64_t)blockIdx.x * a.Bpad + q) * a.cap_wg;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        if (key[e] <= tauf[nt] && row0q + e < a.row1) {
+                                            if (slot < (uint32_t)a.cap_wg) {
+                                                a.wkey[o + slot] = key[e];
+                                                a.widx[o + slot] = (int)(row0q + e);
+                                            }
+                                            ++slot;
+                                        }
                                     }
-                                    ++slot;
                                 }
                             }
                         }
                     }
                 }
             }
+#undef MM_MAX3
+#undef MM_MIN3
         }
         cur = nxt;
         nxt = tile_ptr(v + (ti + 2) * nwg);
@@ -384,8 +462,8 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
         a.dbg[1] = wall_clock64() - dbg_w0;
     }
 #endif
-    if (!a.first)
-        for (int i = tid; i < a.Bpad; i += 512) a.wcnt[(int64_t)blockIdx.x * a.Bpad + i] = s_cnt[i];
+    if constexpr (!FIRST)
+        for (int i = tid; i < a.Bpad; i += 512) a.wcnt[(int64_t)i * a.wg_stride + blockIdx.x] = s_cnt[i];
 #undef MM_GLDS
 #undef MM_SA0
 #undef MM_SA1
@@ -403,47 +481,58 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
 // ---------------------------------------------------------------------------
 constexpr int kMmCompactCap = 4096;  // entries staged in LDS; a query with more is flagged as overflowed
 
-__global__ __launch_bounds__(64) void mm_compact_kernel(uint32_t* __restrict__ cnt, float* __restrict__ ckey,
-                                                       int* __restrict__ cidx, int cap_q, int KC,
-                                                       uint32_t* __restrict__ tau, int* __restrict__ cand,
-                                                       uint32_t* __restrict__ ovf, const uint32_t* __restrict__ wcnt,
-                                                       const float* __restrict__ wkey, const int* __restrict__ widx,
-                                                       int cap_wg, int n_wg, int Bpad) {
+__global__ __launch_bounds__(256) void mm_compact_kernel(uint32_t* __restrict__ cnt, float* __restrict__ ckey,
+                                                        int* __restrict__ cidx, int cap_q, int KC,
+                                                        uint32_t* __restrict__ tau, int* __restrict__ cand,
+                                                        uint32_t* __restrict__ ovf, uint32_t* __restrict__ ovf_any,
+                                                        const uint32_t* __restrict__ wcnt,
+                                                        const float* __restrict__ wkey, const int* __restrict__ widx,
+                                                        int cap_wg, int n_wg, int wg_stride, int Bpad) {
     __shared__ unsigned long long s_v[kMmCompactCap];
-    const int q = blockIdx.x, lane = threadIdx.x;
+    __shared__ unsigned long long s_m[2][4];
+    __shared__ int s_tot[4];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t c = cnt[q];
     int n = c < (uint32_t)cap_q ? (int)c : cap_q;
     bool over = c > (uint32_t)cap_q || n > kMmCompactCap;
     n = n < kMmCompactCap ? n : kMmCompactCap;
     const int64_t o = (int64_t)q * cap_q;
-    for (int i = lane; i < n; i += 64) s_v[i] = pack_key(ckey[o + i], cidx[o + i]);
-    // this segment's survivors: 64 workgroups per step, offsets by a wave prefix sum
-    for (int w0 = 0; w0 < n_wg; w0 += 64) {
-        const int wg = w0 + lane;
-        uint32_t cw = wg < n_wg ? wcnt[(int64_t)wg * Bpad + q] : 0u;
+    for (int i = tid; i < n; i += 256) s_v[i] = pack_key(ckey[o + i], cidx[o + i]);
+    // this segment's survivors: 256 workgroups per step, offsets by a block prefix sum
+    for (int w0 = 0; w0 < n_wg; w0 += 256) {
+        const int wg = w0 + tid;
+        const uint32_t cw = wg < n_wg ? wcnt[(int64_t)q * wg_stride + wg] : 0u;
         over |= cw > (uint32_t)cap_wg;
-        int mine = cw < (uint32_t)cap_wg ? (int)cw : cap_wg;
+        const int mine = cw < (uint32_t)cap_wg ? (int)cw : cap_wg;
         int incl = mine;
 #pragma unroll
         for (int sft = 1; sft < 64; sft <<= 1) {
             const int up = __shfl_up(incl, sft, 64);
             if (lane >= sft) incl += up;
         }
-        const int total = __shfl(incl, 63, 64);
-        const int at = n + incl - mine;
+        if (lane == 63) s_tot[w] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            before += j < w ? s_tot[j] : 0;
+            total += s_tot[j];
+        }
+        const int at = n + before + incl - mine;
         const int64_t wo = ((int64_t)wg * Bpad + q) * cap_wg;
         for (int j = 0; j < mine; ++j) {
             if (at + j < kMmCompactCap) s_v[at + j] = pack_key(wkey[wo + j], widx[wo + j]);
             else over = true;
         }
         n = n + total < kMmCompactCap ? n + total : kMmCompactCap;
+        __syncthreads();
     }
     __syncthreads();
     unsigned long long prev = 0;
     for (int round = 0; round < KC; ++round) {
         // smallest packed value above the previous pick (row ids are unique, so values are)
         unsigned long long m = ~0ull;
-        for (int i = lane; i < n; i += 64) {
+        for (int i = tid; i < n; i += 256) {
             const unsigned long long x = s_v[i];
             if ((round == 0 || x > prev) && x < m) m = x;
         }
@@ -452,7 +541,14 @@ __global__ __launch_bounds__(64) void mm_compact_kernel(uint32_t* __restrict__ c
             const unsigned long long other = __shfl_xor(m, sft, 64);
             m = other < m ? other : m;
         }
-        if (lane == 0) {
+        if (lane == 0) s_m[round & 1][w] = m;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned long long other = s_m[round & 1][j];
+            m = other < m ? other : m;
+        }
+        if (tid == 0) {
             const bool ok = m != ~0ull;
             cand[(int64_t)q * KC + round] = ok ? (int)(uint32_t)m : -1;
             if (ok) {
@@ -463,10 +559,13 @@ __global__ __launch_bounds__(64) void mm_compact_kernel(uint32_t* __restrict__ c
         }
         prev = m;  // once exhausted (m == ~0) nothing is above it: the remaining rounds write -1
     }
-    const bool any_over = __builtin_amdgcn_ballot_w64(over) != 0;
-    if (lane == 0) {
+    const int any_over = __syncthreads_or(over ? 1 : 0);
+    if (tid == 0) {
         cnt[q] = n < KC ? n : KC;
-        if (any_over) ovf[q] = 1u;
+        if (any_over) {
+            ovf[q] = 1u;
+            *ovf_any = 1u;
+        }
     }
 }
 
@@ -474,9 +573,9 @@ bool mm_supported(int d, int store_dtype, int kc) {
     return store_dtype == PRAG_F16 && (d == 256 || d == 512 || d == 768 || d == 1024) && kc >= 8 && kc <= 32;
 }
 
-template <int NKT, int ABL = 0>
-static int launch_mm(const MmArgs& a, int grid, hipStream_t st) {
-    auto kern = scan_mm_kernel<NKT, ABL>;
+template <int NKT, int MODE, int ABL = 0>
+static int launch_mm_impl(const MmArgs& a, int grid, hipStream_t st) {
+    auto kern = scan_mm_kernel<NKT, MODE, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
         PRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -488,19 +587,26 @@ static int launch_mm(const MmArgs& a, int grid, hipStream_t st) {
     return PRAG_OK;
 }
 
+template <int NKT, int ABL = 0>
+static int launch_mm(const MmArgs& a, bool first, int grid, hipStream_t st) {
+    if (first) return launch_mm_impl<NKT, 0, 0>(a, grid, st);
+    if (a.use_norm) return launch_mm_impl<NKT, 2, 0>(a, grid, st);
+    return launch_mm_impl<NKT, 1, ABL>(a, grid, st);
+}
+
 int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
     PRAG_REQUIRE(mm_supported(s.d, PRAG_F16, s.kc) && s.Bpad % 256 == 0 && s.Bpad <= kMmMaxQueries &&
                      s.cap_q >= kMmFirstSeg && s.max_wg >= 1 && s.max_wg <= s.wg_slots,
                  PRAG_EUNSUPPORTED, "internal: MFMA-tiled scan called outside its envelope");
     const int64_t first_rows = std::min<int64_t>(s.N, kMmFirstSeg);
-    PRAG_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s.cnt), (int)first_rows, (size_t)s.Bpad, st));
-    PRAG_HIP(hipMemsetAsync(s.ovf, 0, (size_t)s.Bpad * sizeof(uint32_t), st));
+    // cnt[q] = first_rows, ovf[q] = 0, *ovf_any = 0 were set by the caller (prep_queries_kernel)
     MmArgs a;
     a.rows = s.rows;
     a.xnorm = s.xnorm;
     a.q16 = s.q16;
     a.n_qb = s.Bpad / 256;
     a.alpha = s.alpha;
+    a.inv_alpha = 1.0f / s.alpha;
     a.use_norm = s.use_norm;
     a.tau = s.tau;
     a.ckey = s.ckey;
@@ -508,6 +614,7 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
     a.cap_q = s.cap_q;
     a.Bpad = s.Bpad;
     a.wcnt = s.wcnt;
+    a.wg_stride = s.wg_slots;
     a.wkey = s.wkey;
     a.widx = s.widx;
     a.cap_wg = s.cap_wg;
@@ -524,7 +631,7 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
     while (lo < s.N) {
         a.row0 = lo;
         a.row1 = hi;
-        a.first = lo == 0;
+        const bool first = lo == 0;
         const int64_t n_rt = (hi - lo + 255) / 256;
         a.n_tiles = (int)(n_rt * a.n_qb);
         const int grid = (int)std::min<int64_t>(a.n_tiles, std::max(1, s.max_wg));
@@ -532,31 +639,31 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
         if (biggest) prof.begin(st);
         int rc;
         switch (s.d) {
-            case 256: rc = launch_mm<4>(a, grid, st); break;
-            case 512: rc = launch_mm<8>(a, grid, st); break;
+            case 256: rc = launch_mm<4>(a, first, grid, st); break;
+            case 512: rc = launch_mm<8>(a, first, grid, st); break;
             case 768:
 #ifdef PRAG_MM_DIAG
             {
                 const char* e = getenv("PRAG_MM_ABLATE");
                 switch (e ? atoi(e) : 0) {
-                    case 8: rc = launch_mm<12, 8>(a, grid, st); break;
-                    case 9: rc = launch_mm<12, 9>(a, grid, st); break;
-                    case 10: rc = launch_mm<12, 10>(a, grid, st); break;
-                    case 12: rc = launch_mm<12, 12>(a, grid, st); break;
-                    case 14: rc = launch_mm<12, 14>(a, grid, st); break;
-                    case 15: rc = launch_mm<12, 15>(a, grid, st); break;
-                    case 24: rc = launch_mm<12, 24>(a, grid, st); break;
-                    case 40: rc = launch_mm<12, 40>(a, grid, st); break;
-                    case 56: rc = launch_mm<12, 56>(a, grid, st); break;
-                    default: rc = launch_mm<12>(a, grid, st); break;
+                    case 8: rc = launch_mm<12, 8>(a, first, grid, st); break;
+                    case 9: rc = launch_mm<12, 9>(a, first, grid, st); break;
+                    case 10: rc = launch_mm<12, 10>(a, first, grid, st); break;
+                    case 12: rc = launch_mm<12, 12>(a, first, grid, st); break;
+                    case 14: rc = launch_mm<12, 14>(a, first, grid, st); break;
+                    case 15: rc = launch_mm<12, 15>(a, first, grid, st); break;
+                    case 24: rc = launch_mm<12, 24>(a, first, grid, st); break;
+                    case 40: rc = launch_mm<12, 40>(a, first, grid, st); break;
+                    case 56: rc = launch_mm<12, 56>(a, first, grid, st); break;
+                    default: rc = launch_mm<12>(a, first, grid, st); break;
                 }
                 break;
             }
 #else
-                rc = launch_mm<12>(a, grid, st);
+                rc = launch_mm<12>(a, first, grid, st);
                 break;
 #endif
-            default: rc = launch_mm<16>(a, grid, st); break;
+            default: rc = launch_mm<16>(a, first, grid, st); break;
         }
         if (biggest) prof.end(st);
         if (rc != PRAG_OK) return rc;
@@ -568,8 +675,9 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
                     h[1] ? h[0] / (h[1] / 100.0) : 0.0);
         }
 #endif
-        hipLaunchKernelGGL(mm_compact_kernel, dim3(s.B), dim3(64), 0, st, s.cnt, s.ckey, s.cidx, s.cap_q, s.kc, s.tau,
-                           s.cand, s.ovf, s.wcnt, s.wkey, s.widx, s.cap_wg, a.first ? 0 : grid, s.Bpad);
+        hipLaunchKernelGGL(mm_compact_kernel, dim3(s.B), dim3(256), 0, st, s.cnt, s.ckey, s.cidx, s.cap_q, s.kc, s.tau,
+                           s.cand, s.ovf, s.ovf_any, s.wcnt, s.wkey, s.widx, s.cap_wg, first ? 0 : grid, s.wg_slots,
+                           s.Bpad);
         PRAG_LAUNCH_CHECK();
         lo = hi;
         hi = std::min<int64_t>(s.N, hi * 16);
