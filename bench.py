@@ -226,9 +226,20 @@ def main():
     n_local = hi - lo
     elt = 2 if args.store == "f16" else 4
     alg_bytes = n_local * d_emb * elt + (n_local * 4 if args.metric == "l2" else 0)
-    passes = 1 + (args.queries - 1) // 64
+    # which scan kernel served the step (mirrors prag_index_search's choice)
+    tiled = args.queries > 128 and args.store == "f16"           # MFMA-tiled scan, 256-query tiles
+    per_pass = 128 if (args.queries > 64 and args.store == "f16") else 64
+    passes = 1 if tiled else 1 + (args.queries - 1) // per_pass
     scan_avg_ms = float(np.mean(scan_ms)) if scan_ms else float("nan")
     achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
+    if tiled:
+        # the profiled launch is the last corpus segment (segments: 2048 rows, then x16)
+        seg0 = 2048
+        while seg0 * 16 < n_local:
+            seg0 *= 16
+        rows_last = n_local - seg0 if n_local > 2048 else n_local
+        mm_flops = 2.0 * args.queries * rows_last * d_emb
+        mm_tf = mm_flops / (scan_avg_ms * 1e-3) / 1e12
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_scan_topk.json")
     if os.path.exists(pmc):
@@ -257,10 +268,15 @@ def main():
         "planted_top1_recall": 1.0 if planted_ok else 0.0,
         "recall_at_k_vs_oracle": recall, "topk_ids_bit_exact_vs_oracle": exact_order,
         "recall_sample": f"{min(16, args.queries)} queries x {min(200_000, args.docs)} docs, float64 C oracle",
-        "roofline": {"bound": "hbm", "kernel": "scan_topk_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_ms,
-                     "launches_per_step": passes},
+        "roofline": ({"bound": "mfma", "kernel": "scan_mm_kernel", "achieved": mm_tf, "peak": MFMA_F16_PEAK_TF,
+                      "unit": "TFLOP/s", "frac": mm_tf / MFMA_F16_PEAK_TF, "traffic": None,
+                      "algorithmic_flops_per_launch": mm_flops, "rows_in_launch": rows_last,
+                      "avg_launch_ms": scan_avg_ms, "launches_per_step": passes} if tiled else
+                     {"bound": "hbm", "kernel": "scan_qs_kernel" if per_pass == 128 else "scan_topk_kernel",
+                      "achieved": achieved, "peak": HBM_PEAK_GBS,
+                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_ms,
+                      "launches_per_step": passes}),
         "roofline_gate": {"bound": "mfma", "kernel": "prober_fused_kernel", "achieved": gate_flops / (gate_avg_ms * 1e-3) / 1e12,
                           "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                           "frac": gate_flops / (gate_avg_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF,
