@@ -150,6 +150,45 @@ int prag_pool_masked_mean(const void* hidden_dev, int dtype, const int64_t* mask
                           float* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Prober training step
+ * ---------------------------------------------------------------------- */
+typedef struct prag_trainer prag_trainer_t;
+
+/* One ImprovedProbe (utils.py:29-57) with its optimiser state.  Replaces
+ *   probe = ImprovedProbe(d_model, num_classes); optimizer = AdamW(probe.parameters(), lr=lr);
+ *   scheduler = ExponentialLR(optimizer, gamma=0.995)              (train.py:126-135)
+ * torch.optim.AdamW defaults are beta1 0.9, beta2 0.999, eps 1e-8, weight_decay 0.01;
+ * dropout_p is 0.1 in the reference (utils.py:39).  `seed` keys the dropout masks
+ * (counter hash of (seed, step, site, row, unit): reproducible, not torch's RNG stream). */
+int prag_trainer_create(prag_trainer_t** out, int d_model, int d_hidden, int n_classes, double lr, double beta1,
+                        double beta2, double eps, double weight_decay, double gamma, double dropout_p,
+                        uint32_t seed);
+
+/* Initial parameters: host fp32 tensors in state-dict order (as prag_prober_load_layer).
+ * Copies them and resets the optimiser state and the step counter. */
+int prag_trainer_load(prag_trainer_t* t, const float* ln0_w, const float* ln0_b, const float* W1, const float* b1,
+                      const float* ln1_w, const float* ln1_b, const float* W2, const float* b2, const float* ln2_w,
+                      const float* ln2_b, const float* W3, const float* b3);
+
+/* Replaces method_2_train's `loss.backward(); optim.step(); scheduler.step(); optim.zero_grad()`
+ * (train.py:210-220, utils.py:191-197) including the forward of _method_2_util after pooling:
+ * x_dev float32 [B,d_model] (per-sample mean of the last pred_len hidden states, see
+ * prag_pool_ragged), labels_dev int32 [B].  Optional device outputs of the forward pass:
+ * loss_dev (1 float: CrossEntropyLoss applied to the softmax probabilities, train.py:149-150)
+ * and probs_dev float32 [B,n_classes].  All work is enqueued on `stream`. */
+int prag_trainer_step(prag_trainer_t* t, const float* x_dev, const int32_t* labels_dev, int B, float* loss_dev,
+                      float* probs_dev, void* stream);
+
+/* Current parameters to host fp32 tensors (state-dict order): `probe.state_dict()`. */
+int prag_trainer_export(prag_trainer_t* t, float* ln0_w, float* ln0_b, float* W1, float* b1, float* ln1_w,
+                        float* ln1_b, float* W2, float* b2, float* ln2_w, float* ln2_b, float* W3, float* b3);
+
+/* Learning rate the next step will use (`optim.param_groups[0]['lr']`), steps taken so far. */
+double prag_trainer_lr(const prag_trainer_t* t);
+int64_t prag_trainer_steps(const prag_trainer_t* t);
+void prag_trainer_destroy(prag_trainer_t* t);
+
+/* ------------------------------------------------------------------------
  * Flat (exact, brute-force) index
  * ---------------------------------------------------------------------- */
 typedef struct prag_index prag_index_t;

@@ -304,3 +304,130 @@ def train_eval_forward(state: dict, acts: np.ndarray, pred_lens: np.ndarray,
     loss = float(np.mean(lse - p[np.arange(len(lab)), lab]))
     acc = float((p.argmax(axis=1) == lab).sum()) / len(lab)
     return p.astype(np.float32), np.float32(loss), acc
+
+
+# --------------------------------------------------------------------------
+# prober training step (train.py:141-151, 210-220 / utils.py:191-197:
+# method_2_train = forward in train mode -> CrossEntropyLoss on the softmax
+# PROBABILITIES -> backward -> AdamW.step -> ExponentialLR.step)
+# --------------------------------------------------------------------------
+ADAMW_DEFAULTS = dict(lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01,  # torch.optim.AdamW defaults,
+                      gamma=0.995, dropout_p=0.1)                                     # train.py:131-135, utils.py:39
+
+
+def dropout_keep(seed: int, step: int, site: int, B: int, n: int, p: float) -> np.ndarray:
+    """Bernoulli(1-p) keep mask [B,n] of dropout site `site` (0 after LN1, 1 after LN2) at optimiser
+    step `step`, from the counter hash the HIP trainer uses: the reference draws its masks from
+    torch's global RNG stream, which cannot be reproduced outside torch, so parity is defined on
+    identical masks (the golden generator feeds these masks to the reference's own module)."""
+    idx = (np.arange(B, dtype=np.uint64)[:, None] * np.uint64(n) + np.arange(n, dtype=np.uint64)[None, :])
+    key = _mix32(np.array([(seed & 0xFFFFFFFF) ^ ((step * 0x9E3779B9) & 0xFFFFFFFF)], dtype=np.uint32))
+    site_key = _mix32(key ^ np.uint32(site + 1))[0]
+    h = _mix32(idx.astype(np.uint32) ^ site_key)
+    thresh = np.uint32(min(int(round(p * 4294967296.0)), 4294967295))
+    return h >= thresh
+
+
+def _ln_fwd(x, g, b):
+    mu = x.mean(axis=-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(axis=-1, keepdims=True)
+    r = 1.0 / np.sqrt(var + LN_EPS)
+    xh = (x - mu) * r
+    return xh * g + b, xh, r
+
+
+def _ln_bwd(dy, xh, r, g):
+    dxh = dy * g
+    dx = r * (dxh - dxh.mean(axis=-1, keepdims=True) - xh * (dxh * xh).mean(axis=-1, keepdims=True))
+    return dx, (dy * xh).sum(axis=0), dy.sum(axis=0)
+
+
+def train_loss_and_grads(state: dict, x: np.ndarray, labels: np.ndarray, keep1=None, keep2=None,
+                         dropout_p: float = 0.0):
+    """Forward in train mode + backward, float64.  keep1/keep2: boolean keep masks [B,512] of the two
+    dropout sites (None = no dropout).  Returns (loss, probs [B,C], grads dict keyed like the state)."""
+    s = {k: np.asarray(v, dtype=np.float64) for k, v in state.items()}
+    x = np.asarray(x, dtype=np.float64)
+    B = x.shape[0]
+    scale = np.float64(np.float32(1.0 / (1.0 - dropout_p))) if dropout_p > 0 else 1.0
+    m1 = (keep1.astype(np.float64) * scale) if keep1 is not None else 1.0
+    m2 = (keep2.astype(np.float64) * scale) if keep2 is not None else 1.0
+    y0, xh0, r0 = _ln_fwd(x, s["layer_norm_input.weight"], s["layer_norm_input.bias"])
+    h1 = y0 @ s["fc1.weight"].T + s["fc1.bias"]
+    s1 = _silu(h1)
+    n1, sh1, r1 = _ln_fwd(s1, s["layer_norm1.weight"], s["layer_norm1.bias"])
+    d1 = n1 * m1
+    h2 = d1 @ s["fc2.weight"].T + s["fc2.bias"]
+    s2 = _silu(h2)
+    n2, sh2, r2 = _ln_fwd(s2, s["layer_norm2.weight"], s["layer_norm2.bias"])
+    d2 = n2 * m2
+    z = d2 @ s["fc3.weight"].T + s["fc3.bias"]
+    z = z - z.max(axis=1, keepdims=True)
+    p = np.exp(z)
+    p = p / p.sum(axis=1, keepdims=True)
+    lab = np.asarray(labels).astype(np.int64)
+    ep = np.exp(p)
+    sm = ep / ep.sum(axis=1, keepdims=True)                    # softmax of the probabilities (double softmax)
+    loss = float(np.mean(np.log(ep.sum(axis=1)) - p[np.arange(B), lab]))
+    gp = sm.copy()
+    gp[np.arange(B), lab] -= 1.0
+    gp /= B
+    dz = p * (gp - (gp * p).sum(axis=1, keepdims=True))
+    g = {}
+    g["fc3.weight"] = dz.T @ d2
+    g["fc3.bias"] = dz.sum(axis=0)
+    dn2 = (dz @ s["fc3.weight"]) * m2
+    ds2, g["layer_norm2.weight"], g["layer_norm2.bias"] = _ln_bwd(dn2, sh2, r2, s["layer_norm2.weight"])
+    sg2 = 1.0 / (1.0 + np.exp(-h2))
+    dh2 = ds2 * sg2 * (1.0 + h2 * (1.0 - sg2))
+    g["fc2.weight"] = dh2.T @ d1
+    g["fc2.bias"] = dh2.sum(axis=0)
+    dn1 = (dh2 @ s["fc2.weight"]) * m1
+    ds1, g["layer_norm1.weight"], g["layer_norm1.bias"] = _ln_bwd(dn1, sh1, r1, s["layer_norm1.weight"])
+    sg1 = 1.0 / (1.0 + np.exp(-h1))
+    dh1 = ds1 * sg1 * (1.0 + h1 * (1.0 - sg1))
+    g["fc1.weight"] = dh1.T @ y0
+    g["fc1.bias"] = dh1.sum(axis=0)
+    dy0 = dh1 @ s["fc1.weight"]
+    g["layer_norm_input.weight"] = (dy0 * xh0).sum(axis=0)
+    g["layer_norm_input.bias"] = dy0.sum(axis=0)
+    return loss, p, g
+
+
+def adamw_update(state: dict, grads: dict, opt: dict, step: int, hp: dict):
+    """torch.optim.AdamW.step (decoupled weight decay, bias-corrected moments) with the learning rate
+    ExponentialLR has reached after `step - 1` scheduler steps; `step` counts from 1.  In place on
+    float64 copies held in `state` / `opt` (opt[k] = (exp_avg, exp_avg_sq))."""
+    lr = hp["lr"] * hp["gamma"] ** (step - 1)
+    b1, b2 = hp["beta1"], hp["beta2"]
+    bc1 = 1.0 - b1 ** step
+    bc2 = 1.0 - b2 ** step
+    for k in STATE_KEYS:
+        p = state[k]
+        g = grads[k]
+        m, v = opt[k]
+        p *= 1.0 - lr * hp["weight_decay"]
+        m *= b1
+        m += (1.0 - b1) * g
+        v *= b2
+        v += (1.0 - b2) * g * g
+        p -= (lr / bc1) * m / (np.sqrt(v) / np.sqrt(bc2) + hp["eps"])
+    return lr
+
+
+def train_steps(state: dict, batches: list, seed: int, hp: dict = None):
+    """Run len(batches) optimiser steps (each batch = (x [B,d], labels [B])); returns
+    (final state float64, [loss per step], [lr used per step])."""
+    hp = dict(ADAMW_DEFAULTS, **(hp or {}))
+    st = {k: np.array(v, dtype=np.float64) for k, v in state.items()}
+    opt = {k: (np.zeros_like(st[k]), np.zeros_like(st[k])) for k in STATE_KEYS}
+    losses, lrs = [], []
+    H = st["fc1.bias"].shape[0]
+    for t, (x, labels) in enumerate(batches, start=1):
+        B = x.shape[0]
+        k1 = dropout_keep(seed, t, 0, B, H, hp["dropout_p"]) if hp["dropout_p"] > 0 else None
+        k2 = dropout_keep(seed, t, 1, B, H, hp["dropout_p"]) if hp["dropout_p"] > 0 else None
+        loss, _, g = train_loss_and_grads(st, x, labels, k1, k2, hp["dropout_p"])
+        lrs.append(adamw_update(st, g, opt, t, hp))
+        losses.append(loss)
+    return st, losses, lrs

@@ -64,6 +64,13 @@ SIGNATURES = {
     "prag_pool_accumulate": (_I, [_P, _P, _I, _L, _I, _P]),
     "prag_pool_ragged": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "prag_pool_masked_mean": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
+    "prag_trainer_create": (_I, [ctypes.POINTER(_P), _I, _I, _I] + [ctypes.c_double] * 7 + [ctypes.c_uint32]),
+    "prag_trainer_load": (_I, [_P] + [_FP] * 12),
+    "prag_trainer_step": (_I, [_P, _P, _P, _I, _P, _P, _P]),
+    "prag_trainer_export": (_I, [_P] + [_FP] * 12),
+    "prag_trainer_lr": (ctypes.c_double, [_P]),
+    "prag_trainer_steps": (_L, [_P]),
+    "prag_trainer_destroy": (None, [_P]),
     "prag_index_create": (_I, [ctypes.POINTER(_P), _I, _I, _I, _L]),
     "prag_index_add": (_I, [_P, _P, _L, _I]),
     "prag_index_add_synthetic": (_I, [_P, ctypes.c_uint32, _L, _L]),

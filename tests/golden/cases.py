@@ -67,3 +67,17 @@ def synth_pool_inputs(case: dict):
     pred_lens = np.array([1 + (7 * i + 3) % (T - 1) for i in range(B)], dtype=np.int64)
     labels = np.array([i % 2 for i in range(B)], dtype=np.int64)
     return acts, pred_lens, labels
+
+
+# prober training (utils.py:191-197 method_2_train with train.py:131-135's AdamW / ExponentialLR)
+TRAIN_CASES = [
+    dict(name="train_B8_T24", d=2048, B=8, T=24, wseed=500, xseed=88, steps=3, seed=4242),
+    dict(name="train_B3_T9_nodrop", d=2048, B=3, T=9, wseed=501, xseed=89, steps=2, seed=1, dropout_p=0.0),
+]
+TRAIN_SAMPLE_STRIDE = 251   # fc1/fc2 weights are stored as every 251st element (+ their float64 sums)
+
+
+def synth_train_batch(case: dict, step: int):
+    """(acts [B,T,d] f32, pred_lens int64 [B], labels int64 [B]) of optimiser step `step` (1-based)."""
+    sub = dict(case, xseed=case["xseed"] + 1000 * step)
+    return synth_pool_inputs(sub)

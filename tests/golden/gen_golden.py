@@ -10,8 +10,9 @@ It imports ``/root/reference/utils.py`` (with ``faiss`` / ``spacy`` stubbed in
 ``sys.modules`` — they are only needed by code that is not on the hot path,
 SURVEY.md §8c) and evaluates the genuine ``ImprovedProbe`` (utils.py:29-57),
 ``return_prober_logit_gemma_2b`` (utils.py:389-390), ``_method_2_util``
-(utils.py:181-189) and ``return_acc`` (utils.py:158-170) on deterministic
-inputs.  Weights and inputs come from the counter-based generator
+(utils.py:181-189), ``return_acc`` (utils.py:158-170) and ``method_2_train``
+(utils.py:191-197, with torch.optim.AdamW / ExponentialLR as in train.py:131-135)
+on deterministic inputs.  Weights and inputs come from the counter-based generator
 ``oracle_np.synth_rows`` so that the fixtures only need to store seeds,
 shapes and the reference's OUTPUTS (a few KB), never weights or source.
 
@@ -119,6 +120,67 @@ def main():
             sums = torch.stack([torch.from_numpy(acts[i, T - int(n):, :]).sum(dim=0)
                                 for i, n in enumerate(pred_lens)])
             out[f"{name}/sum_logits"] = m(sums).numpy().astype(np.float32)
+
+    # ---- training step: the reference's method_2_train (utils.py:191-197) with the optimiser and
+    #      scheduler of train.py:131-135 (AdamW(lr), ExponentialLR(gamma=0.995)).  The only change
+    #      to the reference module is the SOURCE of the dropout masks (torch's global RNG stream
+    #      cannot be reproduced by another implementation): `dropout` is replaced by a module that
+    #      applies oracle_np.dropout_keep masks with torch's own scaling x * keep / (1 - p).
+    from torch.optim import AdamW
+    from torch.optim.lr_scheduler import ExponentialLR
+
+    class MaskDropout(torch.nn.Module):
+        def __init__(self, seed, p):
+            super().__init__()
+            self.seed, self.p, self.step, self.site = seed, p, 1, 0
+
+        def forward(self, x):
+            if self.p == 0.0:
+                return x
+            keep = onp.dropout_keep(self.seed, self.step, self.site, x.shape[0], x.shape[1], self.p)
+            self.site += 1
+            return x * torch.from_numpy(keep.astype(np.float32)) * np.float32(1.0 / (1.0 - self.p))
+
+    for case in cases.TRAIN_CASES:
+        name, d = case["name"], case["d"]
+        pdrop = case.get("dropout_p", 0.1)
+        st = cases.synth_state(case["wseed"], d)
+        m = ru.ImprovedProbe(input_size=d, output_size=2)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()})
+        assert m.dropout.p == 0.1                                   # utils.py:39
+        m.dropout = MaskDropout(case["seed"], pdrop)
+        m.train()                                                   # train.py:248
+        optim = AdamW(m.parameters(), lr=onp.ADAMW_DEFAULTS["lr"])  # train.py:131 (--lr 1e-4 in train_prober.sh)
+        sched = ExponentialLR(optim, gamma=0.995)                   # train.py:134
+        args = types.SimpleNamespace(device="cpu")
+        ru.softmax = torch.nn.Softmax(dim=-1)
+        losses, lrs = [], []
+        for t in range(1, case["steps"] + 1):
+            acts, pred_lens, labels = cases.synth_train_batch(case, t)
+            m.dropout.step, m.dropout.site = t, 0
+            lr_used = optim.param_groups[0]["lr"]
+            # method_2_train returns (round(loss, 4), lr after scheduler.step()); recompute the raw
+            # loss of the same forward for a tighter comparison
+            m.dropout.site = 0
+            with torch.no_grad():
+                raw, _ = ru._method_2_util(m, torch.from_numpy(acts), torch.from_numpy(labels),
+                                           torch.from_numpy(pred_lens), args)
+            m.dropout.site = 0
+            lrnd, lr_next = ru.method_2_train(m, optim, sched, torch.from_numpy(acts), torch.from_numpy(labels),
+                                              torch.from_numpy(pred_lens), args)
+            assert abs(lrnd - round(raw.item(), 4)) < 1e-9
+            losses.append(raw.item())
+            lrs.append(lr_used)
+        out[f"{name}/losses"] = np.array(losses, dtype=np.float64)
+        out[f"{name}/lrs"] = np.array(lrs, dtype=np.float64)
+        sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+        for k, v in sd.items():
+            if v.size > 5000:
+                out[f"{name}/final/{k}/sample"] = v.reshape(-1)[::cases.TRAIN_SAMPLE_STRIDE].astype(np.float32)
+                out[f"{name}/final/{k}/sum"] = np.float64(v.astype(np.float64).sum())
+                out[f"{name}/final/{k}/delta_l2"] = np.float64(np.sqrt(((v.astype(np.float64) - st[k]) ** 2).sum()))
+            else:
+                out[f"{name}/final/{k}"] = v.astype(np.float32)
 
     path = os.path.join(HERE, "prober_golden.npz")
     np.savez_compressed(path, **out)

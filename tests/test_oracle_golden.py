@@ -107,3 +107,37 @@ def test_synth_rows_is_shardable_and_normalish():
     b = onp.synth_rows(42, 32, 32, 768)
     assert np.array_equal(a[32:], b)
     assert abs(float(a.mean())) < 0.02 and abs(float(a.std()) - 1.0) < 0.02
+
+
+@pytest.mark.parametrize("case", cases.TRAIN_CASES, ids=lambda c: c["name"])
+def test_training_steps_match_reference(golden, case):
+    """Oracle forward/backward/AdamW/ExponentialLR against the reference's own method_2_train
+    (utils.py:191-197) run with torch.optim.AdamW + ExponentialLR(0.995) (train.py:131-135) on
+    identical dropout masks: losses, learning rates and the parameters after the last step."""
+    name = case["name"]
+    st = cases.synth_state(case["wseed"], case["d"])
+    batches = []
+    for t in range(1, case["steps"] + 1):
+        acts, pred_lens, labels = cases.synth_train_batch(case, t)
+        batches.append((onp.pool_ragged_mean(acts, pred_lens), labels))
+    final, losses, lrs = onp.train_steps(st, batches, case["seed"], {"dropout_p": case.get("dropout_p", 0.1)})
+    np.testing.assert_allclose(losses, golden[f"{name}/losses"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(lrs, golden[f"{name}/lrs"], rtol=1e-12)
+    for k in onp.STATE_KEYS:
+        # the reference holds fp32 parameters; Adam's m / sqrt(v) amplifies rounding where |g| ~ eps
+        if f"{name}/final/{k}" in golden:
+            np.testing.assert_allclose(final[k], golden[f"{name}/final/{k}"], atol=5e-6, rtol=0)
+        else:
+            mine = final[k].reshape(-1)[::cases.TRAIN_SAMPLE_STRIDE]
+            np.testing.assert_allclose(mine, golden[f"{name}/final/{k}/sample"], atol=5e-6, rtol=0)
+            moved = np.sqrt(((final[k] - st[k]) ** 2).sum())
+            assert abs(moved - float(golden[f"{name}/final/{k}/delta_l2"])) < 1e-3 * moved
+        assert np.abs(final[k] - st[k]).max() > 1e-5           # every tensor was actually updated
+
+
+def test_dropout_masks_are_bernoulli_and_keyed():
+    k = onp.dropout_keep(7, 3, 0, 64, 512, 0.1)
+    assert abs(k.mean() - 0.9) < 0.01
+    assert not np.array_equal(k, onp.dropout_keep(7, 3, 1, 64, 512, 0.1))      # site
+    assert not np.array_equal(k, onp.dropout_keep(7, 4, 0, 64, 512, 0.1))      # step
+    assert np.array_equal(k[:8], onp.dropout_keep(7, 3, 0, 8, 512, 0.1))       # rows are independent of B
