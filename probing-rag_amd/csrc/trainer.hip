@@ -15,6 +15,7 @@
 // oracle_np.dropout_keep, which is also what the golden generator feeds the reference module.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -169,26 +170,48 @@ __global__ __launch_bounds__(256) void tr_loss_kernel(const float* __restrict__ 
 }
 
 // ---- backward ----------------------------------------------------------------
-// din[b,k] = sum_n dout[b,n] * W[n,k]: one thread per k (coalesced over W rows), 8 rows at a time.
-__global__ __launch_bounds__(256) void tr_fc_backward_input_kernel(const float* __restrict__ dout,
-                                                                  const float* __restrict__ W, int B, int K, int N,
-                                                                  float* __restrict__ din) {
-    extern __shared__ float s_do[];  // [8][N]
-    const int k = blockIdx.x * 256 + threadIdx.x;
+// din[b,k] = sum_n dout[b,n] * W[n,k].  grid = K / 64, block = 1024: a block owns 64 consecutive k
+// (one 256-B segment of every W row per wave load); its 16 waves split the n range, keep 8 row
+// loads of W in flight, read dout from LDS (a uniform global load per multiply was the whole cost
+// of the first version) and their partial sums are added in wave order (deterministic).
+__global__ __launch_bounds__(1024) void tr_fc_backward_input_kernel(const float* __restrict__ dout,
+                                                                   const float* __restrict__ W, int B, int K, int N,
+                                                                   float* __restrict__ din) {
+    extern __shared__ float s_dyn[];            // [8][N] dout rows, then [16][8][64] partial sums
+    float* s_do = s_dyn;
+    float* s_part = s_dyn + 8 * N;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane;
+    const int per = (N + 15) / 16;
+    const int n0 = w * per < N ? w * per : N, n1 = n0 + per < N ? n0 + per : N;
     for (int b0 = 0; b0 < B; b0 += 8) {
         const int nb = B - b0 < 8 ? B - b0 : 8;
         __syncthreads();
-        for (int i = threadIdx.x; i < nb * N; i += 256) s_do[i] = dout[(int64_t)b0 * N + i];
+        for (int i = threadIdx.x; i < 8 * N; i += 1024) s_do[i] = i < nb * N ? dout[(int64_t)b0 * N + i] : 0.f;
         __syncthreads();
-        if (k < K) {
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int n = 0; n < N; ++n) {
-                const float w = W[(int64_t)n * K + k];
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int n = n0;
+        for (; n + 8 <= n1; n += 8) {
+            float wv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (j < nb) acc[j] = fmaf(s_do[j * N + n], w, acc[j]);
-            }
-            for (int j = 0; j < nb; ++j) din[(int64_t)(b0 + j) * K + k] = acc[j];
+            for (int u = 0; u < 8; ++u) wv[u] = W[(int64_t)(n + u) * K + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(s_do[j * N + n + u], wv[u], acc[j]);
+        }
+        for (; n < n1; ++n) {
+            const float wv = W[(int64_t)n * K + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(s_do[j * N + n], wv, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s_part[(w * 8 + j) * 64 + lane] = acc[j];
+        __syncthreads();
+        if (w < nb) {  // wave j finishes row b0 + j
+            float t = 0.f;
+            for (int u = 0; u < 16; ++u) t += s_part[(u * 8 + w) * 64 + lane];
+            din[(int64_t)(b0 + w) * K + k] = t;
         }
     }
 }
@@ -258,23 +281,33 @@ __global__ __launch_bounds__(256) void tr_adamw_matrix_kernel(float* __restrict_
     v[e] = vv;
 }
 
-// vectors (biases, LayerNorm affines): g[j] = sum_b a[b,j] * (mult ? mult[b,j] : 1)
-__global__ __launch_bounds__(256) void tr_adamw_vector_kernel(float* __restrict__ p, float* __restrict__ m,
-                                                             float* __restrict__ v, const float* __restrict__ a_,
-                                                             const float* __restrict__ mult, int B, int n,
-                                                             AdamStep a) {
+// vectors (biases, LayerNorm affines): g[j] = sum_b a[b,j] * (mult ? mult[b,j] : 1).  All nine
+// vectors of the model in one launch: blockIdx.y picks the vector.
+struct VecJob {
+    float* p;
+    float* m;
+    float* v;
+    const float* a;
+    const float* mult;
+    int n;
+};
+struct VecJobs {
+    VecJob j[9];
+};
+__global__ __launch_bounds__(256) void tr_adamw_vectors_kernel(VecJobs jobs, int B, AdamStep a) {
+    const VecJob job = jobs.j[blockIdx.y];
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
+    if (j >= job.n) return;
     float g = 0.f;
     for (int b = 0; b < B; ++b) {
-        const float t = a_[(int64_t)b * n + j];
-        g = mult ? fmaf(t, mult[(int64_t)b * n + j], g) : g + t;
+        const float t = job.a[(int64_t)b * job.n + j];
+        g = job.mult ? fmaf(t, job.mult[(int64_t)b * job.n + j], g) : g + t;
     }
-    float pp = p[j], mm = m[j], vv = v[j];
+    float pp = job.p[j], mm = job.m[j], vv = job.v[j];
     adamw_apply(pp, mm, vv, g, a);
-    p[j] = pp;
-    m[j] = mm;
-    v[j] = vv;
+    job.p[j] = pp;
+    job.m[j] = mm;
+    job.v[j] = vv;
 }
 
 }  // namespace prag
@@ -445,15 +478,16 @@ extern "C" int prag_trainer_step(prag_trainer_t* t, const float* x_dev, const in
     if (loss_dev) PRAG_HIP(hipMemcpyAsync(loss_dev, t->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
     if (probs_dev) PRAG_HIP(hipMemcpyAsync(probs_dev, t->probs, (size_t)B * C * sizeof(float), hipMemcpyDeviceToDevice, st));
     // ---- backward (activations first: every weight is still the pre-step value) ----
-    hipLaunchKernelGGL(tr_fc_backward_input_kernel, dim3((H + 255) / 256), dim3(256), 8 * C * sizeof(float), st, t->dz,
+    const size_t part_lds = 16 * 8 * 64 * sizeof(float);
+    hipLaunchKernelGGL(tr_fc_backward_input_kernel, dim3(H / 64), dim3(1024), 8 * C * sizeof(float) + part_lds, st, t->dz,
                        par(P_W3), B, H, C, t->dd2);
     hipLaunchKernelGGL(tr_ln_act_backward_kernel, dim3(B), dim3(256), 0, st, t->dd2, par(P_LN2_W), t->sh2, t->r2, t->h2, H,
                        site_key[1], thresh, scale, t->dh2);
-    hipLaunchKernelGGL(tr_fc_backward_input_kernel, dim3((H + 255) / 256), dim3(256), 8 * H * sizeof(float), st, t->dh2,
+    hipLaunchKernelGGL(tr_fc_backward_input_kernel, dim3(H / 64), dim3(1024), 8 * H * sizeof(float) + part_lds, st, t->dh2,
                        par(P_W2), B, H, H, t->dd1);
     hipLaunchKernelGGL(tr_ln_act_backward_kernel, dim3(B), dim3(256), 0, st, t->dd1, par(P_LN1_W), t->sh1, t->r1, t->h1, H,
                        site_key[0], thresh, scale, t->dh1);
-    hipLaunchKernelGGL(tr_fc_backward_input_kernel, dim3((d + 255) / 256), dim3(256), 8 * H * sizeof(float), st, t->dh1,
+    hipLaunchKernelGGL(tr_fc_backward_input_kernel, dim3(d / 64), dim3(1024), 8 * H * sizeof(float) + part_lds, st, t->dh1,
                        par(P_W1), B, d, H, t->dy0);
     // ---- AdamW (torch.optim.AdamW.step), lr of ExponentialLR after `step - 1` scheduler steps ----
     const double lr = t->lr0 * pow(t->gamma, (double)(step - 1));
@@ -470,22 +504,24 @@ extern "C" int prag_trainer_step(prag_trainer_t* t, const float* x_dev, const in
         hipLaunchKernelGGL(tr_adamw_matrix_kernel, dim3((unsigned)(((size_t)N * K + 255) / 256)), dim3(256), 0, st,
                            P + t->off[i], M + t->off[i], V + t->off[i], dout, in, B, K, N, a);
     };
+    VecJobs jobs;
+    int nj = 0;
     auto vec = [&](int i, const float* g, const float* mult, int n) {
-        hipLaunchKernelGGL(tr_adamw_vector_kernel, dim3((n + 255) / 256), dim3(256), 0, st, P + t->off[i], M + t->off[i],
-                           V + t->off[i], g, mult, B, n, a);
+        jobs.j[nj++] = VecJob{P + t->off[i], M + t->off[i], V + t->off[i], g, mult, n};
     };
     mat(P_W3, t->dz, t->d2, H, C);
+    mat(P_W2, t->dh2, t->d1, H, H);
+    mat(P_W1, t->dh1, t->y0, d, H);
     vec(P_B3, t->dz, nullptr, C);
     vec(P_LN2_W, t->dd2, t->sh2, H);   // dd2 now holds dn2 (after the dropout mask)
     vec(P_LN2_B, t->dd2, nullptr, H);
-    mat(P_W2, t->dh2, t->d1, H, H);
     vec(P_B2, t->dh2, nullptr, H);
     vec(P_LN1_W, t->dd1, t->sh1, H);
     vec(P_LN1_B, t->dd1, nullptr, H);
-    mat(P_W1, t->dh1, t->y0, d, H);
     vec(P_B1, t->dh1, nullptr, H);
     vec(P_LN0_W, t->dy0, t->xh0, d);
     vec(P_LN0_B, t->dy0, nullptr, d);
+    hipLaunchKernelGGL(tr_adamw_vectors_kernel, dim3((std::max(d, H) + 255) / 256, 9), dim3(256), 0, st, jobs, B, a);
     PRAG_LAUNCH_CHECK();
     t->step = step;
     return PRAG_OK;
