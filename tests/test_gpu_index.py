@@ -33,7 +33,8 @@ def _check(D, I, D0, I0, metric):
                                      # (fp16 rows and > 128 queries: MFMA-tiled scan, 256-query tiles)
                                      (5000, 130, 10, 768), (3001, 200, 5, 256), (1500, 65, 12, 1024),
                                      (2500, 100, 10, 512), (40_000, 520, 10, 512), (2047, 129, 26, 1024),
-                                     (3000, 4200, 5, 256)])     # > 4096 queries: two chunks of the tiled scan
+                                     (3000, 4200, 5, 256),      # > 4096 queries: two chunks of the tiled scan
+                                     (5, 130, 3, 256), (257, 300, 10, 512)])  # tiled scan on tiny shards
 def test_search_matches_definition(metric, store, N, B, k, d):
     import probing_rag_amd as pra
     X = onp.synth_rows(42, 0, N, d)
