@@ -543,8 +543,14 @@ __global__ __launch_bounds__(512, 1) void scan_topk_flagged_kernel(ScanArgs a, c
 // HBM pass serves 128 queries.  Loads run 4 chunks ahead in four named register
 // sets (static rotation: d/64 is a multiple of 4), one raw barrier per chunk.
 // ---------------------------------------------------------------------------
-template <int NKS /* d/32 */, int KC>
+// No ordinary VMEM load or returning atomic may sit inside the scan loop: its result can only be
+// waited for with s_waitcnt vmcnt(0)-like counts that drain the DMA ring (loads return in order).
+// The per-group side data - row norms (L2) and the chip-wide bounds - therefore travel by LDS-DMA
+// too (two 512-B transfers per group, issued by waves 0 and 1 a whole group ahead of their use).
+template <int NKS /* d/32 */, int KC, bool L2>
 __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
+    constexpr int kSideXn = 4 * 128 * 128;          // LDS: [128] f32 row norms of the running group
+    constexpr int kSideTau = 4 * 128 * 128 + 1024;  //      [128] sortable-uint bounds (one group old)
     constexpr int NCH = NKS / 2;  // 64-element chunks per row
     static_assert(NCH % 4 == 0, "register-set rotation needs d % 256 == 0");
     constexpr int DG = 128;       // rows per workgroup step
@@ -554,8 +560,6 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g4 = lane >> 4;
-    // xnorm loads in the epilogue are the only ordinary VMEM loads inside the scan loop;
-    // everything else is LDS-DMA counted by hand (see the vmcnt(4) below).
     const int d = NKS * 32;
 
     // ---- this wave's 16 queries -> registers (B operand: k = 32s + 8*g4 + j) --------
@@ -577,21 +581,21 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
     typedef const __attribute__((address_space(1))) char* gcptr;
     const gcptr rows = (gcptr) reinterpret_cast<const char*>(a.rows);
     const int64_t row_bytes = (int64_t)d * 2;
-    int st_doc[2], st_col[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int doc = 8 * (2 * w + j) + (lane >> 3);
-        st_doc[j] = doc;
-        st_col[j] = (((lane & 7) ^ ((doc >> 1) & 7)) << 4);
-    }
     gcptr p_cur[2];
     gcptr p_nxt[2];
+    // (per-lane staging geometry is rebuilt from an opaque copy of the lane id once per group: kept
+    // live across the unrolled chunk loop it is spilled, and a spill reload waits behind
+    // s_waitcnt vmcnt(0) - a full drain of the DMA ring twice per group)
     auto group_ptrs = [&](gcptr (&ptr)[2], int group) {
+        int le = lane;
+        asm volatile("" : "+v"(le));
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            int64_t row = (int64_t)group * DG + st_doc[j];
+            const int doc = 8 * (2 * w + j) + (le >> 3);
+            const int col = (((le & 7) ^ ((doc >> 1) & 7)) << 4);
+            int64_t row = (int64_t)group * DG + doc;
             row = row < a.N ? row : a.N - 1;
-            ptr[j] = rows + row * row_bytes + st_col[j];
+            ptr[j] = rows + row * row_bytes + col;
         }
     };
     typedef __attribute__((address_space(3))) char* lptr;
@@ -606,6 +610,8 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
     TopList<KC> top;
     top.init();
     uint32_t gtau = a.g_tau[16 * w + r16];  // +inf, or the pre-pass bound
+    const gcptr xn_g = (gcptr) reinterpret_cast<const char*>(a.xnorm);
+    const gcptr tau_g = (gcptr) reinterpret_cast<const char*>(a.g_tau);
     f32x4 acc[8];  // 8 tiles of 16 rows; C layout: query = lane&15, row = 4*(lane>>4) + reg
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -635,6 +641,16 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
                 __builtin_amdgcn_s_barrier();
                 if (c + 3 < NCH) PRAG_DMA(p_cur, (c + 3) % NCH, (c + 3) % 4)
                 else PRAG_DMA(p_nxt, (c + 3) % NCH, (c + 3) % 4)
+                if (c == 0 && w < 2 && (L2 || w == 1)) {
+                    // side data of THIS group (every wave is past the previous group's epilogue now)
+                    int le = lane;
+                    asm volatile("" : "+v"(le));
+                    if (le < 32) {
+                        const gcptr src = w == 0 ? xn_g + ((int64_t)g * DG) * 4 + le * 16 : tau_g + le * 16;
+                        const lptr dst = lds0 + (w == 0 ? kSideXn : kSideTau);
+                        __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+                    }
+                }
 
                 const char* xs = smem + (c % 4) * STAGE;
                 // four fragment reads in flight at a time (LDS latency would otherwise be paid per MFMA)
@@ -660,7 +676,13 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
             p_cur[1] = p_nxt[1];
             group_ptrs(p_nxt, g + 2 * nWG);
             // ---- epilogue: 8 x 4 rows against this lane's query -----------------------
+            int le = lane;
+            asm volatile("" : "+v"(le));
+            const int g4 = le >> 4;   // (shadows the loop-invariant copy on purpose, see group_ptrs)
             const int64_t doc0 = (int64_t)g * DG;
+            // the chip-wide bound as of the start of this group (LDS copy; a stale value is only a
+            // looser bound - the word never increases)
+            gtau = *reinterpret_cast<const uint32_t*>(smem + kSideTau + (16 * w + (le & 15)) * 4);
             float tau = top.k[KC - 1];
             tau = fminf(tau, __shfl_xor(tau, 16, 64));
             tau = fminf(tau, __shfl_xor(tau, 32, 64));
@@ -668,7 +690,7 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 f32x4 nv = {0.f, 0.f, 0.f, 0.f};
-                if (a.use_norm) nv = *reinterpret_cast<const f32x4*>(a.xnorm + doc0 + 16 * t + 4 * g4);
+                if constexpr (L2) nv = *reinterpret_cast<const f32x4*>(smem + kSideXn + (16 * t + 4 * g4) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int64_t doc = doc0 + 16 * t + 4 * g4 + e;
@@ -677,18 +699,13 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
                 }
                 acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            if ((gi & 3) == 3) {  // every 4th group: trade this query's bound with the chip-wide one
+            if ((gi & 3) == 3) {  // every 4th group: publish this query's bound (no value comes back)
                 float mine_f = top.k[KC - 1];
                 mine_f = fminf(mine_f, __shfl_xor(mine_f, 16, 64));
                 mine_f = fminf(mine_f, __shfl_xor(mine_f, 32, 64));
                 const uint32_t mine = sortable_u32(mine_f);
-                if (g4 == 0) {
-                    const uint32_t glob = __hip_atomic_load(a.g_tau + 16 * w + r16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (mine < glob)
-                        __hip_atomic_fetch_min(a.g_tau + 16 * w + r16, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    gtau = glob < mine ? glob : mine;
-                }
-                gtau = __shfl(gtau, r16, 64);  // lanes of quarter 0 hold the fresh value
+                if (g4 == 0 && mine < gtau)
+                    (void)__hip_atomic_fetch_min(a.g_tau + 16 * w + (le & 15), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail DMAs before LDS is reused
@@ -1203,10 +1220,11 @@ static int dispatch_flagged(int kc, const ScanArgs& a, int grid, const uint32_t*
     return PRAG_EUNSUPPORTED;
 }
 
-template <int NKS, int KC>
+template <int NKS, int KC, bool L2>
 static int launch_qs(const ScanArgs& a, int grid, hipStream_t st, EventRing& prof) {
-    const int lds = 4 * 128 * 128 > 128 * 4 * KC * 8 ? 4 * 128 * 128 : 128 * 4 * KC * 8;  // 4-stage ring
-    auto kern = scan_qs_kernel<NKS, KC>;
+    // 4-stage ring + 2 KiB of side data, reused by the final list merge
+    const int lds = 4 * 128 * 128 + 2048 > 128 * 4 * KC * 8 ? 4 * 128 * 128 + 2048 : 128 * 4 * KC * 8;
+    auto kern = scan_qs_kernel<NKS, KC, L2>;
     static bool attr_set = false;
     if (!attr_set) {
         PRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1228,8 +1246,12 @@ static bool qs_supported(int d, int store, int kc) {
 static int dispatch_qs(int d, int kc, const ScanArgs& a, int grid, hipStream_t st, EventRing& prof) {
 #define PRAG_QS(D_)                                                          \
     if (d == D_) {                                                           \
-        if (kc == 8) return launch_qs<D_ / 32, 8>(a, grid, st, prof);        \
-        return launch_qs<D_ / 32, 16>(a, grid, st, prof);                    \
+        if (a.use_norm) {                                                    \
+            if (kc == 8) return launch_qs<D_ / 32, 8, true>(a, grid, st, prof);  \
+            return launch_qs<D_ / 32, 16, true>(a, grid, st, prof);          \
+        }                                                                    \
+        if (kc == 8) return launch_qs<D_ / 32, 8, false>(a, grid, st, prof); \
+        return launch_qs<D_ / 32, 16, false>(a, grid, st, prof);             \
     }
     PRAG_QS(256) PRAG_QS(512) PRAG_QS(768) PRAG_QS(1024)
 #undef PRAG_QS
