@@ -96,7 +96,10 @@ template <int NA, int NB, int CT, int NWV>
 __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberArgs a) {
     constexpr int NT = 64 * NWV;        // threads
     constexpr int RT = 16 / NWV;        // 32-row hidden tiles per wave
-    constexpr int G = CT >= 2 ? 2 : 1;  // column tiles per fc2 pass
+    // column tiles per fc2 pass.  128-row tiles (CT = 4) take one at a time: with two, the fc2 phase held
+    // 64 + 64 accumulator VGPRs plus fragments and ~40 values went to scratch - every reload waits
+    // behind s_waitcnt vmcnt(0) (51 of them per tile).
+    constexpr int G = (CT >= 2 && CT < 4) ? 2 : 1;
     constexpr int NG = CT / G;
     constexpr bool RAW = (NB == 1);
     constexpr int ROWS = 32 * CT;
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                 const f32x4 ws = *reinterpret_cast<const f32x4*>(s_cst + nb);
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(s_cst + kHidden + nb);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e) {
 #pragma unroll
                     for (int c = 0; c < CT; ++c) {
                         float v = acc[rti][c][4 * g4 + e];
@@ -328,7 +331,11 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                         S1[c] += sv;
                         S2[c] = fmaf(sv, sv, S2[c]);
                     }
-                __builtin_amdgcn_sched_barrier(0);  // bound live ranges: 16 SiLU chains at a time
+                    // bound live ranges: at 128-row tiles the accumulators alone are 128 VGPRs, and 16
+                    // SiLU chains in flight pushed ~40 of them into scratch (each reload then waits
+                    // behind s_waitcnt vmcnt(0)); 8 chains at a time (4 at CT = 4) fit
+                    if (CT >= 4 || (e & 1)) __builtin_amdgcn_sched_barrier(0);
+                }
             }
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
@@ -912,7 +919,7 @@ extern "C" int prag_prober_reserve(prag_prober_t* p, int max_B) {
 
 template <int NA, int NB, int CT, int NWV>
 static int launch_fused(const ProberArgs& a, int n_run, hipStream_t st, EventRing& prof) {
-    constexpr int G = CT >= 2 ? 2 : 1;
+    constexpr int G = (CT >= 2 && CT < 4) ? 2 : 1;
     constexpr int ROWS = 32 * CT;
     constexpr int XSTAGE = NB * ROWS * 128;
     constexpr int EXCH = 2 * 16 * 2 * G * 1024;
@@ -991,7 +998,9 @@ extern "C" int prag_prober_forward(prag_prober_t* p, const void* x_dev, int x_dt
         nb = 2;
     }
     const int max_ct = (p->na == 1 && nb == 1) ? 4 : 2;
-    const int ct = pick_ct(B, n_run, max_ct);
+    int ct = pick_ct(B, n_run, max_ct);
+    static const int ct_force = getenv("PRAG_PROBER_CT") ? atoi(getenv("PRAG_PROBER_CT")) : 0;  // tuning knob
+    if (ct_force == 1 || ct_force == 2 || (ct_force == 4 && max_ct >= 4)) ct = ct_force;
 #define PRAG_DISPATCH(NA_, NB_)                                                      \
     if (p->na == NA_ && nb == NB_) {                                                 \
         if (ct == 1) return launch_fused<NA_, NB_, 1, 4>(a, n_run, st, p->prof);     \
