@@ -481,12 +481,7 @@ __device__ __forceinline__ void scan_topk_body(const ScanArgs& a, char* smem) {
         unsigned long long cur = mine[0];
         const int64_t o = ((int64_t)blockIdx.x * QT + 32 * t + q) * KC;
         for (int round = 0; round < KC; ++round) {
-            unsigned long long m = cur;
-#pragma unroll
-            for (int sft = 1; sft < 16; sft <<= 1) {
-                const unsigned long long other = __shfl_xor(m, sft, 64);
-                m = other < m ? other : m;
-            }
+            const unsigned long long m = group_min16_u64(cur);
             if (cur == m && (uint32_t)m != (uint32_t)kIdxSentinel) {  // unique owner pops
                 ++head;
                 cur = head < KC ? mine[head] : ~0ull;
@@ -728,12 +723,7 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
         unsigned long long cur = mine[0];
         const int64_t o = ((int64_t)blockIdx.x * 128 + q) * KC;
         for (int round = 0; round < KC; ++round) {
-            unsigned long long m = cur;
-#pragma unroll
-            for (int sft = 1; sft < 4; sft <<= 1) {
-                const unsigned long long other = __shfl_xor(m, sft, 64);
-                m = other < m ? other : m;
-            }
+            const unsigned long long m = group_min4_u64(cur);
             if (cur == m && (uint32_t)m != (uint32_t)kIdxSentinel) {
                 ++head;
                 cur = head < KC ? mine[head] : ~0ull;
@@ -810,9 +800,9 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
     }
     // wave-level selection: KC rounds of a 64-lane min, the owner pops (no barriers)
     for (int round = 0; round < KC; ++round) {
-        unsigned long long m = loc[0];
+        unsigned long long m = group_min16_u64(loc[0]);   // DPP inside the 16-lane rows,
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
+        for (int o = 16; o < 64; o <<= 1) {               // two shuffles across them
             const unsigned long long other = __shfl_xor(m, o, 64);
             m = other < m ? other : m;
         }

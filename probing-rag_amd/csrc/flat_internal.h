@@ -21,6 +21,29 @@ __device__ __forceinline__ float unsortable_f32(uint32_t u) {
 __device__ __forceinline__ unsigned long long pack_key(float key, int idx) {
     return ((unsigned long long)sortable_u32(key) << 32) | (uint32_t)idx;
 }
+// Minimum of a 64-bit key over aligned groups of 4 / 16 lanes, result in every lane of the group.
+// DPP moves (quad_perm, row_half_mirror, row_mirror) instead of __shfl_xor: a 64-bit shuffle is
+// two ds_bpermute (~100+ cycles each, serially dependent); the KC selection rounds at the end of
+// every scan launch were ~8 us per 32-query tile of pure cross-lane latency.
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_move_u64(unsigned long long v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, false);
+    return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ unsigned long long min_u64(unsigned long long a, unsigned long long b) { return b < a ? b : a; }
+__device__ __forceinline__ unsigned long long group_min4_u64(unsigned long long m) {
+    m = min_u64(m, dpp_move_u64<0xB1>(m));   // quad_perm [1,0,3,2]
+    m = min_u64(m, dpp_move_u64<0x4E>(m));   // quad_perm [2,3,0,1]
+    return m;
+}
+__device__ __forceinline__ unsigned long long group_min16_u64(unsigned long long m) {
+    m = group_min4_u64(m);
+    m = min_u64(m, dpp_move_u64<0x141>(m));  // row_half_mirror: lane i <-> 7 - i inside each 8
+    m = min_u64(m, dpp_move_u64<0x140>(m));  // row_mirror:      lane i <-> 15 - i inside each 16
+    return m;
+}
+
 constexpr uint32_t kSortablePosInf = 0xFF800000u;  // sortable_u32(+inf)
 constexpr uint32_t kSortableNegInf = 0x007FFFFFu;  // sortable_u32(-inf)
 
