@@ -12,6 +12,7 @@ from .index import (HipFlatIndex, IndexFlatIP, IndexFlatL2, batch_topk_sim, enco
                     find_topk_sim, merge_topk, read_index, write_index)
 from .sharded import ShardedFlatIndex, partition_rows, search_shards_on_one_gpu  # noqa: F401
 from .trainer import HipProberTrainer, method_2_train  # noqa: F401
+from .encoder import MeanPoolEncoder  # noqa: F401
 from .loop import HiddenStatePool, masked_mean_pool, method_2_eval, pool_ragged, retrieve_decide, return_evidences  # noqa: F401
 
 ImprovedProbe = HipProber  # utils.py:29

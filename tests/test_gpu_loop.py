@@ -131,3 +131,46 @@ def test_loop_matches_reference_style_path():
     assert log["hip"] == log["ref"] and len(log["hip"]) >= 4
     # the scripted cap semantics hold on the real decision traces too
     assert all(r in (0, 1, 2, 3) for r in results)
+
+
+def test_device_resident_encoder_feeds_the_index():
+    """utils.py:365-380 on the device: a (random-init, 2-layer) BERT encoder in PyTorch-ROCm ->
+    HIP masked mean pooling -> HIP flat index, through the reference's batch_topk_sim call.
+    Checked against NumPy pooling of the same hidden states and the oracle's flat search."""
+    import torch
+    import probing_rag_amd as pra
+    from transformers import BertConfig, BertModel
+    torch.manual_seed(0)
+    cfg = BertConfig(vocab_size=211, hidden_size=D_EMB, num_hidden_layers=2, num_attention_heads=12,
+                     intermediate_size=1024, max_position_embeddings=64)
+    bert = BertModel(cfg, add_pooling_layer=False)
+
+    class Tok:                                   # whitespace "tokenizer": word -> stable id, padded batch
+        def __call__(self, sentences, padding=True, truncation=True, max_length=64, return_tensors="pt"):
+            rows = [[1] + [2 + sum(map(ord, w)) % 200 for w in s.split()][: max_length - 2] + [3] for s in sentences]
+            T = max(map(len, rows))
+            ids = torch.tensor([r + [0] * (T - len(r)) for r in rows])
+            mask = torch.tensor([[1] * len(r) + [0] * (T - len(r)) for r in rows])
+            return {"input_ids": ids, "attention_mask": mask}
+
+    enc = pra.MeanPoolEncoder(bert, Tok())
+    queries = ["who wrote the iliad", "capital of the country that hosted the 1992 summer olympics", "a", "largest moon"]
+    emb = enc.encode(queries)
+    assert emb.is_cuda and emb.shape == (4, D_EMB) and emb.dtype == torch.float32
+    # pooling against NumPy on the same hidden states
+    t = Tok()(queries)
+    with torch.no_grad():
+        hid = bert.cuda()(input_ids=t["input_ids"].cuda(), attention_mask=t["attention_mask"].cuda()).last_hidden_state
+    m = t["attention_mask"].numpy().astype(np.float64)[:, :, None]
+    want = (hid.double().cpu().numpy() * m).sum(1) / m.sum(1)
+    np.testing.assert_allclose(emb.cpu().numpy(), want, atol=2e-6, rtol=0)
+    # ... and straight into the index: ids as the oracle finds them for those embeddings
+    docs = onp.synth_rows(61, 0, 3000, D_EMB) * np.float32(0.05)
+    docs[1234] = emb[1].cpu().numpy()
+    ix = pra.IndexFlatL2(D_EMB)
+    ix.add(docs)
+    D, I = pra.batch_topk_sim(enc, queries, ix, k=5)
+    assert I.is_cuda and int(I[1, 0]) == 1234
+    D0, I0 = onp.flat_search(docs, emb.cpu().numpy(), 5, onp.METRIC_L2)
+    assert np.array_equal(I.cpu().numpy(), I0)
+    np.testing.assert_allclose(D.cpu().numpy(), D0, rtol=1e-4, atol=1e-6)
