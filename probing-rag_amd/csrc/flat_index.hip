@@ -1262,6 +1262,82 @@ static int launch_merge(int kc, const float* pk, const int* pi, int n_lists, int
     return PRAG_OK;
 }
 
+// > 128 queries on fp16 rows: MFMA-tiled scan (flat_mm.hip) in chunks of kMmMaxQueries, then the
+// device-flagged fallback through the per-lane-list kernel for queries whose candidate store
+// overflowed.  Leaves the candidate ids in ix->cand.
+static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, int n_tiles, int cu_budget,
+                        hipStream_t st) {
+    const int metric_l2 = ix->metric == PRAG_METRIC_L2;
+    MmSearch m;
+    m.rows = reinterpret_cast<const _Float16*>(ix->rows);
+    m.xnorm = ix->xnorm;
+    m.N = ix->ntotal;
+    m.d = ix->d;
+    m.alpha = metric_l2 ? -2.0f : -1.0f;
+    m.use_norm = metric_l2;
+    m.kc = kc;
+    m.ckey = ix->mm_ckey;
+    m.cidx = ix->mm_cidx;
+    m.cap_q = kMmCapQ;
+    m.wcnt = ix->mm_wcnt;
+    m.wkey = ix->mm_wkey;
+    m.widx = ix->mm_widx;
+    m.cap_wg = kMmCapWg;
+    m.wg_slots = ix->n_cu;
+    m.max_wg = cu_budget;
+    int rc = PRAG_OK;
+    for (int c0 = 0; c0 < B; c0 += kMmMaxQueries) {  // chunks of 4096 queries (LDS counters)
+        m.B = std::min(B - c0, kMmMaxQueries);
+        m.Bpad = std::min(Bpad - c0, kMmMaxQueries);
+        m.q16 = ix->q16 + (size_t)c0 * ix->d;
+        m.tau = ix->g_tau + c0;
+        m.cand = ix->cand + (size_t)c0 * kc;
+        m.cnt = ix->mm_cnt + c0;
+        m.ovf = ix->mm_ovf + c0;
+        m.ovf_any = ix->mm_ovf + Bpad;
+        rc = mm_run(m, st, ix->prof);
+        if (rc != PRAG_OK) return rc;
+    }
+    // Queries whose candidate buffer overflowed (flag set on the device): their groups go
+    // through the per-lane-list kernel again; with no flag set this is two empty launches.
+    if (ix->mm_mode == 2) return PRAG_OK;  // PRAG_SCAN_MM=2 (tests of the tests): overflow goes unrepaired
+    const bool fb64 = 64 * qstride + 8 * 4096 + 64 * 4 + 64 <= 160 * 1024 - 64;
+    const int fq = fb64 ? 64 : 32;
+    const int fb_grid = std::max(1, std::min(cu_budget, (n_tiles + 7) / 8));
+    const int n_groups = Bpad / fq;
+    const int64_t part_stride = (int64_t)fb_grid * fq * kc;
+    const size_t fb_need = (size_t)n_groups * part_stride;
+    if (fb_need > ix->part_cap) {
+        if (ix->part_key) (void)hipFree(ix->part_key);
+        if (ix->part_idx) (void)hipFree(ix->part_idx);
+        ix->part_key = nullptr; ix->part_idx = nullptr; ix->part_cap = 0;
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->part_key), fb_need * sizeof(float)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->part_idx), fb_need * sizeof(int)));
+        ix->part_cap = fb_need;
+    }
+    ScanArgs a;
+    a.rows = ix->rows;
+    a.xnorm = ix->xnorm;
+    a.q16 = ix->q16;
+    a.q16lo = ix->q16lo;
+    a.N = ix->ntotal;
+    a.d = ix->d;
+    a.qstride = qstride;
+    a.n_tiles = n_tiles;
+    a.alpha = m.alpha;
+    a.use_norm = metric_l2;
+    a.out_key = ix->part_key;
+    a.out_idx = ix->part_idx;
+    a.g_tau = ix->g_tau;
+    rc = fb64 ? dispatch_flagged<64>(kc, a, fb_grid, ix->mm_ovf, n_groups, part_stride, st)
+              : dispatch_flagged<32>(kc, a, fb_grid, ix->mm_ovf, n_groups, part_stride, st);
+    if (rc != PRAG_OK) return rc;
+    rc = launch_merge(kc, ix->part_key, ix->part_idx, fb_grid, fq, B, ix->cand, nullptr, st, ix->mm_ovf,
+                      part_stride, Bpad);
+    if (rc != PRAG_OK) return rc;
+    return PRAG_OK;
+}
+
 extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D,
                                  int64_t* I, int io_is_device, void* stream) {
     PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
@@ -1372,76 +1448,8 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     if (ix->ntotal == 0) {
         PRAG_HIP(hipMemsetAsync(ix->cand, 0xFF, cand_need * sizeof(int), st));  // all -1
     } else if (use_mm) {
-        MmSearch m;
-        m.rows = reinterpret_cast<const _Float16*>(ix->rows);
-        m.xnorm = ix->xnorm;
-        m.N = ix->ntotal;
-        m.d = ix->d;
-        m.alpha = metric_l2 ? -2.0f : -1.0f;
-        m.use_norm = metric_l2;
-        m.kc = kc;
-        m.ckey = ix->mm_ckey;
-        m.cidx = ix->mm_cidx;
-        m.cap_q = kMmCapQ;
-        m.wcnt = ix->mm_wcnt;
-        m.wkey = ix->mm_wkey;
-        m.widx = ix->mm_widx;
-        m.cap_wg = kMmCapWg;
-        m.wg_slots = ix->n_cu;
-        m.max_wg = cu_budget;
-        int rc = PRAG_OK;
-        for (int c0 = 0; c0 < B; c0 += kMmMaxQueries) {  // chunks of 4096 queries (LDS counters)
-            m.B = std::min(B - c0, kMmMaxQueries);
-            m.Bpad = std::min(Bpad - c0, kMmMaxQueries);
-            m.q16 = ix->q16 + (size_t)c0 * ix->d;
-            m.tau = ix->g_tau + c0;
-            m.cand = ix->cand + (size_t)c0 * kc;
-            m.cnt = ix->mm_cnt + c0;
-            m.ovf = ix->mm_ovf + c0;
-            m.ovf_any = ix->mm_ovf + Bpad;
-            rc = mm_run(m, st, ix->prof);
-            if (rc != PRAG_OK) return rc;
-        }
-        // Queries whose candidate buffer overflowed (flag set on the device): their groups go
-        // through the per-lane-list kernel again; with no flag set this is two empty launches.
-        if (ix->mm_mode == 2) goto mm_done;  // PRAG_SCAN_MM=2 (tests of the tests): overflow goes unrepaired
-        {
-        const bool fb64 = 64 * qstride + 8 * 4096 + 64 * 4 + 64 <= 160 * 1024 - 64;
-        const int fq = fb64 ? 64 : 32;
-        const int fb_grid = std::max(1, std::min(cu_budget, (n_tiles + 7) / 8));
-        const int n_groups = Bpad / fq;
-        const int64_t part_stride = (int64_t)fb_grid * fq * kc;
-        const size_t fb_need = (size_t)n_groups * part_stride;
-        if (fb_need > ix->part_cap) {
-            if (ix->part_key) (void)hipFree(ix->part_key);
-            if (ix->part_idx) (void)hipFree(ix->part_idx);
-            ix->part_key = nullptr; ix->part_idx = nullptr; ix->part_cap = 0;
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->part_key), fb_need * sizeof(float)));
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->part_idx), fb_need * sizeof(int)));
-            ix->part_cap = fb_need;
-        }
-        ScanArgs a;
-        a.rows = ix->rows;
-        a.xnorm = ix->xnorm;
-        a.q16 = ix->q16;
-        a.q16lo = ix->q16lo;
-        a.N = ix->ntotal;
-        a.d = ix->d;
-        a.qstride = qstride;
-        a.n_tiles = n_tiles;
-        a.alpha = m.alpha;
-        a.use_norm = metric_l2;
-        a.out_key = ix->part_key;
-        a.out_idx = ix->part_idx;
-        a.g_tau = ix->g_tau;
-        rc = fb64 ? dispatch_flagged<64>(kc, a, fb_grid, ix->mm_ovf, n_groups, part_stride, st)
-                  : dispatch_flagged<32>(kc, a, fb_grid, ix->mm_ovf, n_groups, part_stride, st);
+        const int rc = search_tiled(ix, B, Bpad, kc, qstride, n_tiles, cu_budget, st);
         if (rc != PRAG_OK) return rc;
-        rc = launch_merge(kc, ix->part_key, ix->part_idx, fb_grid, fq, B, ix->cand, nullptr, st, ix->mm_ovf,
-                          part_stride, Bpad);
-        if (rc != PRAG_OK) return rc;
-        }
-    mm_done:;
     } else {
         ScanArgs a;
         a.rows = ix->rows;
