@@ -141,3 +141,23 @@ def test_dropout_masks_are_bernoulli_and_keyed():
     assert not np.array_equal(k, onp.dropout_keep(7, 3, 1, 64, 512, 0.1))      # site
     assert not np.array_equal(k, onp.dropout_keep(7, 4, 0, 64, 512, 0.1))      # step
     assert np.array_equal(k[:8], onp.dropout_keep(7, 3, 0, 8, 512, 0.1))       # rows are independent of B
+
+
+def test_flat_search_agrees_with_an_independent_brute_force():
+    """faiss (the reference's dependency) is not installable here, so the flat-search oracle stays
+    'parity unpinned' against it; as an independent check of the DEFINITION it restates, compare
+    with scikit-learn's exact brute-force neighbours (Euclidean -> squared, cosine distance ->
+    1 - similarity) on data without ties."""
+    from sklearn.neighbors import NearestNeighbors
+    X = onp.synth_rows(71, 0, 4000, 96)
+    Q = onp.synth_rows(72, 0, 37, 96)
+    k = 7
+    D0, I0 = onp.flat_search(X, Q, k, onp.METRIC_L2)
+    dist, idx = NearestNeighbors(n_neighbors=k, algorithm="brute", metric="euclidean").fit(X.astype(np.float64)).kneighbors(Q.astype(np.float64))
+    assert np.array_equal(I0, idx)
+    np.testing.assert_allclose(D0, dist ** 2, rtol=1e-5)
+    Xn = onp.normalize_rows(X)
+    D1, I1 = onp.flat_search(Xn, Q, k, onp.METRIC_COS)
+    dist, idx = NearestNeighbors(n_neighbors=k, algorithm="brute", metric="cosine").fit(Xn.astype(np.float64)).kneighbors(Q.astype(np.float64))
+    assert np.array_equal(I1, idx)
+    np.testing.assert_allclose(D1, 1.0 - dist, atol=1e-6)
