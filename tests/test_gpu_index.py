@@ -269,3 +269,35 @@ def test_high_precision_selection_resolves_close_inner_products():
     assert np.array_equal(I3[:1], I0)                          # 30 near-ties fit a 32-deep list
     with pytest.raises(pra.PragError, match="PRAG_EINVAL"):
         ix.set_candidate_depth(5)
+
+
+def test_randomised_shapes_against_the_definition():
+    """Seeded sweep over shard sizes, batch sizes, k, d, metric and storage: every combination lands
+    on one of the scan paths (high-precision 32-query, 64-query lists, query-stationary, MFMA-tiled)
+    and must return the oracle's ids bit for bit; a few exact duplicates check the tie order."""
+    import probing_rag_amd as pra
+    rng = np.random.default_rng(20261003)
+    for it in range(64):
+        d = int(rng.choice([64, 128, 256, 512, 768, 1024]))
+        N = int(rng.choice([1, 7, 33, 255, 257, 1000, 2049, 4100, 6000]))
+        B = int(rng.choice([1, 2, 31, 33, 64, 65, 100, 128, 129, 200, 300]))
+        k = int(rng.choice([1, 3, 5, 10, 12, 13, 26]))
+        metric = int(rng.choice(METRICS))
+        store = str(rng.choice(["f32", "f16"]))
+        X = onp.synth_rows(1000 + it, 0, N, d)
+        if N > 40:
+            X[N // 3] = X[5]
+            X[N - 2] = X[5]
+        Q = onp.synth_rows(2000 + it, 0, B, d)
+        if N > 40:
+            Q[B // 2] = X[5]
+        ix = pra.HipFlatIndex(d, metric, store)
+        ix.add(X)
+        D, I = ix.search(Q, k)
+        D0, I0 = onp.flat_search(_stored(X, metric, store), Q, k, metric)
+        assert np.array_equal(I, I0), (it, d, N, B, k, metric, store, np.argwhere(I != I0)[:4])
+        if metric == onp.METRIC_L2:
+            np.testing.assert_allclose(D, D0, rtol=1e-4, atol=1e-6)
+        else:
+            np.testing.assert_allclose(D, D0, atol=1e-4, rtol=0)
+        ix.close()
