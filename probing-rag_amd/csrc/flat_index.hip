@@ -741,37 +741,20 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
 // ---------------------------------------------------------------------------
 
 // KC smallest (key,id) pairs of one query: every thread folds its share of the per-workgroup
-// lists into a sorted register list, each wave selects its KC best with shuffles only, the four
-// wave results are ranked by counting (ids are unique, so ranks are unique).
-template <int KC>
-__global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restrict__ part_key,
-                                                         const int* __restrict__ part_idx, int n_lists,
-                                                         int QT, int* __restrict__ cand_idx /*[q][KC]*/,
-                                                         uint32_t* __restrict__ tau_out /*[q] or null*/,
-                                                         const uint32_t* __restrict__ q_flag /*or null*/,
-                                                         int64_t part_stride, int any_idx) {
-    __shared__ unsigned long long s_w[4 * KC];
-    // flagged mode (fallback of the MFMA-tiled scan): block = global query, lists of its group of QT
-    // queries start at part_stride * group; groups without a flagged query keep their candidates
-    int q = blockIdx.x;
-    const int64_t qglob = blockIdx.x;
-    if (q_flag) {
-        if (q_flag[any_idx] == 0) return;  // nothing was flagged in this search
-        const int grp = q / QT;
-        bool any = false;
-        for (int j = 0; j < QT; ++j) any |= q_flag[grp * QT + j] != 0;
-        if (!any) return;
-        part_key += grp * part_stride;
-        part_idx += grp * part_stride;
-        q -= grp * QT;
-    }
+// lists into a sorted register list, each wave selects its KC best with shuffles only, the NW
+// wave results are ranked by counting (ids are unique, so ranks are unique).  Result: s_out[rank]
+// = packed (key, id), ~0 where there are fewer than KC rows.  NW waves per block.
+template <int KC, int NW>
+__device__ __forceinline__ void merge_lists_block(const float* __restrict__ part_key, const int* __restrict__ part_idx,
+                                                  int n_lists, int QT, int q, unsigned long long* s_w /*[NW*KC]*/,
+                                                  unsigned long long* s_out /*[KC]*/) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const unsigned long long kInf = ~0ull;
     unsigned long long loc[KC];
 #pragma unroll
     for (int j = 0; j < KC; ++j) loc[j] = kInf;
-    for (int l = tid; l < n_lists; l += 256) {
+    for (int l = tid; l < n_lists; l += 64 * NW) {
         const int64_t o = ((int64_t)l * QT + q) * KC;
         if (loc[0] == kInf) {  // first list of this thread: already sorted, take it whole
 #pragma unroll
@@ -814,40 +797,64 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
         if (lane == 0) s_w[w * KC + round] = m;
     }
     __syncthreads();
-    // rank the 4*KC survivors by counting; rank < KC goes out
-    for (int e = tid; e < 4 * KC; e += 256) {
+    // rank the NW*KC survivors by counting; rank < KC goes out
+    for (int e = tid; e < NW * KC; e += 64 * NW) {
         const unsigned long long v = s_w[e];
         int rank = 0;
-        for (int j = 0; j < 4 * KC; ++j) {
+        for (int j = 0; j < NW * KC; ++j) {
             const unsigned long long u = s_w[j];
             rank += (u < v) || (u == v && j < e);   // sentinels tie: order by position
         }
-        if (rank < KC) {
-            cand_idx[qglob * KC + rank] = (v == kInf) ? -1 : (int)(uint32_t)v;
-            // pre-pass use: the KC-th best key of the rows seen = a valid pruning bound for the
-            // full scan (those rows are a subset of the shard)
-            if (tau_out && rank == KC - 1 && v != kInf) tau_out[qglob] = (uint32_t)(v >> 32);
-        }
+        if (rank < KC) s_out[rank] = v;
+    }
+    __syncthreads();
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restrict__ part_key,
+                                                         const int* __restrict__ part_idx, int n_lists,
+                                                         int QT, int* __restrict__ cand_idx /*[q][KC]*/,
+                                                         uint32_t* __restrict__ tau_out /*[q] or null*/,
+                                                         const uint32_t* __restrict__ q_flag /*or null*/,
+                                                         int64_t part_stride, int any_idx) {
+    __shared__ unsigned long long s_w[4 * KC];
+    __shared__ unsigned long long s_out[KC];
+    // flagged mode (fallback of the MFMA-tiled scan): block = global query, lists of its group of QT
+    // queries start at part_stride * group; groups without a flagged query keep their candidates
+    int q = blockIdx.x;
+    const int64_t qglob = blockIdx.x;
+    if (q_flag) {
+        if (q_flag[any_idx] == 0) return;  // nothing was flagged in this search
+        const int grp = q / QT;
+        bool any = false;
+        for (int j = 0; j < QT; ++j) any |= q_flag[grp * QT + j] != 0;
+        if (!any) return;
+        part_key += grp * part_stride;
+        part_idx += grp * part_stride;
+        q -= grp * QT;
+    }
+    merge_lists_block<KC, 4>(part_key, part_idx, n_lists, QT, q, s_w, s_out);
+    if ((int)threadIdx.x < KC) {
+        const unsigned long long v = s_out[threadIdx.x];
+        cand_idx[qglob * KC + threadIdx.x] = (v == ~0ull) ? -1 : (int)(uint32_t)v;
+        // pre-pass use: the KC-th best key of the rows seen = a valid pruning bound for the
+        // full scan (those rows are a subset of the shard)
+        if (tau_out && threadIdx.x == KC - 1 && v != ~0ull) tau_out[qglob] = (uint32_t)(v >> 32);
     }
 }
 
 // ---------------------------------------------------------------------------
-// exact rerank: grid = queries, one wave per candidate (KC waves), 16-B row loads
+// exact rerank of one query's KC candidates: one wave per candidate, 16-B row loads, float64
 // ---------------------------------------------------------------------------
-template <bool F32>
-__global__ __launch_bounds__(1024) void rerank_kernel(const void* __restrict__ rows, int d, int metric_l2,
-                                                     const float* __restrict__ q32,
-                                                     const int* __restrict__ cand_idx, int KC, int k,
-                                                     int64_t id_offset, float* __restrict__ D,
-                                                     int64_t* __restrict__ I) {
-    __shared__ double s_score[64];
-    __shared__ int s_idx[64];
-    const int b = blockIdx.x;
+template <bool F32, typename CandFn>
+__device__ __forceinline__ void rerank_block(const void* __restrict__ rows, int d, int metric_l2,
+                                             const float* __restrict__ q, CandFn cand, int KC, int k,
+                                             int64_t id_offset, float* __restrict__ Db, int64_t* __restrict__ Ib,
+                                             double* s_score /*[64]*/, int* s_idx /*[64]*/) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nw = blockDim.x >> 6;
-    const float* q = q32 + (int64_t)b * d;
     for (int c = w; c < KC; c += nw) {
-        const int idx = cand_idx[(int64_t)b * KC + c];
+        const int idx = cand(c);
         double s = 0.0;
         if (idx >= 0) {
             // 8 consecutive elements per lane per step (d is a multiple of 64)
@@ -910,10 +917,43 @@ __global__ __launch_bounds__(1024) void rerank_kernel(const void* __restrict__ r
         }
         for (int j = 0; j < k; ++j) {
             const bool ok = j < KC && s_idx[j] >= 0;
-            D[(int64_t)b * k + j] = ok ? (float)s_score[j] : (metric_l2 ? FLT_MAX : -FLT_MAX);
-            I[(int64_t)b * k + j] = ok ? (int64_t)s_idx[j] + id_offset : -1;
+            Db[j] = ok ? (float)s_score[j] : (metric_l2 ? FLT_MAX : -FLT_MAX);
+            Ib[j] = ok ? (int64_t)s_idx[j] + id_offset : -1;
         }
     }
+}
+
+template <bool F32>
+__global__ __launch_bounds__(1024) void rerank_kernel(const void* __restrict__ rows, int d, int metric_l2,
+                                                     const float* __restrict__ q32,
+                                                     const int* __restrict__ cand_idx, int KC, int k,
+                                                     int64_t id_offset, float* __restrict__ D,
+                                                     int64_t* __restrict__ I) {
+    __shared__ double s_score[64];
+    __shared__ int s_idx[64];
+    const int b = blockIdx.x;
+    rerank_block<F32>(rows, d, metric_l2, q32 + (int64_t)b * d, [&](int c) { return cand_idx[(int64_t)b * KC + c]; }, KC,
+                      k, id_offset, D + (int64_t)b * k, I + (int64_t)b * k, s_score, s_idx);
+}
+
+// merge of the per-workgroup lists + exact rerank of the survivors in one launch (the end of every
+// search on the per-lane-list paths): grid = queries, 16 waves
+template <int KC, bool F32>
+__global__ __launch_bounds__(1024) void merge_rerank_kernel(const float* __restrict__ part_key,
+                                                           const int* __restrict__ part_idx, int n_lists, int QT,
+                                                           int q0, const void* __restrict__ rows, int d,
+                                                           int metric_l2, const float* __restrict__ q32, int k,
+                                                           int64_t id_offset, float* __restrict__ D,
+                                                           int64_t* __restrict__ I) {
+    __shared__ unsigned long long s_w[16 * KC];
+    __shared__ unsigned long long s_out[KC];
+    __shared__ double s_score[64];
+    __shared__ int s_idx[64];
+    const int b = q0 + blockIdx.x;  // global query; blockIdx.x = its slot in this pass's query tile
+    merge_lists_block<KC, 16>(part_key, part_idx, n_lists, QT, (int)blockIdx.x, s_w, s_out);
+    rerank_block<F32>(rows, d, metric_l2, q32 + (int64_t)b * d,
+                      [&](int c) { return s_out[c] == ~0ull ? -1 : (int)(uint32_t)s_out[c]; }, KC, k, id_offset,
+                      D + (int64_t)b * k, I + (int64_t)b * k, s_score, s_idx);
 }
 
 // ---------------------------------------------------------------------------
@@ -1262,6 +1302,31 @@ static int launch_merge(int kc, const float* pk, const int* pi, int n_lists, int
     return PRAG_OK;
 }
 
+template <int KC>
+static void launch_merge_rerank_kc(bool f32, const float* pk, const int* pi, int n_lists, int QT, int nq, int q0,
+                                   const void* rows, int d, int metric_l2, const float* q32, int k, int64_t id_offset,
+                                   float* D, int64_t* I, hipStream_t st) {
+    if (f32)
+        hipLaunchKernelGGL((merge_rerank_kernel<KC, true>), dim3(nq), dim3(1024), 0, st, pk, pi, n_lists, QT, q0, rows, d,
+                           metric_l2, q32, k, id_offset, D, I);
+    else
+        hipLaunchKernelGGL((merge_rerank_kernel<KC, false>), dim3(nq), dim3(1024), 0, st, pk, pi, n_lists, QT, q0, rows, d,
+                           metric_l2, q32, k, id_offset, D, I);
+}
+
+static int launch_merge_rerank(int kc, bool f32, const float* pk, const int* pi, int n_lists, int QT, int nq, int q0,
+                               const void* rows, int d, int metric_l2, const float* q32, int k, int64_t id_offset,
+                               float* D, int64_t* I, hipStream_t st) {
+    switch (kc) {
+        case 8: launch_merge_rerank_kc<8>(f32, pk, pi, n_lists, QT, nq, q0, rows, d, metric_l2, q32, k, id_offset, D, I, st); break;
+        case 16: launch_merge_rerank_kc<16>(f32, pk, pi, n_lists, QT, nq, q0, rows, d, metric_l2, q32, k, id_offset, D, I, st); break;
+        case 32: launch_merge_rerank_kc<32>(f32, pk, pi, n_lists, QT, nq, q0, rows, d, metric_l2, q32, k, id_offset, D, I, st); break;
+        default: set_error("internal: KC=%d", kc); return PRAG_EUNSUPPORTED;
+    }
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
 // > 128 queries on fp16 rows: MFMA-tiled scan (flat_mm.hip) in chunks of kMmMaxQueries, then the
 // device-flagged fallback through the per-lane-list kernel for queries whose candidate store
 // overflowed.  Leaves the candidate ids in ix->cand.
@@ -1445,6 +1510,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
                        (uint32_t)std::min<int64_t>(ix->ntotal, kMmFirstSeg));
     PRAG_LAUNCH_CHECK();
 
+    bool reranked = false;
     if (ix->ntotal == 0) {
         PRAG_HIP(hipMemsetAsync(ix->cand, 0xFF, cand_need * sizeof(int), st));  // all -1
     } else if (use_mm) {
@@ -1499,17 +1565,22 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
             }
             rc = run_scan(a, grid, ix->prof);
             if (rc != PRAG_OK) return rc;
-            rc = launch_merge(kc, ix->part_key, ix->part_idx, n_lists, QT, nq, ix->cand + (size_t)p0 * kc, nullptr, st);
+            // the end of the search for this query tile: list merge + exact rerank in one launch
+            rc = launch_merge_rerank(kc, ix->store == PRAG_F32, ix->part_key, ix->part_idx, n_lists, QT, nq, p0,
+                                     ix->rows, ix->d, metric_l2, ix->q32, k, id_offset, D_dev, I_dev, st);
             if (rc != PRAG_OK) return rc;
         }
+        reranked = true;
     }
-    if (ix->store == PRAG_F32)
-        hipLaunchKernelGGL(rerank_kernel<true>, dim3(B), dim3(64 * std::min(kc, 16)), 0, st, ix->rows, ix->d, metric_l2, ix->q32,
-                           ix->cand, kc, k, id_offset, D_dev, I_dev);
-    else
-        hipLaunchKernelGGL(rerank_kernel<false>, dim3(B), dim3(64 * std::min(kc, 16)), 0, st, ix->rows, ix->d, metric_l2, ix->q32,
-                           ix->cand, kc, k, id_offset, D_dev, I_dev);
-    PRAG_LAUNCH_CHECK();
+    if (!reranked) {  // empty index, or candidates from the tiled scan
+        if (ix->store == PRAG_F32)
+            hipLaunchKernelGGL(rerank_kernel<true>, dim3(B), dim3(64 * std::min(kc, 16)), 0, st, ix->rows, ix->d, metric_l2,
+                               ix->q32, ix->cand, kc, k, id_offset, D_dev, I_dev);
+        else
+            hipLaunchKernelGGL(rerank_kernel<false>, dim3(B), dim3(64 * std::min(kc, 16)), 0, st, ix->rows, ix->d, metric_l2,
+                               ix->q32, ix->cand, kc, k, id_offset, D_dev, I_dev);
+        PRAG_LAUNCH_CHECK();
+    }
 
     if (!io_is_device) {
         PRAG_HIP(hipMemcpyAsync(D, D_dev, (size_t)B * k * sizeof(float), hipMemcpyDeviceToHost, st));
