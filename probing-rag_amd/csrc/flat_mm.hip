@@ -536,8 +536,9 @@ __global__ __launch_bounds__(256) void mm_compact_kernel(uint32_t* __restrict__ 
             const unsigned long long x = s_v[i];
             if ((round == 0 || x > prev) && x < m) m = x;
         }
+        m = group_min16_u64(m);                       // DPP inside the 16-lane rows,
 #pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) {
+        for (int sft = 16; sft < 64; sft <<= 1) {    // two shuffles across them
             const unsigned long long other = __shfl_xor(m, sft, 64);
             m = other < m ? other : m;
         }
