@@ -1012,6 +1012,16 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(const void* __restrict
     }
 }
 
+__global__ __launch_bounds__(256) void rows_to_f16_kernel(const float* __restrict__ src, int64_t n_vec4,
+                                                         _Float16* __restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n_vec4; i += stride) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+        reinterpret_cast<half4*>(dst)[i] = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    }
+}
+
 }  // namespace prag
 
 // ===========================================================================
@@ -1046,6 +1056,10 @@ struct prag_index {
     int* mm_widx = nullptr;
     int mm_q_cap = 0;
     int mm_mode = 1;   // 0 = never take the MFMA-tiled path (PRAG_SCAN_MM=0)
+    // fp32 indexes: fp16 copy of the rows for the tiled scan's candidate selection (built on the
+    // first search with > 128 queries, dropped by add; the rerank always reads the fp32 rows)
+    _Float16* rows16 = nullptr;
+    int64_t rows16_n = -1, rows16_cap = 0;
     // host-io staging
     float* io_q = nullptr;
     float* io_D = nullptr;
@@ -1333,8 +1347,25 @@ static int launch_merge_rerank(int kc, bool f32, const float* pk, const int* pi,
 static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, int n_tiles, int cu_budget,
                         hipStream_t st) {
     const int metric_l2 = ix->metric == PRAG_METRIC_L2;
+    const _Float16* rows16 = reinterpret_cast<const _Float16*>(ix->rows);
+    if (ix->store == PRAG_F32) {
+        // candidate selection runs on an fp16 copy of the rows (what the list kernels do on the fly)
+        if (ix->rows16_cap < ix->cap) {
+            if (ix->rows16) (void)hipFree(ix->rows16);
+            ix->rows16 = nullptr; ix->rows16_cap = 0; ix->rows16_n = -1;
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->rows16), (size_t)ix->cap * ix->d * sizeof(_Float16)));
+            ix->rows16_cap = ix->cap;
+        }
+        if (ix->rows16_n != ix->ntotal) {
+            hipLaunchKernelGGL(rows_to_f16_kernel, dim3(4096), dim3(256), 0, st, reinterpret_cast<const float*>(ix->rows),
+                               ix->ntotal * (int64_t)ix->d / 4, ix->rows16);
+            PRAG_LAUNCH_CHECK();
+            ix->rows16_n = ix->ntotal;
+        }
+        rows16 = ix->rows16;
+    }
     MmSearch m;
-    m.rows = reinterpret_cast<const _Float16*>(ix->rows);
+    m.rows = rows16;
     m.xnorm = ix->xnorm;
     m.N = ix->ntotal;
     m.d = ix->d;
@@ -1381,7 +1412,7 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
         ix->part_cap = fb_need;
     }
     ScanArgs a;
-    a.rows = ix->rows;
+    a.rows = rows16;
     a.xnorm = ix->xnorm;
     a.q16 = ix->q16;
     a.q16lo = ix->q16lo;
@@ -1441,7 +1472,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     // 64-query tiles when they fit LDS; fp32 rows with 32-deep lists stay at 32 (VGPR budget)
     const bool wide_ok = 64 * qstride + 8 * 4096 + 64 * 4 <= 160 * 1024 && !(ix->store == PRAG_F32 && kc == 32);
     // > 128 queries: the contraction bounds the search -> MFMA-tiled scan, 256 queries per tile
-    const bool use_mm = B > 128 && ix->mm_mode && ix->ntotal > 0 && mm_supported(ix->d, ix->store, kc);
+    const bool use_mm = B > 128 && ix->mm_mode && ix->ntotal > 0 && mm_supported(ix->d, PRAG_F16, kc);
     const bool use_qs = !use_mm && B > 64 && qs_supported(ix->d, ix->store, kc);  // 128 queries per corpus pass
     const int QT = use_mm ? 256 : use_qs ? 128 : ((B > 32 && wide_ok) ? 64 : 32);
     // <= 32 queries (the reference's call shape): high-precision selection, if two query tiles fit LDS
@@ -1672,7 +1703,7 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
     ix->prof.disable();
     void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->q16lo, ix->g_tau, ix->part_key, ix->part_idx, ix->cand,
                     ix->io_q, ix->io_D, ix->io_I, ix->mm_cnt, ix->mm_ovf, ix->mm_ckey, ix->mm_cidx,
-                    ix->mm_wcnt, ix->mm_wkey, ix->mm_widx};
+                    ix->mm_wcnt, ix->mm_wkey, ix->mm_widx, ix->rows16};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete ix;
