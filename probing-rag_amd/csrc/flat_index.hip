@@ -1210,11 +1210,10 @@ static int launch_scan(const ScanArgs& a, int grid, hipStream_t st, EventRing& p
     const int lds_merge = 16 * 32 * KC * 8;                     // in-workgroup list merge
     const int lds = lds_loop > lds_merge ? lds_loop : lds_merge;
     auto kern = scan_topk_kernel<QT, KC, F32, HP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    static LdsOptIn lds_opt_in;
+    {
+        const int rc_ = lds_opt_in.ensure(reinterpret_cast<const void*>(kern), 160 * 1024);
+        if (rc_ != PRAG_OK) return rc_;
     }
     prof.begin(st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
@@ -1241,11 +1240,10 @@ static int launch_flagged(const ScanArgs& a, int grid, const uint32_t* q_flag, i
     const int lds_merge = 16 * 32 * KC * 8;
     const int lds = lds_loop > lds_merge ? lds_loop : lds_merge;
     auto kern = scan_topk_flagged_kernel<QT, KC>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        attr_set = true;
+    static LdsOptIn lds_opt_in;
+    {
+        const int rc_ = lds_opt_in.ensure(reinterpret_cast<const void*>(kern), 160 * 1024 - 64);
+        if (rc_ != PRAG_OK) return rc_;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, q_flag, n_groups, part_stride);
     PRAG_LAUNCH_CHECK();
@@ -1269,11 +1267,10 @@ static int launch_qs(const ScanArgs& a, int grid, hipStream_t st, EventRing& pro
     // 4-stage ring + 2 KiB of side data, reused by the final list merge
     const int lds = 4 * 128 * 128 + 2048 > 128 * 4 * KC * 8 ? 4 * 128 * 128 + 2048 : 128 * 4 * KC * 8;
     auto kern = scan_qs_kernel<NKS, KC, L2>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    static LdsOptIn lds_opt_in;
+    {
+        const int rc_ = lds_opt_in.ensure(reinterpret_cast<const void*>(kern), 160 * 1024);
+        if (rc_ != PRAG_OK) return rc_;
     }
     prof.begin(st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);

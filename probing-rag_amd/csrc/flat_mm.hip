@@ -577,11 +577,10 @@ bool mm_supported(int d, int store_dtype, int kc) {
 template <int NKT, int MODE, int ABL = 0>
 static int launch_mm_impl(const MmArgs& a, int grid, hipStream_t st) {
     auto kern = scan_mm_kernel<NKT, MODE, ABL>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024));
-        attr_set = true;
+    static LdsOptIn lds_opt_in;
+    {
+        const int rc_ = lds_opt_in.ensure(reinterpret_cast<const void*>(kern), 160 * 1024);
+        if (rc_ != PRAG_OK) return rc_;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kMmLdsCnt + 4 * a.Bpad, st, a);
     PRAG_LAUNCH_CHECK();

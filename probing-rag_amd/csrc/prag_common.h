@@ -82,6 +82,20 @@ struct EventRing {
     }
 };
 
+// Kernels that need more than 64 KiB of dynamic LDS: the attribute is per device, so remember per
+// (kernel instantiation, device) - one process may hold handles on several GPUs.
+struct LdsOptIn {
+    uint64_t done = 0;  // bit i = device i has the attribute
+    int ensure(const void* fn, int bytes) {
+        int dev = 0;
+        PRAG_HIP(hipGetDevice(&dev));
+        if (dev < 64 && (done >> dev) & 1) return PRAG_OK;
+        PRAG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        if (dev < 64) done |= 1ull << dev;
+        return PRAG_OK;
+    }
+};
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

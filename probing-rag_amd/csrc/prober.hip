@@ -926,11 +926,10 @@ static int launch_fused(const ProberArgs& a, int n_run, hipStream_t st, EventRin
     constexpr int REGION_A = (2 * XSTAGE > EXCH) ? 2 * XSTAGE : EXCH;
     constexpr int LDS = REGION_A + (2 * NWV * ROWS + 4 * NWV * 64 + 2 * ROWS + 6 * kHidden) * (int)sizeof(float);
     auto kern = prober_fused_kernel<NA, NB, CT, NWV>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
+    static LdsOptIn lds_opt_in;
+    {
+        const int rc_ = lds_opt_in.ensure(reinterpret_cast<const void*>(kern), LDS);
+        if (rc_ != PRAG_OK) return rc_;
     }
     ProberArgs b = a;
     b.n_tiles = (a.B + ROWS - 1) / ROWS;
