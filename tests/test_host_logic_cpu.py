@@ -102,3 +102,43 @@ def test_write_index_emits_faiss_flat_header(tmp_path):
     assert (d, nt, trained, metric) == (4, 3, 1, 1)
     (nf,) = struct.unpack("<Q", raw[37:45])
     assert nf == 12 and np.frombuffer(raw[45:], np.float32).tolist() == list(range(12))
+
+
+def test_merge_topk_properties():
+    """Exchange-step semantics on random shard results (hypothesis): merging the shards' sorted
+    top-k lists equals the top-k of the concatenation under (score, id) order, for both metric
+    directions, with padded (-1) entries and ties across shards."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 5), st.integers(1, 4), st.integers(1, 6), st.integers(0, 2 ** 31 - 1),
+           st.sampled_from([onp.METRIC_L2, onp.METRIC_IP]))
+    def check(parts, B, k, seed, metric):
+        rng = np.random.default_rng(seed)
+        Ds, Is = [], []
+        next_id = 0
+        for _ in range(parts):
+            n = int(rng.integers(0, 2 * k + 1))              # rows in this shard (may be < k)
+            ids = np.arange(next_id, next_id + n)
+            next_id += n
+            sc = rng.integers(0, 4, size=(B, n)).astype(np.float32)   # few distinct values -> ties
+            D = np.full((B, k), np.finfo(np.float32).max if metric == onp.METRIC_L2 else -np.finfo(np.float32).max, np.float32)
+            I = np.full((B, k), -1, np.int64)
+            for b in range(B):
+                key = sc[b] if metric == onp.METRIC_L2 else -sc[b]
+                o = np.lexsort((ids, key))[:k]
+                D[b, :len(o)] = sc[b, o]
+                I[b, :len(o)] = ids[o]
+            Ds.append(D)
+            Is.append(I)
+        D, I = onp.merge_topk(Ds, Is, k, metric)
+        allD, allI = np.concatenate(Ds, 1), np.concatenate(Is, 1)
+        for b in range(B):
+            valid = allI[b] >= 0
+            key = allD[b, valid] if metric == onp.METRIC_L2 else -allD[b, valid]
+            o = np.lexsort((allI[b, valid], key))[:k]
+            want = allI[b, valid][o]
+            assert I[b, :len(want)].tolist() == want.tolist()
+            assert (I[b, len(want):] == -1).all()
+
+    check()
