@@ -65,7 +65,8 @@ constexpr int kMmLdsCnt = 131072 + 2048;   // [Bpad] survivor counters of this w
 
 // ABL != 0: timing-only ablations (wrong results) for tools/mm_ablate.py, built with -DPRAG_MM_DIAG;
 // bit 0 no MFMAs, bit 1 no LDS-DMA, bit 2 no fragment reads, bit 3 no filter, bit 4 vmcnt(14)
-// instead of vmcnt(8) (reads may race the DMA), bit 5 no barrier after the MFMA block
+// instead of vmcnt(8) (reads may race the DMA), bit 5 no barrier after the MFMA block, bit 6 the
+// int8 MFMA on the same bytes (with NKT = d/128: what an 8-bit shadow of the rows would cost)
 // MODE 0: the launch over the first segment (no bound yet; every row becomes a candidate);
 // MODE 1: inner product / cosine (key = -score); MODE 2: squared L2 (key = ||x||^2 - 2 score).
 template <int NKT /* d / 64, even */, int MODE = 1, int ABL = 0>
@@ -191,6 +192,14 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                            \
             if constexpr (ABL & 1) {                                                                  \
                 asm volatile("" ::"v"(AF_[0][ks]), "v"(AF_[1][ks]), "v"(BF_[ks]));                    \
+            } else if constexpr (ABL & 64) {  /* timing probe: the same bytes through the int8 MFMA */ \
+                typedef int i32x16_ __attribute__((ext_vector_type(16)));                              \
+                c0_ = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(                \
+                    __builtin_bit_cast(i32x4, AF_[0][ks]), __builtin_bit_cast(i32x4, BF_[ks]),         \
+                    __builtin_bit_cast(i32x16_, c0_), 0, 0, 0));                                       \
+                c1_ = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(                \
+                    __builtin_bit_cast(i32x4, AF_[1][ks]), __builtin_bit_cast(i32x4, BF_[ks]),         \
+                    __builtin_bit_cast(i32x16_, c1_), 0, 0, 0));                                       \
             } else {                                                                                  \
                 c0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF_[0][ks], BF_[ks], ((first_) && ks == 0) ? zero16 : c0_, 0, 0, 0); \
                 c1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF_[1][ks], BF_[ks], ((first_) && ks == 0) ? zero16 : c1_, 0, 0, 0); \
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     half8 A[2][4], Bx[4], By[4];
     half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};  // ablation 3 only: an opaque constant in place of the fragment reads
     if constexpr (ABL & 4) asm volatile("" : "+v"(hz));
-    if constexpr (ABL & 1) {
+    if constexpr (ABL & (1 | 64)) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i >> 1][i & 1] = zero16;
     }
@@ -655,6 +664,7 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
                     case 24: rc = launch_mm<12, 24>(a, first, grid, st); break;
                     case 40: rc = launch_mm<12, 40>(a, first, grid, st); break;
                     case 56: rc = launch_mm<12, 56>(a, first, grid, st); break;
+                    case 72: rc = launch_mm<6, 72>(a, first, grid, st); break;   // 768 int8 per row
                     default: rc = launch_mm<12>(a, first, grid, st); break;
                 }
                 break;

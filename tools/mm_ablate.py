@@ -25,8 +25,9 @@ print(f"{os.environ.get('PRAG_MM_ABLATE','0')}: search {dt*1e3:.3f} ms, last-seg
 ''' % ROOT
 names = {0: "full kernel", 8: "no filter", 9: "no filter, no MFMAs", 10: "no filter, no LDS-DMA",
          12: "no filter, no fragment reads", 14: "MFMAs + barriers only", 15: "barriers only",
-         24: "no filter, vmcnt(14)", 40: "no filter, one barrier per phase", 56: "no filter, vmcnt(14), one barrier"}
-for abl in (0, 8, 9, 10, 12, 24, 40, 56):
+         24: "no filter, vmcnt(14)", 40: "no filter, one barrier per phase", 56: "no filter, vmcnt(14), one barrier",
+         72: "no filter, int8 MFMA, 768 B rows"}
+for abl in (0, 8, 9, 10, 12, 72):
     env = dict(os.environ, PRAG_LIB=os.path.join(ROOT, "probing-rag_amd", "lib", "libprag_diag.so"),
                PRAG_MM_ABLATE=str(abl), PRAG_MM_CLOCK="1")
     out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
