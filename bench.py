@@ -16,6 +16,8 @@ gate rows are split across ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra
 objects `roofline` (dominant kernel: scan_topk, HBM-bound) and `cpu_baseline`.
+Other sizes are parity/diagnostic cases, e.g. BASELINE config 3:
+  python bench.py --queries 1000 --docs 1000000      # MFMA-tiled scan, roofline.bound = "mfma"
 """
 import argparse
 import json
