@@ -216,6 +216,8 @@ int prag_index_d(const prag_index_t* ix);
  *   q: float32 [B,d] (device pointer if io_is_device, else host);
  *   D: float32 [B,k] squared-L2 ascending (L2) or score descending (IP/COS);
  *   I: int64 [B,k] row ids + id_offset, -1 padded when ntotal < k.
+ * k <= 26 for every d the index accepts; 26 < k <= 911 needs d in {256,512,768,1024} (deep
+ * candidate lists through the MFMA-tiled scan; that path synchronises `stream` once).
  * With io_is_device == 0 the call copies in/out and synchronises `stream`. */
 int prag_index_search(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset,
                       float* D, int64_t* I, int io_is_device, void* stream);

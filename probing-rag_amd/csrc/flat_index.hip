@@ -936,6 +936,93 @@ __global__ __launch_bounds__(1024) void rerank_kernel(const void* __restrict__ r
                       k, id_offset, D + (int64_t)b * k, I + (int64_t)b * k, s_score, s_idx);
 }
 
+// Deep candidate lists (k > 26 -> KC up to 1024, tiled scan only): exact float64 scores by one
+// wave per candidate, then a bitonic sort of (order-preserving score bits, id) pairs in LDS.
+__device__ __forceinline__ unsigned long long sortable_u64(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return u ^ ((u >> 63) ? ~0ull : (1ull << 63));
+}
+__device__ __forceinline__ double unsortable_f64(unsigned long long u) {
+    return __longlong_as_double((long long)(u ^ ((u >> 63) ? (1ull << 63) : ~0ull)));
+}
+
+template <bool F32>
+__global__ __launch_bounds__(1024) void rerank_sort_kernel(const void* __restrict__ rows, int d, int metric_l2,
+                                                          const float* __restrict__ q32,
+                                                          const int* __restrict__ cand_idx, int KC, int k,
+                                                          int64_t id_offset, float* __restrict__ D,
+                                                          int64_t* __restrict__ I) {
+    __shared__ unsigned long long s_key[kMmMaxKc];
+    __shared__ int s_id[kMmMaxKc];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* q = q32 + (int64_t)b * d;
+    int n_pad = 2;
+    while (n_pad < KC) n_pad <<= 1;
+    for (int c = w; c < n_pad; c += 16) {
+        const int idx = c < KC ? cand_idx[(int64_t)b * KC + c] : -1;
+        double s = 0.0;
+        if (idx >= 0) {
+            for (int e = lane * 8; e < d; e += 512) {
+                float xv[8];
+                if constexpr (F32) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(rows) + (int64_t)idx * d + e);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(rows) + (int64_t)idx * d + e + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { xv[j] = a0[j]; xv[4 + j] = a1[j]; }
+                } else {
+                    const half8 h = *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(rows) + (int64_t)idx * d + e);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[j] = (float)h[j];
+                }
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(q + e);
+                const f32x4 q1 = *reinterpret_cast<const f32x4*>(q + e + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double qv = (double)(j < 4 ? q0[j] : q1[j - 4]);
+                    const double x = (double)xv[j];
+                    if (metric_l2) {
+                        const double t = qv - x;
+                        s = fma(t, t, s);
+                    } else {
+                        s = fma(qv, x, s);
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        }
+        if (lane == 0) {
+            // ascending sort key: L2 smaller is better, inner product larger is better; invalid last
+            s_key[c] = idx < 0 ? ~0ull : (metric_l2 ? sortable_u64(s) : ~sortable_u64(s));
+            s_id[c] = idx < 0 ? 0x7fffffff : idx;
+        }
+    }
+    // bitonic sort of (key, id) pairs, ascending
+    for (int size = 2; size <= n_pad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (n_pad >> 1); t += 1024) {
+                const int i = ((t / stride) * 2 * stride) + (t % stride), j = i + stride;
+                const unsigned long long ka = s_key[i], kb = s_key[j];
+                const int ia = s_id[i], ib = s_id[j];
+                const bool gt = ka > kb || (ka == kb && ia > ib);
+                if (gt == ((i & size) == 0)) {
+                    s_key[i] = kb; s_key[j] = ka;
+                    s_id[i] = ib; s_id[j] = ia;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += 1024) {
+        const bool ok = j < KC && s_key[j] != ~0ull;
+        const double sc = ok ? unsortable_f64(metric_l2 ? s_key[j] : ~s_key[j]) : 0.0;
+        D[(int64_t)b * k + j] = ok ? (float)sc : (metric_l2 ? FLT_MAX : -FLT_MAX);
+        I[(int64_t)b * k + j] = ok ? (int64_t)s_id[j] + id_offset : -1;
+    }
+}
+
 // merge of the per-workgroup lists + exact rerank of the survivors in one launch (the end of every
 // search on the per-lane-list paths): grid = queries, 16 waves
 template <int KC, bool F32>
@@ -1054,7 +1141,9 @@ struct prag_index {
     uint32_t* mm_wcnt = nullptr;
     float* mm_wkey = nullptr;
     int* mm_widx = nullptr;
-    int mm_q_cap = 0;
+    int mm_q_cap = 0;             // queries the per-query arrays hold
+    size_t mm_w_entries = 0;      // entries of mm_wkey / mm_widx
+    size_t mm_c_entries = 0;      // entries of mm_ckey / mm_cidx, mm_wcnt words
     int mm_mode = 1;   // 0 = never take the MFMA-tiled path (PRAG_SCAN_MM=0)
     // fp32 indexes: fp16 copy of the rows for the tiled scan's candidate selection (built on the
     // first search with > 128 queries, dropped by add; the rerank always reads the fp32 rows)
@@ -1201,7 +1290,10 @@ static int pick_kc(int k) {
     if (k <= 5) return 8;
     if (k <= 12) return 16;
     if (k <= 26) return 32;
-    return 0;  // a 64-deep per-lane list does not fit the 256-VGPR budget of 2 waves/SIMD
+    // deeper than a per-lane list can hold in registers: the MFMA-tiled scan keeps KC candidates per
+    // query in memory (k plus a margin of near-ties, a multiple of 32, at most kMmMaxKc)
+    const int kc = (k + std::max(16, k / 8) + 31) / 32 * 32;
+    return kc <= kMmMaxKc ? kc : 0;
 }
 
 template <int QT, int KC, bool F32, bool HP = false>
@@ -1342,7 +1434,7 @@ static int launch_merge_rerank(int kc, bool f32, const float* pk, const int* pi,
 // device-flagged fallback through the per-lane-list kernel for queries whose candidate store
 // overflowed.  Leaves the candidate ids in ix->cand.
 static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, int n_tiles, int cu_budget,
-                        hipStream_t st) {
+                        int chunk, int cap_wg, hipStream_t st) {
     const int metric_l2 = ix->metric == PRAG_METRIC_L2;
     const _Float16* rows16 = reinterpret_cast<const _Float16*>(ix->rows);
     if (ix->store == PRAG_F32) {
@@ -1375,13 +1467,21 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
     m.wcnt = ix->mm_wcnt;
     m.wkey = ix->mm_wkey;
     m.widx = ix->mm_widx;
-    m.cap_wg = kMmCapWg;
+    m.cap_wg = cap_wg;
     m.wg_slots = ix->n_cu;
     m.max_wg = cu_budget;
+    // segment growth: keep the expected survivors of a segment (~(growth-1) * KC per query) inside the
+    // per-workgroup regions (64 per query) and the compaction's staging buffer (4096)
+    {
+        const int n_qb = std::min(Bpad, chunk) / 256;
+        const int g_wg = 1 + 16 * cu_budget / std::max(1, kc * n_qb);
+        const int g_lds = 1 + 3000 / kc;
+        m.growth = std::max(2, std::min(16, std::min(g_wg, g_lds)));
+    }
     int rc = PRAG_OK;
-    for (int c0 = 0; c0 < B; c0 += kMmMaxQueries) {  // chunks of 4096 queries (LDS counters)
-        m.B = std::min(B - c0, kMmMaxQueries);
-        m.Bpad = std::min(Bpad - c0, kMmMaxQueries);
+    for (int c0 = 0; c0 < B; c0 += chunk) {  // chunks of <= 4096 queries (LDS counters)
+        m.B = std::min(B - c0, chunk);
+        m.Bpad = std::min(Bpad - c0, chunk);
         m.q16 = ix->q16 + (size_t)c0 * ix->d;
         m.tau = ix->g_tau + c0;
         m.cand = ix->cand + (size_t)c0 * kc;
@@ -1393,6 +1493,17 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
     }
     // Queries whose candidate buffer overflowed (flag set on the device): their groups go
     // through the per-lane-list kernel again; with no flag set this is two empty launches.
+    if (kc > 32) {
+        // deep lists have no list-kernel fallback: look at the overflow word (one sync - k > 26 is
+        // not the latency-critical call shape) and fail loudly rather than return a partial result
+        uint32_t any = 0;
+        PRAG_HIP(hipMemcpyAsync(&any, ix->mm_ovf + Bpad, sizeof(any), hipMemcpyDeviceToHost, st));
+        PRAG_HIP(hipStreamSynchronize(st));
+        PRAG_REQUIRE(any == 0, PRAG_EUNSUPPORTED,
+                     "k > 26: the candidate store overflowed (rows ordered by decreasing distance?); "
+                     "search with k <= 26 or shuffle the rows");
+        return PRAG_OK;
+    }
     if (ix->mm_mode == 2) return PRAG_OK;  // PRAG_SCAN_MM=2 (tests of the tests): overflow goes unrepaired
     const bool fb64 = 64 * qstride + 8 * 4096 + 64 * 4 + 64 <= 160 * 1024 - 64;
     const int fq = fb64 ? 64 : 32;
@@ -1438,7 +1549,9 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     if (B == 0) return PRAG_OK;
     PRAG_REQUIRE(q && D && I, PRAG_EINVAL, "prag_index_search: NULL pointer");
     const int kc = std::max(pick_kc(k), pick_kc(k) ? ix->kc_min : 0);
-    PRAG_REQUIRE(kc != 0, PRAG_EUNSUPPORTED, "k=%d: the fused top-k keeps at most 26 results per query", k);
+    PRAG_REQUIRE(kc != 0, PRAG_EUNSUPPORTED, "k=%d: at most 911 results per query", k);
+    PRAG_REQUIRE(kc <= 32 || mm_supported(ix->d, PRAG_F16, kc), PRAG_EUNSUPPORTED,
+                 "k=%d > 26 needs the MFMA-tiled scan (d in {256,512,768,1024}); d=%d", k, ix->d);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
     // ---- host i/o staging -----------------------------------------------------
@@ -1469,7 +1582,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     // 64-query tiles when they fit LDS; fp32 rows with 32-deep lists stay at 32 (VGPR budget)
     const bool wide_ok = 64 * qstride + 8 * 4096 + 64 * 4 <= 160 * 1024 && !(ix->store == PRAG_F32 && kc == 32);
     // > 128 queries: the contraction bounds the search -> MFMA-tiled scan, 256 queries per tile
-    const bool use_mm = B > 128 && ix->mm_mode && ix->ntotal > 0 && mm_supported(ix->d, PRAG_F16, kc);
+    const bool use_mm = ix->ntotal > 0 && mm_supported(ix->d, PRAG_F16, kc) && ((B > 128 && ix->mm_mode) || kc > 32);
     const bool use_qs = !use_mm && B > 64 && qs_supported(ix->d, ix->store, kc);  // 128 queries per corpus pass
     const int QT = use_mm ? 256 : use_qs ? 128 : ((B > 32 && wide_ok) ? 64 : 32);
     // <= 32 queries (the reference's call shape): high-precision selection, if two query tiles fit LDS
@@ -1492,7 +1605,8 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     const int grid = use_qs ? std::max(1, std::min(cu_budget, (n_tiles + 3) / 4))
                             : std::max(1, std::min(cu_budget, (n_tiles + 7) / 8));
     const int n_lists = grid;  // one merged list per workgroup and query
-    const size_t part_need = (size_t)std::max(grid, 64) * QT * kc;  // the pre-pass may use up to 64 workgroups
+    // (the pre-pass may use up to 64 workgroups; the tiled scan sizes its own fallback lists)
+    const size_t part_need = use_mm ? 0 : (size_t)std::max(grid, 64) * QT * kc;
     if (part_need > ix->part_cap) {
         if (ix->part_key) (void)hipFree(ix->part_key);
         if (ix->part_idx) (void)hipFree(ix->part_idx);
@@ -1509,26 +1623,43 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         ix->cand_cap = cand_need;
     }
 
-    const int mm_chunk = std::min(Bpad, kMmMaxQueries);  // queries per mm_run call
-    if (use_mm && Bpad > ix->mm_q_cap) {
-        void** ws[] = {reinterpret_cast<void**>(&ix->mm_cnt), reinterpret_cast<void**>(&ix->mm_ovf),
-                       reinterpret_cast<void**>(&ix->mm_ckey), reinterpret_cast<void**>(&ix->mm_cidx),
-                       reinterpret_cast<void**>(&ix->mm_wcnt), reinterpret_cast<void**>(&ix->mm_wkey),
-                       reinterpret_cast<void**>(&ix->mm_widx)};
-        for (void** w : ws) {
-            if (*w) (void)hipFree(*w);
-            *w = nullptr;
+    // queries per mm_run call and survivors one workgroup can hold per query and segment.  Deep lists
+    // (k > 26) yield up to KC/8 survivors per 256-row tile right after the first segment: they get
+    // 512 slots and 256-query chunks.
+    const int mm_chunk = kc > 32 ? 256 : std::min(Bpad, kMmMaxQueries);
+    const int mm_cap_wg = kc > 32 ? 512 : kMmCapWg;
+    if (use_mm) {
+        auto regrow = [&](void** ptr, size_t bytes) -> int {
+            if (*ptr) (void)hipFree(*ptr);
+            *ptr = nullptr;
+            PRAG_HIP(hipMalloc(ptr, bytes));
+            return PRAG_OK;
+        };
+        int rc_ws = PRAG_OK;
+        if (Bpad > ix->mm_q_cap) {
+            ix->mm_q_cap = 0;
+            rc_ws = regrow(reinterpret_cast<void**>(&ix->mm_cnt), (size_t)Bpad * sizeof(uint32_t));
+            if (rc_ws == PRAG_OK) rc_ws = regrow(reinterpret_cast<void**>(&ix->mm_ovf), ((size_t)Bpad + 1) * sizeof(uint32_t));
+            if (rc_ws != PRAG_OK) return rc_ws;
+            ix->mm_q_cap = Bpad;
         }
-        ix->mm_q_cap = 0;
-        const size_t per_wg = (size_t)ix->n_cu * mm_chunk;
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_cnt), (size_t)Bpad * sizeof(uint32_t)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_ovf), ((size_t)Bpad + 1) * sizeof(uint32_t)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_ckey), (size_t)mm_chunk * kMmCapQ * sizeof(float)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_cidx), (size_t)mm_chunk * kMmCapQ * sizeof(int)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_wcnt), per_wg * sizeof(uint32_t)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_wkey), per_wg * kMmCapWg * sizeof(float)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->mm_widx), per_wg * kMmCapWg * sizeof(int)));
-        ix->mm_q_cap = Bpad;
+        const size_t c_need = (size_t)std::max(mm_chunk, ix->n_cu) * std::max<size_t>(kMmCapQ, ix->n_cu);
+        if ((size_t)mm_chunk * kMmCapQ > ix->mm_c_entries || (size_t)ix->n_cu * mm_chunk > ix->mm_c_entries) {
+            ix->mm_c_entries = 0;
+            rc_ws = regrow(reinterpret_cast<void**>(&ix->mm_ckey), c_need * sizeof(float));
+            if (rc_ws == PRAG_OK) rc_ws = regrow(reinterpret_cast<void**>(&ix->mm_cidx), c_need * sizeof(int));
+            if (rc_ws == PRAG_OK) rc_ws = regrow(reinterpret_cast<void**>(&ix->mm_wcnt), c_need * sizeof(uint32_t));
+            if (rc_ws != PRAG_OK) return rc_ws;
+            ix->mm_c_entries = c_need;
+        }
+        const size_t w_need = (size_t)ix->n_cu * mm_chunk * mm_cap_wg;
+        if (w_need > ix->mm_w_entries) {
+            ix->mm_w_entries = 0;
+            rc_ws = regrow(reinterpret_cast<void**>(&ix->mm_wkey), w_need * sizeof(float));
+            if (rc_ws == PRAG_OK) rc_ws = regrow(reinterpret_cast<void**>(&ix->mm_widx), w_need * sizeof(int));
+            if (rc_ws != PRAG_OK) return rc_ws;
+            ix->mm_w_entries = w_need;
+        }
     }
 
     const int metric_l2 = ix->metric == PRAG_METRIC_L2;
@@ -1542,7 +1673,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     if (ix->ntotal == 0) {
         PRAG_HIP(hipMemsetAsync(ix->cand, 0xFF, cand_need * sizeof(int), st));  // all -1
     } else if (use_mm) {
-        const int rc = search_tiled(ix, B, Bpad, kc, qstride, n_tiles, cu_budget, st);
+        const int rc = search_tiled(ix, B, Bpad, kc, qstride, n_tiles, cu_budget, mm_chunk, mm_cap_wg, st);
         if (rc != PRAG_OK) return rc;
     } else {
         ScanArgs a;
@@ -1600,7 +1731,15 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         }
         reranked = true;
     }
-    if (!reranked) {  // empty index, or candidates from the tiled scan
+    if (!reranked && kc > 32) {  // deep lists (k > 26): scores + sort in one 1024-thread block per query
+        if (ix->store == PRAG_F32)
+            hipLaunchKernelGGL(rerank_sort_kernel<true>, dim3(B), dim3(1024), 0, st, ix->rows, ix->d, metric_l2, ix->q32,
+                               ix->cand, kc, k, id_offset, D_dev, I_dev);
+        else
+            hipLaunchKernelGGL(rerank_sort_kernel<false>, dim3(B), dim3(1024), 0, st, ix->rows, ix->d, metric_l2, ix->q32,
+                               ix->cand, kc, k, id_offset, D_dev, I_dev);
+        PRAG_LAUNCH_CHECK();
+    } else if (!reranked) {  // empty index, or candidates from the tiled scan
         if (ix->store == PRAG_F32)
             hipLaunchKernelGGL(rerank_kernel<true>, dim3(B), dim3(64 * std::min(kc, 16)), 0, st, ix->rows, ix->d, metric_l2,
                                ix->q32, ix->cand, kc, k, id_offset, D_dev, I_dev);

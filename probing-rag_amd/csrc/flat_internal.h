@@ -77,12 +77,34 @@ struct MmSearch {
     int cap_wg;
     int wg_slots;           // workgroups the workspace was sized for
     int max_wg;             // workgroups the scan may occupy (<= wg_slots)
+    int growth = 16;        // segment i+1 ends at growth x the end of segment i (2..16)
 };
 
 constexpr int kMmFirstSeg = 2048;    // rows of the first segment (all of them become candidates); segments grow x16
 constexpr int kMmCapQ = kMmFirstSeg; // candidate slots per query in ckey/cidx
 constexpr int kMmCapWg = 64;         // survivors one workgroup can hold per query and segment
 constexpr int kMmMaxQueries = 4096;  // queries per mm_run call (LDS counters); larger batches go in chunks
+constexpr int kMmMaxKc = 1024;       // deepest candidate list (k up to 911: see pick_kc)
+
+// In-LDS bitonic sort of n_pad (power of two) 64-bit keys, ascending; all NT threads of the block.
+template <int NT>
+__device__ __forceinline__ void bitonic_sort_u64(unsigned long long* s, int n_pad) {
+    for (int size = 2; size <= n_pad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (n_pad >> 1); t += NT) {
+                const int i = ((t / stride) * 2 * stride) + (t % stride), j = i + stride;
+                const unsigned long long a = s[i], b = s[j];
+                const bool asc = (i & size) == 0;
+                if ((a > b) == asc) {
+                    s[i] = b;
+                    s[j] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
 bool mm_supported(int d, int store_dtype, int kc);
 // Enqueue the segmented scan on `st`; returns PRAG_OK or a negative status.  `prof` brackets
 // the launch over the largest segment.

@@ -579,8 +579,79 @@ __global__ __launch_bounds__(256) void mm_compact_kernel(uint32_t* __restrict__ 
     }
 }
 
+// The same step for deep lists (k > 26 -> KC up to 1024): the gathered entries are sorted in LDS
+// (bitonic, 256 threads) instead of selected round by round.
+__global__ __launch_bounds__(256) void mm_compact_sort_kernel(uint32_t* __restrict__ cnt, float* __restrict__ ckey,
+                                                             int* __restrict__ cidx, int cap_q, int KC,
+                                                             uint32_t* __restrict__ tau, int* __restrict__ cand,
+                                                             uint32_t* __restrict__ ovf, uint32_t* __restrict__ ovf_any,
+                                                             const uint32_t* __restrict__ wcnt,
+                                                             const float* __restrict__ wkey,
+                                                             const int* __restrict__ widx, int cap_wg, int n_wg,
+                                                             int wg_stride, int Bpad) {
+    __shared__ unsigned long long s_v[kMmCompactCap];
+    __shared__ int s_tot[4];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t c = cnt[q];
+    int n = c < (uint32_t)cap_q ? (int)c : cap_q;
+    bool over = c > (uint32_t)cap_q || n > kMmCompactCap;
+    n = n < kMmCompactCap ? n : kMmCompactCap;
+    const int64_t o = (int64_t)q * cap_q;
+    for (int i = tid; i < n; i += 256) s_v[i] = pack_key(ckey[o + i], cidx[o + i]);
+    for (int w0 = 0; w0 < n_wg; w0 += 256) {
+        const int wg = w0 + tid;
+        const uint32_t cw = wg < n_wg ? wcnt[(int64_t)q * wg_stride + wg] : 0u;
+        over |= cw > (uint32_t)cap_wg;
+        const int mine = cw < (uint32_t)cap_wg ? (int)cw : cap_wg;
+        int incl = mine;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const int up = __shfl_up(incl, sft, 64);
+            if (lane >= sft) incl += up;
+        }
+        if (lane == 63) s_tot[w] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            before += j < w ? s_tot[j] : 0;
+            total += s_tot[j];
+        }
+        const int at = n + before + incl - mine;
+        const int64_t wo = ((int64_t)wg * Bpad + q) * cap_wg;
+        for (int j = 0; j < mine; ++j) {
+            if (at + j < kMmCompactCap) s_v[at + j] = pack_key(wkey[wo + j], widx[wo + j]);
+            else over = true;
+        }
+        n = n + total < kMmCompactCap ? n + total : kMmCompactCap;
+        __syncthreads();
+    }
+    int n_pad = 2;
+    while (n_pad < n) n_pad <<= 1;
+    for (int i = n + tid; i < n_pad; i += 256) s_v[i] = ~0ull;
+    bitonic_sort_u64<256>(s_v, n_pad);
+    for (int r = tid; r < KC; r += 256) {
+        const bool ok = r < n;
+        const unsigned long long m = ok ? s_v[r] : ~0ull;
+        cand[(int64_t)q * KC + r] = ok ? (int)(uint32_t)m : -1;
+        if (ok) {
+            ckey[o + r] = unsortable_f32((uint32_t)(m >> 32));
+            cidx[o + r] = (int)(uint32_t)m;
+            if (r == KC - 1) tau[q] = (uint32_t)(m >> 32);
+        }
+    }
+    const int any_over = __syncthreads_or(over ? 1 : 0);
+    if (tid == 0) {
+        cnt[q] = n < KC ? n : KC;
+        if (any_over) {
+            ovf[q] = 1u;
+            *ovf_any = 1u;
+        }
+    }
+}
+
 bool mm_supported(int d, int store_dtype, int kc) {
-    return store_dtype == PRAG_F16 && (d == 256 || d == 512 || d == 768 || d == 1024) && kc >= 8 && kc <= 32;
+    return store_dtype == PRAG_F16 && (d == 256 || d == 512 || d == 768 || d == 1024) && kc >= 8 && kc <= kMmMaxKc;
 }
 
 template <int NKT, int MODE, int ABL = 0>
@@ -685,12 +756,17 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
                     h[1] ? h[0] / (h[1] / 100.0) : 0.0);
         }
 #endif
-        hipLaunchKernelGGL(mm_compact_kernel, dim3(s.B), dim3(256), 0, st, s.cnt, s.ckey, s.cidx, s.cap_q, s.kc, s.tau,
-                           s.cand, s.ovf, s.ovf_any, s.wcnt, s.wkey, s.widx, s.cap_wg, first ? 0 : grid, s.wg_slots,
-                           s.Bpad);
+        if (s.kc <= 32)
+            hipLaunchKernelGGL(mm_compact_kernel, dim3(s.B), dim3(256), 0, st, s.cnt, s.ckey, s.cidx, s.cap_q, s.kc, s.tau,
+                               s.cand, s.ovf, s.ovf_any, s.wcnt, s.wkey, s.widx, s.cap_wg, first ? 0 : grid, s.wg_slots,
+                               s.Bpad);
+        else
+            hipLaunchKernelGGL(mm_compact_sort_kernel, dim3(s.B), dim3(256), 0, st, s.cnt, s.ckey, s.cidx, s.cap_q, s.kc,
+                               s.tau, s.cand, s.ovf, s.ovf_any, s.wcnt, s.wkey, s.widx, s.cap_wg, first ? 0 : grid,
+                               s.wg_slots, s.Bpad);
         PRAG_LAUNCH_CHECK();
         lo = hi;
-        hi = std::min<int64_t>(s.N, hi * 16);
+        hi = std::min<int64_t>(s.N, hi * (int64_t)std::max(2, std::min(16, s.growth)));
     }
     return PRAG_OK;
 }

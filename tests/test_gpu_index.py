@@ -133,7 +133,7 @@ def test_empty_padding_offsets_and_device_io():
     D0, I0 = onp.flat_search(X, Q, 2, onp.METRIC_IP)
     assert np.array_equal(I, I0)
     with pytest.raises(pra.PragError, match="PRAG_EUNSUPPORTED"):
-        ix.search(Q, 100)
+        ix.search(Q, 1000)                      # beyond the deepest candidate list (911)
     with pytest.raises(ValueError):
         ix.add(np.zeros((2, 100), np.float32))
 
@@ -301,3 +301,42 @@ def test_randomised_shapes_against_the_definition():
         else:
             np.testing.assert_allclose(D, D0, atol=1e-4, rtol=0)
         ix.close()
+
+
+@pytest.mark.parametrize("N,B,k,d,metric,store", [
+    (50_000, 3, 100, 768, onp.METRIC_L2, "f16"),       # the usual "retrieve 100, rerank" call
+    (50_000, 1, 100, 768, onp.METRIC_COS, "f32"),
+    (20_000, 40, 300, 256, onp.METRIC_IP, "f16"),
+    (30_000, 200, 64, 512, onp.METRIC_L2, "f16"),
+    (9_000, 2, 911, 1024, onp.METRIC_COS, "f16"),      # the deepest supported list
+    (500, 5, 600, 256, onp.METRIC_L2, "f32"),          # k > ntotal: -1 padding
+])
+def test_large_k_matches_definition(N, B, k, d, metric, store):
+    """k > 26 goes through the MFMA-tiled scan with deep candidate lists (sorted, not selected) for any
+    batch size; results must still be the definition's, in order, with faiss's padding."""
+    import probing_rag_amd as pra
+    X = onp.synth_rows(81, 0, N, d)
+    X[N // 2] = X[7]
+    X[N - 1] = X[7]
+    Q = onp.synth_rows(82, 0, B, d)
+    Q[0] = X[7]
+    ix = pra.HipFlatIndex(d, metric, store)
+    ix.add(X)
+    D, I = ix.search(Q, k)
+    assert D.shape == (B, k) and I.shape == (B, k)
+    D0, I0 = onp.flat_search(_stored(X, metric, store), Q, k, metric)
+    _check(D, I, D0, I0, metric)
+    if metric != onp.METRIC_IP and N > k:
+        assert I[0, :3].tolist() == [7, N // 2, N - 1]
+
+
+def test_k_beyond_the_deepest_list_is_refused():
+    import probing_rag_amd as pra
+    ix = pra.HipFlatIndex(256, "l2", "f16")
+    ix.add(onp.synth_rows(1, 0, 100, 256))
+    with pytest.raises(pra.PragError, match="at most 911"):
+        ix.search(onp.synth_rows(2, 0, 1, 256), 912)
+    ix2 = pra.HipFlatIndex(128, "l2", "f16")         # d outside the tiled scan's set
+    ix2.add(onp.synth_rows(1, 0, 100, 128))
+    with pytest.raises(pra.PragError, match="k=100 > 26"):
+        ix2.search(onp.synth_rows(2, 0, 1, 128), 100)
