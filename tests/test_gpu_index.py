@@ -340,3 +340,21 @@ def test_k_beyond_the_deepest_list_is_refused():
     ix2.add(onp.synth_rows(1, 0, 100, 128))
     with pytest.raises(pra.PragError, match="k=100 > 26"):
         ix2.search(onp.synth_rows(2, 0, 1, 128), 100)
+
+
+def test_shard_simulation_with_large_k():
+    """k = 100 through 4 logical shards on one GPU: deep-list local searches, packed exchange format,
+    (score, id) merge == the unsharded definition."""
+    import torch
+    import probing_rag_amd as pra
+    N, d, B, k = 24_000, 256, 5, 100
+    X = onp.synth_rows(91, 0, N, d)
+    Q = onp.synth_rows(92, 0, B, d)
+    shards = []
+    for lo, hi in [pra.partition_rows(N, 4, r) for r in range(4)]:
+        ix = pra.HipFlatIndex(d, "l2", "f16")
+        ix.add(X[lo:hi])
+        shards.append(ix)
+    D, I = pra.search_shards_on_one_gpu(shards, torch.from_numpy(Q).cuda(), k, "l2")
+    D0, I0 = onp.flat_search(_stored(X, onp.METRIC_L2, "f16"), Q, k, onp.METRIC_L2)
+    _check(D.cpu().numpy(), I.cpu().numpy(), D0, I0, onp.METRIC_L2)
