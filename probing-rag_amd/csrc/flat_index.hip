@@ -233,7 +233,6 @@ __device__ __forceinline__ void scan_topk_body(const ScanArgs& a, char* smem) {
     constexpr bool SPLIT_ROWS = HP && F32;          // rows staged as hi + lo halves
     constexpr int CHK = SPLIT_ROWS ? 32 : 64;       // elements per staged chunk (4 KiB of LDS per wave either way)
     constexpr int KS = CHK / 16;                    // MFMA k-steps per chunk
-    constexpr int RSB = CHK * 2;                    // bytes per staged row (fp16)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -287,7 +286,7 @@ __device__ __forceinline__ void scan_topk_body(const ScanArgs& a, char* smem) {
 #pragma unroll
     for (int t = 0; t < NQ; ++t) top[t].init();
 
-    // staging geometry: NLD 16-B loads per lane per chunk; a staged row is RSB bytes of fp16 and
+    // staging geometry: NLD 16-B loads per lane per chunk; a staged row is 2*CHK bytes of fp16 and
     // its 16-B pieces are XOR-swizzled so that the fragment reads below are conflict-free
     //   64-element chunks (128-B rows): slot = piece ^ ((row>>1)&7)
     //   32-element chunks ( 64-B rows): slot = piece ^ ((row>>2)&3)
