@@ -1,4 +1,5 @@
-// MFMA-tiled flat scan for large query batches (> 128 queries) on MI355X (gfx950):
+// MFMA-tiled flat scan for large query batches (> 128 queries) and deep result lists (k > 26) on
+// MI355X (gfx950):
 // BASELINE config 3 (1k queries x 1M rows x 768, "MFMA tile") - the regime where the
 // [queries x d] x [d x rows] contraction, not the HBM stream, bounds index.search
 // (reference call site: utils.py:378-380 batch_topk_sim -> faiss IndexFlat.search).
@@ -24,7 +25,7 @@
 // tightens the bound to the KC-th best key seen so far, so a segment contributes ~15*KC
 // candidates per query when rows are exchangeable.  A region that overflows anyway (rows sorted
 // by decreasing distance, say) raises a per-query flag and the caller re-runs those queries
-// through the per-lane-list kernels, which cannot overflow.
+// through the per-lane-list kernels, which cannot overflow (k <= 26; deeper lists report it).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
 // ---------------------------------------------------------------------------
 // after each segment: the query's KC best so far (ckey/cidx[q][0..cnt)) + the survivors every
 // workgroup collected for it in this segment -> its KC best by (key, id), in place;
-// bound <- KC-th best key; cand[q][0..KC) <- row ids.  One wave per query.
+// bound <- KC-th best key; cand[q][0..KC) <- row ids.  One 256-thread block per query.
 // ---------------------------------------------------------------------------
 constexpr int kMmCompactCap = 4096;  // entries staged in LDS; a query with more is flagged as overflowed
 
