@@ -201,8 +201,10 @@ int prag_index_create(prag_index_t** out, int d, int metric, int store_dtype,
 
 /* Replaces `index.add(model.encode(texts[...]))` (make_indexer.py:455): append
  * n rows of float32 [n,d] (host pointer if src_is_device == 0).  Row ids are
- * insertion order, 0-based.  Synchronises the device. */
-int prag_index_add(prag_index_t* ix, const float* x, int64_t n, int src_is_device);
+ * insertion order, 0-based.  The copy / conversion runs on `stream` (device rows may
+ * still be in flight there, e.g. an encoder's output) and the call returns after
+ * synchronising that stream. */
+int prag_index_add(prag_index_t* ix, const float* x, int64_t n, int src_is_device, void* stream);
 
 /* Append n synthetic rows generated on the device by the counter-based
  * generator shared with the oracle (oracle_np.synth_rows): row ids
@@ -216,8 +218,13 @@ int prag_index_d(const prag_index_t* ix);
  *   q: float32 [B,d] (device pointer if io_is_device, else host);
  *   D: float32 [B,k] squared-L2 ascending (L2) or score descending (IP/COS);
  *   I: int64 [B,k] row ids + id_offset, -1 padded when ntotal < k.
- * k <= 26 for every d the index accepts; 26 < k <= 911 needs d in {256,512,768,1024} (deep
- * candidate lists through the MFMA-tiled scan; that path synchronises `stream` once).
+ * k <= 911.  The result is the exact brute-force answer on the stored rows, always (what
+ * faiss.IndexFlat guarantees): the matrix-core scan only proposes candidates, the float64 rerank
+ * scores them and CERTIFIES per query that no other row can reach the top k (error bound of the
+ * selection vs the gap to the last candidate); a query that cannot be certified - dense
+ * near-duplicates, squared-L2 cancellation, a deep-list overflow - is recomputed by an exact
+ * float64 scan of every row inside the same call (one more pass over the shard for that query).
+ * No host synchronisation on the device-io path.
  * With io_is_device == 0 the call copies in/out and synchronises `stream`. */
 int prag_index_search(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset,
                       float* D, int64_t* I, int io_is_device, void* stream);
@@ -239,11 +246,15 @@ int prag_merge_topk_packed(const void* parts_dev, int64_t part_stride_bytes, int
 /* Read back stored rows [row0,row0+n) as float32 (what the scan sees). */
 int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n, float* out_host);
 
-/* Robustness knob for near-duplicate-dense corpora: the fused scan keeps KC >= k candidates per
- * query on fp16 operands and the float64 rerank orders them; the returned ids are exact unless more
- * than KC-k rows lie within the fp16 scoring error of the k-th result.  depth = 0 picks the default
- * (8 for k<=5, 16 for k<=12, 32 for k<=26); 16 or 32 force a deeper candidate list. */
+/* Performance knob only (results are exact at every depth): the fused scan keeps KC >= k candidates
+ * per query; a deeper list certifies more queries on near-duplicate-dense corpora without the exact
+ * fallback pass.  depth = 0 picks the default (8 for k<=5, 16 for k<=12, 32 for k<=26); 16 or 32
+ * force a deeper candidate list. */
 int prag_index_set_candidate_depth(prag_index_t* ix, int depth);
+
+/* Measurement hook: how many queries of the most recent search on this handle could not be
+ * certified and went through the exact float64 scan.  Synchronises `stream`. */
+int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out);
 
 /* Cap the number of workgroups (= CUs) the scan kernels occupy; 0 = all CUs.  The scan is
  * HBM-bound, so leaving a few CUs free lets an independent kernel on another stream (e.g. the

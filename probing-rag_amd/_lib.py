@@ -72,7 +72,7 @@ SIGNATURES = {
     "prag_trainer_steps": (_L, [_P]),
     "prag_trainer_destroy": (None, [_P]),
     "prag_index_create": (_I, [ctypes.POINTER(_P), _I, _I, _I, _L]),
-    "prag_index_add": (_I, [_P, _P, _L, _I]),
+    "prag_index_add": (_I, [_P, _P, _L, _I, _P]),
     "prag_index_add_synthetic": (_I, [_P, ctypes.c_uint32, _L, _L]),
     "prag_index_ntotal": (_L, [_P]),
     "prag_index_d": (_I, [_P]),
@@ -81,6 +81,7 @@ SIGNATURES = {
     "prag_merge_topk_packed": (_I, [_P, _L, _I, _I, _I, _I, _P, _P, _P]),
     "prag_index_reconstruct": (_I, [_P, _L, _L, _P]),
     "prag_index_set_candidate_depth": (_I, [_P, _I]),
+    "prag_index_last_fallbacks": (_I, [_P, _P, ctypes.POINTER(_I)]),
     "prag_index_set_scan_workgroups": (_I, [_P, _I]),
     "prag_index_profile": (_I, [_P, _I]),
     "prag_index_profile_read": (_I, [_P, _FP, _I, ctypes.POINTER(_I)]),

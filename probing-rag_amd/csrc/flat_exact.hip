@@ -1,0 +1,272 @@
+// Exact float64 brute-force search for the queries the certificate could not clear
+// (flat_internal.h "Exactness certificate"), for deep-list overflows and for k > 26 on dimensions
+// the MFMA-tiled scan does not cover.  Replaces faiss.IndexFlatL2.search's guarantee
+// (/root/reference: make_indexer.py:449-450, utils.py:378-380 - exact brute force, always) on the
+// rare inputs where the matrix-core selection cannot prove its own result: rows within the
+// selection error of the k-th result (dense near-duplicates, squared-L2 cancellation).
+//
+// exact_scan_kernel: every workgroup streams its share of the rows once per flagged query
+//   (16 lanes per row, direct sum (q - x)^2 or q.x in float64 - no ||x||^2 - 2 q.x cancellation),
+//   keeps the rows that can still reach its top k in an LDS buffer (threshold filter against the
+//   k-th best (score, id) so far; the buffer is sorted and cut to k when it fills) and writes its k
+//   best.  HBM-bound like the list scan: one extra pass over the shard per flagged query.
+// exact_merge_kernel: one workgroup per flagged query folds the per-workgroup lists the same way and
+//   writes D (float32 rounding of the float64 score) / I (row id + offset), faiss padding.
+// Both kernels read the flag count first and return at once when it is zero (the common case).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+
+#include "flat_internal.h"
+
+namespace prag {
+
+constexpr int kExCap = 2048;     // LDS slots per workgroup (k <= 1024 leaves >= 768 free after a cut)
+constexpr int kExCheck = 8;      // row tiles (of 32 rows) between capacity checks
+constexpr int kExThreads = 512;
+
+struct ExTopK {
+    unsigned long long key[kExCap];
+    int id[kExCap];
+    unsigned long long bound;    // k-th best key so far (~0: none yet); ties on the key are kept
+    int cnt;
+};
+
+__device__ __forceinline__ void ex_init(ExTopK& t) {
+    if (threadIdx.x == 0) {
+        t.bound = ~0ull;
+        t.cnt = 0;
+    }
+}
+
+__device__ __forceinline__ void ex_push(ExTopK& t, unsigned long long key, int id) {
+    if (key <= t.bound) {
+        const int slot = atomicAdd(&t.cnt, 1);
+        t.key[slot] = key;   // callers keep cnt <= kExCap between cuts
+        t.id[slot] = id;
+    }
+}
+
+// sort the buffered entries by (key, id), keep the k best, tighten the bound.  All threads.
+__device__ __forceinline__ void ex_cut(ExTopK& t, int k) {
+    __syncthreads();
+    const int n = t.cnt;
+    int n_pad = 2;
+    while (n_pad < n) n_pad <<= 1;
+    for (int i = n + threadIdx.x; i < n_pad; i += kExThreads) {
+        t.key[i] = ~0ull;
+        t.id[i] = 0x7fffffff;
+    }
+    for (int size = 2; size <= n_pad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int p = threadIdx.x; p < (n_pad >> 1); p += kExThreads) {
+                const int i = ((p / stride) * 2 * stride) + (p % stride), j = i + stride;
+                const unsigned long long ka = t.key[i], kb = t.key[j];
+                const int ia = t.id[i], ib = t.id[j];
+                const bool gt = ka > kb || (ka == kb && ia > ib);
+                if (gt == ((i & size) == 0)) {
+                    t.key[i] = kb;
+                    t.key[j] = ka;
+                    t.id[i] = ib;
+                    t.id[j] = ia;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        t.cnt = n < k ? n : k;
+        if (n >= k) t.bound = t.key[k - 1];
+    }
+    __syncthreads();
+}
+
+struct ExactArgs {
+    const void* rows;
+    int64_t N;
+    int d;
+    int metric_l2;
+    const float* q32;
+    const uint32_t* n_flag;
+    const int* flag_list;
+    int f0, f_cap;   // this round handles flag slots [f0, f0 + f_cap)
+    int k;
+    unsigned long long* part_key;   // [f_cap][n_lists][k]
+    int* part_id;
+    int n_lists;
+    int64_t id_offset;
+    float* D;
+    int64_t* I;
+};
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double x) {
+    return __longlong_as_double((long long)dpp_move_u64<CTRL>((unsigned long long)__double_as_longlong(x)));
+}
+// sum over the 16 lanes of a DPP row, same association in every row (bitwise reproducible)
+__device__ __forceinline__ double dpp_add16_f64(double v) {
+    v += dpp_move_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_move_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_move_f64<0x141>(v);   // row_half_mirror
+    v += dpp_move_f64<0x140>(v);   // row_mirror
+    return v;
+}
+
+template <bool F32>
+__global__ __launch_bounds__(kExThreads) void exact_scan_kernel(ExactArgs a) {
+    __shared__ ExTopK tk;
+    __shared__ __attribute__((aligned(16))) float s_q[1536];
+    const uint32_t nf = *a.n_flag;
+    if ((uint32_t)a.f0 >= nf) return;
+    const int f1 = (int)std::min<uint32_t>(nf, (uint32_t)(a.f0 + a.f_cap));
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int sub = lane & 15, slot = lane >> 4;
+    const int d = a.d;
+    const int64_t n_tiles = (a.N + 31) / 32;
+    for (int f = a.f0; f < f1; ++f) {
+        const int b = a.flag_list[f];
+        __syncthreads();
+        for (int c = tid; c < d; c += kExThreads) s_q[c] = a.q32[(int64_t)b * d + c];
+        ex_init(tk);
+        __syncthreads();
+        int since = 0;
+        for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+            const int64_t row = t * 32 + w * 4 + slot;
+            double s = 0.0;
+            if (row < a.N) {
+                // 8 consecutive elements per lane per step, 16 lanes per row: steps of 128 elements
+                constexpr int MAXS = 12;   // d <= 1536
+                u32x4 v0[MAXS], v1[MAXS];
+#pragma unroll
+                for (int it = 0; it < MAXS; ++it) {
+                    const int e = sub * 8 + it * 128;
+                    if (e < d) {
+                        if constexpr (F32) {
+                            const float* p = reinterpret_cast<const float*>(a.rows) + row * d + e;
+                            v0[it] = *reinterpret_cast<const u32x4*>(p);
+                            v1[it] = *reinterpret_cast<const u32x4*>(p + 4);
+                        } else {
+                            v0[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const _Float16*>(a.rows) + row * d + e);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < MAXS; ++it) {
+                    const int e = sub * 8 + it * 128;
+                    if (e < d) {
+                        float xv[8];
+                        if constexpr (F32) {
+                            const f32x4 x0 = __builtin_bit_cast(f32x4, v0[it]);
+                            const f32x4 x1 = __builtin_bit_cast(f32x4, v1[it]);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { xv[j] = x0[j]; xv[4 + j] = x1[j]; }
+                        } else {
+                            const half8 h = __builtin_bit_cast(half8, v0[it]);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) xv[j] = (float)h[j];
+                        }
+                        const f32x4 q0 = *reinterpret_cast<const f32x4*>(s_q + e);
+                        const f32x4 q1 = *reinterpret_cast<const f32x4*>(s_q + e + 4);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const double qv = (double)(j < 4 ? q0[j] : q1[j - 4]);
+                            const double x = (double)xv[j];
+                            if (a.metric_l2) {
+                                const double df = qv - x;
+                                s = fma(df, df, s);
+                            } else {
+                                s = fma(qv, x, s);
+                            }
+                        }
+                    }
+                }
+            }
+            s = dpp_add16_f64(s);
+            if (sub == 0 && row < a.N)
+                ex_push(tk, a.metric_l2 ? sortable_u64(s) : ~sortable_u64(s), (int)row);
+            if (++since == kExCheck) {
+                since = 0;
+                __syncthreads();
+                const int c = tk.cnt;
+                __syncthreads();
+                if (c > kExCap - 32 * kExCheck) ex_cut(tk, a.k);
+            }
+        }
+        ex_cut(tk, a.k);
+        const int64_t o = ((int64_t)(f - a.f0) * a.n_lists + blockIdx.x) * a.k;
+        for (int j = tid; j < a.k; j += kExThreads) {
+            const bool ok = j < tk.cnt;
+            a.part_key[o + j] = ok ? tk.key[j] : ~0ull;
+            a.part_id[o + j] = ok ? tk.id[j] : 0x7fffffff;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kExThreads) void exact_merge_kernel(ExactArgs a) {
+    __shared__ ExTopK tk;
+    const uint32_t nf = *a.n_flag;
+    const int f = a.f0 + blockIdx.x;
+    if ((uint32_t)f >= nf) return;
+    const int b = a.flag_list[f];
+    const int tid = threadIdx.x;
+    ex_init(tk);
+    __syncthreads();
+    const int64_t total = (int64_t)a.n_lists * a.k;
+    const int64_t o = (int64_t)blockIdx.x * total;
+    for (int64_t base = 0; base < total; base += kExThreads) {
+        const int64_t i = base + tid;
+        if (i < total) {
+            const int id = a.part_id[o + i];
+            if (id != 0x7fffffff) ex_push(tk, a.part_key[o + i], id);
+        }
+        __syncthreads();
+        const int c = tk.cnt;
+        __syncthreads();
+        if (c > kExCap - kExThreads) ex_cut(tk, a.k);
+    }
+    ex_cut(tk, a.k);
+    for (int j = tid; j < a.k; j += kExThreads) {
+        const bool ok = j < tk.cnt;
+        const double sc = ok ? unsortable_f64(a.metric_l2 ? tk.key[j] : ~tk.key[j]) : 0.0;
+        a.D[(int64_t)b * a.k + j] = ok ? (float)sc : (a.metric_l2 ? FLT_MAX : -FLT_MAX);
+        a.I[(int64_t)b * a.k + j] = ok ? (int64_t)tk.id[j] + a.id_offset : -1;
+    }
+}
+
+size_t exact_part_entries(int f_cap, int grid, int k) { return (size_t)f_cap * grid * k; }
+
+int exact_run(const ExactRun& r, hipStream_t st) {
+    PRAG_REQUIRE(r.k >= 1 && r.k <= kExCap / 2 && r.d <= 1536 && r.f_cap >= 1 && r.grid >= 1, PRAG_EUNSUPPORTED,
+                 "internal: exact scan called outside its envelope (k=%d d=%d)", r.k, r.d);
+    ExactArgs a;
+    a.rows = r.rows;
+    a.N = r.N;
+    a.d = r.d;
+    a.metric_l2 = r.metric_l2;
+    a.q32 = r.q32;
+    a.n_flag = r.n_flag;
+    a.flag_list = r.flag_list;
+    a.f_cap = r.f_cap;
+    a.k = r.k;
+    a.part_key = r.part_key;
+    a.part_id = r.part_id;
+    a.n_lists = r.grid;
+    a.id_offset = r.id_offset;
+    a.D = r.D;
+    a.I = r.I;
+    for (int f0 = 0; f0 < r.B; f0 += r.f_cap) {
+        a.f0 = f0;
+        if (r.store_f32)
+            hipLaunchKernelGGL(exact_scan_kernel<true>, dim3(r.grid), dim3(kExThreads), 0, st, a);
+        else
+            hipLaunchKernelGGL(exact_scan_kernel<false>, dim3(r.grid), dim3(kExThreads), 0, st, a);
+        PRAG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(exact_merge_kernel, dim3(std::min(r.f_cap, r.B - f0)), dim3(kExThreads), 0, st, a);
+        PRAG_LAUNCH_CHECK();
+    }
+    return PRAG_OK;
+}
+
+}  // namespace prag

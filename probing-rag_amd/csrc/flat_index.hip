@@ -110,10 +110,16 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
                                                           _Float16* __restrict__ q16, _Float16* __restrict__ q16lo,
                                                           uint32_t* __restrict__ g_tau,
                                                           uint32_t* __restrict__ mm_cnt, uint32_t* __restrict__ mm_ovf,
-                                                          uint32_t mm_first_rows) {
+                                                          uint32_t mm_first_rows, float* __restrict__ qinfo,
+                                                          double* __restrict__ qn2, uint32_t* __restrict__ n_flag,
+                                                          int* __restrict__ flag_list, int flag_all) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= Bpad) return;
+    // certificate bookkeeping: the flag list starts empty (or holds every query when the search goes
+    // straight to the exact scan)
+    if (b == 0 && lane == 0) *n_flag = flag_all ? (uint32_t)B : 0u;
+    if (flag_all && b < B && lane == 0) flag_list[b] = b;
     if (mm_cnt && lane == 0) {  // MFMA-tiled scan: candidate counts / overflow flags (word Bpad: "any")
         mm_cnt[b] = mm_first_rows;
         mm_ovf[b] = 0u;
@@ -146,6 +152,8 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
         nrm = sqrt(ss);
         if (!(nrm > 0.0)) nrm = 1.0;
     }
+    // norms for the exactness certificate: ||q||, ||q - q16||, ||q - q16 - q16lo|| of the query as used
+    double n2 = 0.0, r1 = 0.0, r2 = 0.0;
 #pragma unroll
     for (int it = 0; it < 6; ++it) {
         const int c = lane * 4 + it * 256;
@@ -157,12 +165,44 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
                 o[e] = normalise ? (float)((double)v[it][e] / nrm) : v[it][e];
                 h[e] = (_Float16)o[e];
                 lo[e] = (_Float16)(o[e] - (float)h[e]);
+                const double od = (double)o[e];
+                const double e1 = od - (double)h[e];
+                const double e2 = e1 - (double)lo[e];
+                n2 = fma(od, od, n2);
+                r1 = fma(e1, e1, r1);
+                r2 = fma(e2, e2, r2);
             }
             *reinterpret_cast<f32x4*>(q32 + (int64_t)b * d + c) = o;
             *reinterpret_cast<half4*>(q16 + (int64_t)b * d + c) = h;
             *reinterpret_cast<half4*>(q16lo + (int64_t)b * d + c) = lo;
         }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        n2 += __shfl_xor(n2, o, 64);
+        r1 += __shfl_xor(r1, o, 64);
+        r2 += __shfl_xor(r2, o, 64);
+    }
+    if (lane == 0) {
+        qn2[b] = n2;
+        // float roundings upwards: these feed an error BOUND
+        qinfo[4 * b + 0] = (float)(sqrt(n2) * (1.0 + 1e-6));
+        qinfo[4 * b + 1] = (float)(sqrt(r1) * (1.0 + 1e-6));
+        qinfo[4 * b + 2] = (float)(sqrt(r2) * (1.0 + 1e-6));
+        qinfo[4 * b + 3] = 0.f;
+    }
+}
+
+// max_i ||x_i||^2 over rows [row0, row1) folded into *out (float bits; non-negative floats order like
+// uints): the certificate's bound on the norm of a row that is not among the candidates
+__global__ __launch_bounds__(256) void xnorm_max_kernel(const float* __restrict__ xnorm, int64_t row0, int64_t row1,
+                                                       uint32_t* __restrict__ out) {
+    float m = 0.f;
+    for (int64_t i = row0 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < row1; i += (int64_t)gridDim.x * 256)
+        m = fmaxf(m, xnorm[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
 }
 
 // ---------------------------------------------------------------------------
@@ -849,7 +889,8 @@ template <bool F32, typename CandFn>
 __device__ __forceinline__ void rerank_block(const void* __restrict__ rows, int d, int metric_l2,
                                              const float* __restrict__ q, CandFn cand, int KC, int k,
                                              int64_t id_offset, float* __restrict__ Db, int64_t* __restrict__ Ib,
-                                             double* s_score /*[64]*/, int* s_idx /*[64]*/) {
+                                             double* s_score /*[64]*/, int* s_idx /*[64]*/, const CertArgs& cert,
+                                             int b, float kth_sel /* selection key of the KC-th candidate, +inf: list not full */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nw = blockDim.x >> 6;
     for (int c = w; c < KC; c += nw) {
@@ -919,6 +960,9 @@ __device__ __forceinline__ void rerank_block(const void* __restrict__ rows, int 
             Db[j] = ok ? (float)s_score[j] : (metric_l2 ? FLT_MAX : -FLT_MAX);
             Ib[j] = ok ? (int64_t)s_idx[j] + id_offset : -1;
         }
+        // exactness certificate: can a row outside the candidates still belong to the top k?
+        const bool full = k <= KC && s_idx[k - 1] >= 0;
+        if (!cert_ok(cert, b, metric_l2, full ? s_score[k - 1] : 0.0, full ? kth_sel : INFINITY)) cert_flag(cert, b);
     }
 }
 
@@ -927,30 +971,25 @@ __global__ __launch_bounds__(1024) void rerank_kernel(const void* __restrict__ r
                                                      const float* __restrict__ q32,
                                                      const int* __restrict__ cand_idx, int KC, int k,
                                                      int64_t id_offset, float* __restrict__ D,
-                                                     int64_t* __restrict__ I) {
+                                                     int64_t* __restrict__ I, CertArgs cert,
+                                                     const uint32_t* __restrict__ kth_sel /*[B] sortable, or null*/) {
     __shared__ double s_score[64];
     __shared__ int s_idx[64];
     const int b = blockIdx.x;
     rerank_block<F32>(rows, d, metric_l2, q32 + (int64_t)b * d, [&](int c) { return cand_idx[(int64_t)b * KC + c]; }, KC,
-                      k, id_offset, D + (int64_t)b * k, I + (int64_t)b * k, s_score, s_idx);
+                      k, id_offset, D + (int64_t)b * k, I + (int64_t)b * k, s_score, s_idx, cert, b,
+                      kth_sel ? unsortable_f32(kth_sel[b]) : INFINITY);
 }
 
 // Deep candidate lists (k > 26 -> KC up to 1024, tiled scan only): exact float64 scores by one
 // wave per candidate, then a bitonic sort of (order-preserving score bits, id) pairs in LDS.
-__device__ __forceinline__ unsigned long long sortable_u64(double v) {
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    return u ^ ((u >> 63) ? ~0ull : (1ull << 63));
-}
-__device__ __forceinline__ double unsortable_f64(unsigned long long u) {
-    return __longlong_as_double((long long)(u ^ ((u >> 63) ? (1ull << 63) : ~0ull)));
-}
-
 template <bool F32>
 __global__ __launch_bounds__(1024) void rerank_sort_kernel(const void* __restrict__ rows, int d, int metric_l2,
                                                           const float* __restrict__ q32,
                                                           const int* __restrict__ cand_idx, int KC, int k,
                                                           int64_t id_offset, float* __restrict__ D,
-                                                          int64_t* __restrict__ I) {
+                                                          int64_t* __restrict__ I, CertArgs cert,
+                                                          const uint32_t* __restrict__ kth_sel /*[B] sortable*/) {
     __shared__ unsigned long long s_key[kMmMaxKc];
     __shared__ int s_id[kMmMaxKc];
     const int b = blockIdx.x;
@@ -1020,6 +1059,11 @@ __global__ __launch_bounds__(1024) void rerank_sort_kernel(const void* __restric
         D[(int64_t)b * k + j] = ok ? (float)sc : (metric_l2 ? FLT_MAX : -FLT_MAX);
         I[(int64_t)b * k + j] = ok ? (int64_t)s_id[j] + id_offset : -1;
     }
+    if (threadIdx.x == 0) {
+        const bool full = k <= KC && s_key[k - 1] != ~0ull;
+        const double sk = full ? unsortable_f64(metric_l2 ? s_key[k - 1] : ~s_key[k - 1]) : 0.0;
+        if (!cert_ok(cert, b, metric_l2, sk, full ? unsortable_f32(kth_sel[b]) : INFINITY)) cert_flag(cert, b);
+    }
 }
 
 // merge of the per-workgroup lists + exact rerank of the survivors in one launch (the end of every
@@ -1030,7 +1074,7 @@ __global__ __launch_bounds__(1024) void merge_rerank_kernel(const float* __restr
                                                            int q0, const void* __restrict__ rows, int d,
                                                            int metric_l2, const float* __restrict__ q32, int k,
                                                            int64_t id_offset, float* __restrict__ D,
-                                                           int64_t* __restrict__ I) {
+                                                           int64_t* __restrict__ I, CertArgs cert) {
     __shared__ unsigned long long s_w[16 * KC];
     __shared__ unsigned long long s_out[KC];
     __shared__ double s_score[64];
@@ -1039,7 +1083,8 @@ __global__ __launch_bounds__(1024) void merge_rerank_kernel(const float* __restr
     merge_lists_block<KC, 16>(part_key, part_idx, n_lists, QT, (int)blockIdx.x, s_w, s_out);
     rerank_block<F32>(rows, d, metric_l2, q32 + (int64_t)b * d,
                       [&](int c) { return s_out[c] == ~0ull ? -1 : (int)(uint32_t)s_out[c]; }, KC, k, id_offset,
-                      D + (int64_t)b * k, I + (int64_t)b * k, s_score, s_idx);
+                      D + (int64_t)b * k, I + (int64_t)b * k, s_score, s_idx, cert, b,
+                      s_out[KC - 1] == ~0ull ? INFINITY : unsortable_f32((uint32_t)(s_out[KC - 1] >> 32)));
 }
 
 // ---------------------------------------------------------------------------
@@ -1156,6 +1201,16 @@ struct prag_index {
     int n_cu = 256;
     int wg_cap = 0;  // 0 = use every CU
     int kc_min = 0;  // 0 = default candidate depth for k
+    // exactness certificate + exact fallback (flat_internal.h)
+    float* qinfo = nullptr;       // [q_cap][4]
+    double* qn2 = nullptr;        // [q_cap]
+    int* flag_list = nullptr;     // [q_cap]
+    uint32_t* cert_words = nullptr;  // [0] = n_flag of the last search, [1] = bits of max ||x||^2
+    int64_t xn_max_rows = 0;      // rows already folded into cert_words[1]
+    unsigned long long* ex_key = nullptr;
+    int* ex_id = nullptr;
+    size_t ex_entries = 0;
+    int cert_mode = 1;   // 0 = certificate off (PRAG_CERT=0: timing experiments only)
     EventRing prof;
 };
 
@@ -1167,12 +1222,20 @@ static int ensure_capacity(prag_index* ix, int64_t want) {
     ncap = (ncap + 255) / 256 * 256;  // the MFMA-tiled scan reads whole 256-row tiles
     void* nrows = nullptr;
     float* nnorm = nullptr;
+    PRAG_HIP(hipDeviceSynchronize());   // searches still reading the old buffers on other streams
     PRAG_HIP(hipMalloc(&nrows, (size_t)ncap * ix->d * elt(ix)));
-    PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&nnorm), (size_t)ncap * sizeof(float)));
-    PRAG_HIP(hipMemset(nnorm, 0, (size_t)ncap * sizeof(float)));
-    if (ix->ntotal > 0) {
-        PRAG_HIP(hipMemcpy(nrows, ix->rows, (size_t)ix->ntotal * ix->d * elt(ix), hipMemcpyDeviceToDevice));
-        PRAG_HIP(hipMemcpy(nnorm, ix->xnorm, (size_t)ix->ntotal * sizeof(float), hipMemcpyDeviceToDevice));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&nnorm), (size_t)ncap * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(nnorm, 0, (size_t)ncap * sizeof(float));
+    if (e == hipSuccess && ix->ntotal > 0) {
+        e = hipMemcpy(nrows, ix->rows, (size_t)ix->ntotal * ix->d * elt(ix), hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(nnorm, ix->xnorm, (size_t)ix->ntotal * sizeof(float), hipMemcpyDeviceToDevice);
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {   // nothing leaks on the error path
+        (void)hipFree(nrows);
+        if (nnorm) (void)hipFree(nnorm);
+        set_error("prag_index: growing to %lld rows failed: %s", (long long)ncap, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? PRAG_ENOMEM : PRAG_EHIP;
     }
     if (ix->rows) (void)hipFree(ix->rows);
     if (ix->xnorm) (void)hipFree(ix->xnorm);
@@ -1202,9 +1265,20 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
         ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e);
+    if (const char* e = getenv("PRAG_CERT")) ix->cert_mode = atoi(e);
+    {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&ix->cert_words), 2 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(ix->cert_words, 0, 2 * sizeof(uint32_t));
+        if (e != hipSuccess) {
+            set_error("prag_index_create: %s", hipGetErrorString(e));
+            delete ix;
+            return PRAG_EHIP;
+        }
+    }
     if (capacity_rows > 0) {
         int rc = ensure_capacity(ix, capacity_rows);
         if (rc != PRAG_OK) {
+            (void)hipFree(ix->cert_words);
             delete ix;
             return rc;
         }
@@ -1214,11 +1288,11 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
 }
 
 static int launch_add(prag_index* ix, const float* src_dev, bool synth, uint32_t seed, int64_t synth_row0,
-                      int64_t n) {
+                      int64_t n, hipStream_t st) {
     const int normalise = ix->metric == PRAG_METRIC_COS;
     const dim3 grid((unsigned)((n + 3) / 4)), block(256);
 #define PRAG_ADD(F32_, SY_)                                                                          \
-    hipLaunchKernelGGL((add_rows_kernel<F32_, SY_>), grid, block, 0, 0, src_dev, seed, synth_row0, n, \
+    hipLaunchKernelGGL((add_rows_kernel<F32_, SY_>), grid, block, 0, st, src_dev, seed, synth_row0, n, \
                        ix->d, normalise, ix->rows, ix->xnorm, ix->ntotal)
     if (ix->store == PRAG_F32) {
         if (synth) PRAG_ADD(true, true); else PRAG_ADD(true, false);
@@ -1230,7 +1304,8 @@ static int launch_add(prag_index* ix, const float* src_dev, bool synth, uint32_t
     return PRAG_OK;
 }
 
-extern "C" int prag_index_add(prag_index_t* ix, const float* x, int64_t n, int src_is_device) {
+extern "C" int prag_index_add(prag_index_t* ix, const float* x, int64_t n, int src_is_device, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
     PRAG_REQUIRE(n >= 0, PRAG_EINVAL, "n=%lld", (long long)n);
     if (n == 0) return PRAG_OK;  // index.add of an empty batch is a no-op
@@ -1240,9 +1315,10 @@ extern "C" int prag_index_add(prag_index_t* ix, const float* x, int64_t n, int s
     int rc = ensure_capacity(ix, ix->ntotal + n);
     if (rc != PRAG_OK) return rc;
     if (src_is_device) {
-        rc = launch_add(ix, x, false, 0, 0, n);
+        // on the caller's stream: x may still be in flight there (an encoder's output)
+        rc = launch_add(ix, x, false, 0, 0, n, st);
         if (rc != PRAG_OK) return rc;
-        PRAG_HIP(hipDeviceSynchronize());
+        PRAG_HIP(hipStreamSynchronize(st));
         ix->ntotal += n;
         return PRAG_OK;
     }
@@ -1252,10 +1328,10 @@ extern "C" int prag_index_add(prag_index_t* ix, const float* x, int64_t n, int s
     PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&stage), (size_t)chunk * ix->d * sizeof(float)));
     for (int64_t o = 0; o < n; o += chunk) {
         const int64_t m = std::min(chunk, n - o);
-        hipError_t e = hipMemcpy(stage, x + o * ix->d, (size_t)m * ix->d * sizeof(float), hipMemcpyHostToDevice);
+        hipError_t e = hipMemcpyAsync(stage, x + o * ix->d, (size_t)m * ix->d * sizeof(float), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
-            rc = launch_add(ix, stage, false, 0, 0, m);
-            if (rc == PRAG_OK) e = hipDeviceSynchronize();
+            rc = launch_add(ix, stage, false, 0, 0, m, st);
+            if (rc == PRAG_OK) e = hipStreamSynchronize(st);
         }
         if (e != hipSuccess || rc != PRAG_OK) {
             (void)hipFree(stage);
@@ -1275,7 +1351,7 @@ extern "C" int prag_index_add_synthetic(prag_index_t* ix, uint32_t seed, int64_t
     PRAG_REQUIRE(ix->ntotal + n <= 0x7fffffffLL - 64, PRAG_EUNSUPPORTED, "more than 2^31 rows per shard");
     int rc = ensure_capacity(ix, ix->ntotal + n);
     if (rc != PRAG_OK) return rc;
-    rc = launch_add(ix, nullptr, true, seed, row0, n);
+    rc = launch_add(ix, nullptr, true, seed, row0, n, nullptr);
     if (rc != PRAG_OK) return rc;
     PRAG_HIP(hipDeviceSynchronize());
     ix->ntotal += n;
@@ -1407,22 +1483,22 @@ static int launch_merge(int kc, const float* pk, const int* pi, int n_lists, int
 template <int KC>
 static void launch_merge_rerank_kc(bool f32, const float* pk, const int* pi, int n_lists, int QT, int nq, int q0,
                                    const void* rows, int d, int metric_l2, const float* q32, int k, int64_t id_offset,
-                                   float* D, int64_t* I, hipStream_t st) {
+                                   float* D, int64_t* I, const CertArgs& cert, hipStream_t st) {
     if (f32)
         hipLaunchKernelGGL((merge_rerank_kernel<KC, true>), dim3(nq), dim3(1024), 0, st, pk, pi, n_lists, QT, q0, rows, d,
-                           metric_l2, q32, k, id_offset, D, I);
+                           metric_l2, q32, k, id_offset, D, I, cert);
     else
         hipLaunchKernelGGL((merge_rerank_kernel<KC, false>), dim3(nq), dim3(1024), 0, st, pk, pi, n_lists, QT, q0, rows, d,
-                           metric_l2, q32, k, id_offset, D, I);
+                           metric_l2, q32, k, id_offset, D, I, cert);
 }
 
 static int launch_merge_rerank(int kc, bool f32, const float* pk, const int* pi, int n_lists, int QT, int nq, int q0,
                                const void* rows, int d, int metric_l2, const float* q32, int k, int64_t id_offset,
-                               float* D, int64_t* I, hipStream_t st) {
+                               float* D, int64_t* I, const CertArgs& cert, hipStream_t st) {
     switch (kc) {
-        case 8: launch_merge_rerank_kc<8>(f32, pk, pi, n_lists, QT, nq, q0, rows, d, metric_l2, q32, k, id_offset, D, I, st); break;
-        case 16: launch_merge_rerank_kc<16>(f32, pk, pi, n_lists, QT, nq, q0, rows, d, metric_l2, q32, k, id_offset, D, I, st); break;
-        case 32: launch_merge_rerank_kc<32>(f32, pk, pi, n_lists, QT, nq, q0, rows, d, metric_l2, q32, k, id_offset, D, I, st); break;
+        case 8: launch_merge_rerank_kc<8>(f32, pk, pi, n_lists, QT, nq, q0, rows, d, metric_l2, q32, k, id_offset, D, I, cert, st); break;
+        case 16: launch_merge_rerank_kc<16>(f32, pk, pi, n_lists, QT, nq, q0, rows, d, metric_l2, q32, k, id_offset, D, I, cert, st); break;
+        case 32: launch_merge_rerank_kc<32>(f32, pk, pi, n_lists, QT, nq, q0, rows, d, metric_l2, q32, k, id_offset, D, I, cert, st); break;
         default: set_error("internal: KC=%d", kc); return PRAG_EUNSUPPORTED;
     }
     PRAG_LAUNCH_CHECK();
@@ -1492,17 +1568,9 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
     }
     // Queries whose candidate buffer overflowed (flag set on the device): their groups go
     // through the per-lane-list kernel again; with no flag set this is two empty launches.
-    if (kc > 32) {
-        // deep lists have no list-kernel fallback: look at the overflow word (one sync - k > 26 is
-        // not the latency-critical call shape) and fail loudly rather than return a partial result
-        uint32_t any = 0;
-        PRAG_HIP(hipMemcpyAsync(&any, ix->mm_ovf + Bpad, sizeof(any), hipMemcpyDeviceToHost, st));
-        PRAG_HIP(hipStreamSynchronize(st));
-        PRAG_REQUIRE(any == 0, PRAG_EUNSUPPORTED,
-                     "k > 26: the candidate store overflowed (rows ordered by decreasing distance?); "
-                     "search with k <= 26 or shuffle the rows");
-        return PRAG_OK;
-    }
+    // deep lists have no list-kernel fallback: a query whose candidate store overflowed keeps its flag
+    // in mm_ovf, the rerank puts it on the certificate's flag list and the exact scan recomputes it
+    if (kc > 32) return PRAG_OK;
     if (ix->mm_mode == 2) return PRAG_OK;  // PRAG_SCAN_MM=2 (tests of the tests): overflow goes unrepaired
     const bool fb64 = 64 * qstride + 8 * 4096 + 64 * 4 + 64 <= 160 * 1024 - 64;
     const int fq = fb64 ? 64 : 32;
@@ -1535,7 +1603,7 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
     rc = fb64 ? dispatch_flagged<64>(kc, a, fb_grid, ix->mm_ovf, n_groups, part_stride, st)
               : dispatch_flagged<32>(kc, a, fb_grid, ix->mm_ovf, n_groups, part_stride, st);
     if (rc != PRAG_OK) return rc;
-    rc = launch_merge(kc, ix->part_key, ix->part_idx, fb_grid, fq, B, ix->cand, nullptr, st, ix->mm_ovf,
+    rc = launch_merge(kc, ix->part_key, ix->part_idx, fb_grid, fq, B, ix->cand, ix->g_tau, st, ix->mm_ovf,
                       part_stride, Bpad);
     if (rc != PRAG_OK) return rc;
     return PRAG_OK;
@@ -1547,10 +1615,11 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     PRAG_REQUIRE(B >= 0 && k >= 1, PRAG_EINVAL, "B=%d k=%d", B, k);
     if (B == 0) return PRAG_OK;
     PRAG_REQUIRE(q && D && I, PRAG_EINVAL, "prag_index_search: NULL pointer");
-    const int kc = std::max(pick_kc(k), pick_kc(k) ? ix->kc_min : 0);
+    int kc = std::max(pick_kc(k), pick_kc(k) ? ix->kc_min : 0);
     PRAG_REQUIRE(kc != 0, PRAG_EUNSUPPORTED, "k=%d: at most 911 results per query", k);
-    PRAG_REQUIRE(kc <= 32 || mm_supported(ix->d, PRAG_F16, kc), PRAG_EUNSUPPORTED,
-                 "k=%d > 26 needs the MFMA-tiled scan (d in {256,512,768,1024}); d=%d", k, ix->d);
+    // k > 26 on a dimension the MFMA-tiled scan does not cover: straight to the exact float64 scan
+    const bool exact_only = kc > 32 && !mm_supported(ix->d, PRAG_F16, kc);
+    if (exact_only) kc = 32;  // (sizes the unused candidate workspace)
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
     // ---- host i/o staging -----------------------------------------------------
@@ -1581,8 +1650,9 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     // 64-query tiles when they fit LDS; fp32 rows with 32-deep lists stay at 32 (VGPR budget)
     const bool wide_ok = 64 * qstride + 8 * 4096 + 64 * 4 <= 160 * 1024 && !(ix->store == PRAG_F32 && kc == 32);
     // > 128 queries: the contraction bounds the search -> MFMA-tiled scan, 256 queries per tile
-    const bool use_mm = ix->ntotal > 0 && mm_supported(ix->d, PRAG_F16, kc) && ((B > 128 && ix->mm_mode) || kc > 32);
-    const bool use_qs = !use_mm && B > 64 && qs_supported(ix->d, ix->store, kc);  // 128 queries per corpus pass
+    const bool use_mm = !exact_only && ix->ntotal > 0 && mm_supported(ix->d, PRAG_F16, kc) &&
+                        ((B > 128 && ix->mm_mode) || kc > 32);
+    const bool use_qs = !exact_only && !use_mm && B > 64 && qs_supported(ix->d, ix->store, kc);  // 128 queries per corpus pass
     const int QT = use_mm ? 256 : use_qs ? 128 : ((B > 32 && wide_ok) ? 64 : 32);
     // <= 32 queries (the reference's call shape): high-precision selection, if two query tiles fit LDS
     const bool use_hp = ix->hp_mode && QT == 32 && 2 * 32 * qstride + 8 * 4096 + 32 * 4 <= 160 * 1024;
@@ -1592,7 +1662,14 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         if (ix->q16) (void)hipFree(ix->q16);
         if (ix->q16lo) (void)hipFree(ix->q16lo);
         if (ix->g_tau) (void)hipFree(ix->g_tau);
+        if (ix->qinfo) (void)hipFree(ix->qinfo);
+        if (ix->qn2) (void)hipFree(ix->qn2);
+        if (ix->flag_list) (void)hipFree(ix->flag_list);
         ix->q32 = nullptr; ix->q16 = nullptr; ix->q16lo = nullptr; ix->g_tau = nullptr; ix->q_cap = 0;
+        ix->qinfo = nullptr; ix->qn2 = nullptr; ix->flag_list = nullptr;
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->qinfo), (size_t)Bpad * 4 * sizeof(float)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->qn2), (size_t)Bpad * sizeof(double)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->flag_list), (size_t)Bpad * sizeof(int)));
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->q32), (size_t)Bpad * ix->d * sizeof(float)));
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->q16), (size_t)Bpad * ix->d * sizeof(_Float16)));
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->q16lo), (size_t)Bpad * ix->d * sizeof(_Float16)));
@@ -1662,14 +1739,60 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     }
 
     const int metric_l2 = ix->metric == PRAG_METRIC_L2;
+    // ---- exactness certificate: error model of the scan that will run, exact-scan workspace -------
+    const bool certify = ix->cert_mode != 0 || exact_only;
+    const int ex_grid = (int)std::max<int64_t>(1, std::min<int64_t>(2 * (int64_t)cu_budget, (ix->ntotal + 31) / 32));
+    // flagged queries one round of the exact scan can hold: <= 64 MB of per-workgroup lists
+    const int ex_fcap = (int)std::max<int64_t>(1, std::min<int64_t>(B, (64ll << 20) / ((int64_t)ex_grid * k * 12)));
+    if (certify && ix->ntotal > 0) {
+        const size_t need = exact_part_entries(ex_fcap, ex_grid, k);
+        if (need > ix->ex_entries) {
+            if (ix->ex_key) (void)hipFree(ix->ex_key);
+            if (ix->ex_id) (void)hipFree(ix->ex_id);
+            ix->ex_key = nullptr; ix->ex_id = nullptr; ix->ex_entries = 0;
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->ex_key), need * sizeof(unsigned long long)));
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->ex_id), need * sizeof(int)));
+            ix->ex_entries = need;
+        }
+        if (ix->xn_max_rows < ix->ntotal) {  // rows added since the last search
+            const int blocks = (int)std::min<int64_t>(1024, (ix->ntotal - ix->xn_max_rows + 255) / 256);
+            hipLaunchKernelGGL(xnorm_max_kernel, dim3(blocks), dim3(256), 0, st, ix->xnorm, ix->xn_max_rows, ix->ntotal,
+                               ix->cert_words + 1);
+            PRAG_LAUNCH_CHECK();
+            ix->xn_max_rows = ix->ntotal;
+        }
+    }
+    CertArgs cert;
+    cert.qinfo = ix->qinfo;
+    cert.qn2 = ix->qn2;
+    cert.xn_max = ix->cert_words + 1;
+    cert.n_flag = ix->cert_words;
+    cert.flag_list = ix->flag_list;
+    cert.force = nullptr;
+    {
+        // which operands the selection kernel rounds (flat_internal.h "Exactness certificate")
+        const bool hp = !use_mm && !use_qs && use_hp;
+        const bool rows_rounded = ix->store == PRAG_F32;          // fp32 rows -> fp16 terms inside the scan
+        const double u16 = 1.0 / 2048.0, sub = std::sqrt((double)ix->d) * 2.9802322387695312e-08 /* 2^-25 */;
+        cert.rq_sel = hp ? 2 : 1;
+        if (!rows_rounded) { cert.c_row = 0.f; cert.c_abs = 0.f; }
+        else if (hp) { cert.c_row = (float)(3.0 * u16 * u16); cert.c_abs = (float)(2.0 * sub); }
+        else { cert.c_row = (float)(u16 * (1.0 + u16) * 1.001); cert.c_abs = (float)(sub * 1.001); }
+        const int chains = hp ? (rows_rounded ? 3 : 2) : 1;
+        cert.c_acc = (float)((double)ix->d * chains * 1.1920928955078125e-07 /* 2^-23 */ * 1.001);
+        if (!certify) {  // timing experiments: everything certifies
+            cert.c_row = cert.c_abs = cert.c_acc = -1e30f;
+        }
+    }
     hipLaunchKernelGGL(prep_queries_kernel, dim3((Bpad + 3) / 4), dim3(256), 0, st, q_dev, B, Bpad, ix->d,
                        ix->metric == PRAG_METRIC_COS ? 1 : 0, ix->q32, ix->q16, ix->q16lo, ix->g_tau,
                        use_mm ? ix->mm_cnt : nullptr, ix->mm_ovf,
-                       (uint32_t)std::min<int64_t>(ix->ntotal, kMmFirstSeg));
+                       (uint32_t)std::min<int64_t>(ix->ntotal, kMmFirstSeg), ix->qinfo, ix->qn2, ix->cert_words,
+                       ix->flag_list, exact_only && ix->ntotal > 0 ? 1 : 0);
     PRAG_LAUNCH_CHECK();
 
     bool reranked = false;
-    if (ix->ntotal == 0) {
+    if (ix->ntotal == 0 || exact_only) {
         PRAG_HIP(hipMemsetAsync(ix->cand, 0xFF, cand_need * sizeof(int), st));  // all -1
     } else if (use_mm) {
         const int rc = search_tiled(ix, B, Bpad, kc, qstride, n_tiles, cu_budget, mm_chunk, mm_cap_wg, st);
@@ -1723,29 +1846,57 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
             }
             rc = run_scan(a, grid, ix->prof);
             if (rc != PRAG_OK) return rc;
-            // the end of the search for this query tile: list merge + exact rerank in one launch
+            // the end of the search for this query tile: list merge + exact rerank + certificate in one launch
             rc = launch_merge_rerank(kc, ix->store == PRAG_F32, ix->part_key, ix->part_idx, n_lists, QT, nq, p0,
-                                     ix->rows, ix->d, metric_l2, ix->q32, k, id_offset, D_dev, I_dev, st);
+                                     ix->rows, ix->d, metric_l2, ix->q32, k, id_offset, D_dev, I_dev, cert, st);
             if (rc != PRAG_OK) return rc;
         }
         reranked = true;
     }
     if (!reranked && kc > 32) {  // deep lists (k > 26): scores + sort in one 1024-thread block per query
+        CertArgs dc = cert;
+        dc.force = ix->mm_ovf;   // a query whose candidate store overflowed is recomputed by the exact scan
         if (ix->store == PRAG_F32)
             hipLaunchKernelGGL(rerank_sort_kernel<true>, dim3(B), dim3(1024), 0, st, ix->rows, ix->d, metric_l2, ix->q32,
-                               ix->cand, kc, k, id_offset, D_dev, I_dev);
+                               ix->cand, kc, k, id_offset, D_dev, I_dev, dc, ix->g_tau);
         else
             hipLaunchKernelGGL(rerank_sort_kernel<false>, dim3(B), dim3(1024), 0, st, ix->rows, ix->d, metric_l2, ix->q32,
-                               ix->cand, kc, k, id_offset, D_dev, I_dev);
+                               ix->cand, kc, k, id_offset, D_dev, I_dev, dc, ix->g_tau);
         PRAG_LAUNCH_CHECK();
-    } else if (!reranked) {  // empty index, or candidates from the tiled scan
+    } else if (!reranked) {  // empty index / exact-only (all candidates -1), or candidates from the tiled scan
+        CertArgs rc_ = cert;
+        const uint32_t* kth = (ix->ntotal == 0 || exact_only) ? nullptr : ix->g_tau;
+        if (exact_only) rc_.c_acc = -1e30f;   // nothing to certify: every query is already on the flag list
         if (ix->store == PRAG_F32)
             hipLaunchKernelGGL(rerank_kernel<true>, dim3(B), dim3(64 * std::min(kc, 16)), 0, st, ix->rows, ix->d, metric_l2,
-                               ix->q32, ix->cand, kc, k, id_offset, D_dev, I_dev);
+                               ix->q32, ix->cand, kc, k, id_offset, D_dev, I_dev, rc_, kth);
         else
             hipLaunchKernelGGL(rerank_kernel<false>, dim3(B), dim3(64 * std::min(kc, 16)), 0, st, ix->rows, ix->d, metric_l2,
-                               ix->q32, ix->cand, kc, k, id_offset, D_dev, I_dev);
+                               ix->q32, ix->cand, kc, k, id_offset, D_dev, I_dev, rc_, kth);
         PRAG_LAUNCH_CHECK();
+    }
+    // ---- exact float64 scan for the queries on the flag list (none, normally: empty launches) ------
+    if (certify && ix->ntotal > 0) {
+        ExactRun er;
+        er.rows = ix->rows;
+        er.store_f32 = ix->store == PRAG_F32;
+        er.N = ix->ntotal;
+        er.d = ix->d;
+        er.metric_l2 = metric_l2;
+        er.q32 = ix->q32;
+        er.n_flag = ix->cert_words;
+        er.flag_list = ix->flag_list;
+        er.B = B;
+        er.k = k;
+        er.id_offset = id_offset;
+        er.D = D_dev;
+        er.I = I_dev;
+        er.part_key = ix->ex_key;
+        er.part_id = ix->ex_id;
+        er.f_cap = ex_fcap;
+        er.grid = ex_grid;
+        const int rc = exact_run(er, st);
+        if (rc != PRAG_OK) return rc;
     }
 
     if (!io_is_device) {
@@ -1790,18 +1941,34 @@ extern "C" int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n,
     PRAG_REQUIRE(row0 >= 0 && n >= 0 && row0 + n <= ix->ntotal, PRAG_EINVAL, "rows [%lld,%lld) outside [0,%lld)",
                  (long long)row0, (long long)(row0 + n), (long long)ix->ntotal);
     if (n == 0) return PRAG_OK;
+    if (ix->store == PRAG_F32) {  // stored as given: straight copy, no device temporary
+        PRAG_HIP(hipMemcpy(out_host, reinterpret_cast<const float*>(ix->rows) + (size_t)row0 * ix->d,
+                           (size_t)n * ix->d * sizeof(float), hipMemcpyDeviceToHost));
+        return PRAG_OK;
+    }
+    // fp16 rows: widen through a bounded (<= 64 MB) device staging buffer, chunk by chunk
+    const int64_t chunk = std::min<int64_t>(n, std::max<int64_t>(1, (64ll << 20) / ((int64_t)ix->d * 4)));
     float* tmp = nullptr;
-    const int64_t ne = n * ix->d;
-    PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)ne * sizeof(float)));
-    const char* src = reinterpret_cast<const char*>(ix->rows) + (size_t)row0 * ix->d * elt(ix);
-    const int blocks = (int)std::min<int64_t>((ne + 255) / 256, 4096);
-    if (ix->store == PRAG_F32)
-        hipLaunchKernelGGL(reconstruct_kernel<true>, dim3(blocks), dim3(256), 0, 0, src, ne, tmp);
-    else
+    PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)chunk * ix->d * sizeof(float)));
+    hipError_t e = hipSuccess;
+    for (int64_t o = 0; o < n && e == hipSuccess; o += chunk) {
+        const int64_t m = std::min(chunk, n - o), ne = m * ix->d;
+        const char* src = reinterpret_cast<const char*>(ix->rows) + (size_t)(row0 + o) * ix->d * elt(ix);
+        const int blocks = (int)std::min<int64_t>((ne + 255) / 256, 4096);
         hipLaunchKernelGGL(reconstruct_kernel<false>, dim3(blocks), dim3(256), 0, 0, src, ne, tmp);
-    hipError_t e = hipMemcpy(out_host, tmp, (size_t)ne * sizeof(float), hipMemcpyDeviceToHost);
+        e = hipMemcpy(out_host + (size_t)o * ix->d, tmp, (size_t)ne * sizeof(float), hipMemcpyDeviceToHost);
+    }
     (void)hipFree(tmp);
     PRAG_HIP(e);
+    return PRAG_OK;
+}
+
+extern "C" int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out) {
+    PRAG_REQUIRE(ix != nullptr && n_out != nullptr, PRAG_EINVAL, "prag_index_last_fallbacks: NULL pointer");
+    uint32_t n = 0;
+    PRAG_HIP(hipMemcpyAsync(&n, ix->cert_words, sizeof(n), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream)));
+    PRAG_HIP(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    *n_out = (int)n;
     return PRAG_OK;
 }
 
@@ -1838,7 +2005,8 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
     ix->prof.disable();
     void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->q16lo, ix->g_tau, ix->part_key, ix->part_idx, ix->cand,
                     ix->io_q, ix->io_D, ix->io_I, ix->mm_cnt, ix->mm_ovf, ix->mm_ckey, ix->mm_cidx,
-                    ix->mm_wcnt, ix->mm_wkey, ix->mm_widx, ix->rows16};
+                    ix->mm_wcnt, ix->mm_wkey, ix->mm_widx, ix->rows16, ix->qinfo, ix->qn2, ix->flag_list,
+                    ix->cert_words, ix->ex_key, ix->ex_id};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete ix;

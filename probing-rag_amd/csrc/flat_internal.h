@@ -105,6 +105,86 @@ __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* s, int n_pa
     }
     __syncthreads();
 }
+// order-preserving maps of float64 scores (exact rerank / exact scan): ascending uint64 == ascending double
+__device__ __forceinline__ unsigned long long sortable_u64(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return u ^ ((u >> 63) ? ~0ull : (1ull << 63));
+}
+__device__ __forceinline__ double unsortable_f64(unsigned long long u) {
+    return __longlong_as_double((long long)(u ^ ((u >> 63) ? (1ull << 63) : ~0ull)));
+}
+
+// ---------------------------------------------------------------------------
+// Exactness certificate.  The scans select KC >= k candidates per query by an
+// APPROXIMATE key (fp16 operands through the matrix cores, f32 accumulation); the rerank then has
+// the candidates' exact float64 scores.  Every row that is NOT a candidate has a selection key
+// >= the KC-th candidate's selection key `kth_sel`, and a selection key differs from the exact key
+// by at most eps (bound below).  So if the k-th best exact key is < kth_sel - eps no outsider can
+// belong to the top k: the result is the definition's.  Otherwise the query is put on the flag list
+// and recomputed by the exact float64 scan (flat_exact.hip).
+//   eps_dot = rq*nx + nq*(c_row*nx + c_abs) + c_acc*nq*nx        (error of the selection dot product)
+//     nq = ||q||, nx = max_i ||x_i||, rq = ||q - (fp16 terms of q the kernel used)|| (measured per query)
+//     c_row, c_abs: relative / absolute rounding of the rows inside the kernel (0 for fp16 storage)
+//     c_acc = d * n_chains * 2^-23: one rounding (RN or RZ) per product-accumulate, worst case
+//   key = -dot (IP, COS) -> eps = eps_dot ;  key = ||x||^2 - 2 dot (L2) -> eps = 2 eps_dot + 2^-22 (xn_max + 2 nq nx)
+// ---------------------------------------------------------------------------
+struct CertArgs {
+    const float* qinfo;       // [B][4]: ||q||, ||q - q16||, ||q - q16 - q16lo||, unused  (rounded up)
+    const double* qn2;        // [B] ||q||^2
+    const uint32_t* xn_max;   // bits of max_i ||x_i||^2 (float)
+    float c_row, c_abs, c_acc;
+    int rq_sel;               // 1: the kernel used q16 only, 2: q16 + q16lo
+    uint32_t* n_flag;         // number of flagged queries (zeroed by prep_queries_kernel)
+    int* flag_list;           // [B]
+    const uint32_t* force;    // optional [B]: non-zero = flag regardless (deep-list overflow), or null
+};
+
+__device__ __forceinline__ double cert_eps(const CertArgs& c, int b, int metric_l2) {
+    const double nq = (double)c.qinfo[4 * b + 0];
+    const double rq = (double)c.qinfo[4 * b + c.rq_sel];
+    const double xn = (double)__uint_as_float(*c.xn_max) * (1.0 + 1e-6);
+    const double nx = sqrt(xn);
+    const double eps_dot = (rq * nx + nq * ((double)c.c_row * nx + (double)c.c_abs) + (double)c.c_acc * nq * nx) * 1.001;
+    return metric_l2 ? 2.0 * eps_dot + 2.384185791015625e-07 * (xn + 2.0 * nq * nx) : eps_dot;
+}
+
+// true = the k best of the candidates are provably the k best of the shard
+__device__ __forceinline__ bool cert_ok(const CertArgs& c, int b, int metric_l2, double kth_exact_score,
+                                        float kth_sel) {
+    if (c.force && c.force[b]) return false;
+    if (!(kth_sel < INFINITY)) return true;   // the candidate list is not full: every row is in it
+    const double e = metric_l2 ? kth_exact_score - c.qn2[b] : -kth_exact_score;
+    return e < (double)kth_sel - cert_eps(c, b, metric_l2);
+}
+
+__device__ __forceinline__ void cert_flag(const CertArgs& c, int b) {
+    const uint32_t slot = atomicAdd(c.n_flag, 1u);
+    c.flag_list[slot] = b;
+}
+
+// Exact fallback: float64 brute force over every row for the flagged queries (flat_exact.hip).
+struct ExactRun {
+    const void* rows;       // [N][d] as stored
+    int store_f32;
+    int64_t N;
+    int d;
+    int metric_l2;
+    const float* q32;       // [B][d] the queries the rerank uses (normalised for cosine)
+    const uint32_t* n_flag;
+    const int* flag_list;
+    int B, k;
+    int64_t id_offset;
+    float* D;               // [B][k]
+    int64_t* I;
+    unsigned long long* part_key;   // workspace [f_cap][grid][k]
+    int* part_id;
+    int f_cap;              // flagged queries one round can hold
+    int grid;               // workgroups of the scan
+};
+size_t exact_part_entries(int f_cap, int grid, int k);
+// Enqueue ceil(B / f_cap) rounds of {exact scan, merge}; every launch exits at once when no query is flagged.
+int exact_run(const ExactRun& r, hipStream_t st);
+
 bool mm_supported(int d, int store_dtype, int kc);
 // Enqueue the segmented scan on `st`; returns PRAG_OK or a negative status.  `prof` brackets
 // the launch over the largest segment.

@@ -60,8 +60,11 @@ class HipFlatIndex:
     def add(self, x):
         import torch
         ptr, n, is_dev, keep = self._rows_arg(x)
-        with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().prag_index_add(self._h, ptr, n, is_dev))
+        # on the caller's current stream: device rows (an encoder's output, a .float() copy made in
+        # _rows_arg) may still be in flight there
+        dev = keep.device if is_dev else self.device
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().prag_index_add(self._h, ptr, n, is_dev, _lib.current_stream_ptr(dev)))
         del keep
 
     def add_synthetic(self, seed: int, row0: int, n: int):
@@ -235,12 +238,22 @@ def batch_topk_sim(model_retr, query, index, k: int):
 
 
 def _ix_set_candidate_depth(self, depth: int):
-    """Keep `depth` (0=default, 8, 16, 32) candidates per query through the fp16 scan before the
-    float64 rerank - deeper lists tolerate more near-ties at the k-th result."""
+    """Performance knob (results are exact at every depth): keep `depth` (0=default, 8, 16, 32)
+    candidates per query through the scan - deeper lists certify more queries on near-duplicate-dense
+    corpora without the exact fallback pass."""
     _lib.check(_lib.lib().prag_index_set_candidate_depth(self._h, int(depth)))
 
 
+def _ix_last_exact_fallbacks(self) -> int:
+    """Queries of the most recent search that the certificate could not clear and the exact float64
+    scan recomputed (synchronises the current stream)."""
+    n = ctypes.c_int(0)
+    _lib.check(_lib.lib().prag_index_last_fallbacks(self._h, _lib.current_stream_ptr(self.device), ctypes.byref(n)))
+    return n.value
+
+
 HipFlatIndex.set_candidate_depth = _ix_set_candidate_depth
+HipFlatIndex.last_exact_fallbacks = _ix_last_exact_fallbacks
 
 
 def _ix_set_scan_workgroups(self, n: int):

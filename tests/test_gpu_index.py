@@ -218,57 +218,122 @@ def test_c3_full_size_properties():
     np.testing.assert_allclose(D[pick], D0, atol=1e-4, rtol=0)
 
 
-def test_candidate_depth_knob_resolves_dense_near_ties():
-    """30 rows within ~1e-4 of each other around the query: the default 8-deep list for k=5 may
-    pick a different near-tie than the float64 definition; a 32-deep list must be exact."""
+@pytest.mark.parametrize("B", [1, 40, 300])
+def test_dense_near_ties_are_exact_at_the_default_depth(B):
+    """30 rows within ~1e-4 of each other around the query (squared-L2 keys of rows this close cancel
+    catastrophically in the ||x||^2 - 2 q.x form at f32): the 8-deep candidate list for k=5 cannot
+    hold them, the certificate must notice and the exact float64 scan must return the definition's
+    ids - at the DEFAULT depth, for the reference's call shape (1 query) and for the batched kernels.
+    prag_index_set_candidate_depth is a performance knob only."""
     import probing_rag_amd as pra
     N, d, k = 20_000, 256, 5
     X = onp.synth_rows(21, 0, N, d)
-    q = onp.synth_rows(22, 0, 1, d)
+    Q = onp.synth_rows(22, 0, B, d)
     rng = np.random.default_rng(5)
     near = rng.choice(N, 30, replace=False)
-    X[near] = q[0] + 3e-4 * rng.standard_normal((30, d)).astype(np.float32)
+    X[near] = Q[0] + 3e-4 * rng.standard_normal((30, d)).astype(np.float32)
     ix = pra.HipFlatIndex(d, "l2", "f32")
     ix.add(X)
-    D0, I0 = onp.flat_search(X, q, k, onp.METRIC_L2)
-    ix.set_candidate_depth(32)
-    D, I = ix.search(q, k)
+    D0, I0 = onp.flat_search(X, Q, k, onp.METRIC_L2)
+    D, I = ix.search(Q, k)
     assert np.array_equal(I, I0)
     np.testing.assert_allclose(D, D0, rtol=1e-4)
-    ix.set_candidate_depth(0)
-    D1, I1 = ix.search(q, k)
-    assert set(I1[0].tolist()) <= set(near.tolist())          # still the right neighbourhood
-    # (squared-L2 keys of rows this close to the query cancel catastrophically in the
-    # ||x||^2 - 2 q.x form at f32, so only the deep list guarantees the exact ids here)
+    n_fb = ix.last_exact_fallbacks()
+    assert 1 <= n_fb <= max(1, B // 10)                      # query 0 (and hardly anything else)
+    for depth in (32, 0):                                    # the knob changes nothing but speed
+        ix.set_candidate_depth(depth)
+        _, I1 = ix.search(Q, k)
+        assert np.array_equal(I1, I0)
 
 
-def test_high_precision_selection_resolves_close_inner_products():
-    """<= 32 queries take the high-precision selection (query and fp32 rows as hi+lo fp16 terms,
-    f32 accumulation): 30 rows whose inner products with the query differ by 2e-5 relative -
-    below the fp16-operand scoring error - must come back in exact order at the default depth."""
+@pytest.mark.parametrize("B", [1, 40, 300])
+@pytest.mark.parametrize("store", ["f32", "f16"])
+def test_close_inner_products_are_exact_at_the_default_depth(B, store):
+    """30 rows whose inner products with the query differ by 2e-5 relative - below the fp16-operand
+    scoring error of the batched kernels: exact order at the default depth for every batch size
+    (high-precision selection certifies it for <= 32 queries; otherwise the exact scan does)."""
     import probing_rag_amd as pra
     N, d, k = 20_000, 256, 5
     X = onp.synth_rows(31, 0, N, d)
-    q = onp.synth_rows(32, 0, 1, d)
+    Q = onp.synth_rows(32, 0, B, d)
     rng = np.random.default_rng(6)
     near = rng.choice(N, 30, replace=False)
     for j, row in enumerate(near):
-        X[row] = q[0] * np.float32(1.0 + 2e-5 * j)
-    D0, I0 = onp.flat_search(X, q, k, onp.METRIC_IP)
-    assert set(I0[0].tolist()) == set(near[-5:].tolist())
-    ix = pra.HipFlatIndex(d, "ip", "f32")
+        X[row] = Q[0] * np.float32(1.0 + 2e-5 * j)
+    xs = _stored(X, onp.METRIC_IP, store)
+    D0, I0 = onp.flat_search(xs, Q, k, onp.METRIC_IP)
+    ix = pra.HipFlatIndex(d, "ip", store)
     ix.add(X)
-    D, I = ix.search(q, k)                                     # 1 query: high-precision path
+    D, I = ix.search(Q, k)
     assert np.array_equal(I, I0)
     np.testing.assert_allclose(D, D0, rtol=1e-6)
-    Q40 = np.concatenate([q, onp.synth_rows(33, 0, 39, d)])    # 40 queries: fp16-operand kernels
-    _, I2 = ix.search(Q40, k)
-    assert set(I2[0].tolist()) <= set(near.tolist())           # right neighbourhood; order may differ
-    ix.set_candidate_depth(32)
-    _, I3 = ix.search(Q40, k)
-    assert np.array_equal(I3[:1], I0)                          # 30 near-ties fit a 32-deep list
     with pytest.raises(pra.PragError, match="PRAG_EINVAL"):
         ix.set_candidate_depth(5)
+
+
+@pytest.mark.parametrize("metric", METRICS)
+@pytest.mark.parametrize("B", [2, 50, 140, 260])
+def test_more_exact_duplicates_than_the_candidate_list_holds(metric, B):
+    """60 exact copies of query 0's best row: more than any candidate list (8/16/32) holds, so the
+    certificate cannot separate the k-th result from the rows left outside; ids must still be the 10
+    lowest of the copies.  Every scan path (per-lane lists, query-stationary, MFMA-tiled)."""
+    import probing_rag_amd as pra
+    N, d, k = 30_000, 256, 10
+    X = onp.synth_rows(61, 0, N, d)
+    rng = np.random.default_rng(7)
+    dups = np.sort(rng.choice(N, 60, replace=False))
+    X[dups] = X[dups[0]]
+    Q = onp.synth_rows(62, 0, B, d)
+    Q[0] = X[dups[0]]
+    for store in ("f16", "f32"):
+        ix = pra.HipFlatIndex(d, metric, store)
+        ix.add(X)
+        D, I = ix.search(Q, k)
+        D0, I0 = oracle_c.flat_search(_stored(X, metric, store), Q, k, metric)
+        _check(D, I, D0, I0, metric)
+        if metric != onp.METRIC_IP:
+            assert I[0].tolist() == dups[:k].tolist()
+        ix.close()
+
+
+@pytest.mark.parametrize("B,store", [(1, "f32"), (8, "f16"), (64, "f16"), (100, "f16"), (300, "f16"), (300, "f32")])
+def test_certificate_holds_on_adversarial_operands(B, store):
+    """Inputs built to maximise the selection error the certificate has to bound: all-positive
+    vectors (every partial sum of the f32 accumulation is as large as the total), a huge common
+    offset (scores ~1e3 apart by ~1e-3), elements below the fp16 normal range (2^-14), and a wide
+    spread of row norms.  Whatever the certificate decides, ids must equal the float64 definition."""
+    import probing_rag_amd as pra
+    N, d, k = 12_000, 768, 5
+    rng = np.random.default_rng(11)
+    base = np.abs(onp.synth_rows(71, 0, 1, d)[0]) + 0.5
+    X = (base[None, :] * (1.0 + 2e-4 * rng.standard_normal((N, d)))).astype(np.float32)   # near-parallel, positive
+    X[N // 2:] *= rng.uniform(1e-6, 3e-5, size=(N - N // 2, 1)).astype(np.float32)          # fp16-subnormal rows
+    X[: N // 8] *= rng.uniform(0.5, 40.0, size=(N // 8, 1)).astype(np.float32)              # norm spread
+    Q = (base[None, :] * (1.0 + 2e-4 * rng.standard_normal((B, d)))).astype(np.float32)
+    Q[-1] *= 1e-5
+    for metric in METRICS:
+        ix = pra.HipFlatIndex(d, metric, store)
+        ix.add(X)
+        D, I = ix.search(Q, k)
+        D0, I0 = oracle_c.flat_search(_stored(X, metric, store), Q, k, metric)
+        assert np.array_equal(I, I0), (metric, np.argwhere(I != I0)[:4])
+        ix.close()
+
+
+def test_random_corpus_is_certified_without_the_exact_pass():
+    """On exchangeable rows the certificate must clear (almost) every query: the exact scan is a
+    safety net, not the usual path."""
+    import torch
+    import probing_rag_amd as pra
+    N, d = 200_000, 768
+    for store, metric, B, k in [("f16", "cos", 64, 10), ("f32", "l2", 1, 5), ("f16", "l2", 128, 10),
+                                ("f16", "ip", 1000, 10), ("f32", "l2", 32, 5)]:
+        ix = pra.HipFlatIndex(d, metric, store, capacity=N)
+        ix.add_synthetic(42, 0, N)
+        q = torch.from_numpy(onp.synth_rows(7, 0, B, d)).cuda()
+        ix.search(q, k)
+        assert ix.last_exact_fallbacks() <= B // 50, (store, metric, B, ix.last_exact_fallbacks())
+        ix.close()
 
 
 def test_randomised_shapes_against_the_definition():
@@ -336,10 +401,45 @@ def test_k_beyond_the_deepest_list_is_refused():
     ix.add(onp.synth_rows(1, 0, 100, 256))
     with pytest.raises(pra.PragError, match="at most 911"):
         ix.search(onp.synth_rows(2, 0, 1, 256), 912)
-    ix2 = pra.HipFlatIndex(128, "l2", "f16")         # d outside the tiled scan's set
-    ix2.add(onp.synth_rows(1, 0, 100, 128))
-    with pytest.raises(pra.PragError, match="k=100 > 26"):
-        ix2.search(onp.synth_rows(2, 0, 1, 128), 100)
+
+
+@pytest.mark.parametrize("d,store,metric", [(128, "f16", onp.METRIC_L2), (64, "f32", onp.METRIC_IP),
+                                            (1536, "f16", onp.METRIC_COS)])
+def test_large_k_on_dimensions_outside_the_tiled_scan(d, store, metric):
+    """k > 26 with d outside {256,512,768,1024}: no candidate scan covers it, the search goes straight
+    to the exact float64 scan (round 1 refused these with PRAG_EUNSUPPORTED)."""
+    import probing_rag_amd as pra
+    N, B, k = 5000, 3, 100
+    X = onp.synth_rows(83, 0, N, d)
+    X[N - 1] = X[9]
+    Q = onp.synth_rows(84, 0, B, d)
+    Q[0] = X[9]
+    ix = pra.HipFlatIndex(d, metric, store)
+    ix.add(X)
+    D, I = ix.search(Q, k)
+    D0, I0 = onp.flat_search(_stored(X, metric, store), Q, k, metric)
+    _check(D, I, D0, I0, metric)
+    assert ix.last_exact_fallbacks() == B
+
+
+@pytest.mark.parametrize("metric", [onp.METRIC_IP, onp.METRIC_L2])
+def test_large_k_candidate_overflow_is_recomputed_exactly(metric):
+    """Deep lists (k > 26) have no per-lane-list fallback: rows ordered so that each beats all earlier
+    ones overflow the tiled scan's candidate store; round 1 returned PRAG_EUNSUPPORTED, now the
+    flagged queries come out of the exact scan."""
+    import probing_rag_amd as pra
+    N, d, B, k = 60_000, 256, 6, 100
+    X = onp.synth_rows(51, 0, N, d)
+    q0 = onp.synth_rows(52, 0, 1, d)[0]
+    s_ = X @ q0 if metric == onp.METRIC_IP else -((X - q0) ** 2).sum(1)
+    X = np.ascontiguousarray(X[np.argsort(s_, kind="stable")])       # later rows are better matches
+    Q = onp.synth_rows(53, 0, B, d)
+    Q[: B // 2] = q0 + 0.02 * Q[: B // 2]
+    ix = pra.HipFlatIndex(d, metric, "f16")
+    ix.add(X)
+    D, I = ix.search(Q, k)
+    D0, I0 = onp.flat_search(_stored(X, metric, "f16"), Q, k, metric)
+    _check(D, I, D0, I0, metric)
 
 
 def test_shard_simulation_with_large_k():
