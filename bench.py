@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Benchmark of the Probing-RAG retrieval-gating hot path on MI355X.
 
-One "step" = one pass of the hot path over one batch of synthetic input:
+One "step" = `--inner` passes (default 20) of the hot path over one batch of synthetic input:
   gate   : fused 6-layer prober ensemble + softmax/sum/threshold over B_gate
            pooled hidden states (d_model 2048, fp16)           [exp_rag.py:406-415]
   search : cosine top-10 of B_q query embeddings over the row-sharded
            N_docs x 768 fp16 corpus (local fused scan/top-k, all-gather of the
            local top-k over RCCL, (score,id) merge)             [utils.py:378-380]
+(`--inner` exists so that the timed region lasts seconds, not 0.1 s; `value` counts every pass.)
 Workload = BASELINE.json's quoted sizes: d_model=2048, N_docs=21M, d_emb=768.
 Total work is fixed as GPUs are added ("strong"): the 21M rows and the 4096
 gate rows are split across ranks.
@@ -14,8 +15,15 @@ gate rows are split across ranks.
   python bench.py                      # 1 GPU
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with extra
-objects `roofline` (dominant kernel: scan_topk, HBM-bound) and `cpu_baseline`.
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects
+  roofline      dominant kernel of the headline step (scan_topk, HBM-bound), measured live with HIP
+                events on the launch stream inside libprag
+  variants      (1 GPU) the other call shapes SURVEY.md section 8d names, same corpus size:
+                the reference's literal call (float32 rows, squared L2, k=5, one query) and fp16
+                rows with 1 / 32 / 1000 queries - each with its own roofline fraction
+  cpu_baseline  (1 GPU) BASELINE config 1 (128 states x 6 probers; 128 queries x 10k docs L2 top-5)
+                and the reference's batch-1 call shape, torch-cpu and the C restatement, on this
+                box's host cores
 Other sizes are parity/diagnostic cases, e.g. BASELINE config 3:
   python bench.py --queries 1000 --docs 1000000      # MFMA-tiled scan, roofline.bound = "mfma"
 """
@@ -33,6 +41,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA
+D_MODEL, D_EMB, N_LAYERS = 2048, 768, 6
 
 
 def parse():
@@ -40,63 +49,148 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--inner", type=int, default=20, help="passes of the hot path per step")
     ap.add_argument("--docs", type=int, default=21_000_000, help="total corpus rows (all GPUs)")
-    ap.add_argument("--queries", type=int, default=64, help="query embeddings per step")
-    ap.add_argument("--gate-batch", type=int, default=4096, help="pooled hidden states per step (all GPUs)")
+    ap.add_argument("--queries", type=int, default=64, help="query embeddings per pass")
+    ap.add_argument("--gate-batch", type=int, default=4096, help="pooled hidden states per pass (all GPUs)")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="cos", choices=["cos", "l2", "ip"])
     ap.add_argument("--store", default="f16", choices=["f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--overlap-gate", type=int, default=1,
                     help="1: run the gate on a second stream beside the HBM-bound scan (scan capped at "
                          "n_cu-16 workgroups); 0: one stream")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
     return ap.parse_args()
 
 
-def cpu_baseline(args, d_emb, states):
-    """Rank 0, N=1 only: the torch-cpu restatement (oracle/torch_cpu.py) timed on
-    this box's host cores over a bounded sample of the same workload."""
-    import torch
-    from oracle import oracle_np as onp, torch_cpu
-    cores = torch.get_num_threads()
-    # ---- scoring sample: B_q queries x Ns docs, same metric/k ------------------
-    Bq, k = args.queries, args.k
-    Ns = 200_000
-    xs = torch.from_numpy(onp.synth_rows(42, 0, Ns, d_emb))
-    if args.metric == "cos":
-        xs = torch.nn.functional.normalize(xs, dim=1)
-    xn = (xs * xs).sum(1)
-    q = torch.from_numpy(onp.synth_rows(7, 0, Bq, d_emb))
-    torch_cpu.flat_search(xs, xn, q, k, args.metric == "l2")          # warm
+# ---------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N=1): the ONLY part of this file that touches oracle/
+# ---------------------------------------------------------------------------------------------
+def _timed(fn, budget_s, max_reps=400):
+    fn()                                   # warm
     t0 = time.perf_counter()
     reps = 0
     while True:
-        torch_cpu.flat_search(xs, xn, q, k, args.metric == "l2")
+        fn()
         reps += 1
-        if time.perf_counter() - t0 > args.cpu_seconds * 0.6 or reps >= 200:
+        dt = time.perf_counter() - t0
+        if dt > budget_s or reps >= max_reps:
+            return reps, dt
+
+
+def cpu_baseline(args, states, q_c1, x_c1):
+    """BASELINE config 1 - 128 synthetic hidden states (d=2048) through the 6-prober gate and a
+    10k-doc flat L2 index, top-5 - timed on this box's host cores with (a) the torch-cpu port
+    (the structure the reference runs: six module calls + softmax/sum/threshold; one sgemm + topk,
+    faiss-cpu is not installable in this image) and (b) the plain-C restatement (prag_oracle.c,
+    OpenMP), each also at the reference's real call shape (batch 1).  A bounded sample of the
+    metric's own workload (B_q queries x 200k docs, same metric / k) is timed as well."""
+    import torch
+    from oracle import oracle_c, torch_cpu
+    cores = torch.get_num_threads()
+    slice_s = args.cpu_seconds / 8.0
+    N1, k1 = 10_000, 5
+    docs = torch.from_numpy(x_c1)                                  # [10k, 768] float32
+    dn = (docs * docs).sum(1)
+    q128 = torch.from_numpy(q_c1)                                  # [128, 768]
+    out = {"cores": cores, "kind": "port", "unit": "query*doc scores/s"}
+    # ---- flat L2 top-5, torch-cpu ---------------------------------------------------------
+    r, dt = _timed(lambda: torch_cpu.flat_search(docs, dn, q128, k1, True), slice_s)
+    out["value"] = 128 * N1 * r / dt
+    out["sample"] = (f"config 1: torch-cpu flat L2 top-{k1}, 128 queries x {N1} docs x {D_EMB} fp32, {r} reps in "
+                     f"{dt:.1f}s (faiss-cpu is not installed in this image)")
+    r, dt = _timed(lambda: torch_cpu.flat_search(docs, dn, q128[:1], k1, True), slice_s, 4000)
+    out["flat_b1_scores_per_s"] = N1 * r / dt
+    out["flat_b1_ms_per_search"] = dt / r * 1e3
+    # ---- gate, torch-cpu --------------------------------------------------------------------
+    probers = torch_cpu.make_probers(states, D_MODEL)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn((N_LAYERS, 128, D_MODEL), generator=g)
+    r, dt = _timed(lambda: torch_cpu.gate(probers, x), slice_s)
+    out["gate_decisions_per_s"] = 128 * r / dt
+    out["gate_sample"] = f"config 1: torch-cpu 6 x ImprovedProbe(2048) + gate, B=128 fp32, {r} reps in {dt:.1f}s"
+    x1 = x[:, :1].contiguous()
+    r, dt = _timed(lambda: torch_cpu.gate(probers, x1), slice_s, 4000)
+    out["gate_b1_decisions_per_s"] = r / dt
+    out["gate_b1_ms"] = dt / r * 1e3
+    # ---- the C restatement (oracle/prag_oracle.c, float64 accumulators, OpenMP) ---------------------
+    xs_np, q_np, x_np = x_c1, q_c1, x.numpy()
+    r, dt = _timed(lambda: oracle_c.flat_search(xs_np, q_np, k1, 0), slice_s)
+    c = {"threads": oracle_c.num_threads(), "flat_scores_per_s": 128 * N1 * r / dt}
+    r, dt = _timed(lambda: oracle_c.flat_search(xs_np, q_np[:1], k1, 0), slice_s, 2000)
+    c["flat_b1_scores_per_s"] = N1 * r / dt
+
+    def c_gate(xb):
+        lg = np.stack([oracle_c.prober_forward(states[l], xb[l]) for l in range(N_LAYERS)])
+        return oracle_c.gate(lg, 0, 0.0)
+    r, dt = _timed(lambda: c_gate(x_np), slice_s)
+    c["gate_decisions_per_s"] = 128 * r / dt
+    r, dt = _timed(lambda: c_gate(x_np[:, :1]), slice_s, 2000)
+    c["gate_b1_decisions_per_s"] = r / dt
+    out["c_restatement"] = c
+    # ---- bounded sample of the metric's workload -------------------------------------------------
+    Ns, Bq, k = 200_000, args.queries, args.k
+    gq = torch.Generator().manual_seed(7)
+    xs = torch.randn((Ns, D_EMB), generator=gq)
+    qs = torch.randn((Bq, D_EMB), generator=gq)
+    if args.metric == "cos":
+        xs = torch.nn.functional.normalize(xs, dim=1)
+    xn = (xs * xs).sum(1)
+    r, dt = _timed(lambda: torch_cpu.flat_search(xs, xn, qs, k, args.metric == "l2"), slice_s * 1.5, 200)
+    out["metric_workload_sample"] = {
+        "value": Bq * Ns * r / dt, "unit": "query*doc scores/s",
+        "sample": f"torch-cpu flat {args.metric} top-{k}: {Bq} queries x {Ns} docs x {D_EMB} fp32, {r} reps in {dt:.1f}s"}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+def _timed_searches(torch, ix, q, k, min_s=0.6, max_reps=200):
+    """ms per search (host-timed over back-to-back searches) + the profiled scan-kernel launches."""
+    for _ in range(2):
+        ix.search(q, k)
+    torch.cuda.synchronize()
+    ix.profile(1024)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        for _ in range(4):
+            ix.search(q, k)
+        reps += 4
+        torch.cuda.synchronize()
+        if time.perf_counter() - t0 > min_s or reps >= max_reps:
             break
     dt = time.perf_counter() - t0
-    scores_per_s = Bq * Ns * reps / dt
-    # ---- gate sample: BASELINE config 1 (128 states x 6 probers) --------------
-    probers = torch_cpu.make_probers(states, 2048)
-    x = torch.from_numpy(onp.synth_rows(1234, 0, 6 * 128, 2048).reshape(6, 128, 2048))
-    torch_cpu.gate(probers, x)
-    t0 = time.perf_counter()
-    greps = 0
-    while True:
-        torch_cpu.gate(probers, x)
-        greps += 1
-        if time.perf_counter() - t0 > args.cpu_seconds * 0.3 or greps >= 400:
-            break
-    gdt = time.perf_counter() - t0
-    return {
-        "value": scores_per_s, "unit": "query*doc scores/s", "cores": cores, "kind": "port",
-        "sample": f"torch-cpu flat {args.metric} top-{k}: {Bq} queries x {Ns} docs x {d_emb} fp32, "
-                  f"{reps} reps in {dt:.1f}s (faiss-cpu not installed in this image)",
-        "gate_decisions_per_s": 128 * greps / gdt,
-        "gate_sample": f"torch-cpu 6 x ImprovedProbe(2048) + gate, B=128 fp32, {greps} reps in {gdt:.1f}s",
-    }
+    ms = ix.profile_read()
+    ix.profile(0)
+    return dt / reps * 1e3, ms, ix.last_exact_fallbacks()
+
+
+def variant_record(torch, ix, q, k, store, metric, n_local):
+    B = q.shape[0]
+    ms_search, kern_ms, fb = _timed_searches(torch, ix, q, k)
+    elt = 2 if store == "f16" else 4
+    alg_bytes = n_local * D_EMB * elt + (n_local * 4 if metric == "l2" else 0)
+    tiled = B > 128
+    rec = {"store": store, "metric": metric, "k": k, "queries": B, "rows": n_local,
+           "ms_per_search": ms_search, "scores_per_s": B * n_local / (ms_search * 1e-3),
+           "exact_fallbacks_last_search": fb}
+    if tiled:   # MFMA-bound: price the whole search (all segments, compactions, rerank) against the matrix peak
+        tf = 2.0 * B * n_local * D_EMB / (ms_search * 1e-3) / 1e12
+        rec.update({"kernel": "scan_mm_kernel (whole search)", "bound": "mfma", "achieved": tf,
+                    "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TF,
+                    "largest_segment_ms": float(np.mean(kern_ms)) if kern_ms else None})
+    else:
+        passes = 1 + (B - 1) // (128 if (B > 64 and store == "f16") else 64)
+        kms = float(np.mean(kern_ms)) if kern_ms else float("nan")
+        gbs = alg_bytes / (kms * 1e-3) / 1e9
+        rec.update({"kernel": "scan_qs_kernel" if (B > 64 and store == "f16") else "scan_topk_kernel",
+                    "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": kms, "launches_per_search": passes,
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "whole_search_frac": alg_bytes * passes / (ms_search * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    return rec
 
 
 def main():
@@ -124,17 +218,18 @@ def main():
             dist.init_process_group(backend)
 
     import probing_rag_amd as pra
-    from oracle import oracle_np as onp
-    from tests.golden import cases
+    from probing_rag_amd.synth import random_prober_state, synth_rows
 
-    d_model, d_emb, L = 2048, 768, 6
-    # ---- corpus shard (generated on device, bit-identical to oracle_np.synth_rows)
+    d_model, d_emb, L = D_MODEL, D_EMB, N_LAYERS
+    # ---- corpus shard (generated on device by the counter-based generator of add_synthetic)
     lo, hi = pra.partition_rows(args.docs, world, rank)
-    index = pra.ShardedFlatIndex(d_emb, args.metric, args.store, capacity=hi - lo)
-    index.add_synthetic_local(42, lo, hi - lo)
+    n_local = hi - lo
+    index = pra.ShardedFlatIndex(d_emb, args.metric, args.store, capacity=n_local)
+    index.add_synthetic_local(42, lo, n_local)
     index.sync()
-    # ---- gate: 6 probers, this rank's slice of the pooled hidden states
-    states = [cases.synth_state(100 + l, d_model) for l in range(L)]
+    local = index.engine.index
+    # ---- gate: 6 probers (random init of the reference architecture), this rank's slice of the states
+    states = [random_prober_state(100 + l, d_model) for l in range(L)]
     ens = pra.HipProberEnsemble(L, d_model, 2, weights="f16")
     for l, st in enumerate(states):
         ens.load_layer(l, st)
@@ -146,32 +241,37 @@ def main():
                 torch.empty((Bg, 2), dtype=torch.float32, device="cuda"),
                 torch.empty((Bg,), dtype=torch.int32, device="cuda"))
     # ---- queries: replicated on every rank; a few are planted near known rows
-    q_np = onp.synth_rows(7, 0, args.queries, d_emb)
+    q_np = synth_rows(7, 0, args.queries, d_emb)
     n_plant = min(8, args.queries)
     planted = [(i * 2_654_435 + 17) % args.docs for i in range(n_plant)]
     for i, r in enumerate(planted):
-        q_np[i] = onp.synth_rows(42, r, 1, d_emb)[0] + 0.05 * q_np[i]
+        q_np[i] = synth_rows(42, r, 1, d_emb)[0] + 0.05 * q_np[i]
     q = torch.from_numpy(q_np).cuda()
 
     main_stream = torch.cuda.current_stream()
     side_stream = torch.cuda.Stream()
+    n_cu = torch.cuda.get_device_properties(dev_index).multi_processor_count
     if args.overlap_gate:
-        n_cu = torch.cuda.get_device_properties(dev_index).multi_processor_count
-        index.engine.index.set_scan_workgroups(n_cu - 16)
+        local.set_scan_workgroups(n_cu - 16)
 
-    def step():
+    def one_pass():
         if not args.overlap_gate:
             ens.gate(x, 0, 0.0, out=gate_out)
             return index.search(q, args.k)
         # the search goes first so the scan's persistent workgroups settle on their CUs; the gate
         # (independent work: the decisions of the NEXT batch) fills the CUs left free
         start = torch.cuda.Event()
-        start.record(main_stream)                 # everything before this step
+        start.record(main_stream)                 # everything before this pass
         out = index.search(q, args.k)
         side_stream.wait_event(start)             # NOT the search just enqueued
         with torch.cuda.stream(side_stream):
             ens.gate(x, 0, 0.0, out=gate_out)
-        main_stream.wait_stream(side_stream)      # the step ends when both are done
+        main_stream.wait_stream(side_stream)      # the pass ends when both are done
+        return out
+
+    def step():
+        for _ in range(args.inner):
+            out = one_pass()
         return out
 
     def fence():
@@ -181,17 +281,21 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    slots = args.steps * (1 + (args.queries - 1) // 64) + 8
-    index.engine.index.profile(slots)
-    ens.profile(args.steps + 8)
+    n_pass = args.steps * args.inner
+    slots = min(4096, n_pass * (1 + (args.queries - 1) // 64) + 8)
+    local.profile(slots)
+    ens.profile(min(4096, n_pass + 8))
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         D, I = step()
     fence()
     dt = time.perf_counter() - t0
-    scan_ms = index.engine.index.profile_read()
+    scan_ms = local.profile_read()
     gate_ms = ens.profile_read()
+    local.profile(0)
+    ens.profile(0)
+    fallbacks = local.last_exact_fallbacks()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -200,40 +304,42 @@ def main():
 
     # ---- correctness riders (outside the timed region) -------------------------
     I_host = I.cpu().numpy()
+    D_host = D.cpu().numpy()
     planted_ok = all(int(I_host[i, 0]) == planted[i] for i in range(n_plant))
-    recall = None
-    if rank == 0:
-        # top-k recall against the oracle (exact float64 brute force, C) on a bounded
-        # sub-corpus searched by the same kernels: first 200k rows, 16 of the queries
-        from oracle import oracle_c
-        n_sub = min(200_000, args.docs)
-        sub = pra.HipFlatIndex(d_emb, args.metric, args.store, capacity=n_sub)
-        sub.add_synthetic(42, 0, n_sub)
-        qs = q[: min(16, args.queries)]
-        _, I_sub = sub.search(qs, args.k)
-        metric_id = {"l2": onp.METRIC_L2, "ip": onp.METRIC_IP, "cos": onp.METRIC_COS}[args.metric]
-        _, I_ref = oracle_c.flat_search(sub.reconstruct_n(0, n_sub), qs.cpu().numpy(), args.k, metric_id)
-        I_sub = I_sub.cpu().numpy()
-        recall = float(np.mean([len(set(a) & set(b)) / args.k for a, b in zip(I_sub.tolist(), I_ref.tolist())]))
-        exact_order = bool(np.array_equal(I_sub, I_ref))
-        del sub
+    sorted_ok = bool((np.diff(D_host, axis=1) >= 0).all() if args.metric == "l2" else (np.diff(D_host, axis=1) <= 0).all())
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
+    # top-k recall against the oracle (exact float64 brute force, C) on a bounded sub-corpus searched
+    # by the same kernels: first 200k rows, 16 of the queries
+    from oracle import oracle_c
+    n_sub = min(200_000, args.docs)
+    sub = pra.HipFlatIndex(d_emb, args.metric, args.store, capacity=n_sub)
+    sub.add_synthetic(42, 0, n_sub)
+    qs = q[: min(16, args.queries)]
+    _, I_sub = sub.search(qs, args.k)
+    metric_id = {"l2": 0, "ip": 1, "cos": 2}[args.metric]
+    _, I_ref = oracle_c.flat_search(sub.reconstruct_n(0, n_sub), qs.cpu().numpy(), args.k, metric_id)
+    I_sub = I_sub.cpu().numpy()
+    recall = float(np.mean([len(set(a) & set(b)) / args.k for a, b in zip(I_sub.tolist(), I_ref.tolist())]))
+    exact_order = bool(np.array_equal(I_sub, I_ref))
+    sub.close()
+
+    passes_total = args.steps * args.inner
     scores = args.queries * args.docs
-    value = scores / (dt / args.steps)
-    n_local = hi - lo
+    value = scores * passes_total / dt
     elt = 2 if args.store == "f16" else 4
     alg_bytes = n_local * d_emb * elt + (n_local * 4 if args.metric == "l2" else 0)
-    # which scan kernel served the step (mirrors prag_index_search's choice)
-    tiled = args.queries > 128 and args.store == "f16"           # MFMA-tiled scan, 256-query tiles
+    # which scan kernel served the pass (mirrors prag_index_search's choice)
+    tiled = args.queries > 128                                        # MFMA-tiled scan, 256-query tiles
     per_pass = 128 if (args.queries > 64 and args.store == "f16") else 64
-    passes = 1 if tiled else 1 + (args.queries - 1) // per_pass
+    launches = 1 if tiled else 1 + (args.queries - 1) // per_pass
     scan_avg_ms = float(np.mean(scan_ms)) if scan_ms else float("nan")
     achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
+    mm_tf = mm_flops = rows_last = None
     if tiled:
         # the profiled launch is the last corpus segment (segments: 2048 rows, then x16)
         seg0 = 2048
@@ -258,35 +364,77 @@ def main():
         "value": value, "unit": "query*doc scores/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f16 (MFMA, f32 accumulate; f64 rerank)", "data": "synthetic",
+        "dtype": "f16 (MFMA, f32 accumulate; f64 rerank + exactness certificate)", "data": "synthetic",
         "config": {"workload": f"gate B={args.gate_batch} x 6 layers x d_model=2048 fp16 + flat {args.metric} "
                                f"top-{args.k} of {args.queries} queries over {args.docs} x 768 {args.store} docs",
+                   "passes_per_step": args.inner, "ms_per_pass": ms_per_step / args.inner,
+                   "timed_region_s": dt,
                    "docs_total": args.docs, "docs_per_gpu": n_local, "d_emb": d_emb, "queries": args.queries,
                    "k": args.k, "gate_batch": args.gate_batch, "gate_batch_per_gpu": Bg, "d_model": d_model,
                    "parallelism": f"corpus rows sharded x{world}; gate rows split x{world}",
                    "gate_overlapped_with_scan": bool(args.overlap_gate)},
         "probe_decisions_per_s": args.gate_batch / (gate_avg_ms * 1e-3) if gate_ms else None,
         "scores_per_s_per_gpu": value / world,
-        "planted_top1_recall": 1.0 if planted_ok else 0.0,
+        "planted_top1_recall": 1.0 if planted_ok else 0.0, "result_lists_sorted": sorted_ok,
+        "exact_fallbacks_last_search": fallbacks,
         "recall_at_k_vs_oracle": recall, "topk_ids_bit_exact_vs_oracle": exact_order,
-        "recall_sample": f"{min(16, args.queries)} queries x {min(200_000, args.docs)} docs, float64 C oracle",
+        "recall_sample": f"{min(16, args.queries)} queries x {n_sub} docs, float64 C oracle",
         "roofline": ({"bound": "mfma", "kernel": "scan_mm_kernel", "achieved": mm_tf, "peak": MFMA_F16_PEAK_TF,
                       "unit": "TFLOP/s", "frac": mm_tf / MFMA_F16_PEAK_TF, "traffic": None,
                       "algorithmic_flops_per_launch": mm_flops, "rows_in_launch": rows_last,
-                      "avg_launch_ms": scan_avg_ms, "launches_per_step": passes} if tiled else
+                      "avg_launch_ms": scan_avg_ms, "launches_per_pass": launches} if tiled else
                      {"bound": "hbm", "kernel": "scan_qs_kernel" if per_pass == 128 else "scan_topk_kernel",
                       "achieved": achieved, "peak": HBM_PEAK_GBS,
                       "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                       "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_ms,
-                      "launches_per_step": passes}),
+                      "launches_per_pass": launches, "launches_timed": len(scan_ms)}),
         "roofline_gate": {"bound": "mfma", "kernel": "prober_fused_kernel", "achieved": gate_flops / (gate_avg_ms * 1e-3) / 1e12,
                           "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                           "frac": gate_flops / (gate_avg_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF,
                           "avg_launch_ms": gate_avg_ms,
                           "hbm_GBs": (L * Bg * d_model * 2 + L * 1318914 * 2) / (gate_avg_ms * 1e-3) / 1e9},
     }
+
+    # ---- variants: the other call shapes of SURVEY.md section 8d on the same corpus size (1 GPU) --------
+    if world == 1 and not args.no_variants:
+        variants = {}
+        local.set_scan_workgroups(0)          # searches alone on the chip
+        try:
+            qv = torch.from_numpy(synth_rows(7, 0, 1000, d_emb)).cuda()
+            if args.store == "f16" and args.metric == "cos":
+                for B in (1, 32, 1000):
+                    variants[f"f16_cos_k{args.k}_q{B}"] = variant_record(torch, local, qv[:B], args.k, "f16", "cos", n_local)
+            # the reference's literal call: IndexFlatL2 (float32 rows), one query, k = 5
+            # (make_indexer.py:449-450, utils.py:378-380, exp_rag.py:432)
+            ref_ix = pra.HipFlatIndex(d_emb, "l2", "f32", capacity=args.docs)
+            ref_ix.add_synthetic(42, 0, args.docs)
+            variants["f32_l2_k5_q1 (reference call)"] = variant_record(torch, ref_ix, qv[:1], 5, "f32", "l2", args.docs)
+            variants["f32_l2_k5_q32"] = variant_record(torch, ref_ix, qv[:32], 5, "f32", "l2", args.docs)
+            ref_ix.close()
+            # the gate at the reference's call shape (one query: six probers, float32 states)
+            e32 = pra.HipProberEnsemble(L, d_model, 2, weights="f32")
+            for l, st in enumerate(states):
+                e32.load_layer(l, st)
+            x1 = torch.randn((L, 1, d_model), device="cuda")
+            for _ in range(10):
+                e32.gate(x1, 0, 0.0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(500):
+                e32.gate(x1, 0, 0.0)
+            torch.cuda.synchronize()
+            variants["gate_b1_f32"] = {"us_per_decision": (time.perf_counter() - t1) / 500 * 1e6,
+                                       "what": "fused 6-prober gate, one pooled state, fp32-parity weights, host-timed"}
+        except Exception as e:                # a variant must never take the headline down with it
+            variants["error"] = f"{type(e).__name__}: {e}"
+        out["variants"] = variants
+    else:
+        out["variants"] = None
+
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, d_emb, states)
+        q_c1 = synth_rows(7, 0, 128, d_emb)
+        x_c1 = synth_rows(42, 0, 10_000, d_emb)
+        out["cpu_baseline"] = cpu_baseline(args, states, q_c1, x_c1)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)

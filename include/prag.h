@@ -94,14 +94,15 @@ int prag_prober_forward(prag_prober_t* p, const void* x_dev, int x_dtype,
 /* Replaces return_prober_logit_gemma_2b + the softmax / sum / threshold of
  * exp_rag.py:406-415 for a whole batch: all layers' probers, then
  * probsum[b] = sum_{n>=ablation} softmax(logits[n,b]) (float32, layer order)
- * and decision[b] = (probsum[b,0] + theta < probsum[b,1]) ? 0 : 1
- * (1 = retrieve).  logits_dev [L,B,2], probsum_dev [B,2], decision_dev [B]. */
+ * and decision[b] = ((double)probsum[b,0] + theta < (double)probsum[b,1]) ? 0 : 1
+ * (1 = retrieve; the reference compares Python floats, exp_rag.py:414).
+ * logits_dev [L,B,2], probsum_dev [B,2], decision_dev [B]. */
 int prag_gate(prag_prober_t* p, const void* x_dev, int x_dtype, int64_t x_layer_stride,
-              int B, int ablation, float theta, float* logits_dev, float* probsum_dev,
+              int B, int ablation, double theta, float* logits_dev, float* probsum_dev,
               int32_t* decision_dev, void* stream);
 
 /* The gate arithmetic alone (exp_rag.py:407-415) on existing logits. */
-int prag_gate_from_logits(const float* logits_dev, int L, int B, int ablation, float theta,
+int prag_gate_from_logits(const float* logits_dev, int L, int B, int ablation, double theta,
                           float* probsum_dev, int32_t* decision_dev, void* stream);
 
 /* Test/inspection hook: the weights the kernels actually compute with, as a
@@ -182,6 +183,10 @@ int prag_trainer_step(prag_trainer_t* t, const float* x_dev, const int32_t* labe
 /* Current parameters to host fp32 tensors (state-dict order): `probe.state_dict()`. */
 int prag_trainer_export(prag_trainer_t* t, float* ln0_w, float* ln0_b, float* W1, float* b1, float* ln1_w,
                         float* ln1_b, float* W2, float* b2, float* ln2_w, float* ln2_b, float* W3, float* b3);
+
+/* `probe.train()` / `probe.eval()` (train.py:255-257, 299): with training == 0 the dropout of the
+ * following steps is the identity.  Handles start in training mode. */
+int prag_trainer_set_training(prag_trainer_t* t, int training);
 
 /* Learning rate the next step will use (`optim.param_groups[0]['lr']`), steps taken so far. */
 double prag_trainer_lr(const prag_trainer_t* t);

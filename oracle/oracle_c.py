@@ -53,7 +53,7 @@ def gate(logits: np.ndarray, ablation: int = 0, theta: float = 0.0):
     L, B, _ = lg.shape
     ps = np.empty((B, 2), np.float32)
     dec = np.empty((B,), np.int32)
-    rc = lib().oracle_gate(_fp(lg), L, B, int(ablation), ctypes.c_float(theta), _fp(ps),
+    rc = lib().oracle_gate(_fp(lg), L, B, int(ablation), ctypes.c_double(theta), _fp(ps),
                            dec.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
     assert rc == 0
     return ps, dec

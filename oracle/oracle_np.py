@@ -91,10 +91,11 @@ def gate(logits: np.ndarray, ablation: int = 0, theta: float = 0.0):
     """logits [L, B, 2] -> (probsum float32 [B, 2], decision int32 [B]).
 
     ``for num in range(args.ablation, len(logits)): s += softmax(logits[num])``
-    then ``0 if s[0] + theta < s[1] else 1`` (1 = retrieve).  The reference
-    does this in float32 on CPU, layer by layer in increasing order; the
-    restatement keeps that order and float32 accumulation so that decisions
-    are comparable bit for bit.
+    then ``0 if s[0].item() + theta < s[1].item() else 1`` (1 = retrieve,
+    exp_rag.py:414).  The reference sums in float32 on CPU, layer by layer in
+    increasing order, and compares Python floats (the float32 sums widened to
+    double, theta a double); the restatement keeps both so that decisions are
+    comparable bit for bit.
     """
     lg = np.asarray(logits, dtype=np.float32)
     L, B, _ = lg.shape
@@ -105,8 +106,7 @@ def gate(logits: np.ndarray, ablation: int = 0, theta: float = 0.0):
         e = np.exp(z)
         p = (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
         s = (s + p).astype(np.float32)
-    th = np.float32(theta)
-    decision = np.where((s[:, 0] + th) < s[:, 1], 0, 1).astype(np.int32)
+    decision = np.where((s[:, 0].astype(np.float64) + float(theta)) < s[:, 1].astype(np.float64), 0, 1).astype(np.int32)
     return s, decision
 
 

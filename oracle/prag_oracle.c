@@ -87,7 +87,7 @@ int oracle_prober_forward(const float* x, int B, int d, int h, int c,
 
 /* logits [L,B,2] -> probsum [B,2] (float accumulation in layer order, as the
  * reference's CPU tensors do), decision[b] = (s0 + theta < s1) ? 0 : 1 */
-int oracle_gate(const float* logits, int L, int B, int ablation, float theta,
+int oracle_gate(const float* logits, int L, int B, int ablation, double theta,
                 float* probsum, int32_t* decision) {
     for (int b = 0; b < B; ++b) {
         float s0 = 0.f, s1 = 0.f;
@@ -100,7 +100,7 @@ int oracle_gate(const float* logits, int L, int B, int ablation, float theta,
             s1 += (float)(e1 / (e0 + e1));
         }
         probsum[2 * b] = s0; probsum[2 * b + 1] = s1;
-        decision[b] = (s0 + theta < s1) ? 0 : 1;
+        decision[b] = ((double)s0 + theta < (double)s1) ? 0 : 1;   /* Python-float compare, exp_rag.py:414 */
     }
     return 0;
 }

@@ -54,8 +54,8 @@ SIGNATURES = {
     "prag_prober_create": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I, _I]),
     "prag_prober_load_layer": (_I, [_P, _I] + [_FP] * 12),
     "prag_prober_forward": (_I, [_P, _P, _I, _L, _I, _I, _I, _P, _P]),
-    "prag_gate": (_I, [_P, _P, _I, _L, _I, _I, _F, _P, _P, _P, _P]),
-    "prag_gate_from_logits": (_I, [_P, _I, _I, _I, _F, _P, _P, _P]),
+    "prag_gate": (_I, [_P, _P, _I, _L, _I, _I, ctypes.c_double, _P, _P, _P, _P]),
+    "prag_gate_from_logits": (_I, [_P, _I, _I, _I, ctypes.c_double, _P, _P, _P]),
     "prag_prober_effective_weights": (_I, [_P, _I] + [_FP] * 6),
     "prag_prober_reserve": (_I, [_P, _I]),
     "prag_prober_profile": (_I, [_P, _I]),
@@ -68,6 +68,7 @@ SIGNATURES = {
     "prag_trainer_load": (_I, [_P] + [_FP] * 12),
     "prag_trainer_step": (_I, [_P, _P, _P, _I, _P, _P, _P]),
     "prag_trainer_export": (_I, [_P] + [_FP] * 12),
+    "prag_trainer_set_training": (_I, [_P, _I]),
     "prag_trainer_lr": (ctypes.c_double, [_P]),
     "prag_trainer_steps": (_L, [_P]),
     "prag_trainer_destroy": (None, [_P]),

@@ -44,10 +44,14 @@ struct EventRing {
     bool on = false;
     int enable(int slots) {
         disable();
-        a.resize(slots);
-        b.resize(slots);
-        for (int i = 0; i < slots; ++i) {
-            if (hipEventCreate(&a[i]) != hipSuccess || hipEventCreate(&b[i]) != hipSuccess) return PRAG_EHIP;
+        a.reserve(slots);
+        b.reserve(slots);
+        for (int i = 0; i < slots; ++i) {   // only successfully created events are ever tracked
+            hipEvent_t ea, eb;
+            if (hipEventCreate(&ea) != hipSuccess) { disable(); return PRAG_EHIP; }
+            if (hipEventCreate(&eb) != hipSuccess) { (void)hipEventDestroy(ea); disable(); return PRAG_EHIP; }
+            a.push_back(ea);
+            b.push_back(eb);
         }
         n = 0;
         on = slots > 0;

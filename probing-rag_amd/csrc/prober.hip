@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void pool_masked_mean_kernel(const T* __restri
 // gate: exp_rag.py:407-415 in the reference's own order (float32, layer by layer)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ logits, int L, int B,
-                                                  int ablation, float theta,
+                                                  int ablation, double theta,
                                                   float* __restrict__ probsum,
                                                   int32_t* __restrict__ decision) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -626,7 +626,9 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ log
         probsum[2 * b] = s0;
         probsum[2 * b + 1] = s1;
     }
-    if (decision) decision[b] = (s0 + theta < s1) ? 0 : 1;
+    // the reference compares Python floats: `s[0].item() + threshold < s[1].item()` (exp_rag.py:414)
+    // - float32 sums widened to double, theta a double
+    if (decision) decision[b] = ((double)s0 + theta < (double)s1) ? 0 : 1;
 }
 
 // ---------------------------------------------------------------------------
@@ -692,7 +694,8 @@ struct prag_prober {
     std::vector<bool> loaded;
     std::vector<LayerDev> h_layers;
     std::vector<HostLayer> eff;
-    std::vector<void*> allocs;
+    std::vector<std::vector<void*>> allocs;  // device buffers per layer (freed when the layer is reloaded)
+    int upload_layer = 0;
     LayerDev* d_layers = nullptr;
     _Float16* ws_h = nullptr;  // [L][maxB][d] hi / lo workspace for fp32 activations
     _Float16* ws_l = nullptr;
@@ -738,7 +741,7 @@ template <typename T>
 static int upload(prag_prober* p, const std::vector<T>& v, const T** out) {
     void* dptr = nullptr;
     PRAG_HIP(hipMalloc(&dptr, v.size() * sizeof(T)));
-    p->allocs.push_back(dptr);
+    p->allocs[p->upload_layer].push_back(dptr);
     PRAG_HIP(hipMemcpy(dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = reinterpret_cast<const T*>(dptr);
     return PRAG_OK;
@@ -764,6 +767,7 @@ extern "C" int prag_prober_create(prag_prober_t** out, int n_layers, int d_model
     p->loaded.assign(n_layers, false);
     p->h_layers.resize(n_layers);
     p->eff.resize(n_layers);
+    p->allocs.resize(n_layers);
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_layers), sizeof(LayerDev) * n_layers);
     if (e != hipSuccess) {
         set_error("hipMalloc failed: %s", hipGetErrorString(e));
@@ -786,6 +790,15 @@ extern "C" int prag_prober_load_layer(prag_prober_t* p, int li, const float* ln0
     const int d = p->d, H = kHidden;
     LayerDev& L = p->h_layers[li];
     HostLayer& E = p->eff[li];
+    // a reload (checkpoint swap, load_state_dict per epoch) replaces the layer's buffers: wait for
+    // launches that may still read the old ones, then free them
+    if (!p->allocs[li].empty()) {
+        PRAG_HIP(hipDeviceSynchronize());
+        for (void* q : p->allocs[li]) (void)hipFree(q);
+        p->allocs[li].clear();
+        p->loaded[li] = false;
+    }
+    p->upload_layer = li;
 
     // ---- fc1: fold ln0 affine, scale, pack ---------------------------------
     std::vector<double> Wg((size_t)H * d);
@@ -1019,7 +1032,7 @@ extern "C" int prag_prober_forward(prag_prober_t* p, const void* x_dev, int x_dt
     return PRAG_EUNSUPPORTED;
 }
 
-extern "C" int prag_gate_from_logits(const float* logits_dev, int L, int B, int ablation, float theta,
+extern "C" int prag_gate_from_logits(const float* logits_dev, int L, int B, int ablation, double theta,
                                      float* probsum_dev, int32_t* decision_dev, void* stream) {
     PRAG_REQUIRE(logits_dev != nullptr, PRAG_EINVAL, "logits_dev is NULL");
     PRAG_REQUIRE(L >= 1 && B >= 1, PRAG_EINVAL, "L=%d B=%d", L, B);
@@ -1032,7 +1045,7 @@ extern "C" int prag_gate_from_logits(const float* logits_dev, int L, int B, int 
 }
 
 extern "C" int prag_gate(prag_prober_t* p, const void* x_dev, int x_dtype, int64_t x_layer_stride, int B,
-                         int ablation, float theta, float* logits_dev, float* probsum_dev,
+                         int ablation, double theta, float* logits_dev, float* probsum_dev,
                          int32_t* decision_dev, void* stream) {
     PRAG_REQUIRE(p != nullptr, PRAG_EINVAL, "prober handle is NULL");
     int rc = prag_prober_forward(p, x_dev, x_dtype, x_layer_stride, 0, p->n_layers, B, logits_dev, stream);
@@ -1058,7 +1071,8 @@ extern "C" int prag_prober_profile_read(prag_prober_t* p, float* ms, int cap, in
 extern "C" void prag_prober_destroy(prag_prober_t* p) {
     if (!p) return;
     p->prof.disable();
-    for (void* q : p->allocs) (void)hipFree(q);
+    for (auto& layer : p->allocs)
+        for (void* q : layer) (void)hipFree(q);
     if (p->d_layers) (void)hipFree(p->d_layers);
     if (p->ws_h) (void)hipFree(p->ws_h);
     if (p->ws_l) (void)hipFree(p->ws_l);

@@ -155,7 +155,9 @@ __global__ __launch_bounds__(256) void tr_loss_kernel(const float* __restrict__ 
             probs[(int64_t)b * C + c] = p[c];
             e2 += expf(p[c]);
         }
-        const int y = labels[b];
+        // labels are validated by the host layer (torch's CrossEntropyLoss raises on a class outside
+        // [0,C)); the clamp only keeps a stray value from indexing outside p[]
+        const int y = min(max(labels[b], 0), C - 1);
         local += logf(e2) - p[y];
         // d loss / d p = (softmax(p) - onehot) / B ; through the first softmax: dz = p * (gp - sum(gp * p))
         float gp[16], dot = 0.f;
@@ -323,6 +325,7 @@ struct prag_trainer {
     uint32_t seed;
     int64_t step = 0;  // optimiser steps taken
     bool loaded = false;
+    bool training = true;  // false: dropout is the identity (`probe.eval()`)
     // parameters / moments: one buffer each, state-dict order
     float* params = nullptr;
     float* exp_avg = nullptr;
@@ -418,6 +421,12 @@ extern "C" double prag_trainer_lr(const prag_trainer_t* t) {
 }
 extern "C" int64_t prag_trainer_steps(const prag_trainer_t* t) { return t ? t->step : -1; }
 
+extern "C" int prag_trainer_set_training(prag_trainer_t* t, int training) {
+    PRAG_REQUIRE(t != nullptr, PRAG_EINVAL, "trainer handle is NULL");
+    t->training = training != 0;
+    return PRAG_OK;
+}
+
 static int trainer_reserve(prag_trainer* t, int B) {
     if (B <= t->b_cap) return PRAG_OK;
     if (t->ws) (void)hipFree(t->ws);
@@ -460,7 +469,7 @@ extern "C" int prag_trainer_step(prag_trainer_t* t, const float* x_dev, const in
     const uint32_t site_key[2] = {tmix32(key ^ 1u), tmix32(key ^ 2u)};
     uint32_t thresh = 0;
     float scale = 1.0f;
-    if (t->dropout_p > 0.0) {
+    if (t->training && t->dropout_p > 0.0) {
         const double th = nearbyint(t->dropout_p * 4294967296.0);
         thresh = th >= 4294967295.0 ? 4294967295u : (uint32_t)th;
         scale = (float)(1.0 / (1.0 - t->dropout_p));

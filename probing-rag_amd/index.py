@@ -189,32 +189,60 @@ def merge_topk(D_parts, I_parts, k: int, metric) -> tuple:
 #   fourcc "IxF2"(L2) | "IxFI"(IP); int32 d; int64 ntotal; int64 dummy(1<<20) x2;
 #   uint8 is_trained; int32 metric_type (0 = IP, 1 = L2); uint64 n_floats; float32[]
 # ---------------------------------------------------------------------------
-def write_index(index: HipFlatIndex, path: str):
-    rows = index.reconstruct_n(0, index.ntotal)
+_HDR = "<iqqqBi"          # d, ntotal, dummy, dummy, is_trained, metric_type
+
+
+def write_index(index: HipFlatIndex, path: str, chunk_rows: int = 1 << 16):
+    """``faiss.write_index(index, path)`` (make_indexer.py:457).  The rows are streamed out in
+    bounded chunks (device -> host -> file): no second copy of the corpus in HBM or host RAM."""
     l2 = index.metric == METRIC_L2
+    n, d = index.ntotal, index.d
     with open(path, "wb") as f:
         f.write(b"IxF2" if l2 else b"IxFI")
-        f.write(struct.pack("<iqqqBi", index.d, index.ntotal, 1 << 20, 1 << 20, 1, 1 if l2 else 0))
-        f.write(struct.pack("<Q", rows.size))
-        f.write(rows.tobytes())
+        f.write(struct.pack(_HDR, d, n, 1 << 20, 1 << 20, 1, 1 if l2 else 0))
+        f.write(struct.pack("<Q", n * d))
+        for lo in range(0, n, chunk_rows):
+            index.reconstruct_n(lo, min(chunk_rows, n - lo)).tofile(f)
+
+
+def read_index_header(f):
+    """Parse the IndexFlat header at the current position of binary file `f`;
+    returns (d, ntotal, metric_name) and leaves `f` at the first row."""
+    cc = f.read(4)
+    if cc not in (b"IxF2", b"IxFI", b"IxFl"):
+        raise ValueError(f"not a flat faiss index (fourcc {cc!r})")
+    raw = f.read(struct.calcsize(_HDR))
+    if len(raw) != struct.calcsize(_HDR):
+        raise ValueError("truncated faiss index header")
+    d, ntotal, _, _, _, metric_type = struct.unpack(_HDR, raw)
+    if metric_type > 1:
+        f.read(4)  # metric_arg
+    raw = f.read(8)
+    if len(raw) != 8:
+        raise ValueError("truncated faiss index header")
+    (n_floats,) = struct.unpack("<Q", raw)
+    if d <= 0 or ntotal < 0 or n_floats != ntotal * d:
+        raise ValueError(f"header says {ntotal}x{d} but holds {n_floats} floats")
+    if metric_type not in (0, 1):
+        raise ValueError(f"metric_type {metric_type}: only inner product (0) and L2 (1) flat indexes are supported")
+    return d, ntotal, "l2" if metric_type == 1 else "ip"
 
 
 def read_index(path: str, store: str = "f32", chunk_rows: int = 1 << 18) -> HipFlatIndex:
+    """``faiss.read_index(path)`` (exp_rag.py:248) for IndexFlatL2 / IndexFlatIP files."""
     with open(path, "rb") as f:
-        cc = f.read(4)
-        if cc not in (b"IxF2", b"IxFI", b"IxFl"):
-            raise ValueError(f"{path}: not a flat faiss index (fourcc {cc!r})")
-        d, ntotal, _, _, _, metric_type = struct.unpack("<iqqqBi", f.read(4 + 8 * 3 + 1 + 4))
-        if metric_type > 1:
-            f.read(4)  # metric_arg
-        (n_floats,) = struct.unpack("<Q", f.read(8))
-        if n_floats != ntotal * d:
-            raise ValueError(f"{path}: header says {ntotal}x{d} but holds {n_floats} floats")
-        ix = HipFlatIndex(d, "l2" if metric_type == 1 else "ip", store, capacity=ntotal)
+        try:
+            d, ntotal, metric = read_index_header(f)
+        except ValueError as e:
+            raise ValueError(f"{path}: {e}") from None
+        ix = HipFlatIndex(d, metric, store, capacity=ntotal)
         done = 0
         while done < ntotal:
             m = min(chunk_rows, ntotal - done)
-            ix.add(np.frombuffer(f.read(m * d * 4), dtype=np.float32).reshape(m, d))
+            buf = f.read(m * d * 4)
+            if len(buf) != m * d * 4:
+                raise ValueError(f"{path}: truncated after {done + len(buf) // (d * 4)} of {ntotal} rows")
+            ix.add(np.frombuffer(buf, dtype=np.float32).reshape(m, d))
             done += m
     return ix
 

@@ -232,8 +232,13 @@ class _LayerView:
         return self
 
     def train(self, mode: bool = True):
+        """``probe.train()`` (train.py:255-257): this object is the eval-mode forward (dropout =
+        identity, utils.py:329).  The training step lives in ``HipProberTrainer`` (train.py:126-135,
+        210-220 -> prag_trainer_*), which also hands its parameters back as a state dict."""
         if mode:
-            raise NotImplementedError("the HIP prober is forward-only (training is outside the hot path)")
+            raise RuntimeError("HipProber is the eval-mode prober (utils.py:329); train with "
+                               "probing_rag_amd.HipProberTrainer(d_model, ...) / method_2_train and load its "
+                               "state_dict() here")
         return self
 
 
@@ -270,17 +275,63 @@ def load_prober_cfg_gemma_2b(model, config, position, device, start, end, step):
     return [config(model, "tokens_mean", j, position, device) for j in range(start, end, step)]
 
 
-def load_prober_models(state_dicts, cfg_list, weights: str = "f32"):
-    """utils.py:385-387.  The reference maps ``--ds`` to hard-coded checkpoint
-    paths (utils.py:303-326) that are not shipped; here ``state_dicts`` is either
-    a list of state dicts / checkpoint paths (one per cfg) or a callable
-    ``cfg -> state dict``.  Returns the list of per-layer probers, all living in
-    one ensemble (``probers[0]._ens``)."""
+def prober_checkpoint_path(_ds, cfg):
+    """The ``--ds`` -> checkpoint path table of utils.py:303-326, as a function: returns the path the
+    reference would ``torch.load`` for this cfg, or None where the reference loads nothing (its
+    ``else: assert '<string>'`` is a no-op, utils.py:328, so an unknown ``model_id`` silently keeps the
+    randomly initialised prober; here such a prober stays unloaded and its first call raises)."""
+    m, l, p = cfg.method, cfg.layer, cfg.position
+    if cfg.model_id == "mistralai/Mistral-7B-Instruct-v0.1":
+        return f"ckpt/probing_ckpt/Mistral-7B-Instruct-v0.1_{m}_probe_2_l{l}_{p}_1.pt"
+    if cfg.model_id != "google/gemma-2b":
+        return None
+    table = {
+        25: f"ckpt/_25/0.25_gemma-2b_{m}_2_l{l}_{p}_ep1.pt",
+        50: f"ckpt/_5/0.5_gemma-2b_{m}_2_l{l}_{p}_ep1.pt",
+        75: f"ckpt/_75/0.75_gemma-2b_{m}_2_l{l}_{p}_ep1.pt",
+        777: f"ckpt/_75_full/0.75_gemma-2b_{m}_2_l{l}_{p}_ep.pt",
+        3: f"ckpt/_3/in3_1.0_gemma-2b_{m}_2_l{l}_{p}_ep1.pt",
+        333: f"ckpt/_3_3/in3_0.33_gemma-2b_{m}_2_l{l}_{p}_ep.pt",
+        366: f"ckpt/_3_6/in3_0.66_gemma-2b_{m}_2_l{l}_{p}_ep.pt",
+        3000: f"ckpt/_3_1000/in3_1000_gemma-2b_{m}_2_l{l}_{p}_ep11.pt",
+        1000: f"ckpt/_1000/1000_gemma-2b_{m}_2_l{l}_{p}_ep11.pt",
+    }
+    return table.get(_ds, f"ckpt/prob_model_cot_v1/gemma-2b_linear995_{m}_probe_2_l{l}_{p}_1.pt")
+
+
+def _cfg_device(cfg):
+    return cfg.device if str(cfg.device) not in ("cuda", "cpu") else None
+
+
+def load_prober(_ds, cfg, weights: str = "f32"):
+    """utils.py:291-330: ``ImprovedProbe(cfg.d_model, cfg.num_classes).to(cfg.device)``, then
+    ``load_state_dict(torch.load(<path chosen by cfg.model_id and --ds>))`` (paths relative to the
+    working directory, like the reference's), then ``.eval()``."""
+    import torch
+    prober = HipProber(cfg.d_model, cfg.num_classes, weights=weights, device=_cfg_device(cfg))
+    path = prober_checkpoint_path(_ds, cfg)
+    if path is not None:
+        prober.load_state_dict(torch.load(path, map_location="cpu"))
+    return prober.eval()
+
+
+def load_prober_models(_ds, cfg_list, weights: str = "f32"):
+    """utils.py:385-387, ``[load_prober(_ds, cfg) for cfg in cfg_list]`` - exp_rag.py:312 calls it
+    with the ``--ds`` integer.  The probers of all layers live in ONE ensemble
+    (``probers[0]._ens``) so the gate can run them in a single launch; each list element still
+    behaves like its own ``ImprovedProbe``.  Besides the reference's integer, ``_ds`` may be a list
+    of state dicts / checkpoint paths (one per cfg) or a callable ``cfg -> state dict | path``
+    (checkpoints are not shipped with the reference)."""
     import torch
     ens = HipProberEnsemble(len(cfg_list), cfg_list[0].d_model, cfg_list[0].num_classes, weights=weights,
-                            device=cfg_list[0].device if str(cfg_list[0].device) != "cuda" else None)
+                            device=_cfg_device(cfg_list[0]))
     for i, cfg in enumerate(cfg_list):
-        sd = state_dicts(cfg) if callable(state_dicts) else state_dicts[i]
+        if isinstance(_ds, int):
+            sd = prober_checkpoint_path(_ds, cfg)
+            if sd is None:
+                continue                      # the reference loads nothing for this model_id
+        else:
+            sd = _ds(cfg) if callable(_ds) else _ds[i]
         if isinstance(sd, (str, bytes)):
             sd = torch.load(sd, map_location="cpu")
         ens.load_layer(i, sd)

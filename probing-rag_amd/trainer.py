@@ -66,8 +66,13 @@ class HipProberTrainer:
         return {k: torch.from_numpy(a) for k, a in zip(STATE_KEYS, arrs)}
 
     def train(self, mode: bool = True):
-        self.training = mode
+        """``probe.train()`` / ``probe.eval()``: in eval mode the dropout of ``step`` is the identity."""
+        self.training = bool(mode)
+        _lib.check(_lib.lib().prag_trainer_set_training(self._h, 1 if mode else 0))
         return self
+
+    def eval(self):
+        return self.train(False)
 
     def to(self, device):
         return self
@@ -88,7 +93,13 @@ class HipProberTrainer:
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
         if x.dim() != 2 or x.shape[1] != self.d_model:
             raise ValueError(f"expected [B,{self.d_model}], got {tuple(x.shape)}")
-        lab = torch.as_tensor(labels).to(device=self.device, dtype=torch.int32).contiguous()
+        lab = torch.as_tensor(labels)
+        if lab.dim() != 1 or lab.shape[0] != x.shape[0]:
+            raise ValueError(f"expected {x.shape[0]} labels, got {tuple(lab.shape)}")
+        if lab.numel() and (int(lab.min()) < 0 or int(lab.max()) >= self.num_classes):
+            # torch.nn.CrossEntropyLoss raises for a class index outside [0, C) (train.py:149-150)
+            raise IndexError(f"Target {int(lab.min()) if int(lab.min()) < 0 else int(lab.max())} is out of bounds.")
+        lab = lab.to(device=self.device, dtype=torch.int32).contiguous()
         B = x.shape[0]
         loss = torch.empty((), dtype=torch.float32, device=self.device)
         probs = torch.empty((B, self.num_classes), dtype=torch.float32, device=self.device)

@@ -458,3 +458,58 @@ def test_shard_simulation_with_large_k():
     D, I = pra.search_shards_on_one_gpu(shards, torch.from_numpy(Q).cuda(), k, "l2")
     D0, I0 = onp.flat_search(_stored(X, onp.METRIC_L2, "f16"), Q, k, onp.METRIC_L2)
     _check(D.cpu().numpy(), I.cpu().numpy(), D0, I0, onp.METRIC_L2)
+
+
+def test_read_index_accepts_a_hand_assembled_faiss_file(tmp_path):
+    """exp_rag.py:248 `faiss.read_index(path)`: the file below is put together byte by byte from the
+    IndexFlat layout of faiss's index_write.cpp (fourcc, d, ntotal, 2 dummies, is_trained,
+    metric_type, float count, rows) - not written by this package - and must load, search and
+    write back to the same bytes; a file cut short must be refused."""
+    import struct
+    import probing_rag_amd as pra
+    d, n = 768, 300
+    X = onp.synth_rows(3, 0, n, d)
+    for fourcc, mt, metric in ((b"IxF2", 1, onp.METRIC_L2), (b"IxFI", 0, onp.METRIC_IP)):
+        raw = (fourcc + struct.pack("<i", d) + struct.pack("<q", n) + struct.pack("<q", 1 << 20) * 2 +
+               struct.pack("<B", 1) + struct.pack("<i", mt) + struct.pack("<Q", n * d) + X.astype("<f4").tobytes())
+        p = tmp_path / f"contriever_nq_2_{mt}.bin"
+        p.write_bytes(raw)
+        ix = pra.read_index(str(p), chunk_rows=128)
+        assert ix.ntotal == n and ix.d == d and ix.metric == metric
+        Q = onp.synth_rows(4, 0, 3, d)
+        D, I = ix.search(Q, 5)
+        D0, I0 = onp.flat_search(X, Q, 5, metric)
+        _check(D, I, D0, I0, metric)
+        out = tmp_path / "back.bin"
+        pra.write_index(ix, str(out), chunk_rows=77)                 # streamed in bounded chunks
+        assert out.read_bytes() == raw
+        (tmp_path / "cut.bin").write_bytes(raw[: len(raw) - 1000])
+        with pytest.raises(ValueError, match="truncated"):
+            pra.read_index(str(tmp_path / "cut.bin"))
+    # fp16 storage writes the (widened) stored rows - still a valid float32 faiss file
+    h = pra.HipFlatIndex(d, "l2", "f16")
+    h.add(X)
+    pra.write_index(h, str(tmp_path / "h.bin"), chunk_rows=100)
+    back = pra.read_index(str(tmp_path / "h.bin"))
+    assert np.array_equal(back.reconstruct_n(), X.astype(np.float16).astype(np.float32))
+
+
+def test_add_waits_for_rows_produced_on_the_callers_stream():
+    """`index.add(cuda_tensor)` used to launch on the NULL stream while the tensor was still
+    being produced on torch's (non-blocking) current stream."""
+    import torch
+    import probing_rag_amd as pra
+    d, n = 768, 200_000
+    X = onp.synth_rows(8, 0, 2000, d)
+    ix = pra.HipFlatIndex(d, "l2", "f32")
+    s = torch.cuda.Stream()
+    big = torch.zeros((n, d), device="cuda")
+    src = torch.from_numpy(np.tile(X, (n // 2000, 1))).cuda()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        for _ in range(6):                      # keep the side stream busy, then produce the rows on it
+            big = big * 0.5 + 1.0
+        rows = src * 2.0 - src                  # == src, computed late on stream s
+        ix.add(rows)
+    got = ix.reconstruct_n(n - 2000, 2000)
+    assert np.array_equal(got, X)

@@ -213,3 +213,93 @@ def test_method_2_eval_matches_reference_golden(torch_cuda, golden):
     np.testing.assert_allclose(probs.cpu().numpy(), golden[f"{case['name']}/probs"], atol=TOL, rtol=0)
     assert abs(float(loss) - float(golden[f"{case['name']}/loss"])) < 1e-4
     assert acc == round(float(golden[f"{case['name']}/acc"]), 4) and n == case["B"]
+
+
+def _model_with_cfg(model_id="google/gemma-2b"):
+    class Cfg:
+        d_model, tokenizer_name = 2048, model_id
+
+    class Model:
+        cfg = Cfg()
+    return Model()
+
+
+@pytest.mark.parametrize("ds", [3, 25, 12345])
+def test_load_prober_models_with_the_reference_call(torch_cuda, golden, tmp_path, monkeypatch, ds):
+    """exp_rag.py:311-312 verbatim: ``cfg_list = load_prober_cfg_gemma_2b(model, Config_Maker, position,
+    device, 6, 17, 2); probers = load_prober_models(_ds, cfg_list)`` with the --ds INTEGER.  The
+    checkpoints (not shipped with the reference) are written under the names utils.py:303-326 builds,
+    relative to the working directory, then the reference's own per-layer loop runs on the result."""
+    import probing_rag_amd as pra
+    torch = torch_cuda
+    case = cases.PROBER_CASES[1]
+    model = _model_with_cfg()
+    cfg_list = pra.load_prober_cfg_gemma_2b(model, pra.Config_Maker, "resid_post", "cuda", 6, 17, 2)
+    states = [cases.synth_state(case["wseed"] + l, case["d"]) for l in range(case["L"])]
+    monkeypatch.chdir(tmp_path)
+    for cfg, st in zip(cfg_list, states):
+        path = tmp_path / pra.prober_checkpoint_path(ds, cfg)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        torch.save({k: torch.from_numpy(v) for k, v in st.items()}, str(path))    # train.py:344-345
+    probers = pra.load_prober_models(ds, cfg_list)
+    assert len(probers) == 6
+    x = torch.from_numpy(cases.case_x(case)).cuda()
+    logits = pra.return_prober_logit_gemma_2b(lambda cfg, prober: prober(x[cfg_list.index(cfg)]), cfg_list, probers)
+    got = np.stack([t.numpy() for t in logits])
+    np.testing.assert_allclose(got, golden[f"{case['name']}/logits"], atol=TOL, rtol=0)
+    # one prober at a time, as utils.py:291-330 does it
+    single = pra.load_prober(ds, cfg_list[2])
+    np.testing.assert_allclose(single(x[2]).cpu().numpy(), got[2], atol=1e-6, rtol=0)
+    with pytest.raises(RuntimeError, match="eval-mode"):
+        single.train()                                         # points at HipProberTrainer
+    assert single.train(False) is single
+    # a missing checkpoint is the reference's FileNotFoundError
+    with pytest.raises(FileNotFoundError):
+        pra.load_prober_models(777, cfg_list)
+    # a model id without a branch in utils.py:303-326: nothing is loaded (no-op assert), first call raises
+    other = pra.load_prober_cfg_gemma_2b(_model_with_cfg("meta-llama/Llama-2-7b"), pra.Config_Maker,
+                                         "resid_post", "cuda", 6, 9, 2)
+    unloaded = pra.load_prober_models(ds, other)
+    with pytest.raises(pra.PragError, match="PRAG_ESTATE"):
+        unloaded[0](x[0])
+
+
+def test_reloading_a_layer_replaces_its_weights(torch_cuda):
+    """load_state_dict per epoch / checkpoint swap: the layer's device buffers are replaced (and the
+    old ones freed), other layers keep theirs."""
+    import probing_rag_amd as pra
+    torch = torch_cuda
+    case = cases.PROBER_CASES[1]
+    ens, states = _ensemble(case, "f32")
+    x = cases.case_x(case)
+    xd = torch.from_numpy(x).cuda()
+    before = ens.forward(xd).cpu().numpy()
+    new3 = cases.synth_state(999, case["d"])
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        ens.load_layer(3, new3)
+    assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)            # 20 reloads do not pile up buffers
+    after = ens.forward(xd).cpu().numpy()
+    np.testing.assert_allclose(after[3], onp.prober_forward(new3, x[3]), atol=TOL, rtol=0)
+    keep = [l for l in range(case["L"]) if l != 3]
+    assert np.array_equal(after[keep], before[keep])
+
+
+def test_gate_threshold_is_compared_in_double_like_python(torch_cuda):
+    """exp_rag.py:414 compares Python floats: float32 sums widened to double, theta a double.  A
+    threshold that only differs from the knife edge below float32 resolution must still decide."""
+    import probing_rag_amd as pra
+    torch = torch_cuda
+    lg = np.zeros((1, 4, 2), np.float32)
+    lg[0, :, 1] = [0.0, 1.0, -1.0, 0.3]
+    logits = torch.from_numpy(lg).cuda()
+    ps, _ = pra.gate_from_logits(logits, 0, 0.0)
+    ps = ps.cpu().numpy().astype(np.float64)
+    edge = ps[:, 1] - ps[:, 0]                                  # s0 + theta < s1  <=>  theta < edge
+    for b in range(4):
+        for theta in (np.nextafter(edge[b], -np.inf), edge[b], np.nextafter(edge[b], np.inf)):
+            _, dec = pra.gate_from_logits(logits, 0, float(theta))
+            want = 0 if ps[b, 0] + float(theta) < ps[b, 1] else 1
+            assert int(dec[b]) == want
+            _, odec = onp.gate(lg, 0, float(theta))
+            assert int(odec[b]) == want

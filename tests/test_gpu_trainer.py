@@ -121,3 +121,32 @@ def test_training_step_matches_oracle_and_torch_autograd(B, d):
         opt.zero_grad()
     for k in onp.STATE_KEYS:
         _params_close(sd[k].numpy(), W[k].detach().cpu().numpy())
+
+
+def test_labels_are_validated_and_eval_mode_disables_dropout():
+    """torch's CrossEntropyLoss raises for a class outside [0, C) (train.py:149-150); `probe.eval()`
+    makes dropout the identity (train.py:299)."""
+    import torch
+    import probing_rag_amd as pra
+    d, B = 2048, 6
+    st = cases.synth_state(77, d)
+    x = torch.from_numpy(onp.synth_rows(78, 0, B, d)).cuda()
+    tr = pra.HipProberTrainer(d, 2, seed=5).load_state_dict(st)
+    for bad in ([0, 1, 2, 0, 1, 0], [0, -1, 1, 0, 1, 0], [0, 1, -100, 0, 1, 0]):
+        with pytest.raises(IndexError, match="out of bounds"):
+            tr.step(x, torch.tensor(bad))
+    with pytest.raises(ValueError):
+        tr.step(x, torch.tensor([0, 1]))
+    assert tr.steps == 0
+    labels = torch.tensor([0, 1, 1, 0, 1, 0])
+    # eval-mode step: forward == the inference prober's probabilities (no dropout mask)
+    tr.eval()
+    _, probs = tr.step(x, labels)
+    want = onp.prober_forward(st, x.cpu().numpy()).astype(np.float64)
+    want = np.exp(want - want.max(1, keepdims=True))
+    want /= want.sum(1, keepdims=True)
+    np.testing.assert_allclose(probs.cpu().numpy(), want, atol=2e-5, rtol=0)
+    # back in train mode the masks are applied again (p = 0.1 changes the forward)
+    tr2 = pra.HipProberTrainer(d, 2, seed=5).load_state_dict(st)
+    _, p_train = tr2.train().step(x, labels)
+    assert np.abs(p_train.cpu().numpy() - want).max() > 1e-4

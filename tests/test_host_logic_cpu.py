@@ -142,3 +142,93 @@ def test_merge_topk_properties():
             assert (I[b, len(want):] == -1).all()
 
     check()
+
+
+def _cfg(model_id="google/gemma-2b", layer=6, position="resid_post", method="tokens_mean"):
+    class Cfg:
+        pass
+    c = Cfg()
+    c.model_id, c.layer, c.position, c.method, c.device, c.d_model, c.num_classes = \
+        model_id, layer, position, method, "cuda", 2048, 2
+    return c
+
+
+def test_checkpoint_path_table_matches_the_reference():
+    """utils.py:303-326, every branch: the strings below are what the reference passes to torch.load
+    for --ds in {25,50,75,777,3,333,366,3000,1000, anything else} and for the Mistral model id."""
+    c = _cfg(layer=12, position="resid_mid")
+    want = {
+        25: "ckpt/_25/0.25_gemma-2b_tokens_mean_2_l12_resid_mid_ep1.pt",
+        50: "ckpt/_5/0.5_gemma-2b_tokens_mean_2_l12_resid_mid_ep1.pt",
+        75: "ckpt/_75/0.75_gemma-2b_tokens_mean_2_l12_resid_mid_ep1.pt",
+        777: "ckpt/_75_full/0.75_gemma-2b_tokens_mean_2_l12_resid_mid_ep.pt",
+        3: "ckpt/_3/in3_1.0_gemma-2b_tokens_mean_2_l12_resid_mid_ep1.pt",
+        333: "ckpt/_3_3/in3_0.33_gemma-2b_tokens_mean_2_l12_resid_mid_ep.pt",
+        366: "ckpt/_3_6/in3_0.66_gemma-2b_tokens_mean_2_l12_resid_mid_ep.pt",
+        3000: "ckpt/_3_1000/in3_1000_gemma-2b_tokens_mean_2_l12_resid_mid_ep11.pt",
+        1000: "ckpt/_1000/1000_gemma-2b_tokens_mean_2_l12_resid_mid_ep11.pt",
+        0: "ckpt/prob_model_cot_v1/gemma-2b_linear995_tokens_mean_probe_2_l12_resid_mid_1.pt",
+        42: "ckpt/prob_model_cot_v1/gemma-2b_linear995_tokens_mean_probe_2_l12_resid_mid_1.pt",
+    }
+    for ds, path in want.items():
+        assert pra.prober_checkpoint_path(ds, c) == path
+    m = _cfg("mistralai/Mistral-7B-Instruct-v0.1", 14, "attn_out")
+    assert pra.prober_checkpoint_path(3, m) == \
+        "ckpt/probing_ckpt/Mistral-7B-Instruct-v0.1_tokens_mean_probe_2_l14_attn_out_1.pt"
+    # any other model id: the reference's `assert '<string>'` is a no-op and nothing is loaded
+    assert pra.prober_checkpoint_path(3, _cfg("meta-llama/Llama-2-7b")) is None
+
+
+def test_docstore_round_trip_and_lookup(tmp_path):
+    """make_indexer.py:461-464 writer, exp_rag.py:298 reader, exp_rag.py:436 lookup."""
+    import pandas as pd
+    texts = ["first passage, with a comma", 'second "quoted" passage', "third\nline break", "4th"]
+    ids = ["a1", "b2", "c3", "d4"]
+    p = str(tmp_path / "nq_index_2.csv")
+    pra.write_docstore(texts, ids, p)
+    assert open(p).readline().strip() == "doc,doc_id"                   # df.columns = ['doc','doc_id'], index=False
+    ref = pd.DataFrame([texts, ids]).T                                   # the reference's own three lines
+    ref.columns = ["doc", "doc_id"]
+    corpus = pra.read_docstore(p)
+    assert corpus.equals(pd.read_csv(p)) and list(corpus["doc"]) == texts and list(corpus["doc_id"]) == ids
+    I = np.array([[2, 0, 3, 1, 2]], dtype=np.int64)
+    assert pra.lookup_passages(corpus, I[0].tolist()) == list(ref.iloc[I[0].tolist(), 0])
+    look = pra.Docstore(p)
+    assert len(look) == 4 and look([3, 3, 0]) == ["4th", "4th", texts[0]]
+    with np.testing.assert_raises(IndexError):
+        look([4])
+
+
+def _faiss_flat_bytes(fourcc, d, ntotal, metric_type, rows, n_floats=None):
+    """An IndexFlat file assembled by hand from the layout of faiss's index_write.cpp
+    (write_index_header + WRITEXBVECTOR of the codes), the layout index.py's comment cites."""
+    n_floats = rows.size if n_floats is None else n_floats
+    return (fourcc + struct.pack("<i", d) + struct.pack("<q", ntotal) + struct.pack("<q", 1 << 20) * 2 +
+            struct.pack("<B", 1) + struct.pack("<i", metric_type) + struct.pack("<Q", n_floats) +
+            rows.astype("<f4").tobytes())
+
+
+def test_read_index_header_against_hand_assembled_faiss_files(tmp_path):
+    import io
+    rows = np.arange(15, dtype=np.float32).reshape(3, 5)
+    for fourcc, mt, name in ((b"IxF2", 1, "l2"), (b"IxFI", 0, "ip")):
+        raw = _faiss_flat_bytes(fourcc, 5, 3, mt, rows)
+        f = io.BytesIO(raw)
+        assert pra.read_index_header(f) == (5, 3, name)
+        assert np.frombuffer(f.read(), "<f4").tolist() == rows.ravel().tolist()   # positioned at row 0
+    # byte-level golden of the writer: the same bytes, from the same layout
+    class Fake:
+        d, ntotal, metric = 5, 3, pra.index.METRIC_IP
+        def reconstruct_n(self, a, n): return rows[a:a + n]
+    p = tmp_path / "w.bin"
+    pra.write_index(Fake(), str(p), chunk_rows=2)                         # streamed in 2 chunks
+    assert p.read_bytes() == _faiss_flat_bytes(b"IxFI", 5, 3, 0, rows)
+    # errors: wrong fourcc, truncated header, header/payload mismatch
+    for bad, msg in ((b"IxHN" + raw[4:], "fourcc"), (raw[:20], "truncated"),
+                     (_faiss_flat_bytes(b"IxF2", 5, 3, 1, rows, n_floats=14), "holds 14 floats")):
+        try:
+            pra.read_index_header(io.BytesIO(bad))
+        except ValueError as e:
+            assert msg in str(e)
+        else:
+            raise AssertionError(f"accepted a bad header ({msg})")
