@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__
     if (lane == 0) xnorm[dst_row0 + i] = (float)q;
 }
 
+constexpr int kSlotWordsFwd = 64;
 // ---------------------------------------------------------------------------
 // queries: q32[b] = (cosine ? q/||q|| : q) in f32 ; q16 = fp16(q32), rows padded
 // with zeros up to a multiple of the tile height.
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
                                                           uint32_t* __restrict__ mm_cnt, uint32_t* __restrict__ mm_ovf,
                                                           uint32_t mm_first_rows, float* __restrict__ qinfo,
                                                           double* __restrict__ qn2, uint32_t* __restrict__ n_flag,
-                                                          int* __restrict__ flag_list, int flag_all) {
+                                                          int* __restrict__ flag_list, int flag_all,
+                                                          uint32_t* __restrict__ g_slot) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= Bpad) return;
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
     }
     // the scan's chip-wide pruning bound: +inf for real queries; padding rows never collect anything
     if (lane == 0) g_tau[b] = b < B ? kSortablePosInf : kSortableNegInf;
+    g_slot[(int64_t)b * kSlotWordsFwd + lane] = kSortablePosInf;   // bound slots of the list scan (2 epochs x 32)
     if (b >= B) {
         for (int c = lane * 4; c < d; c += 256) {
             *reinterpret_cast<half4*>(q16 + (int64_t)b * d + c) = half4{0, 0, 0, 0};
@@ -222,7 +225,18 @@ struct ScanArgs {
     float* out_key;          // [n_lists][QT][KC]
     int* out_idx;
     uint32_t* g_tau;         // [QT] chip-wide pruning bound per query (sortable-uint keys, +inf at start)
+    uint32_t* g_slot;        // [QT][2 epochs][32] bound slots (below), or null: bound from g_tau only
 };
+
+// Chip-wide pruning bound without a pre-pass.  After its 2nd and its 8th tile ("epochs") every
+// lane-list publishes its two best keys: list l (one per wave and row-half, holding rows no other list
+// holds) min-s its j-th best key into slot (2l + j) mod KC of the query.  Within one epoch a list
+// contributes once, so the values in different slots belong to DIFFERENT rows, whenever they were
+// written; if all KC slots are set, KC distinct rows have keys <= max(slots), i.e. the KC-th best key
+// of the shard is <= max(slots) - at any time, whatever the interleaving.  The bound of a query is the
+// smaller of the two epochs' maxima.  With ~4000 lists per query it reaches the ~0.05 % quantile two
+// tiles into the scan (the pre-pass it replaces gave 0.2 % for two extra launches).
+constexpr int kSlotWords = kSlotWordsFwd;   // per query: 2 epochs x 32 slots (KC <= 32)
 
 template <int KC>
 struct TopList {
@@ -472,6 +486,47 @@ __device__ __forceinline__ void scan_topk_body(const ScanArgs& a, char* smem) {
             // global one every 8th tile (any lane's KC-th best anywhere is a valid upper bound;
             // a stale value is only looser).  Kept rare: 2048 waves on 64 hot words serialise.
             ++tiles_done;
+            // (not for 64 queries x 32-deep lists: 128 list registers leave no room, the whole list
+            // state went to scratch; that shape keeps the pre-pass)
+            constexpr bool SLOTS = !(QT == 64 && KC == 32);
+            if (SLOTS && a.g_slot) {
+                if (tiles_done == 2 || tiles_done == 8) {   // publish this wave's lists (see kSlotWords)
+                    const int epoch = tiles_done == 2 ? 0 : 1;
+                    const unsigned list2 = 2u * (unsigned)(gw * 2 + hh);
+#pragma unroll
+                    for (int t = 0; t < NQ; ++t)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float kj = top[t].k[j];
+                            if (kj < INFINITY)
+                                (void)__hip_atomic_fetch_min(a.g_slot + ((32 * t + r) * 2 + epoch) * 32 + ((list2 + j) % KC),
+                                                             sortable_u32(kj), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                }
+                // wave 0 folds the slots into the workgroup bound: often while they fill, then rarely
+                const bool rd = (tiles_done >= 3 && tiles_done <= 6) || (tiles_done >= 9 && tiles_done <= 11) ||
+                                (tiles_done & 7) == 0;
+                if (w == 0 && rd) {
+#pragma unroll
+                    for (int t = 0; t < NQ; ++t) {
+                        uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+                        for (int epoch = 0; epoch < 2; ++epoch) {
+                            const uint32_t* sl = a.g_slot + ((32 * t + r) * 2 + epoch) * 32 + hh * (KC / 2);
+                            uint32_t m = 0u;
+#pragma unroll
+                            for (int s2 = 0; s2 < KC / 2; ++s2) {
+                                const uint32_t v = __hip_atomic_load(sl + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                m = v > m ? v : m;
+                            }
+                            const uint32_t o = (uint32_t)__shfl_xor((int)m, 32, 64);
+                            m = o > m ? o : m;                  // max over the KC slots of this epoch
+                            best = m < best ? m : best;
+                        }
+                        if (hh == 0 && best < s_tau[32 * t + r]) atomicMin(&s_tau[32 * t + r], best);
+                    }
+                }
+            }
             if (w == 0 && (tiles_done & 7) == 0 && hh == 0) {
 #pragma unroll
                 for (int t = 0; t < NQ; ++t) {
@@ -561,6 +616,7 @@ __global__ __launch_bounds__(512, 1) void scan_topk_flagged_kernel(ScanArgs a, c
         ScanArgs b = a;
         b.q16 = a.q16 + (int64_t)g * QT * a.d;
         b.g_tau = a.g_tau + g * QT;
+        b.g_slot = nullptr;
         b.out_key = a.out_key + g * part_stride;
         b.out_idx = a.out_idx + g * part_stride;
         scan_topk_body<QT, KC, false, false>(b, smem);
@@ -779,71 +835,63 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
 // merge the per-lane lists of one query tile: grid = queries, 256 threads
 // ---------------------------------------------------------------------------
 
-// KC smallest (key,id) pairs of one query: every thread folds its share of the per-workgroup
-// lists into a sorted register list, each wave selects its KC best with shuffles only, the NW
-// wave results are ranked by counting (ids are unique, so ranks are unique).  Result: s_out[rank]
-// = packed (key, id), ~0 where there are fewer than KC rows.  NW waves per block.
-template <int KC, int NW>
+// KC smallest (key,id) pairs of one query out of n_lists sorted lists of KC (sentinel-terminated).
+// Latency-lean: no per-thread lists, no selection rounds.
+//   1. the list heads go to LDS; tau = the KC-th smallest head (rank by counting).  KC heads are <= tau,
+//      so the KC-th best of the union is <= tau, and only the KC lists whose head is <= tau can hold
+//      anything <= tau: at most KC*KC entries survive (usually KC plus a few);
+//   2. every entry <= tau is appended to an LDS buffer (atomic counter);
+//   3. the survivors are ranked by counting (row ids are unique, so packed values are).
+// Result: s_out[rank] = packed (key, id) for rank < KC, ~0 where there are fewer than KC rows.
+// All NT threads of the block; s_head [kMergeMaxLists], s_surv [KC*KC], s_misc [4].
+constexpr int kMergeMaxLists = 1024;
+template <int KC, int NT>
 __device__ __forceinline__ void merge_lists_block(const float* __restrict__ part_key, const int* __restrict__ part_idx,
-                                                  int n_lists, int QT, int q, unsigned long long* s_w /*[NW*KC]*/,
+                                                  int n_lists, int QT, int q, unsigned long long* s_head,
+                                                  unsigned long long* s_surv, unsigned long long* s_misc,
                                                   unsigned long long* s_out /*[KC]*/) {
     const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
     const unsigned long long kInf = ~0ull;
-    unsigned long long loc[KC];
-#pragma unroll
-    for (int j = 0; j < KC; ++j) loc[j] = kInf;
-    for (int l = tid; l < n_lists; l += 64 * NW) {
+    int* s_cnt = reinterpret_cast<int*>(s_misc + 1);
+    for (int l = tid; l < n_lists; l += NT) {
         const int64_t o = ((int64_t)l * QT + q) * KC;
-        if (loc[0] == kInf) {  // first list of this thread: already sorted, take it whole
-#pragma unroll
-            for (int j = 0; j < KC; ++j) {
-                const int idx = part_idx[o + j];
-                loc[j] = idx == kIdxSentinel ? kInf : pack_key(part_key[o + j], idx);
-            }
-            continue;
-        }
-        for (int j = 0; j < KC; ++j) {
-            const int idx = part_idx[o + j];
-            if (idx == kIdxSentinel) break;  // lists are sorted, sentinels last
-            const unsigned long long v = pack_key(part_key[o + j], idx);
-            if (!(v < loc[KC - 1])) break;
-            bool prev = false;
-            unsigned long long old = 0;
-#pragma unroll
-            for (int i = 0; i < KC; ++i) {
-                const unsigned long long cur = loc[i];
-                const bool c = v < cur;
-                loc[i] = prev ? old : (c ? v : cur);
-                prev = c;
-                old = cur;
-            }
-        }
+        const int idx = part_idx[o];
+        s_head[l] = idx == kIdxSentinel ? kInf : pack_key(part_key[o], idx);
     }
-    // wave-level selection: KC rounds of a 64-lane min, the owner pops (no barriers)
-    for (int round = 0; round < KC; ++round) {
-        unsigned long long m = group_min16_u64(loc[0]);   // DPP inside the 16-lane rows,
-#pragma unroll
-        for (int o = 16; o < 64; o <<= 1) {               // two shuffles across them
-            const unsigned long long other = __shfl_xor(m, o, 64);
-            m = other < m ? other : m;
+    if (tid == 0) {
+        s_misc[0] = kInf;   // tau: everything passes unless KC heads exist
+        *s_cnt = 0;
+    }
+    if (tid < KC) s_out[tid] = kInf;
+    __syncthreads();
+    for (int l = tid; l < n_lists; l += NT) {
+        const unsigned long long h = s_head[l];
+        if (h != kInf) {
+            int rank = 0;
+            for (int j = 0; j < n_lists; ++j) rank += s_head[j] < h;   // broadcast reads
+            if (rank == KC - 1) s_misc[0] = h;
         }
-        if (loc[0] == m && m != kInf) {  // unique owner: every row id appears once
-#pragma unroll
-            for (int i = 0; i + 1 < KC; ++i) loc[i] = loc[i + 1];
-            loc[KC - 1] = kInf;
-        }
-        if (lane == 0) s_w[w * KC + round] = m;
     }
     __syncthreads();
-    // rank the NW*KC survivors by counting; rank < KC goes out
-    for (int e = tid; e < NW * KC; e += 64 * NW) {
-        const unsigned long long v = s_w[e];
-        int rank = 0;
-        for (int j = 0; j < NW * KC; ++j) {
-            const unsigned long long u = s_w[j];
-            rank += (u < v) || (u == v && j < e);   // sentinels tie: order by position
+    const unsigned long long tau = s_misc[0];
+    const int total = n_lists * KC;
+    for (int e = tid; e < total; e += NT) {
+        const int l = e / KC, j = e - l * KC;
+        if (s_head[l] <= tau && s_head[l] != kInf) {       // only KC lists get past this
+            const int64_t o = ((int64_t)l * QT + q) * KC + j;
+            const int idx = part_idx[o];
+            if (idx != kIdxSentinel) {
+                const unsigned long long v = pack_key(part_key[o], idx);
+                if (v <= tau) s_surv[atomicAdd(s_cnt, 1)] = v;
+            }
         }
+    }
+    __syncthreads();
+    const int S = *s_cnt;
+    for (int e = tid; e < S; e += NT) {
+        const unsigned long long v = s_surv[e];
+        int rank = 0;
+        for (int j = 0; j < S; ++j) rank += s_surv[j] < v;
         if (rank < KC) s_out[rank] = v;
     }
     __syncthreads();
@@ -856,7 +904,9 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
                                                          uint32_t* __restrict__ tau_out /*[q] or null*/,
                                                          const uint32_t* __restrict__ q_flag /*or null*/,
                                                          int64_t part_stride, int any_idx) {
-    __shared__ unsigned long long s_w[4 * KC];
+    __shared__ unsigned long long s_head[kMergeMaxLists];
+    __shared__ unsigned long long s_surv[KC * KC];
+    __shared__ unsigned long long s_misc[4];
     __shared__ unsigned long long s_out[KC];
     // flagged mode (fallback of the MFMA-tiled scan): block = global query, lists of its group of QT
     // queries start at part_stride * group; groups without a flagged query keep their candidates
@@ -872,7 +922,7 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
         part_idx += grp * part_stride;
         q -= grp * QT;
     }
-    merge_lists_block<KC, 4>(part_key, part_idx, n_lists, QT, q, s_w, s_out);
+    merge_lists_block<KC, 256>(part_key, part_idx, n_lists, QT, q, s_head, s_surv, s_misc, s_out);
     if ((int)threadIdx.x < KC) {
         const unsigned long long v = s_out[threadIdx.x];
         cand_idx[qglob * KC + threadIdx.x] = (v == ~0ull) ? -1 : (int)(uint32_t)v;
@@ -933,36 +983,35 @@ __device__ __forceinline__ void rerank_block(const void* __restrict__ rows, int 
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        // insertion sort by (score better, id lower); invalid (-1) entries last
-        for (int i = 1; i < KC; ++i) {
-            const double sv = s_score[i];
-            const int iv = s_idx[i];
-            int j = i - 1;
-            while (j >= 0) {
-                const double sj = s_score[j];
-                const int ij = s_idx[j];
-                bool before;  // does (sv,iv) go before (sj,ij)?
-                if (iv < 0) before = false;
-                else if (ij < 0) before = true;
-                else if (sv != sj) before = metric_l2 ? (sv < sj) : (sv > sj);
-                else before = iv < ij;
-                if (!before) break;
-                s_score[j + 1] = sj;
-                s_idx[j + 1] = ij;
-                --j;
-            }
-            s_score[j + 1] = sv;
-            s_idx[j + 1] = iv;
+    // order by (score better, id lower), invalid (-1) entries last in candidate order: every candidate
+    // finds its rank by counting (KC <= 32 threads, no serial sort)
+    if ((int)threadIdx.x < KC) {
+        const int c = threadIdx.x;
+        const double sv = s_score[c];
+        const int iv = s_idx[c];
+        int rank = 0;
+        for (int j = 0; j < KC; ++j) {
+            const double sj = s_score[j];
+            const int ij = s_idx[j];
+            bool before;  // does (sj,ij) go before (sv,iv)?
+            if (ij < 0) before = iv < 0 && j < c;
+            else if (iv < 0) before = true;
+            else if (sj != sv) before = metric_l2 ? (sj < sv) : (sj > sv);
+            else before = ij < iv;
+            rank += (j != c) && before;
         }
-        for (int j = 0; j < k; ++j) {
-            const bool ok = j < KC && s_idx[j] >= 0;
-            Db[j] = ok ? (float)s_score[j] : (metric_l2 ? FLT_MAX : -FLT_MAX);
-            Ib[j] = ok ? (int64_t)s_idx[j] + id_offset : -1;
+        const bool ok = iv >= 0;
+        if (rank < k) {
+            Db[rank] = ok ? (float)sv : (metric_l2 ? FLT_MAX : -FLT_MAX);
+            Ib[rank] = ok ? (int64_t)iv + id_offset : -1;
         }
-        // exactness certificate: can a row outside the candidates still belong to the top k?
-        const bool full = k <= KC && s_idx[k - 1] >= 0;
-        if (!cert_ok(cert, b, metric_l2, full ? s_score[k - 1] : 0.0, full ? kth_sel : INFINITY)) cert_flag(cert, b);
+        // exactness certificate (the k-th result's owner): can a row outside the candidates still
+        // belong to the top k?  Fewer than k valid candidates = the list is not full = every row is in it.
+        if (rank == k - 1 && !cert_ok(cert, b, metric_l2, ok ? sv : 0.0, ok ? kth_sel : INFINITY)) cert_flag(cert, b);
+    }
+    for (int j = KC + (int)threadIdx.x; j < k; j += blockDim.x) {   // k > KC never happens on these paths; pad anyway
+        Db[j] = metric_l2 ? FLT_MAX : -FLT_MAX;
+        Ib[j] = -1;
     }
 }
 
@@ -1075,12 +1124,14 @@ __global__ __launch_bounds__(1024) void merge_rerank_kernel(const float* __restr
                                                            int metric_l2, const float* __restrict__ q32, int k,
                                                            int64_t id_offset, float* __restrict__ D,
                                                            int64_t* __restrict__ I, CertArgs cert) {
-    __shared__ unsigned long long s_w[16 * KC];
+    __shared__ unsigned long long s_head[kMergeMaxLists];
+    __shared__ unsigned long long s_surv[KC * KC];
+    __shared__ unsigned long long s_misc[4];
     __shared__ unsigned long long s_out[KC];
     __shared__ double s_score[64];
     __shared__ int s_idx[64];
     const int b = q0 + blockIdx.x;  // global query; blockIdx.x = its slot in this pass's query tile
-    merge_lists_block<KC, 16>(part_key, part_idx, n_lists, QT, (int)blockIdx.x, s_w, s_out);
+    merge_lists_block<KC, 1024>(part_key, part_idx, n_lists, QT, (int)blockIdx.x, s_head, s_surv, s_misc, s_out);
     rerank_block<F32>(rows, d, metric_l2, q32 + (int64_t)b * d,
                       [&](int c) { return s_out[c] == ~0ull ? -1 : (int)(uint32_t)s_out[c]; }, KC, k, id_offset,
                       D + (int64_t)b * k, I + (int64_t)b * k, s_score, s_idx, cert, b,
@@ -1177,6 +1228,8 @@ struct prag_index {
     int* cand = nullptr;
     size_t cand_cap = 0;
     uint32_t* g_tau = nullptr;  // [q_cap]
+    uint32_t* g_slot = nullptr; // [q_cap][kSlotWords]
+    int prepass_mode = 0;       // 1 = the round-1 pre-pass launches instead of the bound slots (PRAG_PREPASS=1)
     // MFMA-tiled scan (> 128 queries): per-query candidate buffers
     uint32_t* mm_cnt = nullptr;
     uint32_t* mm_ovf = nullptr;
@@ -1266,6 +1319,7 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
         ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e);
     if (const char* e = getenv("PRAG_CERT")) ix->cert_mode = atoi(e);
+    if (const char* e = getenv("PRAG_PREPASS")) ix->prepass_mode = atoi(e);
     {
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&ix->cert_words), 2 * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemset(ix->cert_words, 0, 2 * sizeof(uint32_t));
@@ -1600,6 +1654,7 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
     a.out_key = ix->part_key;
     a.out_idx = ix->part_idx;
     a.g_tau = ix->g_tau;
+    a.g_slot = nullptr;
     rc = fb64 ? dispatch_flagged<64>(kc, a, fb_grid, ix->mm_ovf, n_groups, part_stride, st)
               : dispatch_flagged<32>(kc, a, fb_grid, ix->mm_ovf, n_groups, part_stride, st);
     if (rc != PRAG_OK) return rc;
@@ -1662,6 +1717,8 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         if (ix->q16) (void)hipFree(ix->q16);
         if (ix->q16lo) (void)hipFree(ix->q16lo);
         if (ix->g_tau) (void)hipFree(ix->g_tau);
+        if (ix->g_slot) (void)hipFree(ix->g_slot);
+        ix->g_slot = nullptr;
         if (ix->qinfo) (void)hipFree(ix->qinfo);
         if (ix->qn2) (void)hipFree(ix->qn2);
         if (ix->flag_list) (void)hipFree(ix->flag_list);
@@ -1674,6 +1731,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->q16), (size_t)Bpad * ix->d * sizeof(_Float16)));
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->q16lo), (size_t)Bpad * ix->d * sizeof(_Float16)));
         PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->g_tau), (size_t)Bpad * sizeof(uint32_t)));
+        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->g_slot), (size_t)Bpad * kSlotWords * sizeof(uint32_t)));
         ix->q_cap = Bpad;
     }
     const int n_tiles = (int)((ix->ntotal + 31) / 32);
@@ -1788,7 +1846,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
                        ix->metric == PRAG_METRIC_COS ? 1 : 0, ix->q32, ix->q16, ix->q16lo, ix->g_tau,
                        use_mm ? ix->mm_cnt : nullptr, ix->mm_ovf,
                        (uint32_t)std::min<int64_t>(ix->ntotal, kMmFirstSeg), ix->qinfo, ix->qn2, ix->cert_words,
-                       ix->flag_list, exact_only && ix->ntotal > 0 ? 1 : 0);
+                       ix->flag_list, exact_only && ix->ntotal > 0 ? 1 : 0, ix->g_slot);
     PRAG_LAUNCH_CHECK();
 
     bool reranked = false;
@@ -1825,12 +1883,16 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         // full scan starts pruned (~0.2 % quantile) instead of inserting at every slot while its
         // per-lane lists warm up.  Only worth it when the shard is much larger than the sample.
         constexpr int64_t kSample = 8192;
-        const bool prepass = ix->ntotal >= 16 * kSample;
+        // (the list scan now gets its bound from the slots filled inside the launch; the pre-pass remains
+        // for the query-stationary kernel and behind PRAG_PREPASS=1 for A/B timing)
+        const bool use_slots = !use_qs && !ix->prepass_mode && !(QT == 64 && kc == 32);
+        const bool prepass = ix->ntotal >= 16 * kSample && !use_slots;
         static EventRing no_prof;  // the pre-pass is not part of the profiled scan launches
         for (int p0 = 0; p0 < Bpad; p0 += QT) {
             a.q16 = ix->q16 + (size_t)p0 * ix->d;
             a.q16lo = ix->q16lo + (size_t)p0 * ix->d;
             a.g_tau = ix->g_tau + p0;
+            a.g_slot = use_slots ? ix->g_slot + (size_t)p0 * kSlotWords : nullptr;
             const int nq = std::min(QT, B - p0);
             int rc;
             if (prepass) {
@@ -1875,31 +1937,44 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
                                ix->q32, ix->cand, kc, k, id_offset, D_dev, I_dev, rc_, kth);
         PRAG_LAUNCH_CHECK();
     }
-    // ---- exact float64 scan for the queries on the flag list (none, normally: empty launches) ------
-    if (certify && ix->ntotal > 0) {
-        ExactRun er;
-        er.rows = ix->rows;
-        er.store_f32 = ix->store == PRAG_F32;
-        er.N = ix->ntotal;
-        er.d = ix->d;
-        er.metric_l2 = metric_l2;
-        er.q32 = ix->q32;
-        er.n_flag = ix->cert_words;
-        er.flag_list = ix->flag_list;
-        er.B = B;
-        er.k = k;
-        er.id_offset = id_offset;
-        er.D = D_dev;
-        er.I = I_dev;
-        er.part_key = ix->ex_key;
-        er.part_id = ix->ex_id;
-        er.f_cap = ex_fcap;
-        er.grid = ex_grid;
+    // ---- exact float64 scan for the queries on the flag list --------------------------------------
+    // Device i/o: always enqueued, the kernels return at once when the list is empty (~3 us each, no
+    // host round trip).  Host i/o synchronises anyway: look at the flag count first and launch only
+    // when something was flagged.
+    ExactRun er;
+    er.rows = ix->rows;
+    er.store_f32 = ix->store == PRAG_F32;
+    er.N = ix->ntotal;
+    er.d = ix->d;
+    er.metric_l2 = metric_l2;
+    er.q32 = ix->q32;
+    er.n_flag = ix->cert_words;
+    er.flag_list = ix->flag_list;
+    er.B = B;
+    er.k = k;
+    er.id_offset = id_offset;
+    er.D = D_dev;
+    er.I = I_dev;
+    er.part_key = ix->ex_key;
+    er.part_id = ix->ex_id;
+    er.f_cap = ex_fcap;
+    er.grid = ex_grid;
+    const bool may_flag = certify && ix->ntotal > 0;
+    if (io_is_device) {
+        if (may_flag) {
+            const int rc = exact_run(er, st);
+            if (rc != PRAG_OK) return rc;
+        }
+        return PRAG_OK;
+    }
+    uint32_t n_flag = 0;
+    if (may_flag) PRAG_HIP(hipMemcpyAsync(&n_flag, ix->cert_words, sizeof(n_flag), hipMemcpyDeviceToHost, st));
+    PRAG_HIP(hipMemcpyAsync(D, D_dev, (size_t)B * k * sizeof(float), hipMemcpyDeviceToHost, st));
+    PRAG_HIP(hipMemcpyAsync(I, I_dev, (size_t)B * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    PRAG_HIP(hipStreamSynchronize(st));
+    if (n_flag > 0) {
         const int rc = exact_run(er, st);
         if (rc != PRAG_OK) return rc;
-    }
-
-    if (!io_is_device) {
         PRAG_HIP(hipMemcpyAsync(D, D_dev, (size_t)B * k * sizeof(float), hipMemcpyDeviceToHost, st));
         PRAG_HIP(hipMemcpyAsync(I, I_dev, (size_t)B * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
         PRAG_HIP(hipStreamSynchronize(st));
@@ -2005,7 +2080,7 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
     ix->prof.disable();
     void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->q16lo, ix->g_tau, ix->part_key, ix->part_idx, ix->cand,
                     ix->io_q, ix->io_D, ix->io_I, ix->mm_cnt, ix->mm_ovf, ix->mm_ckey, ix->mm_cidx,
-                    ix->mm_wcnt, ix->mm_wkey, ix->mm_widx, ix->rows16, ix->qinfo, ix->qn2, ix->flag_list,
+                    ix->mm_wcnt, ix->mm_wkey, ix->mm_widx, ix->rows16, ix->qinfo, ix->qn2, ix->flag_list, ix->g_slot,
                     ix->cert_words, ix->ex_key, ix->ex_id};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

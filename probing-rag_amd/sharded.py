@@ -27,6 +27,7 @@ class HipEngine:
         from .index import HipFlatIndex
         self.index = HipFlatIndex(d, metric, store, capacity=capacity, device=device)
         self.device = self.index.device
+        self._ws = {}
 
     @property
     def ntotal(self):
@@ -50,16 +51,27 @@ class HipEngine:
 
     # single-collective exchange: results are written straight into one packed
     # buffer per shard (D then I), all-gathered once, merged from the packed form
-    def search_packed(self, q, k, id_offset):
+    def search_packed(self, q, k, id_offset, world: int = 1):
+        """Local search straight into this rank's slot-sized packed buffer (D then I).  The buffers of a
+        (B, k, world) shape are allocated once and reused: a search allocates nothing (the caller owns
+        the results until the next search of the same shape)."""
         from .index import packed_result_buffer, packed_views
         q = torch.as_tensor(q)
         if not q.is_cuda:
             q = q.to(self.device)
         B = q.shape[0]
-        buf, stride, i_off = packed_result_buffer(B, k, q.device)
-        D, I = packed_views(buf[0], B, k, i_off)
+        key = (B, k, world, q.device)
+        ws = self._ws.get(key)
+        if ws is None:
+            buf, stride, i_off = packed_result_buffer(B, k, q.device)
+            gathered = torch.empty((world, stride), dtype=torch.uint8, device=q.device) if world > 1 else None
+            ws = (buf, packed_views(buf[0], B, k, i_off), gathered)
+            if len(self._ws) > 16:
+                self._ws.clear()
+            self._ws[key] = ws
+        buf, (D, I), gathered = ws
         self.index.search(q, k, id_offset=id_offset, out=(D, I))
-        return buf, D, I
+        return buf, D, I, gathered
 
     def merge_packed(self, gathered, B, k, metric):
         from .index import merge_topk_packed
@@ -120,10 +132,9 @@ class ShardedFlatIndex:
         if not self._synced:
             raise RuntimeError("ShardedFlatIndex.sync() must run (on every rank) after adding rows")
         if hasattr(self.engine, "search_packed"):
-            buf, D_loc, I_loc = self.engine.search_packed(q, k, self.id_offset)
-            if self.world == 1:
-                return D_loc, I_loc
-            gathered = torch.empty((self.world, buf.shape[1]), dtype=torch.uint8, device=buf.device)
+            if self.world == 1:     # nothing to exchange: plain local search, results owned by the caller
+                return self.engine.search(q, k, self.id_offset)
+            buf, D_loc, I_loc, gathered = self.engine.search_packed(q, k, self.id_offset, self.world)
             self.dist.all_gather_into_tensor(gathered, buf, group=self.group)
             return self.engine.merge_packed(gathered, D_loc.shape[0], k, self.metric)
         D_loc, I_loc = self.engine.search(q, k, self.id_offset)

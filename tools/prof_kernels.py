@@ -26,19 +26,18 @@ def main():
     args = ap.parse_args()
     import torch
     import probing_rag_amd as pra
-    from oracle import oracle_np as onp
-    from tests.golden import cases
+    from probing_rag_amd.synth import random_prober_state, synth_rows
     torch.cuda.set_device(0)
     if not args.skip_scan:
         ix = pra.HipFlatIndex(768, args.metric, args.store, capacity=args.docs)
         ix.add_synthetic(42, 0, args.docs)
-        q = torch.from_numpy(onp.synth_rows(7, 0, args.queries, 768)).cuda()
+        q = torch.from_numpy(synth_rows(7, 0, args.queries, 768)).cuda()
         for _ in range(args.iters):
             ix.search(q, 10)
     if not args.skip_gate:
         ens = pra.HipProberEnsemble(6, 2048, 2, weights="f16")
         for l in range(6):
-            ens.load_layer(l, cases.synth_state(100 + l, 2048))
+            ens.load_layer(l, random_prober_state(100 + l, 2048))
         x = torch.randn((6, args.gate_batch, 2048), device="cuda").half()
         for _ in range(args.iters):
             ens.gate(x, 0, 0.0)
