@@ -228,14 +228,15 @@ struct ScanArgs {
     uint32_t* g_slot;        // [QT][2 epochs][32] bound slots (below), or null: bound from g_tau only
 };
 
-// Chip-wide pruning bound without a pre-pass.  After its 2nd and its 8th tile ("epochs") every
-// lane-list publishes its two best keys: list l (one per wave and row-half, holding rows no other list
-// holds) min-s its j-th best key into slot (2l + j) mod KC of the query.  Within one epoch a list
-// contributes once, so the values in different slots belong to DIFFERENT rows, whenever they were
-// written; if all KC slots are set, KC distinct rows have keys <= max(slots), i.e. the KC-th best key
-// of the shard is <= max(slots) - at any time, whatever the interleaving.  The bound of a query is the
-// smaller of the two epochs' maxima.  With ~4000 lists per query it reaches the ~0.05 % quantile two
-// tiles into the scan (the pre-pass it replaces gave 0.2 % for two extra launches).
+// Chip-wide pruning bound without a pre-pass.  Twice per launch ("epochs": after a wave's 1st and 4th
+// tile) every lane min-s the best key of its list into an LDS word per query; a tile later wave 0
+// min-s the workgroup's best key of each query into global slot (workgroup mod KC) of that query and
+// epoch.  The slots of one epoch receive from DISJOINT sets of workgroups, i.e. of rows: whenever all
+// KC slots are set, KC distinct rows of the shard have keys <= max(slots), so the KC-th best key of the
+// shard is <= max(slots) - at any time, whatever the interleaving (values only decrease).  One global
+// atomic instruction per workgroup and epoch; with 240 workgroups a slot is the best of ~4 k rows after
+// one tile (~16 k after four), the max over 16 slots the ~0.09 % (0.02 %) quantile: tighter than the
+// 0.2 % the round-1 pre-pass bought with two extra launches.  The waves take turns polling the slots.
 constexpr int kSlotWords = kSlotWordsFwd;   // per query: 2 epochs x 32 slots (KC <= 32)
 
 template <int KC>
@@ -299,7 +300,12 @@ __device__ __forceinline__ void scan_topk_body(const ScanArgs& a, char* smem) {
     char* s_ql = smem + QT * qstride;               // HP only
     char* s_st = smem + NQT * QT * qstride + w * 4096;
     uint32_t* s_tau = reinterpret_cast<uint32_t*>(smem + NQT * QT * qstride + 8 * 4096);  // [QT] sortable keys
-    if (tid < QT) s_tau[tid] = a.g_tau[tid];  // +inf, or the pre-pass bound (valid: subset of the shard)
+    uint32_t* s_best = s_tau + QT;   // [2 epochs][QT] best key this workgroup has seen per query (bound slots)
+    if (tid < QT) {
+        s_tau[tid] = a.g_tau[tid];  // +inf, or the pre-pass bound (valid: subset of the shard)
+        s_best[tid] = 0xFFFFFFFFu;
+        s_best[QT + tid] = 0xFFFFFFFFu;
+    }
 
     // ---- query tile(s) -> LDS (swizzled 16-B pieces); loads issued in batches of 8 so their
     //      latencies overlap (a one-load-at-a-time loop costs ~25 us per launch) -----------
@@ -490,41 +496,33 @@ __device__ __forceinline__ void scan_topk_body(const ScanArgs& a, char* smem) {
             // state went to scratch; that shape keeps the pre-pass)
             constexpr bool SLOTS = !(QT == 64 && KC == 32);
             if (SLOTS && a.g_slot) {
-                if (tiles_done == 2 || tiles_done == 8) {   // publish this wave's lists (see kSlotWords)
-                    const int epoch = tiles_done == 2 ? 0 : 1;
-                    const unsigned list2 = 2u * (unsigned)(gw * 2 + hh);
-#pragma unroll
-                    for (int t = 0; t < NQ; ++t)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const float kj = top[t].k[j];
-                            if (kj < INFINITY)
-                                (void)__hip_atomic_fetch_min(a.g_slot + ((32 * t + r) * 2 + epoch) * 32 + ((list2 + j) % KC),
-                                                             sortable_u32(kj), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                }
-                // wave 0 folds the slots into the workgroup bound: often while they fill, then rarely
-                const bool rd = (tiles_done >= 3 && tiles_done <= 6) || (tiles_done >= 9 && tiles_done <= 11) ||
-                                (tiles_done & 7) == 0;
-                if (w == 0 && rd) {
+                if (tiles_done == 1 || tiles_done == 4) {        // every list: best key -> LDS
+                    const int epoch = tiles_done == 1 ? 0 : 1;
 #pragma unroll
                     for (int t = 0; t < NQ; ++t) {
-                        uint32_t best = 0xFFFFFFFFu;
-#pragma unroll
-                        for (int epoch = 0; epoch < 2; ++epoch) {
-                            const uint32_t* sl = a.g_slot + ((32 * t + r) * 2 + epoch) * 32 + hh * (KC / 2);
-                            uint32_t m = 0u;
-#pragma unroll
-                            for (int s2 = 0; s2 < KC / 2; ++s2) {
-                                const uint32_t v = __hip_atomic_load(sl + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                m = v > m ? v : m;
-                            }
-                            const uint32_t o = (uint32_t)__shfl_xor((int)m, 32, 64);
-                            m = o > m ? o : m;                  // max over the KC slots of this epoch
-                            best = m < best ? m : best;
-                        }
-                        if (hh == 0 && best < s_tau[32 * t + r]) atomicMin(&s_tau[32 * t + r], best);
+                        const float k0 = top[t].k[0];
+                        if (k0 < INFINITY) atomicMin(&s_best[epoch * QT + 32 * t + r], sortable_u32(k0));
                     }
+                }
+                if (w == 0 && (tiles_done == 2 || tiles_done == 5) && lane < QT) {   // workgroup -> its slot
+                    const int epoch = tiles_done == 2 ? 0 : 1;
+                    const uint32_t v = s_best[epoch * QT + lane];
+                    if (v != 0xFFFFFFFFu)
+                        (void)__hip_atomic_fetch_min(a.g_slot + (lane * 2 + epoch) * 32 + (blockIdx.x % KC), v,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // polls: epoch 0 at tiles 3..5, epoch 1 at tiles 6..9, one wave each (spreads the stall)
+                const int poll = tiles_done - 3;
+                if (poll >= 0 && poll < 7 && w == poll && lane < QT) {
+                    const int epoch = poll < 3 ? 0 : 1;
+                    const uint32_t* sl = a.g_slot + (lane * 2 + epoch) * 32;
+                    uint32_t m = 0u;
+#pragma unroll
+                    for (int s2 = 0; s2 < KC; ++s2) {
+                        const uint32_t v = __hip_atomic_load(sl + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        m = v > m ? v : m;                       // max over the KC slots
+                    }
+                    if (m < s_tau[lane]) atomicMin(&s_tau[lane], m);
                 }
             }
             if (w == 0 && (tiles_done & 7) == 0 && hh == 0) {
@@ -1229,7 +1227,7 @@ struct prag_index {
     size_t cand_cap = 0;
     uint32_t* g_tau = nullptr;  // [q_cap]
     uint32_t* g_slot = nullptr; // [q_cap][kSlotWords]
-    int prepass_mode = 0;       // 1 = the round-1 pre-pass launches instead of the bound slots (PRAG_PREPASS=1)
+    int prepass_mode = -1;      // PRAG_PREPASS: 1 = always the pre-pass launches, 0 = always the bound slots, unset = by shard size
     // MFMA-tiled scan (> 128 queries): per-query candidate buffers
     uint32_t* mm_cnt = nullptr;
     uint32_t* mm_ovf = nullptr;
@@ -1427,7 +1425,7 @@ static int pick_kc(int k) {
 
 template <int QT, int KC, bool F32, bool HP = false>
 static int launch_scan(const ScanArgs& a, int grid, hipStream_t st, EventRing& prof) {
-    const int lds_loop = (HP ? 2 : 1) * QT * a.qstride + 8 * 4096 + QT * 4;   // queries + stages + thresholds
+    const int lds_loop = (HP ? 2 : 1) * QT * a.qstride + 8 * 4096 + QT * 12;   // queries + stages + thresholds + best keys
     const int lds_merge = 16 * 32 * KC * 8;                     // in-workgroup list merge
     const int lds = lds_loop > lds_merge ? lds_loop : lds_merge;
     auto kern = scan_topk_kernel<QT, KC, F32, HP>;
@@ -1457,7 +1455,7 @@ static int dispatch_scan_kc(int kc, const ScanArgs& a, int grid, hipStream_t st,
 template <int QT, int KC>
 static int launch_flagged(const ScanArgs& a, int grid, const uint32_t* q_flag, int n_groups, int64_t part_stride,
                           hipStream_t st) {
-    const int lds_loop = QT * a.qstride + 8 * 4096 + QT * 4;
+    const int lds_loop = QT * a.qstride + 8 * 4096 + QT * 12;
     const int lds_merge = 16 * 32 * KC * 8;
     const int lds = lds_loop > lds_merge ? lds_loop : lds_merge;
     auto kern = scan_topk_flagged_kernel<QT, KC>;
@@ -1626,7 +1624,7 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
     // in mm_ovf, the rerank puts it on the certificate's flag list and the exact scan recomputes it
     if (kc > 32) return PRAG_OK;
     if (ix->mm_mode == 2) return PRAG_OK;  // PRAG_SCAN_MM=2 (tests of the tests): overflow goes unrepaired
-    const bool fb64 = 64 * qstride + 8 * 4096 + 64 * 4 + 64 <= 160 * 1024 - 64;
+    const bool fb64 = 64 * qstride + 8 * 4096 + 64 * 12 + 64 <= 160 * 1024 - 64;
     const int fq = fb64 ? 64 : 32;
     const int fb_grid = std::max(1, std::min(cu_budget, (n_tiles + 7) / 8));
     const int n_groups = Bpad / fq;
@@ -1703,14 +1701,14 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     // ---- workspace --------------------------------------------------------------
     const int qstride = (ix->d * 2 + 255) / 256 * 256;
     // 64-query tiles when they fit LDS; fp32 rows with 32-deep lists stay at 32 (VGPR budget)
-    const bool wide_ok = 64 * qstride + 8 * 4096 + 64 * 4 <= 160 * 1024 && !(ix->store == PRAG_F32 && kc == 32);
+    const bool wide_ok = 64 * qstride + 8 * 4096 + 64 * 12 <= 160 * 1024 && !(ix->store == PRAG_F32 && kc == 32);
     // > 128 queries: the contraction bounds the search -> MFMA-tiled scan, 256 queries per tile
     const bool use_mm = !exact_only && ix->ntotal > 0 && mm_supported(ix->d, PRAG_F16, kc) &&
                         ((B > 128 && ix->mm_mode) || kc > 32);
     const bool use_qs = !exact_only && !use_mm && B > 64 && qs_supported(ix->d, ix->store, kc);  // 128 queries per corpus pass
     const int QT = use_mm ? 256 : use_qs ? 128 : ((B > 32 && wide_ok) ? 64 : 32);
     // <= 32 queries (the reference's call shape): high-precision selection, if two query tiles fit LDS
-    const bool use_hp = ix->hp_mode && QT == 32 && 2 * 32 * qstride + 8 * 4096 + 32 * 4 <= 160 * 1024;
+    const bool use_hp = ix->hp_mode && QT == 32 && 2 * 32 * qstride + 8 * 4096 + 32 * 12 <= 160 * 1024;
     const int Bpad = (B + QT - 1) / QT * QT;
     if (Bpad > ix->q_cap) {
         if (ix->q32) (void)hipFree(ix->q32);
@@ -1885,7 +1883,11 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         constexpr int64_t kSample = 8192;
         // (the list scan now gets its bound from the slots filled inside the launch; the pre-pass remains
         // for the query-stationary kernel and behind PRAG_PREPASS=1 for A/B timing)
-        const bool use_slots = !use_qs && !ix->prepass_mode && !(QT == 64 && kc == 32);
+        // Bound for the list scan: slots filled inside the launch (no extra launches: best on shards
+        // of a few million rows, where two launches are ~6 % of the search) or the pre-pass (its bound
+        // is there from the first tile: measured 1.5 % faster at 21 M rows).  Crossover ~8 M rows.
+        const bool want_slots = ix->prepass_mode < 0 ? ix->ntotal <= (8ll << 20) : ix->prepass_mode == 0;
+        const bool use_slots = !use_qs && want_slots && !(QT == 64 && kc == 32);
         const bool prepass = ix->ntotal >= 16 * kSample && !use_slots;
         static EventRing no_prof;  // the pre-pass is not part of the profiled scan launches
         for (int p0 = 0; p0 < Bpad; p0 += QT) {
