@@ -1245,9 +1245,12 @@ struct prag_index {
     _Float16* rows16 = nullptr;
     int64_t rows16_n = -1, rows16_cap = 0;
     // host-io staging
+    // one device block [I int64 | D float | flag count] and its pinned host mirror, plus a pinned/device
+    // pair for the queries: a host-io search is one H2D and one D2H transfer
     float* io_q = nullptr;
-    float* io_D = nullptr;
-    int64_t* io_I = nullptr;
+    char* io_res = nullptr;
+    float* io_q_host = nullptr;
+    char* io_res_host = nullptr;
     int io_B = 0, io_k = 0;
     int n_cu = 256;
     int wg_cap = 0;  // 0 = use every CU
@@ -1262,6 +1265,7 @@ struct prag_index {
     int* ex_id = nullptr;
     size_t ex_entries = 0;
     int cert_mode = 1;   // 0 = certificate off (PRAG_CERT=0: timing experiments only)
+    int last_flagged = -1;   // flag count of the last host-io search (-1: last search was device-io)
     EventRing prof;
 };
 
@@ -1682,20 +1686,25 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     if (!io_is_device) {
         if (B > ix->io_B || k > ix->io_k) {
             if (ix->io_q) (void)hipFree(ix->io_q);
-            if (ix->io_D) (void)hipFree(ix->io_D);
-            if (ix->io_I) (void)hipFree(ix->io_I);
-            ix->io_q = nullptr; ix->io_D = nullptr; ix->io_I = nullptr;
+            if (ix->io_res) (void)hipFree(ix->io_res);
+            if (ix->io_q_host) (void)hipHostFree(ix->io_q_host);
+            if (ix->io_res_host) (void)hipHostFree(ix->io_res_host);
+            ix->io_q = nullptr; ix->io_res = nullptr; ix->io_q_host = nullptr; ix->io_res_host = nullptr;
             const int nb = std::max(B, ix->io_B), nk = std::max(k, ix->io_k);
+            ix->io_B = ix->io_k = 0;
+            const size_t res_bytes = (size_t)nb * nk * 12 + 8;
             PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->io_q), (size_t)nb * ix->d * sizeof(float)));
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->io_D), (size_t)nb * nk * sizeof(float)));
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->io_I), (size_t)nb * nk * sizeof(int64_t)));
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->io_res), res_bytes));
+            PRAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->io_q_host), (size_t)nb * ix->d * sizeof(float)));
+            PRAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->io_res_host), res_bytes));
             ix->io_B = nb;
             ix->io_k = nk;
         }
-        PRAG_HIP(hipMemcpyAsync(ix->io_q, q, (size_t)B * ix->d * sizeof(float), hipMemcpyHostToDevice, st));
+        memcpy(ix->io_q_host, q, (size_t)B * ix->d * sizeof(float));
+        PRAG_HIP(hipMemcpyAsync(ix->io_q, ix->io_q_host, (size_t)B * ix->d * sizeof(float), hipMemcpyHostToDevice, st));
         q_dev = ix->io_q;
-        D_dev = ix->io_D;
-        I_dev = ix->io_I;
+        I_dev = reinterpret_cast<int64_t*>(ix->io_res);
+        D_dev = reinterpret_cast<float*>(ix->io_res + (size_t)B * k * 8);
     }
 
     // ---- workspace --------------------------------------------------------------
@@ -1822,7 +1831,9 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     cert.qinfo = ix->qinfo;
     cert.qn2 = ix->qn2;
     cert.xn_max = ix->cert_words + 1;
-    cert.n_flag = ix->cert_words;
+    // host i/o: the flag count lives behind the results so that one transfer brings everything back
+    uint32_t* flag_word = io_is_device ? ix->cert_words : reinterpret_cast<uint32_t*>(ix->io_res + (size_t)B * k * 12);
+    cert.n_flag = flag_word;
     cert.flag_list = ix->flag_list;
     cert.force = nullptr;
     {
@@ -1843,7 +1854,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     hipLaunchKernelGGL(prep_queries_kernel, dim3((Bpad + 3) / 4), dim3(256), 0, st, q_dev, B, Bpad, ix->d,
                        ix->metric == PRAG_METRIC_COS ? 1 : 0, ix->q32, ix->q16, ix->q16lo, ix->g_tau,
                        use_mm ? ix->mm_cnt : nullptr, ix->mm_ovf,
-                       (uint32_t)std::min<int64_t>(ix->ntotal, kMmFirstSeg), ix->qinfo, ix->qn2, ix->cert_words,
+                       (uint32_t)std::min<int64_t>(ix->ntotal, kMmFirstSeg), ix->qinfo, ix->qn2, flag_word,
                        ix->flag_list, exact_only && ix->ntotal > 0 ? 1 : 0, ix->g_slot);
     PRAG_LAUNCH_CHECK();
 
@@ -1950,7 +1961,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     er.d = ix->d;
     er.metric_l2 = metric_l2;
     er.q32 = ix->q32;
-    er.n_flag = ix->cert_words;
+    er.n_flag = flag_word;
     er.flag_list = ix->flag_list;
     er.B = B;
     er.k = k;
@@ -1963,24 +1974,32 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     er.grid = ex_grid;
     const bool may_flag = certify && ix->ntotal > 0;
     if (io_is_device) {
+        ix->last_flagged = -1;
         if (may_flag) {
             const int rc = exact_run(er, st);
             if (rc != PRAG_OK) return rc;
         }
         return PRAG_OK;
     }
+    const size_t res_bytes = (size_t)B * k * 12 + 4;
+    auto fetch = [&]() -> int {
+        PRAG_HIP(hipMemcpyAsync(ix->io_res_host, ix->io_res, res_bytes, hipMemcpyDeviceToHost, st));
+        PRAG_HIP(hipStreamSynchronize(st));
+        return PRAG_OK;
+    };
+    int rc_io = fetch();
+    if (rc_io != PRAG_OK) return rc_io;
     uint32_t n_flag = 0;
-    if (may_flag) PRAG_HIP(hipMemcpyAsync(&n_flag, ix->cert_words, sizeof(n_flag), hipMemcpyDeviceToHost, st));
-    PRAG_HIP(hipMemcpyAsync(D, D_dev, (size_t)B * k * sizeof(float), hipMemcpyDeviceToHost, st));
-    PRAG_HIP(hipMemcpyAsync(I, I_dev, (size_t)B * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    PRAG_HIP(hipStreamSynchronize(st));
-    if (n_flag > 0) {
+    memcpy(&n_flag, ix->io_res_host + (size_t)B * k * 12, sizeof(n_flag));
+    ix->last_flagged = (int)n_flag;
+    if (may_flag && n_flag > 0) {
         const int rc = exact_run(er, st);
         if (rc != PRAG_OK) return rc;
-        PRAG_HIP(hipMemcpyAsync(D, D_dev, (size_t)B * k * sizeof(float), hipMemcpyDeviceToHost, st));
-        PRAG_HIP(hipMemcpyAsync(I, I_dev, (size_t)B * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        PRAG_HIP(hipStreamSynchronize(st));
+        rc_io = fetch();
+        if (rc_io != PRAG_OK) return rc_io;
     }
+    memcpy(I, ix->io_res_host, (size_t)B * k * sizeof(int64_t));
+    memcpy(D, ix->io_res_host + (size_t)B * k * 8, (size_t)B * k * sizeof(float));
     return PRAG_OK;
 }
 
@@ -2042,6 +2061,10 @@ extern "C" int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n,
 
 extern "C" int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out) {
     PRAG_REQUIRE(ix != nullptr && n_out != nullptr, PRAG_EINVAL, "prag_index_last_fallbacks: NULL pointer");
+    if (ix->last_flagged >= 0) {   // host-io search: the count came back with the results
+        *n_out = ix->last_flagged;
+        return PRAG_OK;
+    }
     uint32_t n = 0;
     PRAG_HIP(hipMemcpyAsync(&n, ix->cert_words, sizeof(n), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream)));
     PRAG_HIP(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
@@ -2081,10 +2104,12 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
     if (!ix) return;
     ix->prof.disable();
     void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->q16lo, ix->g_tau, ix->part_key, ix->part_idx, ix->cand,
-                    ix->io_q, ix->io_D, ix->io_I, ix->mm_cnt, ix->mm_ovf, ix->mm_ckey, ix->mm_cidx,
+                    ix->io_q, ix->io_res, ix->mm_cnt, ix->mm_ovf, ix->mm_ckey, ix->mm_cidx,
                     ix->mm_wcnt, ix->mm_wkey, ix->mm_widx, ix->rows16, ix->qinfo, ix->qn2, ix->flag_list, ix->g_slot,
                     ix->cert_words, ix->ex_key, ix->ex_id};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (ix->io_q_host) (void)hipHostFree(ix->io_q_host);
+    if (ix->io_res_host) (void)hipHostFree(ix->io_res_host);
     delete ix;
 }

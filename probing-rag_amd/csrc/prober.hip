@@ -41,6 +41,7 @@
 #include <vector>
 
 #include "prag_common.h"
+#include "prober_small.h"
 
 namespace prag {
 
@@ -697,6 +698,11 @@ struct prag_prober {
     std::vector<std::vector<void*>> allocs;  // device buffers per layer (freed when the layer is reloaded)
     int upload_layer = 0;
     LayerDev* d_layers = nullptr;
+    // small-batch path (prober_small.hip): f32 effective weights + two [L][8][512] workspaces
+    std::vector<SmallLayer> h_small;
+    SmallLayer* d_small = nullptr;
+    float* small_ws = nullptr;
+    int small_mode = 1;   // PRAG_PROBER_SMALL=0: always the MFMA-tiled kernel
     _Float16* ws_h = nullptr;  // [L][maxB][d] hi / lo workspace for fp32 activations
     _Float16* ws_l = nullptr;
     int64_t ws_rows = 0;
@@ -768,8 +774,15 @@ extern "C" int prag_prober_create(prag_prober_t** out, int n_layers, int d_model
     p->h_layers.resize(n_layers);
     p->eff.resize(n_layers);
     p->allocs.resize(n_layers);
+    p->h_small.resize(n_layers);
+    if (const char* ev = getenv("PRAG_PROBER_SMALL")) p->small_mode = atoi(ev);
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_layers), sizeof(LayerDev) * n_layers);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_small), sizeof(SmallLayer) * n_layers);
+    if (e == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void**>(&p->small_ws), sizeof(float) * 2 * n_layers * kSmallMaxB * kHidden);
     if (e != hipSuccess) {
+        if (p->d_layers) (void)hipFree(p->d_layers);
+        if (p->d_small) (void)hipFree(p->d_small);
         set_error("hipMalloc failed: %s", hipGetErrorString(e));
         delete p;
         return PRAG_EHIP;
@@ -894,6 +907,19 @@ extern "C" int prag_prober_load_layer(prag_prober_t* p, int li, const float* ln0
     }
     if ((rc = upload(p, W3e, &L.W3)) != PRAG_OK) return rc;
 
+    // ---- small-batch path: the same effective weights as plain f32 rows ------------------------
+    {
+        SmallLayer& S = p->h_small[li];
+        if ((rc = upload(p, E.W1, &S.W1)) != PRAG_OK) return rc;
+        if ((rc = upload(p, E.W2, &S.W2)) != PRAG_OK) return rc;
+        S.b1 = L.b1;
+        S.b2 = L.b2;
+        S.W3 = L.W3;
+        S.b3[0] = L.b3[0];
+        S.b3[1] = L.b3[1];
+        PRAG_HIP(hipMemcpy(p->d_small + li, &S, sizeof(SmallLayer), hipMemcpyHostToDevice));
+    }
+
     PRAG_HIP(hipMemcpy(p->d_layers + li, &L, sizeof(LayerDev), hipMemcpyHostToDevice));
     PRAG_HIP(hipDeviceSynchronize());
     p->loaded[li] = true;
@@ -962,9 +988,15 @@ static int pick_ct(int B, int n_run, int max_ct) {
     return ct;
 }
 
-extern "C" int prag_prober_forward(prag_prober_t* p, const void* x_dev, int x_dtype,
-                                   int64_t x_layer_stride, int layer0, int n_run, int B,
-                                   float* logits_dev, void* stream) {
+struct GateOut {   // fused gate of the small-batch path
+    int ablation;
+    double theta;
+    float* probsum;
+    int32_t* decision;
+};
+
+static int forward_impl(prag_prober_t* p, const void* x_dev, int x_dtype, int64_t x_layer_stride, int layer0,
+                        int n_run, int B, float* logits_dev, void* stream, const GateOut* gate, bool* gate_done) {
     PRAG_REQUIRE(p != nullptr, PRAG_EINVAL, "prober handle is NULL");
     PRAG_REQUIRE(x_dev && logits_dev, PRAG_EINVAL, "prag_prober_forward: NULL device pointer");
     PRAG_REQUIRE(B >= 1, PRAG_EINVAL, "B=%d must be >= 1", B);
@@ -977,6 +1009,34 @@ extern "C" int prag_prober_forward(prag_prober_t* p, const void* x_dev, int x_dt
     for (int l = layer0; l < layer0 + n_run; ++l)
         PRAG_REQUIRE(p->loaded[l], PRAG_ESTATE, "layer %d has no weights loaded", l);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+    // a handful of rows (the reference's call shape is ONE): weight rows spread over the whole chip
+    // (measured: 28 us at one row against 64 us / 34 us for the tiled kernel with f32-parity / fp16
+    // weights; the VALU dot products cross over at ~4 / ~2 rows)
+    if (p->small_mode && small_supported(B, p->d) && B <= (p->na == 2 ? 4 : 2)) {
+        SmallRun r;
+        r.layers = p->d_small;
+        r.x = x_dev;
+        r.x_dtype = x_dtype;
+        r.x_layer_stride = x_layer_stride;
+        r.layer0 = layer0;
+        r.n_run = n_run;
+        r.B = B;
+        r.d = p->d;
+        r.h1 = p->small_ws;
+        r.h2 = p->small_ws + (size_t)p->n_layers * kSmallMaxB * kHidden;
+        r.logits = logits_dev;
+        const bool fuse = gate && layer0 == 0 && n_run == p->n_layers;
+        r.ablation = fuse ? gate->ablation : 0;
+        r.theta = fuse ? gate->theta : 0.0;
+        r.probsum = fuse ? gate->probsum : nullptr;
+        r.decision = fuse ? gate->decision : nullptr;
+        p->prof.begin(st);
+        const int rc = small_run(r, st);
+        p->prof.end(st);
+        if (rc == PRAG_OK && fuse && gate_done) *gate_done = true;
+        return rc;
+    }
 
     ProberArgs a;
     a.layers = p->d_layers;
@@ -1032,6 +1092,12 @@ extern "C" int prag_prober_forward(prag_prober_t* p, const void* x_dev, int x_dt
     return PRAG_EUNSUPPORTED;
 }
 
+extern "C" int prag_prober_forward(prag_prober_t* p, const void* x_dev, int x_dtype,
+                                   int64_t x_layer_stride, int layer0, int n_run, int B,
+                                   float* logits_dev, void* stream) {
+    return forward_impl(p, x_dev, x_dtype, x_layer_stride, layer0, n_run, B, logits_dev, stream, nullptr, nullptr);
+}
+
 extern "C" int prag_gate_from_logits(const float* logits_dev, int L, int B, int ablation, double theta,
                                      float* probsum_dev, int32_t* decision_dev, void* stream) {
     PRAG_REQUIRE(logits_dev != nullptr, PRAG_EINVAL, "logits_dev is NULL");
@@ -1048,8 +1114,12 @@ extern "C" int prag_gate(prag_prober_t* p, const void* x_dev, int x_dtype, int64
                          int ablation, double theta, float* logits_dev, float* probsum_dev,
                          int32_t* decision_dev, void* stream) {
     PRAG_REQUIRE(p != nullptr, PRAG_EINVAL, "prober handle is NULL");
-    int rc = prag_prober_forward(p, x_dev, x_dtype, x_layer_stride, 0, p->n_layers, B, logits_dev, stream);
-    if (rc != PRAG_OK) return rc;
+    PRAG_REQUIRE(ablation >= 0 && ablation <= p->n_layers, PRAG_EINVAL, "ablation=%d outside [0,%d]", ablation,
+                 p->n_layers);
+    const GateOut g{ablation, theta, probsum_dev, decision_dev};
+    bool done = false;
+    int rc = forward_impl(p, x_dev, x_dtype, x_layer_stride, 0, p->n_layers, B, logits_dev, stream, &g, &done);
+    if (rc != PRAG_OK || done) return rc;
     return prag_gate_from_logits(logits_dev, p->n_layers, B, ablation, theta, probsum_dev, decision_dev,
                                  stream);
 }
@@ -1074,6 +1144,8 @@ extern "C" void prag_prober_destroy(prag_prober_t* p) {
     for (auto& layer : p->allocs)
         for (void* q : layer) (void)hipFree(q);
     if (p->d_layers) (void)hipFree(p->d_layers);
+    if (p->d_small) (void)hipFree(p->d_small);
+    if (p->small_ws) (void)hipFree(p->small_ws);
     if (p->ws_h) (void)hipFree(p->ws_h);
     if (p->ws_l) (void)hipFree(p->ws_l);
     delete p;

@@ -1,0 +1,43 @@
+// Small-batch prober path (prober_small.hip): the reference's own call shape is ONE pooled state per
+// probed layer (exp_rag.py:381-389, batch_size 1).  At a handful of rows the MFMA-tiled kernel has one
+// workgroup per layer pulling that layer's 5 MB of weights through a single CU (~60 us); here the
+// weight rows are spread over the whole chip instead: three short launches of plain f32 dot products.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace prag {
+
+struct SmallLayer {        // LayerNorm-folded ("effective") weights of one layer, f32, row-major [out][in]
+    const float* W1;       // [512][d]   W1 * diag(ln0_w)
+    const float* b1;       // [512]      b1 + W1 . ln0_b
+    const float* W2;       // [512][512] W2 * diag(ln1_w)
+    const float* b2;       // [512]
+    const float* W3;       // [2][512]   W3 * diag(ln2_w)
+    float b3[2];
+};
+
+struct SmallRun {
+    const SmallLayer* layers;   // device array, all layers of the handle
+    const void* x;              // activations of layer `layer0` onwards
+    int x_dtype;                // PRAG_F32 | PRAG_F16 | PRAG_BF16
+    int64_t x_layer_stride;
+    int layer0, n_run, B, d;
+    float* h1;                  // workspace [n_run][B][512]
+    float* h2;                  // workspace [n_run][B][512]
+    float* logits;              // out [n_run][B][2]
+    // gate fused into the last launch (exp_rag.py:407-415), only when probsum/decision are given
+    int ablation;
+    double theta;
+    float* probsum;             // [B][2] or null
+    int32_t* decision;          // [B] or null
+};
+
+constexpr int kSmallMaxB = 8;
+constexpr int kSmallMaxElems = 16384;   // B * d staged in LDS as f32 (64 KiB)
+inline bool small_supported(int B, int d) { return B >= 1 && B <= kSmallMaxB && (int64_t)B * d <= kSmallMaxElems; }
+// Enqueue the three launches on `st`.
+int small_run(const SmallRun& r, hipStream_t st);
+
+}  // namespace prag
