@@ -1264,6 +1264,23 @@ struct prag_index {
     unsigned long long* ex_key = nullptr;
     int* ex_id = nullptr;
     size_t ex_entries = 0;
+    // 8-bit shadow (flat_shadow.hip): 0 off, 1 on for shards >= kShadowMinRows, 2 on at any size
+    int shadow_mode = 0;
+    signed char* rows8 = nullptr;
+    float* sscale = nullptr;
+    float* serr = nullptr;
+    int64_t shadow_cap = 0, shadow_rows = 0;
+    uint32_t* shadow_err_max = nullptr;
+    signed char* sh_q8 = nullptr;      // [2][q_cap][d]
+    void* sh_sq = nullptr;
+    uint32_t* sh_slots = nullptr;
+    uint32_t* sh_ovf = nullptr;
+    int sh_q_cap = 0;
+    int* sh_cand = nullptr;
+    uint32_t* sh_ccnt = nullptr;
+    unsigned long long* sh_pkey = nullptr;
+    int* sh_pid = nullptr;
+    size_t sh_part_entries = 0;
     int cert_mode = 1;   // 0 = certificate off (PRAG_CERT=0: timing experiments only)
     int last_flagged = -1;   // flag count of the last host-io search (-1: last search was device-io)
     EventRing prof;
@@ -1322,6 +1339,7 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
     if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e);
     if (const char* e = getenv("PRAG_CERT")) ix->cert_mode = atoi(e);
     if (const char* e = getenv("PRAG_PREPASS")) ix->prepass_mode = atoi(e);
+    if (const char* e = getenv("PRAG_SHADOW")) ix->shadow_mode = atoi(e);
     {
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&ix->cert_words), 2 * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemset(ix->cert_words, 0, 2 * sizeof(uint32_t));
@@ -1674,6 +1692,10 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     PRAG_REQUIRE(q && D && I, PRAG_EINVAL, "prag_index_search: NULL pointer");
     int kc = std::max(pick_kc(k), pick_kc(k) ? ix->kc_min : 0);
     PRAG_REQUIRE(kc != 0, PRAG_EUNSUPPORTED, "k=%d: at most 911 results per query", k);
+    // float32 rows with 33..64 queries are rounded to fp16 inside the scan (no high-precision terms at
+    // that tile height): the certificate's error bound is ~5e-4 ||q|| ||x||, which an 8-deep list clears
+    // only ~99 % of the time at 21 M rows - and a miss costs a 64 GB exact pass.  A 16-deep list does.
+    if (ix->store == PRAG_F32 && kc == 8 && B > 32) kc = 16;
     // k > 26 on a dimension the MFMA-tiled scan does not cover: straight to the exact float64 scan
     const bool exact_only = kc > 32 && !mm_supported(ix->d, PRAG_F16, kc);
     if (exact_only) kc = 32;  // (sizes the unused candidate workspace)
@@ -1858,8 +1880,97 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
                        ix->flag_list, exact_only && ix->ntotal > 0 ? 1 : 0, ix->g_slot);
     PRAG_LAUNCH_CHECK();
 
+    // ---- two-level search through the 8-bit shadow (HBM-bound batches on large shards) --------------
+    constexpr int64_t kShadowMinRows = 1 << 20;
+    constexpr int kShadowCap = 128;
+    const bool use_shadow = ix->shadow_mode && !exact_only && !use_mm && !use_qs && ix->ntotal > 0 &&
+                            (ix->shadow_mode >= 2 || ix->ntotal >= kShadowMinRows) && shadow_supported(ix->d, kc, k, B);
     bool reranked = false;
-    if (ix->ntotal == 0 || exact_only) {
+    if (use_shadow) {
+        int rc = PRAG_OK;
+        if (ix->shadow_cap < ix->cap) {    // (re)allocate with the rows; rebuilt from row 0
+            for (void* p : {(void*)ix->rows8, (void*)ix->sscale, (void*)ix->serr})
+                if (p) (void)hipFree(p);
+            ix->rows8 = nullptr; ix->sscale = nullptr; ix->serr = nullptr; ix->shadow_cap = 0; ix->shadow_rows = 0;
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->rows8), (size_t)ix->cap * ix->d));
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sscale), (size_t)ix->cap * sizeof(float)));
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->serr), (size_t)ix->cap * sizeof(float)));
+            if (!ix->shadow_err_max) {
+                PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->shadow_err_max), sizeof(uint32_t)));
+                PRAG_HIP(hipMemsetAsync(ix->shadow_err_max, 0, sizeof(uint32_t), st));
+            }
+            ix->shadow_cap = ix->cap;
+        }
+        ShadowSearch ss;
+        ss.store.rows = ix->rows;
+        ss.store.store_f32 = ix->store == PRAG_F32;
+        ss.store.d = ix->d;
+        ss.store.rows8 = ix->rows8;
+        ss.store.sscale = ix->sscale;
+        ss.store.serr = ix->serr;
+        ss.store.err_max = ix->shadow_err_max;
+        if (ix->shadow_rows < ix->ntotal) {
+            rc = shadow_build(ss.store, ix->shadow_rows, ix->ntotal, st);
+            if (rc != PRAG_OK) return rc;
+            ix->shadow_rows = ix->ntotal;
+        }
+        const int BpadS = (B + 63) / 64 * 64;
+        if (BpadS > ix->sh_q_cap) {
+            for (void* p : {(void*)ix->sh_q8, ix->sh_sq, (void*)ix->sh_slots, (void*)ix->sh_ovf})
+                if (p) (void)hipFree(p);
+            ix->sh_q8 = nullptr; ix->sh_sq = nullptr; ix->sh_slots = nullptr; ix->sh_ovf = nullptr; ix->sh_q_cap = 0;
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_q8), (size_t)2 * BpadS * ix->d));
+            PRAG_HIP(hipMalloc(&ix->sh_sq, (size_t)BpadS * shadow_q_bytes()));
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_slots), (size_t)BpadS * shadow_slot_words() * sizeof(uint32_t)));
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_ovf), (size_t)BpadS * sizeof(uint32_t)));
+            ix->sh_q_cap = BpadS;
+        }
+        if (!ix->sh_cand) {
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_cand), (size_t)ix->n_cu * 64 * kShadowCap * sizeof(int)));
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_ccnt), (size_t)ix->n_cu * 64 * sizeof(uint32_t)));
+        }
+        const size_t pe = (size_t)BpadS * shadow_split() * k;
+        if (pe > ix->sh_part_entries) {
+            if (ix->sh_pkey) (void)hipFree(ix->sh_pkey);
+            if (ix->sh_pid) (void)hipFree(ix->sh_pid);
+            ix->sh_pkey = nullptr; ix->sh_pid = nullptr; ix->sh_part_entries = 0;
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_pkey), pe * sizeof(unsigned long long)));
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_pid), pe * sizeof(int)));
+            ix->sh_part_entries = pe;
+        }
+        ss.xnorm = ix->xnorm;
+        ss.N = ix->ntotal;
+        ss.d = ix->d;
+        ss.metric_l2 = metric_l2;
+        ss.alpha = metric_l2 ? -2.0f : -1.0f;
+        ss.q32 = ix->q32;
+        ss.xn_max = ix->cert_words + 1;
+        ss.B = B;
+        ss.Bpad_ws = std::min(ix->sh_q_cap, Bpad);
+        ss.qt_max = QT;
+        ss.k = k;
+        ss.kc = kc;
+        ss.id_offset = id_offset;
+        ss.D = D_dev;
+        ss.I = I_dev;
+        ss.g_tau = ix->g_tau;
+        ss.q8a = ix->sh_q8;
+        ss.q8b = ix->sh_q8 + (size_t)ix->sh_q_cap * ix->d;
+        ss.sq = ix->sh_sq;
+        ss.slots = ix->sh_slots;
+        ss.cand = ix->sh_cand;
+        ss.ccnt = ix->sh_ccnt;
+        ss.cap = kShadowCap;
+        ss.wg_slots = ix->n_cu;
+        ss.max_wg = cu_budget;
+        ss.part_key = ix->sh_pkey;
+        ss.part_id = ix->sh_pid;
+        ss.ovf = ix->sh_ovf;
+        ss.cert = cert;
+        rc = shadow_search(ss, st, ix->prof);
+        if (rc != PRAG_OK) return rc;
+        reranked = true;
+    } else if (ix->ntotal == 0 || exact_only) {
         PRAG_HIP(hipMemsetAsync(ix->cand, 0xFF, cand_need * sizeof(int), st));  // all -1
     } else if (use_mm) {
         const int rc = search_tiled(ix, B, Bpad, kc, qstride, n_tiles, cu_budget, mm_chunk, mm_cap_wg, st);
@@ -2080,6 +2191,12 @@ extern "C" int prag_index_set_candidate_depth(prag_index_t* ix, int depth) {
     return PRAG_OK;
 }
 
+extern "C" int prag_index_set_shadow(prag_index_t* ix, int mode) {
+    PRAG_REQUIRE(ix != nullptr && mode >= 0 && mode <= 2, PRAG_EINVAL, "prag_index_set_shadow: mode %d (0, 1 or 2)", mode);
+    ix->shadow_mode = mode;
+    return PRAG_OK;
+}
+
 extern "C" int prag_index_set_scan_workgroups(prag_index_t* ix, int n_workgroups) {
     PRAG_REQUIRE(ix != nullptr && n_workgroups >= 0, PRAG_EINVAL, "prag_index_set_scan_workgroups: bad argument");
     ix->wg_cap = n_workgroups;
@@ -2106,7 +2223,8 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
     void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->q16lo, ix->g_tau, ix->part_key, ix->part_idx, ix->cand,
                     ix->io_q, ix->io_res, ix->mm_cnt, ix->mm_ovf, ix->mm_ckey, ix->mm_cidx,
                     ix->mm_wcnt, ix->mm_wkey, ix->mm_widx, ix->rows16, ix->qinfo, ix->qn2, ix->flag_list, ix->g_slot,
-                    ix->cert_words, ix->ex_key, ix->ex_id};
+                    ix->cert_words, ix->ex_key, ix->ex_id, ix->rows8, ix->sscale, ix->serr, ix->shadow_err_max, ix->sh_q8,
+                    ix->sh_sq, ix->sh_slots, ix->sh_ovf, ix->sh_cand, ix->sh_ccnt, ix->sh_pkey, ix->sh_pid};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ix->io_q_host) (void)hipHostFree(ix->io_q_host);

@@ -185,6 +185,52 @@ size_t exact_part_entries(int f_cap, int grid, int k);
 // Enqueue ceil(B / f_cap) rounds of {exact scan, merge}; every launch exits at once when no query is flagged.
 int exact_run(const ExactRun& r, hipStream_t st);
 
+// ---------------------------------------------------------------------------
+// 8-bit shadow, two-level exact search (flat_shadow.hip)
+// ---------------------------------------------------------------------------
+struct ShadowStore {
+    const void* rows;        // the stored rows (exact scores come from these)
+    int store_f32;
+    int d;
+    signed char* rows8;      // [cap][d]
+    float* sscale;           // [cap] s_i
+    float* serr;             // [cap] e_i = ||x_i - s_i x^_i||, rounded up
+    uint32_t* err_max;       // float bits of max_i e_i (diagnostic)
+};
+struct ShadowSearch {
+    ShadowStore store;
+    const float* xnorm;
+    int64_t N;
+    int d, metric_l2;
+    float alpha;             // key = (L2 ? ||x||^2 : 0) + alpha * sel
+    const float* q32;        // [B][d] as the rerank uses them
+    const uint32_t* xn_max;
+    int B, Bpad_ws, k, kc;
+    int qt_max;              // query-tile height the caller padded for (32 or 64)
+    int64_t id_offset;
+    float* D;
+    int64_t* I;
+    uint32_t* g_tau;         // [Bpad] preset by prep_queries_kernel
+    // workspace
+    signed char* q8a;        // [Bpad][d]
+    signed char* q8b;
+    void* sq;                // [Bpad] ShadowQ
+    uint32_t* slots;         // [Bpad][shadow_slot_words()]
+    int* cand;               // [wg_slots][64][cap]
+    uint32_t* ccnt;          // [wg_slots][64]
+    int cap, wg_slots, max_wg;
+    unsigned long long* part_key;   // [Bpad][shadow_split()][k]
+    int* part_id;
+    uint32_t* ovf;           // [Bpad]
+    CertArgs cert;           // flag list: queries whose candidate regions overflowed go to the exact scan
+};
+bool shadow_supported(int d, int kc, int k, int B);
+size_t shadow_slot_words();
+size_t shadow_q_bytes();
+int shadow_split();
+int shadow_build(const ShadowStore& s, int64_t row0, int64_t row1, hipStream_t st);
+int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof);
+
 bool mm_supported(int d, int store_dtype, int kc);
 // Enqueue the segmented scan on `st`; returns PRAG_OK or a negative status.  `prof` brackets
 // the launch over the largest segment.

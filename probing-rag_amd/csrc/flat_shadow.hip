@@ -1,0 +1,782 @@
+// Two-level exact search: an 8-bit shadow of the stored rows is scanned instead of the rows
+// themselves (half the bytes of fp16 storage, a quarter of float32), a proof-carrying filter keeps
+// every row that can still belong to the top k, and the survivors are scored exactly (float64) from
+// the stored rows.  Results are the definition's (faiss.IndexFlat semantics; /root/reference:
+// make_indexer.py:449-450, utils.py:378-380) - the shadow only decides which rows need not be looked at.
+//
+// Shadow (built on the device from the stored rows, one wave per row):
+//   x^_i = rint(x_i / s_i) in [-127,127], s_i = max|x_i| / 127 ;  e_i = ||x_i - s_i x^_i|| (float64, rounded up)
+// Query (per search): two int8 terms, q ~ sq (q^1 + q^2 / 128), residual rq = ||q - q~|| ~ 2^-15 ||q||.
+// Selection score  sel = sq s_i (q^1.x^_i + q^2.x^_i / 128)   (v_mfma_i32_32x32x32_i8: exact integers)
+// differs from the exact q.x_i by at most
+//   eps_i = ||q~|| e_i + rq ||x_i||      (Cauchy-Schwarz; ~0.8 % of ||q|| ||x|| for 768 Gaussian elements)
+// so with key = -sel (IP, COS) or ||x_i||^2 - 2 sel (L2):  key - a eps_i <= exact key <= key + a eps_i.
+// Filter: tau is an upper bound on the k-th best EXACT key as soon as k rows with key + a eps <= tau
+// have been seen (per-lane lists of key_hi = key + a eps, shared through LDS and the chip-wide bound
+// slots, exactly as the fp16 scan shares its bound).  A row is dropped only if key - a eps_i > tau,
+// i.e. only if it provably is not among the k best; everything else is a candidate.  tau only
+// tightens, so rows seen early are tested against a looser bound: a superset, never a miss.
+// Candidates go to per-(workgroup, query) regions (LDS counter, fire-and-forget stores); a region
+// that overflows flags its query for the exact float64 scan (flat_exact.hip).
+// Warm-up: while a wave's bound is still +inf (its first few tiles, until the bound slots of the
+// first epoch arrive) nothing can be dropped, so nothing is collected either: those tiles only feed
+// the lists, and the wave visits them a second time at the end of its scan - filter only, no list
+// pushes (a row must not enter a list twice) - when the bound is tight.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+#include "flat_internal.h"
+
+namespace prag {
+
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------
+// shadow build: one wave per row
+// ---------------------------------------------------------------------------
+template <bool F32>
+__global__ __launch_bounds__(256) void shadow_build_kernel(const void* __restrict__ rows, int64_t row0, int64_t row1,
+                                                          int d, signed char* __restrict__ rows8,
+                                                          float* __restrict__ sscale, float* __restrict__ serr,
+                                                          uint32_t* __restrict__ err_max) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = row0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= row1) return;
+    auto get = [&](int c) -> float {
+        if constexpr (F32) return reinterpret_cast<const float*>(rows)[i * d + c];
+        else return (float)reinterpret_cast<const _Float16*>(rows)[i * d + c];
+    };
+    float mx = 0.f;
+    for (int c = lane; c < d; c += 64) mx = fmaxf(mx, fabsf(get(c)));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float s = mx > 0.f ? mx / 127.0f : 1.0f;
+    double err2 = 0.0;
+    for (int c = lane; c < d; c += 64) {
+        const float v = get(c);
+        float qv = rintf(v / s);
+        qv = fminf(fmaxf(qv, -127.f), 127.f);
+        rows8[i * d + c] = (signed char)(int)qv;
+        const double df = (double)v - (double)s * (double)qv;
+        err2 = fma(df, df, err2);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) err2 += __shfl_xor(err2, o, 64);
+    if (lane == 0) {
+        const float e = (float)(sqrt(err2) * (1.0 + 1e-6)) + FLT_MIN;   // rounded up: it feeds a bound
+        sscale[i] = s;
+        serr[i] = e;
+        atomicMax(err_max, __float_as_uint(e));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// query terms + per-query constants (after prep_queries_kernel wrote q32 / qinfo)
+// ---------------------------------------------------------------------------
+struct ShadowQ {     // per query, consumed by the scan
+    float kscale;    // alpha * sq : key = xnorm_i + kscale * s_i * (acc1 + acc2 / 128)
+    float A2, C2;    // two query terms:  eps_i = A e_i + C,  A = |alpha| ||q~||, C = |alpha| rq max||x|| + rounding slack
+    float A1, C1;    // first term only (64-query tiles: the matrix pipe has no room for the second)
+    float pad[3];
+};
+
+__global__ __launch_bounds__(256) void shadow_prep_kernel(const float* __restrict__ q32, int B, int Bpad, int d,
+                                                         float alpha, const uint32_t* __restrict__ xn_max,
+                                                         signed char* __restrict__ q8a, signed char* __restrict__ q8b,
+                                                         ShadowQ* __restrict__ sq_out, uint32_t* __restrict__ slots,
+                                                         int slot_words, uint32_t* __restrict__ ovf) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= Bpad) return;
+    for (int w = lane; w < slot_words; w += 64) slots[(int64_t)b * slot_words + w] = kSortablePosInf;
+    if (lane == 0) ovf[b] = 0u;
+    if (b >= B) {
+        for (int c = lane; c < d; c += 64) {
+            q8a[(int64_t)b * d + c] = 0;
+            q8b[(int64_t)b * d + c] = 0;
+        }
+        if (lane == 0) sq_out[b] = ShadowQ{0.f, 0.f, 0.f, 0.f, 0.f, {0.f, 0.f, 0.f}};
+        return;
+    }
+    const float* q = q32 + (int64_t)b * d;
+    float mx = 0.f;
+    for (int c = lane; c < d; c += 64) mx = fmaxf(mx, fabsf(q[c]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float s1 = mx > 0.f ? mx / 127.0f : 1.0f;
+    const float s2 = s1 * (1.0f / 128.0f);          // exact (power of two)
+    double r2 = 0.0, n2 = 0.0, r1 = 0.0, n1 = 0.0;
+    for (int c = lane; c < d; c += 64) {
+        const float v = q[c];
+        float a = fminf(fmaxf(rintf(v / s1), -127.f), 127.f);
+        const float rem = v - s1 * a;
+        float bq = fminf(fmaxf(rintf(rem / s2), -127.f), 127.f);
+        q8a[(int64_t)b * d + c] = (signed char)(int)a;
+        q8b[(int64_t)b * d + c] = (signed char)(int)bq;
+        const double qt = (double)s1 * (double)a + (double)s2 * (double)bq;
+        const double df = (double)v - qt;
+        r2 = fma(df, df, r2);
+        n2 = fma(qt, qt, n2);
+        const double q1 = (double)s1 * (double)a, d1 = (double)v - q1;
+        r1 = fma(d1, d1, r1);
+        n1 = fma(q1, q1, n1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        r2 += __shfl_xor(r2, o, 64);
+        n2 += __shfl_xor(n2, o, 64);
+        r1 += __shfl_xor(r1, o, 64);
+        n1 += __shfl_xor(n1, o, 64);
+    }
+    if (lane == 0) {
+        const double aa = fabs((double)alpha);
+        const double xn = (double)__uint_as_float(*xn_max) * (1.0 + 1e-6);
+        const double nx = sqrt(xn);
+        ShadowQ o;
+        o.kscale = alpha * s1;
+        // eps = A e_i + C;  C = query residual against the largest row + float32 roundings of key / eps
+        auto consts = [&](double nq, double rq, float& A, float& C) {
+            A = (float)(aa * nq * (1.0 + 1e-5)) + FLT_MIN;
+            C = (float)((aa * rq * nx + 1e-6 * (xn + 2.0 * aa * (nq + rq) * nx)) * (1.0 + 1e-5)) + FLT_MIN;
+        };
+        consts(sqrt(n2), sqrt(r2), o.A2, o.C2);
+        consts(sqrt(n1), sqrt(r1), o.A1, o.C1);
+        o.pad[0] = o.pad[1] = o.pad[2] = 0.f;
+        sq_out[b] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// the scan
+// ---------------------------------------------------------------------------
+struct Scan8Args {
+    const signed char* rows8;   // [N][d]
+    const float* sscale;        // [roundup(N,32)]
+    const float* serr;
+    const float* xnorm;
+    const signed char* q8a;     // [QT][d] this pass's query tile
+    const signed char* q8b;
+    const ShadowQ* sq;          // [QT]
+    int64_t N;
+    int d;
+    int qstride;                // LDS bytes per query row (multiple of 256)
+    int n_tiles;                // ceil(N / 32)
+    int use_norm;               // L2: key includes ||x||^2
+    uint32_t* g_tau;            // [QT] chip-wide bound (sortable), +inf at start, -inf for padding
+    uint32_t* g_slot;           // [QT][kShadowEpochs][32]
+    int* cand;                  // [grid][QT][cap]
+    uint32_t* ccnt;             // [grid][QT]
+    int cap;
+};
+
+constexpr int kShadowEpochs = 9;                    // bound slots refreshed after tiles 1, 2, 4, ..., 256
+constexpr int kShadowSlotWords = kShadowEpochs * 32;
+
+template <int KC>
+struct KeyList {   // sorted KC smallest keys (no ids: the lists only feed the bound)
+    float k[KC];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int j = 0; j < KC; ++j) k[j] = INFINITY;
+    }
+    __device__ __forceinline__ void push(float key, float tau) {
+        if (key < k[KC - 1] && key <= tau) {
+            float prev = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < KC; ++j) {
+                const float cur = k[j];
+                k[j] = __builtin_amdgcn_fmed3f(prev, cur, key);
+                prev = cur;
+            }
+        }
+    }
+};
+
+template <int QT, int KC>
+__global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NQ = QT / 32;
+    // 32-query tiles carry the query as two int8 terms (the HBM-bound loop has matrix-pipe slack for the
+    // second MFMA); 64-query tiles use the first term only and pay with a wider eps (more candidates)
+    constexpr int TERMS = QT == 32 ? 2 : 1;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int d = a.d;
+    const int NCH = d >> 7;                       // 128-byte chunks per row
+    const int qstride = a.qstride;
+    char* s_qa = smem;
+    char* s_qb = smem + QT * qstride;
+    char* s_st = smem + 2 * QT * qstride + w * 4096;
+    float* s_meta = reinterpret_cast<float*>(smem + 2 * QT * qstride + 8 * 4096) + w * 96;   // [3][32] per wave
+    uint32_t* s_tau = reinterpret_cast<uint32_t*>(smem + 2 * QT * qstride + 8 * 4096 + 8 * 384);
+    uint32_t* s_best = s_tau + QT;
+    uint32_t* s_ccnt = s_best + QT;
+    uint32_t* s_slot_ok = s_ccnt + QT;     // set once a poll found every query's slot bound finite
+    if (tid < QT) {
+        s_tau[tid] = a.g_tau[tid];
+        s_best[tid] = 0xFFFFFFFFu;
+        s_ccnt[tid] = 0u;
+    }
+    if (tid == 0) *s_slot_ok = 0u;
+    // ---- query tiles -> LDS (swizzled 16-B pieces, as the fp16 scan) -----------------------------
+    {
+        const int ppr = d >> 4;
+        const int total = QT * ppr;
+#pragma unroll
+        for (int plane = 0; plane < TERMS; ++plane) {
+            const signed char* qsrc = plane == 0 ? a.q8a : a.q8b;
+            char* qdst = plane == 0 ? s_qa : s_qb;
+            for (int e0 = tid; e0 < total; e0 += 512 * 4) {
+                u32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * 512;
+                    const int ec = e < total ? e : total - 1;
+                    const int row = ec / ppr, pc = ec - row * ppr;
+                    v[u] = *reinterpret_cast<const u32x4*>(qsrc + (int64_t)row * d + 16 * pc);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * 512;
+                    if (e < total) {
+                        const int row = e / ppr, pc = e - row * ppr;
+                        *reinterpret_cast<u32x4*>(qdst + row * qstride + (((pc & ~15) | ((pc ^ row) & 15)) << 4)) = v[u];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int nW = gridDim.x * 8;
+    const int gw = blockIdx.x * 8 + w;
+    const int n_my = gw < a.n_tiles ? (a.n_tiles - gw + nW - 1) / nW : 0;
+
+    KeyList<KC> top[NQ];
+    float kscale[NQ], cA[NQ], cC[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        top[t].init();
+        const ShadowQ s = a.sq[32 * t + r];
+        kscale[t] = s.kscale;
+        cA[t] = TERMS == 2 ? s.A2 : s.A1;
+        cC[t] = TERMS == 2 ? s.C2 : s.C1;
+    }
+
+    // staging geometry: 4 x 16-B loads per lane per 128-byte chunk of 32 rows
+    int st_doc[4], st_dst[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int doc = 8 * i + (lane >> 3), q = lane & 7;
+        st_doc[i] = doc;
+        st_dst[i] = doc * 128 + ((q ^ ((doc >> 1) & 7)) << 4);
+    }
+    const int col_b = (lane & 7) * 16;
+    const int64_t row_bytes = d;
+    const char* rows = reinterpret_cast<const char*>(a.rows8);
+    u32x4 ldA[4], ldB[4];
+    auto issue = [&](u32x4 (&ld)[4], int tile, int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int64_t row = (int64_t)tile * 32 + st_doc[i];
+            row = row < a.N ? row : a.N - 1;
+            ld[i] = *reinterpret_cast<const u32x4*>(rows + row * row_bytes + c * 128 + col_b);
+        }
+    };
+    const int a_off = r * 128;
+    const int a_sw = (r >> 1) & 7;
+
+    i32x16 acc1[NQ], acc2[TERMS == 2 ? NQ : 1];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            acc1[t][e] = 0;
+            if (TERMS == 2) acc2[t][e] = 0;
+        }
+
+    // virtual tile sequence of this wave: its n_my tiles, then the first `redo` of them again
+    constexpr int kWarmMax = 16;
+    int redo = 0;
+    bool warm = true;
+    auto vtile = [&](int vt) {
+        int at = vt < n_my ? vt : vt - n_my;
+        at = at < n_my ? at : n_my - 1;             // prefetch past the end: any valid tile
+        return gw + at * nW;
+    };
+    int vt_cur = 0, c_cur = 0;
+    int vt_nx = 0, c_nx = 0;
+    auto advance = [&](int& t, int& c) {
+        const bool wrap = (c + 1 == NCH);
+        c = wrap ? 0 : c + 1;
+        t = wrap ? t + 1 : t;
+    };
+    float m_s = 1.f, m_e = 0.f, m_x = 0.f;   // metadata of row (tile*32 + r), requested at the tile's first chunk
+    int tiles_done = 0;
+
+    auto body = [&](u32x4 (&ld)[4]) {
+        const int tile_cur = vtile(vt_cur);
+        if (c_cur == 0) {
+            const int64_t row = (int64_t)tile_cur * 32 + r;     // (arrays are padded to a multiple of 32 rows)
+            m_s = a.sscale[row];
+            m_e = a.serr[row];
+            m_x = a.use_norm ? a.xnorm[row] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(s_st + st_dst[i]) = ld[i];
+        issue(ld, vtile(vt_nx), c_nx);
+        advance(vt_nx, c_nx);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {               // 4 k-steps of 32 elements per 128-byte chunk
+            const i32x4 av = *reinterpret_cast<const i32x4*>(s_st + a_off + (((2 * s + hh) ^ a_sw) << 4));
+            const int P = c_cur * 8 + 2 * s + hh;
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) {
+                const int qrow = 32 * t + r;
+                const int q_addr = qrow * qstride + (((P & ~15) | ((P ^ qrow) & 15)) << 4);
+                const i32x4 b1 = *reinterpret_cast<const i32x4*>(s_qa + q_addr);
+                acc1[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b1, acc1[t], 0, 0, 0);
+                if constexpr (TERMS == 2) {
+                    const i32x4 b2 = *reinterpret_cast<const i32x4*>(s_qb + q_addr);
+                    acc2[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b2, acc2[t], 0, 0, 0);
+                }
+            }
+        }
+        if (c_cur == NCH - 1) {
+            // ---- epilogue: 16 rows x this lane's queries ---------------------------------------
+            const bool second = vt_cur >= n_my;     // second visit of a warm-up tile: filter only
+            const bool collect = second || !warm;
+            if (hh == 0) {
+                s_meta[r] = m_s;
+                s_meta[32 + r] = m_e;
+                s_meta[64 + r] = m_x;
+            }
+            const int64_t doc0 = (int64_t)tile_cur * 32;
+            float tau[NQ];
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) tau[t] = unsortable_f32(s_tau[32 * t + r]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 rs = *reinterpret_cast<const f32x4*>(s_meta + 8 * g + 4 * hh);
+                const f32x4 re = *reinterpret_cast<const f32x4*>(s_meta + 32 + 8 * g + 4 * hh);
+                const f32x4 rx = *reinterpret_cast<const f32x4*>(s_meta + 64 + 8 * g + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int64_t doc = doc0 + 8 * g + 4 * hh + e;
+                    const bool valid = doc < a.N;
+#pragma unroll
+                    for (int t = 0; t < NQ; ++t) {
+                        float dq = (float)acc1[t][4 * g + e];
+                        if constexpr (TERMS == 2) dq = fmaf((float)acc2[t][4 * g + e], 1.0f / 128.0f, dq);
+                        const float mid = fmaf(kscale[t] * rs[e], dq, rx[e]);
+                        const float eps = fmaf(cA[t], re[e], cC[t]);
+                        if (!second) top[t].push(valid ? mid + eps : INFINITY, tau[t]);
+                        if (collect && valid && mid - eps <= tau[t]) {     // cannot be excluded: candidate
+                            const uint32_t slot = atomicAdd(&s_ccnt[32 * t + r], 1u);
+                            if (slot < (uint32_t)a.cap)
+                                a.cand[((int64_t)blockIdx.x * QT + 32 * t + r) * a.cap + slot] = (int)doc;
+                        }
+                        acc1[t][4 * g + e] = 0;
+                        if constexpr (TERMS == 2) acc2[t][4 * g + e] = 0;
+                    }
+                }
+            }
+            if (!second) {
+#pragma unroll
+                for (int t = 0; t < NQ; ++t)
+                    if (top[t].k[KC - 1] < tau[t]) atomicMin(&s_tau[32 * t + r], sortable_u32(top[t].k[KC - 1]));
+                ++tiles_done;
+                if (warm) {
+                    ++redo;
+                    // leave the warm-up when a chip-wide slot bound has arrived for every query (a lane's own
+                    // 16th-best-of-16 is a bound too, but one that lets nearly every row through)
+                    if (*s_slot_ok != 0u || redo >= kWarmMax) warm = false;
+                }
+                // bound slots (see flat_index.hip kSlotWords): epoch e is fed after tile 2^e
+                if ((tiles_done & (tiles_done - 1)) == 0 && tiles_done <= (1 << (kShadowEpochs - 1))) {
+#pragma unroll
+                    for (int t = 0; t < NQ; ++t) {
+                        const float k0 = top[t].k[0];
+                        if (k0 < INFINITY) atomicMin(&s_best[32 * t + r], sortable_u32(k0));
+                    }
+                }
+                {
+                    const int tm = tiles_done - 1;          // published one tile after the lists fed s_best
+                    if (w == 0 && tm >= 1 && (tm & (tm - 1)) == 0 && tm <= (1 << (kShadowEpochs - 1)) && lane < QT) {
+                        const int epoch = 31 - __builtin_clz(tm);
+                        const uint32_t v = s_best[lane];
+                        if (v != 0xFFFFFFFFu)
+                            (void)__hip_atomic_fetch_min(a.g_slot + (lane * kShadowEpochs + epoch) * 32 + (blockIdx.x % KC), v,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    // two polls per epoch (2 and 3 tiles after it was fed), waves take turns
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int tp = tiles_done - 2 - i;
+                        if (tp >= 1 && (tp & (tp - 1)) == 0 && tp <= (1 << (kShadowEpochs - 1))) {
+                            const int epoch = 31 - __builtin_clz(tp);
+                            if (w == ((2 * epoch + i) & 7) && lane < QT) {
+                                const uint32_t* sl = a.g_slot + (lane * kShadowEpochs + epoch) * 32;
+                                uint32_t m = 0u;
+#pragma unroll
+                                for (int s2 = 0; s2 < KC; ++s2) {
+                                    const uint32_t v = __hip_atomic_load(sl + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    m = v > m ? v : m;
+                                }
+                                if (m < s_tau[lane]) atomicMin(&s_tau[lane], m);
+                                // padding queries (bound -inf) never get slot values: they do not count
+                                const bool missing = m == kSortablePosInf && s_tau[lane] != kSortableNegInf;
+                                if (__builtin_amdgcn_ballot_w64(missing) == 0 && lane == 0) *s_slot_ok = 1u;
+                            }
+                        }
+                    }
+                }
+                if (w == 0 && (tiles_done & 7) == 0 && hh == 0) {
+#pragma unroll
+                    for (int t = 0; t < NQ; ++t) {
+                        const uint32_t loc = s_tau[32 * t + r];
+                        const uint32_t glob = __hip_atomic_load(a.g_tau + 32 * t + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (loc < glob)
+                            __hip_atomic_fetch_min(a.g_tau + 32 * t + r, loc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else if (glob < loc)
+                            atomicMin(&s_tau[32 * t + r], glob);
+                    }
+                }
+            }
+        }
+        advance(vt_cur, c_cur);
+    };
+
+    if (n_my > 0) {
+        issue(ldA, vtile(vt_nx), c_nx);
+        advance(vt_nx, c_nx);
+        issue(ldB, vtile(vt_nx), c_nx);
+        advance(vt_nx, c_nx);
+        // (`redo` grows during the first tiles only, long before the loop bound is reached - or, on a
+        // shard of a few tiles, up to n_my: every tile is then visited twice)
+        for (int it = 0; it < (n_my + redo) * NCH; it += 2) {
+            body(ldA);
+            if (it + 1 < (n_my + redo) * NCH) body(ldB);
+            else break;
+        }
+    }
+    __syncthreads();
+    if (tid < QT) a.ccnt[(int64_t)blockIdx.x * QT + tid] = s_ccnt[tid];
+}
+
+// ---------------------------------------------------------------------------
+// exact float64 scores of the candidates -> top k per query
+// ---------------------------------------------------------------------------
+constexpr int kShCap = 2048;
+constexpr int kShThreads = 512;
+constexpr int kShSplit = 8;      // workgroups per query
+constexpr int kShIds = 6144;     // candidate ids one workgroup stages in LDS
+
+struct ShTopK {
+    unsigned long long key[kShCap];
+    int id[kShCap];
+    unsigned long long bound;
+    int cnt;
+};
+
+__device__ __forceinline__ void sh_cut(ShTopK& t, int k) {
+    __syncthreads();
+    const int n = t.cnt;
+    int n_pad = 2;
+    while (n_pad < n) n_pad <<= 1;
+    for (int i = n + threadIdx.x; i < n_pad; i += kShThreads) {
+        t.key[i] = ~0ull;
+        t.id[i] = 0x7fffffff;
+    }
+    for (int size = 2; size <= n_pad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int p = threadIdx.x; p < (n_pad >> 1); p += kShThreads) {
+                const int i = ((p / stride) * 2 * stride) + (p % stride), j = i + stride;
+                const unsigned long long ka = t.key[i], kb = t.key[j];
+                const int ia = t.id[i], ib = t.id[j];
+                const bool gt = ka > kb || (ka == kb && ia > ib);
+                if (gt == ((i & size) == 0)) {
+                    t.key[i] = kb;
+                    t.key[j] = ka;
+                    t.id[i] = ib;
+                    t.id[j] = ia;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        t.cnt = n < k ? n : k;
+        if (n >= k) t.bound = t.key[k - 1];
+    }
+    __syncthreads();
+}
+
+template <int CTRL>
+__device__ __forceinline__ double sh_dpp_f64(double x) {
+    return __longlong_as_double((long long)dpp_move_u64<CTRL>((unsigned long long)__double_as_longlong(x)));
+}
+
+struct GatherArgs {
+    const void* rows;       // stored rows
+    int d;
+    int metric_l2;
+    const float* q32;       // [B][d]
+    const int* cand;        // [n_wg][QT][cap] of the query tile this launch serves
+    const uint32_t* ccnt;   // [n_wg][QT]
+    int n_wg, QT, cap;
+    int q0;                 // first query of the tile
+    int k;
+    unsigned long long* part_key;   // [B][kShSplit][k]
+    int* part_id;
+    uint32_t* ovf;          // [B] set when a region overflowed (or the id stage did)
+    CertArgs cert;          // flag list for the exact fallback
+};
+
+template <bool F32>
+__global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a) {
+    __shared__ ShTopK tk;
+    __shared__ int s_ids[kShIds];
+    __shared__ __attribute__((aligned(16))) float s_q[1024];
+    __shared__ int s_n, s_over;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int sub = lane & 15, slot = lane >> 4;
+    const int qi = blockIdx.y;                // query inside the tile
+    const int b = a.q0 + qi;
+    const int d = a.d;
+    if (tid == 0) {
+        s_n = 0;
+        s_over = 0;
+        tk.bound = ~0ull;
+        tk.cnt = 0;
+    }
+    for (int c = tid; c < d; c += kShThreads) s_q[c] = a.q32[(int64_t)b * d + c];
+    __syncthreads();
+    // ---- stage this slice's candidate ids ---------------------------------------------------------
+    const int per = (a.n_wg + kShSplit - 1) / kShSplit;
+    const int wg0 = blockIdx.x * per, wg1 = min(a.n_wg, wg0 + per);
+    for (int wg = wg0 + w; wg < wg1; wg += kShThreads / 64) {
+        const uint32_t c = a.ccnt[(int64_t)wg * a.QT + qi];
+        if (c > (uint32_t)a.cap && lane == 0) s_over = 1;
+        const int n = (int)min(c, (uint32_t)a.cap);
+        int base = 0;
+        if (lane == 0 && n > 0) base = atomicAdd(&s_n, n);
+        base = __shfl(base, 0, 64);
+        for (int j = lane; j < n; j += 64) {
+            if (base + j < kShIds) s_ids[base + j] = a.cand[((int64_t)wg * a.QT + qi) * a.cap + j];
+            else s_over = 1;
+        }
+    }
+    __syncthreads();
+    const int n_ids = min(s_n, kShIds);
+    if (s_over && tid == 0 && atomicExch(a.ovf + b, 1u) == 0u) cert_flag(a.cert, b);   // exact scan recomputes b
+    // ---- exact scores, 16 lanes per candidate row -------------------------------------------------
+    for (int i0 = 0; i0 < n_ids; i0 += 32) {
+        const int ci = i0 + w * 4 + slot;
+        const bool have = ci < n_ids;
+        const int64_t row = have ? s_ids[ci] : 0;
+        double s = 0.0;
+        if (have) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {       // d <= 1024
+                const int e = sub * 8 + it * 128;
+                if (e < d) {
+                    float xv[8];
+                    if constexpr (F32) {
+                        const float* p = reinterpret_cast<const float*>(a.rows) + row * d + e;
+                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(p);
+                        const f32x4 x1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { xv[j] = x0[j]; xv[4 + j] = x1[j]; }
+                    } else {
+                        const half8 h = *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(a.rows) + row * d + e);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xv[j] = (float)h[j];
+                    }
+                    const f32x4 q0 = *reinterpret_cast<const f32x4*>(s_q + e);
+                    const f32x4 q1 = *reinterpret_cast<const f32x4*>(s_q + e + 4);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const double qv = (double)(j < 4 ? q0[j] : q1[j - 4]);
+                        const double x = (double)xv[j];
+                        if (a.metric_l2) {
+                            const double df = qv - x;
+                            s = fma(df, df, s);
+                        } else {
+                            s = fma(qv, x, s);
+                        }
+                    }
+                }
+            }
+        }
+        s += sh_dpp_f64<0xB1>(s);
+        s += sh_dpp_f64<0x4E>(s);
+        s += sh_dpp_f64<0x141>(s);
+        s += sh_dpp_f64<0x140>(s);
+        if (sub == 0 && have) {
+            const unsigned long long key = a.metric_l2 ? sortable_u64(s) : ~sortable_u64(s);
+            if (key <= tk.bound) {
+                const int sl = atomicAdd(&tk.cnt, 1);
+                tk.key[sl] = key;
+                tk.id[sl] = (int)row;
+            }
+        }
+        if (((i0 >> 5) & 7) == 7) {     // every 8 steps (<= 256 pushes): room check
+            __syncthreads();
+            const int c = tk.cnt;
+            __syncthreads();
+            if (c > kShCap - 256) sh_cut(tk, a.k);
+        }
+    }
+    sh_cut(tk, a.k);
+    const int64_t o = ((int64_t)b * kShSplit + blockIdx.x) * a.k;
+    for (int j = tid; j < a.k; j += kShThreads) {
+        const bool ok = j < tk.cnt;
+        a.part_key[o + j] = ok ? tk.key[j] : ~0ull;
+        a.part_id[o + j] = ok ? tk.id[j] : 0x7fffffff;
+    }
+}
+
+// merge of the kShSplit partial lists of every query -> D / I   (k <= 32: one wave's worth of entries)
+__global__ __launch_bounds__(256) void shadow_merge_kernel(const unsigned long long* __restrict__ part_key,
+                                                          const int* __restrict__ part_id, int k, int metric_l2,
+                                                          int64_t id_offset, float* __restrict__ D,
+                                                          int64_t* __restrict__ I) {
+    __shared__ unsigned long long s_key[kShSplit * 32];
+    __shared__ int s_id[kShSplit * 32];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = kShSplit * k;
+    for (int i = tid; i < n; i += 256) {
+        s_key[i] = part_key[(int64_t)b * n + i];
+        s_id[i] = part_id[(int64_t)b * n + i];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const unsigned long long kv = s_key[i];
+        const int iv = s_id[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const unsigned long long kj = s_key[j];
+            const int ij = s_id[j];
+            rank += (kj < kv) || (kj == kv && (ij < iv || (ij == iv && j < i)));
+        }
+        if (rank < k) {
+            const bool ok = iv != 0x7fffffff;
+            const double sc = ok ? unsortable_f64(metric_l2 ? kv : ~kv) : 0.0;
+            D[(int64_t)b * k + rank] = ok ? (float)sc : (metric_l2 ? FLT_MAX : -FLT_MAX);
+            I[(int64_t)b * k + rank] = ok ? (int64_t)iv + id_offset : -1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+bool shadow_supported(int d, int kc, int k, int B) {
+    return d % 128 == 0 && d <= 1024 && (kc == 8 || kc == 16) && k <= 32 && B >= 1;
+}
+
+int shadow_build(const ShadowStore& s, int64_t row0, int64_t row1, hipStream_t st) {
+    if (row1 <= row0) return PRAG_OK;
+    const dim3 grid((unsigned)((row1 - row0 + 3) / 4)), block(256);
+    if (s.store_f32)
+        hipLaunchKernelGGL(shadow_build_kernel<true>, grid, block, 0, st, s.rows, row0, row1, s.d, s.rows8, s.sscale, s.serr,
+                           s.err_max);
+    else
+        hipLaunchKernelGGL(shadow_build_kernel<false>, grid, block, 0, st, s.rows, row0, row1, s.d, s.rows8, s.sscale,
+                           s.serr, s.err_max);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+size_t shadow_slot_words() { return kShadowSlotWords; }
+size_t shadow_q_bytes() { return sizeof(ShadowQ); }
+int shadow_split() { return kShSplit; }
+
+template <int QT, int KC>
+static int launch_scan8(const Scan8Args& a, int grid, hipStream_t st, EventRing& prof) {
+    const int lds = 2 * QT * a.qstride + 8 * 4096 + 8 * 384 + 3 * QT * 4 + 16;
+    auto kern = scan8_kernel<QT, KC>;
+    static LdsOptIn lds_opt_in;
+    {
+        const int rc_ = lds_opt_in.ensure(reinterpret_cast<const void*>(kern), 160 * 1024);
+        if (rc_ != PRAG_OK) return rc_;
+    }
+    prof.begin(st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    prof.end(st);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
+    const int qstride = (s.d + 255) / 256 * 256;
+    const bool wide = s.qt_max >= 64 && s.B > 32 && 2 * 64 * qstride + 8 * 4096 + 8 * 384 + 3 * 64 * 4 + 16 <= 160 * 1024;
+    const int QT = wide ? 64 : 32;
+    const int Bpad = (s.B + QT - 1) / QT * QT;
+    PRAG_REQUIRE(Bpad <= s.Bpad_ws, PRAG_EUNSUPPORTED, "internal: shadow workspace too small");
+    const int n_tiles = (int)((s.N + 31) / 32);
+    const int grid = std::max(1, std::min(s.max_wg, (n_tiles + 7) / 8));
+    PRAG_REQUIRE(grid <= s.wg_slots, PRAG_EUNSUPPORTED, "internal: shadow candidate regions too few");
+    hipLaunchKernelGGL(shadow_prep_kernel, dim3((Bpad + 3) / 4), dim3(256), 0, st, s.q32, s.B, Bpad, s.d, s.alpha, s.xn_max,
+                       s.q8a, s.q8b, reinterpret_cast<ShadowQ*>(s.sq), s.slots, (int)kShadowSlotWords, s.ovf);
+    PRAG_LAUNCH_CHECK();
+    for (int p0 = 0; p0 < Bpad; p0 += QT) {
+        Scan8Args a;
+        a.rows8 = s.store.rows8;
+        a.sscale = s.store.sscale;
+        a.serr = s.store.serr;
+        a.xnorm = s.xnorm;
+        a.q8a = s.q8a + (size_t)p0 * s.d;
+        a.q8b = s.q8b + (size_t)p0 * s.d;
+        a.sq = reinterpret_cast<const ShadowQ*>(s.sq) + p0;
+        a.N = s.N;
+        a.d = s.d;
+        a.qstride = qstride;
+        a.n_tiles = n_tiles;
+        a.use_norm = s.metric_l2;
+        a.g_tau = s.g_tau + p0;
+        a.g_slot = s.slots + (size_t)p0 * kShadowSlotWords;
+        a.cand = s.cand;
+        a.ccnt = s.ccnt;
+        a.cap = s.cap;
+        int rc;
+        if (QT == 64) rc = s.kc == 8 ? launch_scan8<64, 8>(a, grid, st, prof) : launch_scan8<64, 16>(a, grid, st, prof);
+        else rc = s.kc == 8 ? launch_scan8<32, 8>(a, grid, st, prof) : launch_scan8<32, 16>(a, grid, st, prof);
+        if (rc != PRAG_OK) return rc;
+        const int nq = std::min(QT, s.B - p0);
+        GatherArgs g;
+        g.rows = s.store.rows;
+        g.d = s.d;
+        g.metric_l2 = s.metric_l2;
+        g.q32 = s.q32;
+        g.cand = s.cand;
+        g.ccnt = s.ccnt;
+        g.n_wg = grid;
+        g.QT = QT;
+        g.cap = s.cap;
+        g.q0 = p0;
+        g.k = s.k;
+        g.part_key = s.part_key;
+        g.part_id = s.part_id;
+        g.ovf = s.ovf;
+        g.cert = s.cert;
+        if (s.store.store_f32)
+            hipLaunchKernelGGL(shadow_gather_kernel<true>, dim3(kShSplit, nq), dim3(kShThreads), 0, st, g);
+        else
+            hipLaunchKernelGGL(shadow_gather_kernel<false>, dim3(kShSplit, nq), dim3(kShThreads), 0, st, g);
+        PRAG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(shadow_merge_kernel, dim3(s.B), dim3(256), 0, st, s.part_key, s.part_id, s.k, s.metric_l2,
+                       s.id_offset, s.D, s.I);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+}  // namespace prag

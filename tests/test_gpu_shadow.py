@@ -1,0 +1,102 @@
+"""GPU: two-level exact search through the 8-bit shadow (prag_index_set_shadow, flat_shadow.hip).
+The shadow only decides which rows need not be looked at: results must be the float64 definition's,
+bit for bit, for every shape - and the int8 matrix-core operand layout is pinned by them."""
+import numpy as np
+import pytest
+
+from oracle import oracle_c, oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+
+METRICS = [onp.METRIC_L2, onp.METRIC_IP, onp.METRIC_COS]
+
+
+def _stored(X, metric, store):
+    xs = onp.normalize_rows(X) if metric == onp.METRIC_COS else X
+    return onp.store_round(xs, store)
+
+
+def _check(D, I, D0, I0, metric):
+    assert np.array_equal(I, I0), np.argwhere(I != I0)[:4]
+    if metric == onp.METRIC_L2:
+        np.testing.assert_allclose(D, D0, rtol=1e-4, atol=1e-6)
+    else:
+        np.testing.assert_allclose(D, D0, atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("store", ["f16", "f32"])
+@pytest.mark.parametrize("metric", METRICS)
+@pytest.mark.parametrize("N,B,k,d", [(10_000, 64, 5, 768), (1, 1, 5, 768), (31, 3, 10, 128), (2049, 33, 10, 256),
+                                     (4097, 40, 12, 512), (777, 1, 1, 1024), (30_000, 7, 10, 768),
+                                     (5000, 70, 5, 384)])
+def test_shadow_search_matches_definition(metric, store, N, B, k, d):
+    import probing_rag_amd as pra
+    X = onp.synth_rows(42, 0, N, d)
+    if N > 40:
+        X[N // 2] = X[3]
+        X[N - 1] = X[3]
+    Q = onp.synth_rows(7, 0, B, d)
+    if N > 40:
+        Q[0] = X[3]
+    ix = pra.HipFlatIndex(d, metric, store)
+    ix.set_shadow(2)
+    ix.add(X[: N // 2])
+    ix.add(X[N // 2:])                         # the shadow follows incremental adds
+    D, I = ix.search(Q, k)
+    D0, I0 = oracle_c.flat_search(_stored(X, metric, store), Q, k, metric)
+    _check(D, I, D0, I0, metric)
+    ix.add(X[:100] * np.float32(1.5))          # grow after a search: rows 0..99 scaled get new ids
+    X2 = np.concatenate([X, X[:100] * np.float32(1.5)])
+    D, I = ix.search(Q, k)
+    D0, I0 = oracle_c.flat_search(_stored(X2, metric, store), Q, k, metric)
+    _check(D, I, D0, I0, metric)
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_shadow_on_rows_the_quantiser_handles_badly(metric):
+    """Near-parallel rows with one huge element each: the per-row 8-bit grid is coarse relative to the
+    differences that decide the ranking, the filter cannot exclude much, candidate regions overflow -
+    flagged queries must come out of the exact scan; results still exact."""
+    import probing_rag_amd as pra
+    N, d, B, k = 40_000, 256, 20, 10
+    rng = np.random.default_rng(3)
+    base = onp.synth_rows(5, 0, 1, d)[0]
+    X = (base[None, :] + 1e-3 * rng.standard_normal((N, d))).astype(np.float32)
+    X[np.arange(N), rng.integers(0, d, N)] += 50.0           # one outlier element per row sets the scale
+    Q = (base[None, :] + 1e-3 * rng.standard_normal((B, d))).astype(np.float32)
+    for store in ("f16", "f32"):
+        ix = pra.HipFlatIndex(d, metric, store)
+        ix.set_shadow(2)
+        ix.add(X)
+        D, I = ix.search(Q, k)
+        D0, I0 = oracle_c.flat_search(_stored(X, metric, store), Q, k, metric)
+        _check(D, I, D0, I0, metric)
+        ix.close()
+
+
+def test_shadow_filter_statistics_on_a_random_corpus():
+    """1 M exchangeable rows: the filter must leave a few hundred candidates per query, no overflow
+    (no exact fallback), and agree with the plain fp16 scan bit for bit."""
+    import torch
+    import probing_rag_amd as pra
+    N, d, k = 1_200_000, 768, 10       # >= 2^20 rows: mode 1 switches the shadow on
+    ix = pra.HipFlatIndex(d, "cos", "f16", capacity=N)
+    ix.add_synthetic(42, 0, N)
+    Q = onp.synth_rows(7, 0, 64, d)
+    for i in range(8):
+        Q[i] = onp.synth_rows(42, 1000 + 7919 * i, 1, d)[0] + 0.05 * Q[i]
+    q = torch.from_numpy(Q).cuda()
+    for B in (64, 1, 32):
+        D0, I0 = ix.search(q[:B], k)
+        ix.set_shadow(1)
+        D1, I1 = ix.search(q[:B], k)
+        assert ix.last_exact_fallbacks() == 0
+        ix.set_shadow(0)
+        assert torch.equal(I0, I1)
+        assert torch.allclose(D0, D1, rtol=1e-6, atol=0)
+    assert (I0[:1, 0].cpu().numpy() == [1000]).all()
+    ix.set_shadow(1)
+    Dn, In = ix.search(Q[:5], 5)                                  # NumPy in/out (host i/o path)
+    ix.set_shadow(0)
+    Dm, Im = ix.search(Q[:5], 5)
+    assert np.array_equal(In, Im) and np.allclose(Dn, Dm, rtol=1e-6)
