@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--store", default="f16", choices=["f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--shadow", type=int, default=1,
+                    help="1: two-level exact search through the 8-bit shadow of the rows (prag_index_set_shadow); "
+                         "0: scan the stored rows themselves")
     ap.add_argument("--overlap-gate", type=int, default=1,
                     help="1: run the gate on a second stream beside the HBM-bound scan (scan capped at "
                          "n_cu-16 workgroups); 0: one stream")
@@ -167,13 +170,27 @@ def _timed_searches(torch, ix, q, k, min_s=0.6, max_reps=200):
     return dt / reps * 1e3, ms, ix.last_exact_fallbacks()
 
 
-def variant_record(torch, ix, q, k, store, metric, n_local):
-    B = q.shape[0]
-    ms_search, kern_ms, fb = _timed_searches(torch, ix, q, k)
+def scan_model(B, k, store, metric, n_local, shadow):
+    """(kernel name, algorithmic bytes per launch, launches per search) - mirrors prag_index_search's choice.
+    Algorithmic bytes = what one pass over the shard has to read: the rows in the form that is scanned
+    (+4 B of ||x||^2 per row for L2; the 8-bit shadow carries 8 B of scale and error bound per row)."""
+    if B > 128:
+        return "scan_mm_kernel", None, 1
+    if B > 64 and store == "f16":
+        return "scan_qs_kernel", n_local * D_EMB * 2 + (n_local * 4 if metric == "l2" else 0), 1 + (B - 1) // 128
+    if shadow and k <= 12 and n_local >= (1 << 20):
+        return "scan8_kernel", n_local * (D_EMB + 8) + (n_local * 4 if metric == "l2" else 0), 1 + (B - 1) // 64
     elt = 2 if store == "f16" else 4
-    alg_bytes = n_local * D_EMB * elt + (n_local * 4 if metric == "l2" else 0)
+    return "scan_topk_kernel", n_local * D_EMB * elt + (n_local * 4 if metric == "l2" else 0), 1 + (B - 1) // 64
+
+
+def variant_record(torch, ix, q, k, store, metric, n_local, shadow=0):
+    B = q.shape[0]
+    ix.set_shadow(1 if shadow else 0)
+    ms_search, kern_ms, fb = _timed_searches(torch, ix, q, k)
+    kernel, alg_bytes, passes = scan_model(B, k, store, metric, n_local, shadow)
     tiled = B > 128
-    rec = {"store": store, "metric": metric, "k": k, "queries": B, "rows": n_local,
+    rec = {"store": store, "metric": metric, "k": k, "queries": B, "rows": n_local, "shadow": bool(shadow),
            "ms_per_search": ms_search, "scores_per_s": B * n_local / (ms_search * 1e-3),
            "exact_fallbacks_last_search": fb}
     if tiled:   # MFMA-bound: price the whole search (all segments, compactions, rerank) against the matrix peak
@@ -182,10 +199,9 @@ def variant_record(torch, ix, q, k, store, metric, n_local):
                     "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TF,
                     "largest_segment_ms": float(np.mean(kern_ms)) if kern_ms else None})
     else:
-        passes = 1 + (B - 1) // (128 if (B > 64 and store == "f16") else 64)
         kms = float(np.mean(kern_ms)) if kern_ms else float("nan")
         gbs = alg_bytes / (kms * 1e-3) / 1e9
-        rec.update({"kernel": "scan_qs_kernel" if (B > 64 and store == "f16") else "scan_topk_kernel",
+        rec.update({"kernel": kernel,
                     "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": kms, "launches_per_search": passes,
                     "algorithmic_bytes_per_launch": alg_bytes,
@@ -253,6 +269,7 @@ def main():
     n_cu = torch.cuda.get_device_properties(dev_index).multi_processor_count
     if args.overlap_gate:
         local.set_scan_workgroups(n_cu - 16)
+    local.set_shadow(1 if args.shadow else 0)
 
     def one_pass():
         if not args.overlap_gate:
@@ -319,6 +336,7 @@ def main():
     n_sub = min(200_000, args.docs)
     sub = pra.HipFlatIndex(d_emb, args.metric, args.store, capacity=n_sub)
     sub.add_synthetic(42, 0, n_sub)
+    sub.set_shadow(2 if args.shadow else 0)        # the rider checks the path the headline ran
     qs = q[: min(16, args.queries)]
     _, I_sub = sub.search(qs, args.k)
     metric_id = {"l2": 0, "ip": 1, "cos": 2}[args.metric]
@@ -331,12 +349,11 @@ def main():
     passes_total = args.steps * args.inner
     scores = args.queries * args.docs
     value = scores * passes_total / dt
-    elt = 2 if args.store == "f16" else 4
-    alg_bytes = n_local * d_emb * elt + (n_local * 4 if args.metric == "l2" else 0)
-    # which scan kernel served the pass (mirrors prag_index_search's choice)
+    # which scan kernel served the pass
+    scan_kernel, alg_bytes, launches = scan_model(args.queries, args.k, args.store, args.metric, n_local, args.shadow)
     tiled = args.queries > 128                                        # MFMA-tiled scan, 256-query tiles
-    per_pass = 128 if (args.queries > 64 and args.store == "f16") else 64
-    launches = 1 if tiled else 1 + (args.queries - 1) // per_pass
+    if tiled:
+        alg_bytes = n_local * d_emb * 2
     scan_avg_ms = float(np.mean(scan_ms)) if scan_ms else float("nan")
     achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
     mm_tf = mm_flops = rows_last = None
@@ -353,7 +370,7 @@ def main():
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
-            if rec.get("rows_per_launch") == n_local and rec.get("store") == args.store:
+            if rec.get("rows_per_launch") == n_local and rec.get("store") == args.store and rec.get("kernel") == scan_kernel:
                 traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -364,7 +381,9 @@ def main():
         "value": value, "unit": "query*doc scores/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f16 (MFMA, f32 accumulate; f64 rerank + exactness certificate)", "data": "synthetic",
+        "dtype": ("i8 shadow scan (MFMA i8, i32 accumulate) over f16 rows; f64 exact rerank of the filter's survivors"
+                  if scan_kernel == "scan8_kernel" else "f16 (MFMA, f32 accumulate; f64 rerank + exactness certificate)"),
+        "data": "synthetic",
         "config": {"workload": f"gate B={args.gate_batch} x 6 layers x d_model=2048 fp16 + flat {args.metric} "
                                f"top-{args.k} of {args.queries} queries over {args.docs} x 768 {args.store} docs",
                    "passes_per_step": args.inner, "ms_per_pass": ms_per_step / args.inner,
@@ -372,7 +391,8 @@ def main():
                    "docs_total": args.docs, "docs_per_gpu": n_local, "d_emb": d_emb, "queries": args.queries,
                    "k": args.k, "gate_batch": args.gate_batch, "gate_batch_per_gpu": Bg, "d_model": d_model,
                    "parallelism": f"corpus rows sharded x{world}; gate rows split x{world}",
-                   "gate_overlapped_with_scan": bool(args.overlap_gate)},
+                   "gate_overlapped_with_scan": bool(args.overlap_gate),
+                   "two_level_shadow": scan_kernel == "scan8_kernel"},
         "probe_decisions_per_s": args.gate_batch / (gate_avg_ms * 1e-3) if gate_ms else None,
         "scores_per_s_per_gpu": value / world,
         "planted_top1_recall": 1.0 if planted_ok else 0.0, "result_lists_sorted": sorted_ok,
@@ -383,7 +403,7 @@ def main():
                       "unit": "TFLOP/s", "frac": mm_tf / MFMA_F16_PEAK_TF, "traffic": None,
                       "algorithmic_flops_per_launch": mm_flops, "rows_in_launch": rows_last,
                       "avg_launch_ms": scan_avg_ms, "launches_per_pass": launches} if tiled else
-                     {"bound": "hbm", "kernel": "scan_qs_kernel" if per_pass == 128 else "scan_topk_kernel",
+                     {"bound": "hbm", "kernel": scan_kernel,
                       "achieved": achieved, "peak": HBM_PEAK_GBS,
                       "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                       "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_ms,
@@ -402,14 +422,22 @@ def main():
         try:
             qv = torch.from_numpy(synth_rows(7, 0, 1000, d_emb)).cuda()
             if args.store == "f16" and args.metric == "cos":
+                # the stored fp16 rows scanned directly (no shadow), then the two-level search
+                variants[f"f16_cos_k{args.k}_q{args.queries}_rows_scanned_directly"] = \
+                    variant_record(torch, local, q, args.k, "f16", "cos", n_local, 0)
                 for B in (1, 32, 1000):
-                    variants[f"f16_cos_k{args.k}_q{B}"] = variant_record(torch, local, qv[:B], args.k, "f16", "cos", n_local)
+                    variants[f"f16_cos_k{args.k}_q{B}"] = variant_record(torch, local, qv[:B], args.k, "f16", "cos", n_local, 0)
+                for B in (1, 32):
+                    variants[f"f16_cos_k{args.k}_q{B}_shadow"] = variant_record(torch, local, qv[:B], args.k, "f16", "cos", n_local, 1)
+                local.set_shadow(1 if args.shadow else 0)
             # the reference's literal call: IndexFlatL2 (float32 rows), one query, k = 5
             # (make_indexer.py:449-450, utils.py:378-380, exp_rag.py:432)
             ref_ix = pra.HipFlatIndex(d_emb, "l2", "f32", capacity=args.docs)
             ref_ix.add_synthetic(42, 0, args.docs)
-            variants["f32_l2_k5_q1 (reference call)"] = variant_record(torch, ref_ix, qv[:1], 5, "f32", "l2", args.docs)
-            variants["f32_l2_k5_q32"] = variant_record(torch, ref_ix, qv[:32], 5, "f32", "l2", args.docs)
+            variants["f32_l2_k5_q1 (reference call)"] = variant_record(torch, ref_ix, qv[:1], 5, "f32", "l2", args.docs, 0)
+            variants["f32_l2_k5_q32"] = variant_record(torch, ref_ix, qv[:32], 5, "f32", "l2", args.docs, 0)
+            variants["f32_l2_k5_q1_shadow (reference call, two-level)"] = \
+                variant_record(torch, ref_ix, qv[:1], 5, "f32", "l2", args.docs, 1)
             ref_ix.close()
             # the gate at the reference's call shape (one query: six probers, float32 states)
             e32 = pra.HipProberEnsemble(L, d_model, 2, weights="f32")

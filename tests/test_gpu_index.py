@@ -1,6 +1,8 @@
 """GPU parity: HIP flat index (through the C ABI) vs the oracle's definition of
 faiss.IndexFlatL2 / IP search.  Bar: indices bit-exact, scores within 1e-4
 (relative for L2 — SURVEY.md §7 hard part 4)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -239,7 +241,8 @@ def test_dense_near_ties_are_exact_at_the_default_depth(B):
     assert np.array_equal(I, I0)
     np.testing.assert_allclose(D, D0, rtol=1e-4)
     n_fb = ix.last_exact_fallbacks()
-    assert 1 <= n_fb <= max(1, B // 10)                      # query 0 (and hardly anything else)
+    if not os.environ.get("PRAG_SHADOW"):                    # (the 8-bit shadow path decides differently)
+        assert 1 <= n_fb <= max(1, B // 10)                  # query 0 (and hardly anything else)
     for depth in (32, 0):                                    # the knob changes nothing but speed
         ix.set_candidate_depth(depth)
         _, I1 = ix.search(Q, k)

@@ -28,7 +28,8 @@ def main(tag, src, rows_per_launch, store):
     full_grid = max((int(r["Grid_Size"]) for r in rows if "scan_topk" in r["Kernel_Name"]), default=0)
     for r in rows:
         k = r["Kernel_Name"]
-        name = "scan_topk_kernel" if "scan_topk" in k else "prober_fused_kernel" if "prober_fused" in k else None
+        name = ("scan_topk_kernel" if "scan_topk" in k else "scan8_kernel" if "scan8" in k else
+                "prober_fused_kernel" if "prober_fused" in k else None)
         if name == "scan_topk_kernel" and int(r["Grid_Size"]) != full_grid:
             continue
         if name:
@@ -45,9 +46,10 @@ def main(tag, src, rows_per_launch, store):
             c["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
-    s = out.get("scan_topk_kernel", {})
+    scan_name = "scan8_kernel" if "scan8_kernel" in out else "scan_topk_kernel"
+    s = out.get(scan_name, {})
     if "FETCH_SIZE" in s:
-        rec = {"kernel": "scan_topk_kernel", "rows_per_launch": rows_per_launch, "store": store,
+        rec = {"kernel": scan_name, "rows_per_launch": rows_per_launch, "store": store,
                "hbm_bytes_per_launch": s["hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)"] +
                                        s.get("hbm_write_bytes_per_launch(WRITE_SIZE*1024)", 0.0),
                "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); reads doubled per "

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--store", default="f16")
     ap.add_argument("--metric", default="cos")
     ap.add_argument("--skip-gate", action="store_true")
+    ap.add_argument("--shadow", type=int, default=1)
     ap.add_argument("--skip-scan", action="store_true")
     args = ap.parse_args()
     import torch
@@ -31,6 +32,7 @@ def main():
     if not args.skip_scan:
         ix = pra.HipFlatIndex(768, args.metric, args.store, capacity=args.docs)
         ix.add_synthetic(42, 0, args.docs)
+        ix.set_shadow(args.shadow)
         q = torch.from_numpy(synth_rows(7, 0, args.queries, 768)).cuda()
         for _ in range(args.iters):
             ix.search(q, 10)
