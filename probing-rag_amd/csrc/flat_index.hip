@@ -1926,7 +1926,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
             ix->sh_q_cap = BpadS;
         }
         if (!ix->sh_cand) {
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_cand), (size_t)ix->n_cu * 64 * kShadowCap * sizeof(int)));
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_cand), (size_t)ix->n_cu * 64 * kShadowCap * 2 * sizeof(int)));
             PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_ccnt), (size_t)ix->n_cu * 64 * sizeof(uint32_t)));
         }
         const size_t pe = (size_t)BpadS * shadow_split() * k;

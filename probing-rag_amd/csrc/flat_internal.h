@@ -216,7 +216,7 @@ struct ShadowSearch {
     signed char* q8b;
     void* sq;                // [Bpad] ShadowQ
     uint32_t* slots;         // [Bpad][shadow_slot_words()]
-    int* cand;               // [wg_slots][64][cap]
+    int* cand;               // [wg_slots][64][cap] x 2 ints (row id, bits of key - a eps)
     uint32_t* ccnt;          // [wg_slots][64]
     int cap, wg_slots, max_wg;
     unsigned long long* part_key;   // [Bpad][shadow_split()][k]

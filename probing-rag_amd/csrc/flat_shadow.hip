@@ -167,7 +167,7 @@ struct Scan8Args {
     int use_norm;               // L2: key includes ||x||^2
     uint32_t* g_tau;            // [QT] chip-wide bound (sortable), +inf at start, -inf for padding
     uint32_t* g_slot;           // [QT][kShadowEpochs][32]
-    int* cand;                  // [grid][QT][cap]
+    int2* cand;                 // [grid][QT][cap]  (row id, bits of key - a eps)
     uint32_t* ccnt;             // [grid][QT]
     int cap;
 };
@@ -376,10 +376,12 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                         const float mid = fmaf(kscale[t] * rs[e], dq, rx[e]);
                         const float eps = fmaf(cA[t], re[e], cC[t]);
                         if (!second) top[t].push(valid ? mid + eps : INFINITY, tau[t]);
-                        if (collect && valid && mid - eps <= tau[t]) {     // cannot be excluded: candidate
+                        const float lo = mid - eps;
+                        if (collect && valid && lo <= tau[t]) {     // cannot be excluded: candidate
                             const uint32_t slot = atomicAdd(&s_ccnt[32 * t + r], 1u);
                             if (slot < (uint32_t)a.cap)
-                                a.cand[((int64_t)blockIdx.x * QT + 32 * t + r) * a.cap + slot] = (int)doc;
+                                a.cand[((int64_t)blockIdx.x * QT + 32 * t + r) * a.cap + slot] =
+                                    int2{(int)doc, (int)__float_as_uint(lo)};
                         }
                         acc1[t][4 * g + e] = 0;
                         if constexpr (TERMS == 2) acc2[t][4 * g + e] = 0;
@@ -466,7 +468,11 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
         }
     }
     __syncthreads();
-    if (tid < QT) a.ccnt[(int64_t)blockIdx.x * QT + tid] = s_ccnt[tid];
+    if (tid < QT) {
+        a.ccnt[(int64_t)blockIdx.x * QT + tid] = s_ccnt[tid];
+        // the final bound of this workgroup: the gather drops candidates that a later, tighter bound excludes
+        (void)__hip_atomic_fetch_min(a.g_tau + tid, s_tau[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
 constexpr int kShCap = 2048;
 constexpr int kShThreads = 512;
 constexpr int kShSplit = 8;      // workgroups per query
-constexpr int kShIds = 6144;     // candidate ids one workgroup stages in LDS
+constexpr int kShIds = 4096;     // candidate ids one workgroup stages in LDS (after the final-bound filter)
 
 struct ShTopK {
     unsigned long long key[kShCap];
@@ -528,8 +534,9 @@ struct GatherArgs {
     int d;
     int metric_l2;
     const float* q32;       // [B][d]
-    const int* cand;        // [n_wg][QT][cap] of the query tile this launch serves
+    const int2* cand;       // [n_wg][QT][cap] of the query tile this launch serves: (row id, key - a eps)
     const uint32_t* ccnt;   // [n_wg][QT]
+    const uint32_t* g_tau;  // [QT] final bound of the scan (sortable): upper bound on the k-th best exact key
     int n_wg, QT, cap;
     int q0;                 // first query of the tile
     int k;
@@ -558,19 +565,23 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
     }
     for (int c = tid; c < d; c += kShThreads) s_q[c] = a.q32[(int64_t)b * d + c];
     __syncthreads();
-    // ---- stage this slice's candidate ids ---------------------------------------------------------
+    // ---- stage this slice's candidate ids: only those the FINAL bound of the scan still admits -----
+    // (rows were collected against the bound of their time; key - a eps > final bound >= k-th best exact
+    // key means the row is provably not among the k best)
+    const float tau_final = unsortable_f32(a.g_tau[qi]);
     const int per = (a.n_wg + kShSplit - 1) / kShSplit;
     const int wg0 = blockIdx.x * per, wg1 = min(a.n_wg, wg0 + per);
     for (int wg = wg0 + w; wg < wg1; wg += kShThreads / 64) {
         const uint32_t c = a.ccnt[(int64_t)wg * a.QT + qi];
         if (c > (uint32_t)a.cap && lane == 0) s_over = 1;
         const int n = (int)min(c, (uint32_t)a.cap);
-        int base = 0;
-        if (lane == 0 && n > 0) base = atomicAdd(&s_n, n);
-        base = __shfl(base, 0, 64);
         for (int j = lane; j < n; j += 64) {
-            if (base + j < kShIds) s_ids[base + j] = a.cand[((int64_t)wg * a.QT + qi) * a.cap + j];
-            else s_over = 1;
+            const int2 e = a.cand[((int64_t)wg * a.QT + qi) * a.cap + j];
+            if (__uint_as_float((uint32_t)e.y) <= tau_final) {
+                const int at = atomicAdd(&s_n, 1);
+                if (at < kShIds) s_ids[at] = e.x;
+                else s_over = 1;
+            }
         }
     }
     __syncthreads();
@@ -743,7 +754,7 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         a.use_norm = s.metric_l2;
         a.g_tau = s.g_tau + p0;
         a.g_slot = s.slots + (size_t)p0 * kShadowSlotWords;
-        a.cand = s.cand;
+        a.cand = reinterpret_cast<int2*>(s.cand);
         a.ccnt = s.ccnt;
         a.cap = s.cap;
         int rc;
@@ -756,8 +767,9 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         g.d = s.d;
         g.metric_l2 = s.metric_l2;
         g.q32 = s.q32;
-        g.cand = s.cand;
+        g.cand = reinterpret_cast<const int2*>(s.cand);
         g.ccnt = s.ccnt;
+        g.g_tau = s.g_tau + p0;
         g.n_wg = grid;
         g.QT = QT;
         g.cap = s.cap;
