@@ -5,8 +5,10 @@ One "step" = `--inner` passes (default 20) of the hot path over one batch of syn
   gate   : fused 6-layer prober ensemble + softmax/sum/threshold over B_gate
            pooled hidden states (d_model 2048, fp16)           [exp_rag.py:406-415]
   search : cosine top-10 of B_q query embeddings over the row-sharded
-           N_docs x 768 fp16 corpus (local fused scan/top-k, all-gather of the
-           local top-k over RCCL, (score,id) merge)             [utils.py:378-380]
+           N_docs x 768 fp16 corpus (local two-level exact search: 8-bit shadow
+           scan + proof-carrying filter + float64 rerank; --shadow 0 scans the
+           fp16 rows directly; all-gather of the local top-k over RCCL,
+           (score,id) merge)                                   [utils.py:378-380]
 (`--inner` exists so that the timed region lasts seconds, not 0.1 s; `value` counts every pass.)
 Workload = BASELINE.json's quoted sizes: d_model=2048, N_docs=21M, d_emb=768.
 Total work is fixed as GPUs are added ("strong"): the 21M rows and the 4096
@@ -16,8 +18,9 @@ gate rows are split across ranks.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects
-  roofline      dominant kernel of the headline step (scan_topk, HBM-bound), measured live with HIP
-                events on the launch stream inside libprag
+  roofline      dominant kernel of the headline step (scan8 - or scan_topk with --shadow 0 -, HBM-bound),
+                measured live with HIP events on the launch stream inside libprag; algorithmic bytes =
+                the rows in the form that is scanned
   variants      (1 GPU) the other call shapes SURVEY.md section 8d names, same corpus size:
                 the reference's literal call (float32 rows, squared L2, k=5, one query) and fp16
                 rows with 1 / 32 / 1000 queries - each with its own roofline fraction
