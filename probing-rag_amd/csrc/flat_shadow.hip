@@ -279,7 +279,9 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     const int col_b = (lane & 7) * 16;
     const int64_t row_bytes = d;
     const char* rows = reinterpret_cast<const char*>(a.rows8);
-    u32x4 ldA[4], ldB[4];
+    // three chunks (12 KiB per wave, 96 KiB per CU) in flight: at half the bytes per row the loop turns
+    // over twice as fast as the fp16 scan's, and with two it starved at 64 queries
+    u32x4 ldA[4], ldB[4], ldC[4];
     auto issue = [&](u32x4 (&ld)[4], int tile, int c) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -408,7 +410,11 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                     }
                 }
                 {
-                    const int tm = tiles_done - 1;          // published one tile after the lists fed s_best
+                    // published by wave 0 right away (whatever the other waves have fed so far) and once
+                    // more a tile later (the same slot: min-ing twice changes nothing about which rows
+                    // the slots stand for)
+                    const bool now = (tiles_done & (tiles_done - 1)) == 0;
+                    const int tm = now ? tiles_done : tiles_done - 1;
                     if (w == 0 && tm >= 1 && (tm & (tm - 1)) == 0 && tm <= (1 << (kShadowEpochs - 1)) && lane < QT) {
                         const int epoch = 31 - __builtin_clz(tm);
                         const uint32_t v = s_best[lane];
@@ -416,13 +422,13 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                             (void)__hip_atomic_fetch_min(a.g_slot + (lane * kShadowEpochs + epoch) * 32 + (blockIdx.x % KC), v,
                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    // two polls per epoch (2 and 3 tiles after it was fed), waves take turns
+                    // three polls per epoch (1, 2 and 3 tiles after it was fed), waves take turns
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int tp = tiles_done - 2 - i;
+                    for (int i = 0; i < 3; ++i) {
+                        const int tp = tiles_done - 1 - i;
                         if (tp >= 1 && (tp & (tp - 1)) == 0 && tp <= (1 << (kShadowEpochs - 1))) {
                             const int epoch = 31 - __builtin_clz(tp);
-                            if (w == ((2 * epoch + i) & 7) && lane < QT) {
+                            if (w == ((3 * epoch + i + 1) & 7) && lane < QT) {
                                 const uint32_t* sl = a.g_slot + (lane * kShadowEpochs + epoch) * 32;
                                 uint32_t m = 0u;
 #pragma unroll
@@ -459,12 +465,16 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
         advance(vt_nx, c_nx);
         issue(ldB, vtile(vt_nx), c_nx);
         advance(vt_nx, c_nx);
+        issue(ldC, vtile(vt_nx), c_nx);
+        advance(vt_nx, c_nx);
         // (`redo` grows during the first tiles only, long before the loop bound is reached - or, on a
         // shard of a few tiles, up to n_my: every tile is then visited twice)
-        for (int it = 0; it < (n_my + redo) * NCH; it += 2) {
+        for (int it = 0; it < (n_my + redo) * NCH; it += 3) {
             body(ldA);
-            if (it + 1 < (n_my + redo) * NCH) body(ldB);
-            else break;
+            if (it + 1 >= (n_my + redo) * NCH) break;
+            body(ldB);
+            if (it + 2 >= (n_my + redo) * NCH) break;
+            body(ldC);
         }
     }
     __syncthreads();
