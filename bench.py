@@ -64,9 +64,10 @@ def parse():
     ap.add_argument("--shadow", type=int, default=1,
                     help="1: two-level exact search through the 8-bit shadow of the rows (prag_index_set_shadow); "
                          "0: scan the stored rows themselves")
-    ap.add_argument("--overlap-gate", type=int, default=1,
+    ap.add_argument("--overlap-gate", type=int, default=-1,
                     help="1: run the gate on a second stream beside the HBM-bound scan (scan capped at "
-                         "n_cu-16 workgroups); 0: one stream")
+                         "n_cu-16 workgroups); 0: one stream; -1 (default): overlap only on shards below 8 M "
+                         "rows, where the scan is short enough for the gate to matter (measured both ways)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     return ap.parse_args()
 
@@ -243,6 +244,8 @@ def main():
     # ---- corpus shard (generated on device by the counter-based generator of add_synthetic)
     lo, hi = pra.partition_rows(args.docs, world, rank)
     n_local = hi - lo
+    if args.overlap_gate < 0:
+        args.overlap_gate = 1 if n_local < (8 << 20) else 0
     index = pra.ShardedFlatIndex(d_emb, args.metric, args.store, capacity=n_local)
     index.add_synthetic_local(42, lo, n_local)
     index.sync()

@@ -410,11 +410,10 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                     }
                 }
                 {
-                    // published by wave 0 right away (whatever the other waves have fed so far) and once
-                    // more a tile later (the same slot: min-ing twice changes nothing about which rows
-                    // the slots stand for)
-                    const bool now = (tiles_done & (tiles_done - 1)) == 0;
-                    const int tm = now ? tiles_done : tiles_done - 1;
+                    // (publishing right away and polling a tile earlier was tried: the first epoch then
+                    // carries fewer lists, the warm-up ends on a weaker bound and the early tiles flood the
+                    // candidate regions - 0.53 -> 0.57 ms on a 2.6 M-row shard)
+                    const int tm = tiles_done - 1;          // published one tile after the lists fed s_best
                     if (w == 0 && tm >= 1 && (tm & (tm - 1)) == 0 && tm <= (1 << (kShadowEpochs - 1)) && lane < QT) {
                         const int epoch = 31 - __builtin_clz(tm);
                         const uint32_t v = s_best[lane];
@@ -422,13 +421,13 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                             (void)__hip_atomic_fetch_min(a.g_slot + (lane * kShadowEpochs + epoch) * 32 + (blockIdx.x % KC), v,
                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    // three polls per epoch (1, 2 and 3 tiles after it was fed), waves take turns
+                    // two polls per epoch (2 and 3 tiles after it was fed), waves take turns
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const int tp = tiles_done - 1 - i;
+                    for (int i = 0; i < 2; ++i) {
+                        const int tp = tiles_done - 2 - i;
                         if (tp >= 1 && (tp & (tp - 1)) == 0 && tp <= (1 << (kShadowEpochs - 1))) {
                             const int epoch = 31 - __builtin_clz(tp);
-                            if (w == ((3 * epoch + i + 1) & 7) && lane < QT) {
+                            if (w == ((2 * epoch + i) & 7) && lane < QT) {
                                 const uint32_t* sl = a.g_slot + (lane * kShadowEpochs + epoch) * 32;
                                 uint32_t m = 0u;
 #pragma unroll
