@@ -378,13 +378,18 @@ __device__ __forceinline__ void scan_topk_body(const ScanArgs& a, char* smem) {
     // (clamped) last row - so the registers never merge across control flow and
     // the compiler keeps counted vmcnt waits instead of draining the queue.
     u32x4 ldA[NLD], ldB[NLD];
-    auto issue = [&](u32x4 (&ld)[NLD], int tile, int c) {
+    // wave-uniform tile base (scalar registers) + a per-lane 32-bit offset: no 64-bit vector address
+    // arithmetic and no per-row clamp in the loop.  The rows are allocated in multiples of 256, so the
+    // rows of the last, partial tile past N are readable; their scores are masked in the epilogue.
+    int lane_off[NLD];
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            int64_t row = (int64_t)tile * 32 + st_doc[i];
-            row = row < a.N ? row : a.N - 1;
-            ld[i] = *reinterpret_cast<const u32x4*>(rows + row * row_bytes + c * chunk_bytes + col_b);
-        }
+    for (int i = 0; i < NLD; ++i) lane_off[i] = st_doc[i] * (int)row_bytes + col_b;
+    const int tile_last = a.n_tiles - 1;
+    auto issue = [&](u32x4 (&ld)[NLD], int tile, int c) {
+        const int tc = tile < tile_last ? tile : tile_last;     // prefetch past the end: re-read the last tile
+        const char* base = rows + (int64_t)tc * (32 * row_bytes) + c * chunk_bytes;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) ld[i] = *reinterpret_cast<const u32x4*>(base + lane_off[i]);
     };
 
     const int a_off = r * 128;

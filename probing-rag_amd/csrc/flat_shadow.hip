@@ -282,13 +282,16 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     // three chunks (12 KiB per wave, 96 KiB per CU) in flight: at half the bytes per row the loop turns
     // over twice as fast as the fp16 scan's, and with two it starved at 64 queries
     u32x4 ldA[4], ldB[4], ldC[4];
-    auto issue = [&](u32x4 (&ld)[4], int tile, int c) {
+    // wave-uniform tile base (scalar registers) + a per-lane 32-bit offset: no 64-bit vector address
+    // arithmetic and no per-row clamp in the loop - the shadow is allocated in multiples of 256 rows, so
+    // the rows of the last, partial tile past N are readable (their scores are masked in the epilogue)
+    int lane_off[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int64_t row = (int64_t)tile * 32 + st_doc[i];
-            row = row < a.N ? row : a.N - 1;
-            ld[i] = *reinterpret_cast<const u32x4*>(rows + row * row_bytes + c * 128 + col_b);
-        }
+    for (int i = 0; i < 4; ++i) lane_off[i] = st_doc[i] * d + col_b;
+    auto issue = [&](u32x4 (&ld)[4], int tile, int c) {
+        const char* base = rows + (int64_t)tile * (32 * row_bytes) + c * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ld[i] = *reinterpret_cast<const u32x4*>(base + lane_off[i]);
     };
     const int a_off = r * 128;
     const int a_sw = (r >> 1) & 7;
