@@ -267,7 +267,8 @@ int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out);
  * proof-carrying filter (Cauchy-Schwarz bound on the quantisation error of every row) keeps each row
  * that can still belong to the top k, the survivors are scored in float64 from the stored rows, and a
  * query whose candidate store overflows is recomputed by the exact scan.
- * mode 0 = off (default), 1 = shards of >= 2^20 rows, 2 = any size. */
+ * mode 0 = off (the stored rows are scanned directly), 1 = shards of >= 2^20 rows when the device has
+ * room for the shadow next to the rows (the default), 2 = any size. */
 int prag_index_set_shadow(prag_index_t* ix, int mode);
 
 /* Cap the number of workgroups (= CUs) the scan kernels occupy; 0 = all CUs.  The scan is

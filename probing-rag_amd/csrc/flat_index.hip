@@ -1269,8 +1269,10 @@ struct prag_index {
     unsigned long long* ex_key = nullptr;
     int* ex_id = nullptr;
     size_t ex_entries = 0;
-    // 8-bit shadow (flat_shadow.hip): 0 off, 1 on for shards >= kShadowMinRows, 2 on at any size
-    int shadow_mode = 0;
+    // 8-bit shadow (flat_shadow.hip): 0 off, 1 (default) on for shards >= kShadowMinRows when the device has
+    // room for it, 2 on at any size
+    int shadow_mode = 1;
+    bool shadow_no_room = false;   // mode 1: the allocation did not fit next to the rows; rows are scanned directly
     signed char* rows8 = nullptr;
     float* sscale = nullptr;
     float* serr = nullptr;
@@ -1888,8 +1890,19 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     // ---- two-level search through the 8-bit shadow (HBM-bound batches on large shards) --------------
     constexpr int64_t kShadowMinRows = 1 << 20;
     constexpr int kShadowCap = 128;
-    const bool use_shadow = ix->shadow_mode && !exact_only && !use_mm && !use_qs && ix->ntotal > 0 &&
-                            (ix->shadow_mode >= 2 || ix->ntotal >= kShadowMinRows) && shadow_supported(ix->d, kc, k, B);
+    bool use_shadow = ix->shadow_mode && !exact_only && !use_mm && !use_qs && ix->ntotal > 0 &&
+                      (ix->shadow_mode >= 2 || (ix->ntotal >= kShadowMinRows && !ix->shadow_no_room)) &&
+                      shadow_supported(ix->d, kc, k, B);
+    if (use_shadow && ix->shadow_cap < ix->cap && ix->shadow_mode == 1) {
+        // automatic mode: only when the shadow (d + 8 bytes per row) fits with 2 GB to spare
+        size_t free_b = 0, total_b = 0;
+        const size_t have = ix->rows8 ? (size_t)ix->shadow_cap * (ix->d + 8) : 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
+            free_b + have < (size_t)ix->cap * (ix->d + 8) + ((size_t)2 << 30)) {
+            ix->shadow_no_room = true;
+            use_shadow = false;
+        }
+    }
     bool reranked = false;
     if (use_shadow) {
         int rc = PRAG_OK;
@@ -2199,6 +2212,7 @@ extern "C" int prag_index_set_candidate_depth(prag_index_t* ix, int depth) {
 extern "C" int prag_index_set_shadow(prag_index_t* ix, int mode) {
     PRAG_REQUIRE(ix != nullptr && mode >= 0 && mode <= 2, PRAG_EINVAL, "prag_index_set_shadow: mode %d (0, 1 or 2)", mode);
     ix->shadow_mode = mode;
+    ix->shadow_no_room = false;
     return PRAG_OK;
 }
 

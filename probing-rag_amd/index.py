@@ -282,8 +282,9 @@ def _ix_last_exact_fallbacks(self) -> int:
 
 def _ix_set_shadow(self, mode=1):
     """Two-level exact search through an 8-bit shadow of the rows (prag_index_set_shadow): 0/False off,
-    1/True for shards of >= 2^20 rows, 2 at any size.  Same results, about half the scan time for
-    batches of <= 64 queries on fp16 rows (a quarter of the bytes of float32 rows)."""
+    1/True (the default) for shards of >= 2^20 rows when the device has room, 2 at any size.  Same
+    results, about half the scan time for batches of <= 64 queries on fp16 rows (a quarter of the bytes
+    of float32 rows)."""
     _lib.check(_lib.lib().prag_index_set_shadow(self._h, int(mode)))
 
 
