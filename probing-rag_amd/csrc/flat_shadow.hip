@@ -490,10 +490,10 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
 // ---------------------------------------------------------------------------
 // exact float64 scores of the candidates -> top k per query
 // ---------------------------------------------------------------------------
-constexpr int kShCap = 2048;
+constexpr int kShCap = 1024;
 constexpr int kShThreads = 512;
-constexpr int kShSplit = 8;      // workgroups per query
-constexpr int kShIds = 4096;     // candidate ids one workgroup stages in LDS (after the final-bound filter)
+constexpr int kShSplit = 16;     // workgroups per query (small LDS footprint: several per CU)
+constexpr int kShIds = 2048;     // candidate ids one workgroup stages in LDS (after the final-bound filter)
 
 struct ShTopK {
     unsigned long long key[kShCap];
@@ -564,6 +564,7 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
     __shared__ int s_ids[kShIds];
     __shared__ __attribute__((aligned(16))) float s_q[1024];
     __shared__ int s_n, s_over;
+    __shared__ int s_rc[128];                 // candidates held by each region of this slice
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int sub = lane & 15, slot = lane >> 4;
     const int qi = blockIdx.y;                // query inside the tile
@@ -583,15 +584,29 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
     const float tau_final = unsortable_f32(a.g_tau[qi]);
     const int per = (a.n_wg + kShSplit - 1) / kShSplit;
     const int wg0 = blockIdx.x * per, wg1 = min(a.n_wg, wg0 + per);
-    for (int wg = wg0 + w; wg < wg1; wg += kShThreads / 64) {
-        const uint32_t c = a.ccnt[(int64_t)wg * a.QT + qi];
-        if (c > (uint32_t)a.cap && lane == 0) s_over = 1;
-        const int n = (int)min(c, (uint32_t)a.cap);
-        for (int j = lane; j < n; j += 64) {
-            const int2 e = a.cand[((int64_t)wg * a.QT + qi) * a.cap + j];
-            if (__uint_as_float((uint32_t)e.y) <= tau_final) {
+    // two dependent memory steps for the whole slice (region counts, then every filled slot at once)
+    // instead of a count -> entries chain per region
+    const int nreg = wg1 - wg0;
+    for (int i = tid; i < nreg; i += kShThreads) {
+        const uint32_t c = a.ccnt[(int64_t)(wg0 + i) * a.QT + qi];
+        if (c > (uint32_t)a.cap) s_over = 1;
+        s_rc[i] = (int)min(c, (uint32_t)a.cap);
+    }
+    __syncthreads();
+    for (int base = 0; base < nreg * a.cap; base += 8 * kShThreads) {
+        int2 ev[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {          // all loads of the batch in flight before the first use
+            const int e0 = base + u * kShThreads + tid;
+            const int rg = e0 / a.cap, j = e0 - rg * a.cap;
+            const bool ok = e0 < nreg * a.cap && j < s_rc[rg < nreg ? rg : 0];
+            ev[u] = ok ? a.cand[((int64_t)(wg0 + rg) * a.QT + qi) * a.cap + j] : int2{0, 0x7fc00000};   // key = NaN: never <= the bound
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (__uint_as_float((uint32_t)ev[u].y) <= tau_final) {
                 const int at = atomicAdd(&s_n, 1);
-                if (at < kShIds) s_ids[at] = e.x;
+                if (at < kShIds) s_ids[at] = ev[u].x;
                 else s_over = 1;
             }
         }
