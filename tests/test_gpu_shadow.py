@@ -100,3 +100,40 @@ def test_shadow_filter_statistics_on_a_random_corpus():
     ix.set_shadow(0)
     Dm, Im = ix.search(Q[:5], 5)
     assert np.array_equal(In, Im) and np.allclose(Dn, Dm, rtol=1e-6)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_shadow_equals_the_direct_scan_on_clustered_rows(seed):
+    """Mid-size shards (a few tiles per wave: the warm-up / second-visit logic and the early bound slots
+    carry the whole search) with clustered, unevenly scaled rows: the two-level search and the direct
+    scan of the stored rows are independent routes to the same answer and must agree bit for bit; a few
+    queries are also checked against the float64 oracle."""
+    import torch
+    import probing_rag_amd as pra
+    rng = np.random.default_rng(100 + seed)
+    d, k = 768, 10
+    N = int(rng.choice([70_000, 200_000, 400_000]))
+    n_clusters = 40
+    centres = rng.standard_normal((n_clusters, d)).astype(np.float32) * rng.uniform(0.5, 3.0, (n_clusters, 1)).astype(np.float32)
+    which = rng.integers(0, n_clusters, N)
+    X = centres[which] + (0.15 * rng.standard_normal((N, d))).astype(np.float32)
+    X *= rng.lognormal(0.0, 0.5, (N, 1)).astype(np.float32)            # norm spread
+    B = 64
+    Q = centres[rng.integers(0, n_clusters, B)] + (0.15 * rng.standard_normal((B, d))).astype(np.float32)
+    Q[:8] = X[rng.integers(0, N, 8)] * np.float32(1.001)                # near-copies of stored rows
+    for metric, store in ((onp.METRIC_COS, "f16"), (onp.METRIC_L2, "f32"), (onp.METRIC_IP, "f16")):
+        ix = pra.HipFlatIndex(d, metric, store, capacity=N)
+        ix.add(X)
+        qd = torch.from_numpy(Q).cuda()
+        out = {}
+        for mode in (0, 2):
+            ix.set_shadow(mode)
+            for Bq in (64, 32, 5):
+                Dm, I = ix.search(qd[:Bq], k)
+                out[(mode, Bq)] = (Dm.cpu().numpy(), I.cpu().numpy())
+        for Bq in (64, 32, 5):
+            assert np.array_equal(out[(0, Bq)][1], out[(2, Bq)][1]), (metric, store, Bq)
+            np.testing.assert_allclose(out[(0, Bq)][0], out[(2, Bq)][0], rtol=1e-6, atol=1e-6)
+        D0, I0 = oracle_c.flat_search(_stored(X, metric, store), Q[:6], k, metric)
+        _check(out[(2, 64)][0][:6], out[(2, 64)][1][:6], D0, I0, metric)
+        ix.close()
