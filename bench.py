@@ -182,7 +182,7 @@ def scan_model(B, k, store, metric, n_local, shadow):
         return "scan_mm_kernel", None, 1
     if B > 64 and store == "f16":
         return "scan_qs_kernel", n_local * D_EMB * 2 + (n_local * 4 if metric == "l2" else 0), 1 + (B - 1) // 128
-    if shadow and k <= 12 and n_local >= (1 << 20):
+    if shadow and k <= 26 and n_local >= (1 << 20):
         return "scan8_kernel", n_local * (D_EMB + 8) + (n_local * 4 if metric == "l2" else 0), 1 + (B - 1) // 64
     elt = 2 if store == "f16" else 4
     return "scan_topk_kernel", n_local * D_EMB * elt + (n_local * 4 if metric == "l2" else 0), 1 + (B - 1) // 64

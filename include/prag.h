@@ -263,7 +263,7 @@ int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out);
 
 /* Two-level exact search: keep an 8-bit shadow of the stored rows (+d bytes per row, built on the
  * device at the next search) and scan IT for batches of <= 64 queries (d a multiple of 128, <= 1024,
- * k <= 12): half the bytes of fp16 storage, a quarter of float32.  Results do not change: a
+ * k <= 26): half the bytes of fp16 storage, a quarter of float32.  Results do not change: a
  * proof-carrying filter (Cauchy-Schwarz bound on the quantisation error of every row) keeps each row
  * that can still belong to the top k, the survivors are scored in float64 from the stored rows, and a
  * query whose candidate store overflows is recomputed by the exact scan.

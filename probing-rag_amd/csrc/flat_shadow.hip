@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void shadow_merge_kernel(const unsigned long l
 // host side
 // ---------------------------------------------------------------------------
 bool shadow_supported(int d, int kc, int k, int B) {
-    return d % 128 == 0 && d <= 1024 && (kc == 8 || kc == 16) && k <= 32 && B >= 1;
+    return d % 128 == 0 && d <= 1024 && (kc == 8 || kc == 16 || kc == 32) && k <= 32 && B >= 1;
 }
 
 int shadow_build(const ShadowStore& s, int64_t row0, int64_t row1, hipStream_t st) {
@@ -785,8 +785,12 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         a.ccnt = s.ccnt;
         a.cap = s.cap;
         int rc;
-        if (QT == 64) rc = s.kc == 8 ? launch_scan8<64, 8>(a, grid, st, prof) : launch_scan8<64, 16>(a, grid, st, prof);
-        else rc = s.kc == 8 ? launch_scan8<32, 8>(a, grid, st, prof) : launch_scan8<32, 16>(a, grid, st, prof);
+        if (QT == 64)
+            rc = s.kc == 8 ? launch_scan8<64, 8>(a, grid, st, prof)
+                           : s.kc == 16 ? launch_scan8<64, 16>(a, grid, st, prof) : launch_scan8<64, 32>(a, grid, st, prof);
+        else
+            rc = s.kc == 8 ? launch_scan8<32, 8>(a, grid, st, prof)
+                           : s.kc == 16 ? launch_scan8<32, 16>(a, grid, st, prof) : launch_scan8<32, 32>(a, grid, st, prof);
         if (rc != PRAG_OK) return rc;
         const int nq = std::min(QT, s.B - p0);
         GatherArgs g;

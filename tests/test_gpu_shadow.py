@@ -28,6 +28,7 @@ def _check(D, I, D0, I0, metric):
 @pytest.mark.parametrize("metric", METRICS)
 @pytest.mark.parametrize("N,B,k,d", [(10_000, 64, 5, 768), (1, 1, 5, 768), (31, 3, 10, 128), (2049, 33, 10, 256),
                                      (4097, 40, 12, 512), (777, 1, 1, 1024), (30_000, 7, 10, 768),
+                                     (20_000, 3, 26, 256), (9000, 50, 20, 768),      # 32-deep bound lists
                                      (5000, 70, 5, 384)])
 def test_shadow_search_matches_definition(metric, store, N, B, k, d):
     import probing_rag_amd as pra
