@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "flat_internal.h"
 
@@ -170,6 +171,8 @@ struct Scan8Args {
     int2* cand;                 // [grid][QT][cap]  (row id, bits of key - a eps)
     uint32_t* ccnt;             // [grid][QT]
     int cap;
+    int dbg;                    // timing experiments only (PRAG_SHADOW_DBG; results are WRONG): bit 0 no warm-up
+                                // (no second visits), bit 1 nothing is collected
 };
 
 constexpr int kShadowEpochs = 9;                    // bound slots refreshed after tiles 1, 2, 4, ..., 256
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     // virtual tile sequence of this wave: its n_my tiles, then the first `redo` of them again
     constexpr int kWarmMax = 16;
     int redo = 0;
-    bool warm = true;
+    bool warm = !(a.dbg & 1);
     auto vtile = [&](int vt) {
         int at = vt < n_my ? vt : vt - n_my;
         at = at < n_my ? at : n_my - 1;             // prefetch past the end: any valid tile
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
         if (c_cur == NCH - 1) {
             // ---- epilogue: 16 rows x this lane's queries ---------------------------------------
             const bool second = vt_cur >= n_my;     // second visit of a warm-up tile: filter only
-            const bool collect = second || !warm;
+            const bool collect = (second || !warm) && !(a.dbg & 2);
             if (hh == 0) {
                 s_meta[r] = m_s;
                 s_meta[32 + r] = m_e;
@@ -784,6 +787,8 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         a.cand = reinterpret_cast<int2*>(s.cand);
         a.ccnt = s.ccnt;
         a.cap = s.cap;
+        static const int dbg_env = getenv("PRAG_SHADOW_DBG") ? atoi(getenv("PRAG_SHADOW_DBG")) : 0;
+        a.dbg = dbg_env;
         int rc;
         if (QT == 64)
             rc = s.kc == 8 ? launch_scan8<64, 8>(a, grid, st, prof)
