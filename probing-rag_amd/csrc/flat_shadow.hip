@@ -220,12 +220,13 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     uint32_t* s_best = s_tau + QT;
     uint32_t* s_ccnt = s_best + QT;
     uint32_t* s_slot_ok = s_ccnt + QT;     // set once a poll found every query's slot bound finite
+    uint32_t* s_arrive = s_slot_ok + 1;    // waves that have fed epoch 0
     if (tid < QT) {
         s_tau[tid] = a.g_tau[tid];
         s_best[tid] = 0xFFFFFFFFu;
         s_ccnt[tid] = 0u;
     }
-    if (tid == 0) *s_slot_ok = 0u;
+    if (tid <= kShadowEpochs) s_slot_ok[tid] = 0u;   // the flag and the arrival counters behind it
     // ---- query tiles -> LDS (swizzled 16-B pieces, as the fp16 scan) -----------------------------
     {
         const int ppr = d >> 4;
@@ -414,11 +415,29 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                         const float k0 = top[t].k[0];
                         if (k0 < INFINITY) atomicMin(&s_best[32 * t + r], sortable_u32(k0));
                     }
+                    if (tiles_done == 1) {
+                        // epoch 0: the LAST wave of the workgroup to get here publishes at once (every list
+                        // has fed by then: LDS operations of a wave complete in order), so the bound can
+                        // be polled one tile earlier: the warm-up is a tile shorter and fewer early rows
+                        // pass the filter (2.6 M-row shard: scan 474 -> 412 us).  Doing the same for the
+                        // later epochs, with a third poll each, made the whole scan 8 % SLOWER (3.12 ->
+                        // 3.38 ms at 21 M rows; the extra in-loop polls, presumably their vmcnt(0)).
+                        const int n_active = min(8, max(0, a.n_tiles - (int)blockIdx.x * 8));
+                        uint32_t old = 0;
+                        if (lane == 0) old = atomicAdd(s_arrive, 1u);
+                        old = (uint32_t)__shfl((int)old, 0, 64);
+                        if ((int)old + 1 == n_active && lane < QT) {
+                            const uint32_t v = s_best[lane];
+                            if (v != 0xFFFFFFFFu)
+                                (void)__hip_atomic_fetch_min(a.g_slot + (lane * kShadowEpochs + 0) * 32 + (blockIdx.x % KC), v,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
                 }
                 {
-                    // (publishing right away and polling a tile earlier was tried: the first epoch then
-                    // carries fewer lists, the warm-up ends on a weaker bound and the early tiles flood the
-                    // candidate regions - 0.53 -> 0.57 ms on a 2.6 M-row shard)
+                    // (wave 0 publishing epoch 0 right away, before the other waves had fed, was tried: the
+                    // warm-up then ends on a weaker bound and the early tiles flood the candidate regions,
+                    // 0.53 -> 0.57 ms on a 2.6 M-row shard - hence the last-arriver rule above)
                     const int tm = tiles_done - 1;          // published one tile after the lists fed s_best
                     if (w == 0 && tm >= 1 && (tm & (tm - 1)) == 0 && tm <= (1 << (kShadowEpochs - 1)) && lane < QT) {
                         const int epoch = 31 - __builtin_clz(tm);
@@ -427,13 +446,13 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                             (void)__hip_atomic_fetch_min(a.g_slot + (lane * kShadowEpochs + epoch) * 32 + (blockIdx.x % KC), v,
                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    // two polls per epoch (2 and 3 tiles after it was fed), waves take turns
+                    // polls 2 and 3 tiles after an epoch was fed (epoch 0 also after 1), waves take turns
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
+                    for (int i = -1; i < 2; ++i) {
                         const int tp = tiles_done - 2 - i;
-                        if (tp >= 1 && (tp & (tp - 1)) == 0 && tp <= (1 << (kShadowEpochs - 1))) {
+                        if (tp >= 1 && (tp & (tp - 1)) == 0 && tp <= (1 << (kShadowEpochs - 1)) && (i >= 0 || tp == 1)) {
                             const int epoch = 31 - __builtin_clz(tp);
-                            if (w == ((2 * epoch + i) & 7) && lane < QT) {
+                            if (w == ((2 * epoch + i + 5) & 7) && lane < QT) {
                                 const uint32_t* sl = a.g_slot + (lane * kShadowEpochs + epoch) * 32;
                                 uint32_t m = 0u;
 #pragma unroll
@@ -742,7 +761,7 @@ int shadow_split() { return kShSplit; }
 
 template <int QT, int KC>
 static int launch_scan8(const Scan8Args& a, int grid, hipStream_t st, EventRing& prof) {
-    const int lds = 2 * QT * a.qstride + 8 * 4096 + 8 * 384 + 3 * QT * 4 + 16;
+    const int lds = 2 * QT * a.qstride + 8 * 4096 + 8 * 384 + 3 * QT * 4 + 64;   // (+ slot_ok, arrival words)
     auto kern = scan8_kernel<QT, KC>;
     static LdsOptIn lds_opt_in;
     {
@@ -758,7 +777,7 @@ static int launch_scan8(const Scan8Args& a, int grid, hipStream_t st, EventRing&
 
 int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
     const int qstride = (s.d + 255) / 256 * 256;
-    const bool wide = s.qt_max >= 64 && s.B > 32 && 2 * 64 * qstride + 8 * 4096 + 8 * 384 + 3 * 64 * 4 + 16 <= 160 * 1024;
+    const bool wide = s.qt_max >= 64 && s.B > 32 && 2 * 64 * qstride + 8 * 4096 + 8 * 384 + 3 * 64 * 4 + 64 <= 160 * 1024;
     const int QT = wide ? 64 : 32;
     const int Bpad = (s.B + QT - 1) / QT * QT;
     PRAG_REQUIRE(Bpad <= s.Bpad_ws, PRAG_EUNSUPPORTED, "internal: shadow workspace too small");
