@@ -355,6 +355,23 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     float* bufP1 = bufP0 + NWV * 64;
     const gptr_u32x4 w2p = as_global(L.W2f) + (size_t)(RT * w) * 64 + lane;  // + ((part*32 + ks)*16 + rti)*64
     float mean1[CT], rstd1[CT];
+    // fc2 weight fragments: two slots, refilled right after use.  The fragments do not depend on the
+    // column tile, so the refills at the end of one pass wrap around to k-steps 0 and 1 and the next
+    // pass starts with its first fragments already in registers (no exposed load latency per pass).
+    half8 a2[2][NA][RT];
+    auto a2_load = [&](int slot, int ks) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p)
+#pragma unroll
+            for (int rti = 0; rti < RT; ++rti) {
+                const u32x4 v = w2p[((size_t)(p * 32 + ks) * 16 + rti) * 64];
+                a2[slot][p][rti] = __builtin_bit_cast(half8, v);
+            }
+    };
+    a2_load(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    a2_load(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         if (g > 0) __syncthreads();  // previous pass finished reading the exchange area / T buffers
@@ -389,20 +406,6 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc2[i][c][e] = 0.f;
 
-        half8 a2[2][NA][RT];
-        auto a2_load = [&](int slot, int ks) {
-#pragma unroll
-            for (int p = 0; p < NA; ++p)
-#pragma unroll
-                for (int rti = 0; rti < RT; ++rti) {
-                    const u32x4 v = w2p[((size_t)(p * 32 + ks) * 16 + rti) * 64];
-                    a2[slot][p][rti] = __builtin_bit_cast(half8, v);
-                }
-        };
-        a2_load(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        a2_load(1, 1);
-        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();  // fragments (and, first time, the LN1 partial sums) of all waves are in LDS
 
         if (g == 0) {
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                             acc2[rti][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
                                 a2[u][1][rti], b2h[c2], acc2[rti][c2], 0, 0, 0);
                     }
-                a2_load(u, ks + 2 < 32 ? ks + 2 : 31);  // clamped refill, no branch
+                a2_load(u, (ks + 2) & 31);  // refill, wrapping to the next pass's first fragments: no branch
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
