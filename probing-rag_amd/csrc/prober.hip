@@ -73,7 +73,29 @@ struct ProberArgs {
     int n_tiles;    // row tiles per layer (set by the launcher)
     int n_run;      // layers in this launch
     float* logits;  // [n_run][B][2]
+#ifdef PRAG_MM_DIAG
+    int stamps;     // 1: phase stamps of three workgroups
+#endif
 };
+
+#ifdef PRAG_MM_DIAG
+// timing-only build (make diag): s_memtime stamps of three workgroups, read by tools/prober_stamps.py
+__device__ unsigned long long g_pstamp[3 * 8 * 32];
+#define PSTAMP_T(var)                                                                         \
+    {                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    }
+#define PSTAMP(i)                                                                             \
+    if (ps_sel >= 0) {                                                                        \
+        unsigned long long t_;                                                                \
+        PSTAMP_T(t_)                                                                          \
+        if (lane == 0) g_pstamp[(ps_sel * 8 + w) * 32 + (i)] = t_;                            \
+    }
+#else
+#define PSTAMP(i)
+#endif
 
 __device__ __forceinline__ float silu_f(float h) {
     // h * sigmoid(h) as v_mul + v_exp_f32 + v_add + v_rcp_f32 + v_mul; the two transcendentals
@@ -93,14 +115,44 @@ __device__ __forceinline__ gptr_f32 as_global(const float* p) { return (gptr_f32
 
 __device__ __forceinline__ float xor32(float v) { return v + __shfl_xor(v, 32, 64); }
 
+// Streams with a uniform base go through buffer loads: resource in SGPRs, one loop-invariant 32-bit lane
+// offset in a VGPR, the moving part of the address in an SGPR.  (global_load with 64-bit lane pointers
+// needs a v_lshl_add_u64 per load and moves 512 B of addresses per instruction: in the fc1 loop that alone
+// cost ~800 of ~3200 cycles per K step - tools/micro/fc1_loop.hip.)  Out-of-range reads return 0.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0,
+                                             bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes, 0x00020000);
+}
+// Values that are the same for the whole workgroup but reach it through a vector load (anything read from
+// the layer table after the first store or barrier): pin them to SGPRs.  A buffer resource the compiler
+// cannot prove uniform is otherwise "waterfalled" - a readfirstlane loop around every load.
+__device__ __forceinline__ float uniform_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+template <typename T>
+__device__ __forceinline__ const T* uniform_p(const T* p) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uni_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, uni_off, 0);
+}
+
+// column tiles per fc2 pass: two wherever the tile has two (every W2 fragment then feeds 4 MFMAs and the
+// 512 KiB of W2 stream through the CU half as often); the 4-wave 128-row variant keeps one (its fc2 phase
+// would hold 128 + 64 accumulator VGPRs)
+template <int CT, int NWV>
+constexpr int fc2_group() {
+    return (CT >= 2 && !(CT == 4 && NWV == 4)) ? 2 : 1;
+}
+
 template <int NA, int NB, int CT, int NWV>
 __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberArgs a) {
     constexpr int NT = 64 * NWV;        // threads
     constexpr int RT = 16 / NWV;        // 32-row hidden tiles per wave
-    // column tiles per fc2 pass.  128-row tiles (CT = 4) take one at a time: with two, the fc2 phase held
-    // 64 + 64 accumulator VGPRs plus fragments and ~40 values went to scratch - every reload waits
-    // behind s_waitcnt vmcnt(0) (51 of them per tile).
-    constexpr int G = (CT >= 2 && CT < 4) ? 2 : 1;
+    constexpr int G = fc2_group<CT, NWV>();
     constexpr int NG = CT / G;
     constexpr bool RAW = (NB == 1);
     constexpr int ROWS = 32 * CT;
@@ -132,9 +184,19 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     const int lrun = vidx / a.n_tiles;
     const LayerDev& L = a.layers[a.layer0 + lrun];
     const int m0 = (vidx - lrun * a.n_tiles) * ROWS;
+    // the layer record, read once before anything is stored (scalar loads) and pinned to SGPRs
+    const __amdgpu_buffer_rsrc_t rs_w1 = make_rsrc(uniform_p(L.W1f), (size_t)NA * a.d * 1024);
+    const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(uniform_p(L.W2f), (size_t)NA * 32 * 16 * 1024);
+    const float L_sc1 = uniform_f(L.sc1), L_sc2 = uniform_f(L.sc2);
+    const float L_b3[2] = {uniform_f(L.b3[0]), uniform_f(L.b3[1])};
+    const float L_w3sum[2] = {uniform_f(L.w3sum[0]), uniform_f(L.w3sum[1])};
     const int d = a.d;
     const int S16 = d >> 4;
     const int T = d >> 6;
+#ifdef PRAG_MM_DIAG
+    const int ps_sel = !a.stamps ? -1 : vidx == 0 ? 0 : vidx == 17 ? 1 : vidx == a.n_tiles * a.n_run - 1 ? 2 : -1;
+    PSTAMP(0)
+#endif
 
     // epilogue constants -> LDS once, so no epilogue ever waits on a global load
     for (int i = tid; i < 6 * kHidden / 4; i += NT) {
@@ -147,17 +209,22 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
 
     // ---- activation staging: thread -> 16-B piece(s) of the [ROWS x 64] tile ----
     // (threads beyond the tile duplicate an in-range piece: no divergent loads)
-    const _Float16* xsrc[NB][NPASS];
+    static_assert((256 * CT) % NT == 0, "every 16-B piece of a staged tile has exactly one owner");
+    __amdgpu_buffer_rsrc_t rs_x[NB];   // this tile's rows of this layer
+    {
+        const int64_t tile0 = (int64_t)lrun * a.x_layer_stride + (int64_t)m0 * d;
+        const size_t bytes = (size_t)(a.B - m0) * d * 2;
+        rs_x[0] = make_rsrc(uniform_p(a.xh + tile0), bytes);
+        if constexpr (NB == 2) rs_x[1] = make_rsrc(uniform_p(a.xl + tile0), bytes);
+    }
+    unsigned x_off[NPASS];
     int st_off[NPASS];
 #pragma unroll
     for (int c = 0; c < NPASS; ++c) {
-        const int e = (tid + c * NT) % (256 * CT);
+        const int e = tid + c * NT;
         const int row = e >> 3, q = e & 7;
-        int grow = m0 + row;
-        grow = grow < a.B ? grow : a.B - 1;
-        const int64_t base = (int64_t)lrun * a.x_layer_stride + (int64_t)grow * d + 8 * q;
-        xsrc[0][c] = a.xh + base;
-        if constexpr (NB == 2) xsrc[1][c] = a.xl + base;
+        const int lrow = m0 + row < a.B ? row : a.B - 1 - m0;   // rows past the batch re-read its last row
+        x_off[c] = (unsigned)(lrow * d + 8 * q) * 2u;
         st_off[c] = row * 128 + ((q ^ ((row >> 1) & 7)) << 4);
     }
     // fragment read offsets: lane (r,hh), tile c, sub-step -> piece 2*sub+hh of row 32c+r
@@ -174,8 +241,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
 #pragma unroll
         for (int p = 0; p < NB; ++p)
 #pragma unroll
-            for (int c = 0; c < NPASS; ++c)
-                xreg[p][c] = *reinterpret_cast<const u32x4*>(xsrc[p][c] + 64 * t);
+            for (int c = 0; c < NPASS; ++c) xreg[p][c] = buf_load16(rs_x[p], x_off[c], (unsigned)t * 128u);
     };
     auto x_store = [&](int stage) {
 #pragma unroll
@@ -186,14 +252,15 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     };
 
     // ---- weight fragments: straight from global, 1 KiB per wave-load --------------
-    const gptr_u32x4 w1p = as_global(L.W1f) + (size_t)(RT * w) * 64 + lane;  // + ((part*S16 + s16)*16 + rti)*64
+    const unsigned lane16 = lane * 16;
+    const unsigned w_frag0 = RT * w;   // fragment ((part*S16 + s16)*16 + RT*w + rti), 1 KiB each
     half8 afr[4][NA][RT];
     auto a_load = [&](int slot, int s16) {
 #pragma unroll
         for (int p = 0; p < NA; ++p)
 #pragma unroll
             for (int rti = 0; rti < RT; ++rti) {
-                const u32x4 v = w1p[((size_t)(p * S16 + s16) * 16 + rti) * 64];
+                const u32x4 v = buf_load16(rs_w1, lane16, ((unsigned)(p * S16 + s16) * 16u + w_frag0 + rti) << 10);
                 afr[slot][p][rti] = __builtin_bit_cast(half8, v);
             }
     };
@@ -206,19 +273,32 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][c][e] = 0.f;
 
-    // in-flight LayerNorm-0 statistics (RAW only): wave w accumulates column tile
-    // (w % CT) from its own extra fragment read - no wave-dependent branch in the loop
-    const int stat_c = w % CT;
-    const int stat_row = 32 * stat_c + r;
-    const int stat_off = stat_row * 128;
-    const int stat_sw = (stat_row >> 1) & 7;
-    float st_s = 0.f, st_q2 = 0.f;
+    // in-flight LayerNorm-0 statistics (RAW only): every thread sums the 16-B pieces it stages, straight
+    // from the staging registers (each element of the tile is touched once per workgroup; the 8 lanes that
+    // share a row are combined after the loop)
+    float st_s[NPASS], st_q2[NPASS];
+#pragma unroll
+    for (int c = 0; c < NPASS; ++c) st_s[c] = st_q2[c] = 0.f;
     const half2_t kOnes2 = {(_Float16)1.f, (_Float16)1.f};
+    auto x_stats = [&]() {
+        // LayerNorm-0 sums with v_dot2_f32_f16: products of halves are exact in f32,
+        // accumulation is f32 (error ~1e-6 * (1 + mean^2/var) on the variance)
+#pragma unroll
+        for (int c = 0; c < NPASS; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned int u = xreg[0][c][j];   // (bit_cast of the element lvalue itself reads element 0)
+                const half2_t xv = __builtin_bit_cast(half2_t, u);
+                st_s[c] = __builtin_amdgcn_fdot2(xv, kOnes2, st_s[c], false);
+                st_q2[c] = __builtin_amdgcn_fdot2(xv, xv, st_q2[c], false);
+            }
+    };
 
     // ---- prologue ---------------------------------------------------------------
     // (issue order mirrors the loop body - activations first, then the four weight
     // slots - so the counted vmcnt waits at the loop head hold on entry too)
     x_load(0);
+    if constexpr (RAW) x_stats();
     x_store(0);
     x_load(1);
 #pragma unroll
@@ -227,6 +307,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
         a_load(s, s);
     }
     __builtin_amdgcn_sched_barrier(0);
+    PSTAMP(1)
 
     // ---- fc1 main loop: one barrier per 64-wide K step, no other control flow -----
     for (int t = 0; t < T; ++t) {
@@ -235,14 +316,15 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
         // which would serialise the weight prefetch every K step.)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if constexpr (RAW)
+            if (t + 1 < T) x_stats();          // tile t+1; the tail's re-read of the last tile does not count
         x_store((t + 1) & 1);                  // tile t+1 (loaded one step ago)
         x_load(t + 2 < T ? t + 2 : T - 1);     // clamped: the tail re-reads the last tile
         const char* xs = s_x + (t & 1) * XSTAGE;
         const int s16n = 4 * (t + 1 < T ? t + 1 : T - 1);
-        // B fragments (and the statistics fragment) of sub-step s+1 are read while the
-        // MFMAs of sub-step s run: only the first read of a K step is exposed
+        // B fragments of sub-step s+1 are read while the MFMAs of sub-step s run: only the first read
+        // of a K step is exposed
         half8 bfr[2][NB][CT];
-        half8 sfr[2];
         auto b_read = [&](int buf, int sub) {
 #pragma unroll
             for (int p = 0; p < NB; ++p)
@@ -251,24 +333,12 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                     const int off = p * XPART + rd_row_off[c] + (((2 * sub + hh) ^ rd_sw[c]) << 4);
                     bfr[buf][p][c] = *reinterpret_cast<const half8*>(xs + off);
                 }
-            if constexpr (RAW)
-                sfr[buf] = *reinterpret_cast<const half8*>(xs + stat_off + (((2 * sub + hh) ^ stat_sw) << 4));
         };
         b_read(0, 0);
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
             const int cb = sub & 1;
             if (sub < 3) b_read(cb ^ 1, sub + 1);
-            if constexpr (RAW) {
-                // LayerNorm-0 sums with v_dot2_f32_f16: products of halves are exact in f32,
-                // accumulation is f32 (error ~1e-6 * (1 + mean^2/var) on the variance)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const half2_t xv = half2_t{sfr[cb][2 * j], sfr[cb][2 * j + 1]};
-                    st_s = __builtin_amdgcn_fdot2(xv, kOnes2, st_s, false);
-                    st_q2 = __builtin_amdgcn_fdot2(xv, xv, st_q2, false);
-                }
-            }
 #pragma unroll
             for (int rti = 0; rti < RT; ++rti)
 #pragma unroll
@@ -287,19 +357,29 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
         }
     }
 
+    PSTAMP(2)
     // ---- LayerNorm-0 statistics -> LDS -------------------------------------------
     if constexpr (RAW) {
-        // this lane summed half of the row (k = 16s + 8hh + j); partner lane^32 the other half
-        const float s1 = st_s + __shfl_xor(st_s, 32, 64);
-        const float s2 = st_q2 + __shfl_xor(st_q2, 32, 64);
-        const float mean = s1 / (float)d;
-        const float var = fmaxf(s2 / (float)d - mean * mean, 0.f);
-        if (hh == 0 && w < CT) {
-            s_mu0[stat_row] = mean;
-            s_rs0[stat_row] = 1.0f / sqrtf(var + kLnEps);
+#pragma unroll
+        for (int c = 0; c < NPASS; ++c) {
+            // lanes 8j..8j+7 staged the eight pieces of one row
+            float s1 = st_s[c], s2 = st_q2[c];
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                s1 += __shfl_xor(s1, o, 64);
+                s2 += __shfl_xor(s2, o, 64);
+            }
+            const float mean = s1 / (float)d;
+            const float var = fmaxf(s2 / (float)d - mean * mean, 0.f);
+            if ((tid & 7) == 0) {
+                const int row = (tid + c * NT) >> 3;
+                s_mu0[row] = mean;
+                s_rs0[row] = 1.0f / sqrtf(var + kLnEps);
+            }
         }
     }
     __syncthreads();  // stats visible; every wave is done with the staging ring
+    PSTAMP(3)
 
     // ---- epilogue 1: LN0 fold, bias, SiLU, one-pass LN1 sums ---------------------------
     // LayerNorm-1 is NOT applied element-wise: fc2 consumes the raw SiLU outputs and
@@ -311,7 +391,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             mu[c] = RAW ? s_mu0[32 * c + r] : 0.f;
-            rs[c] = (RAW ? s_rs0[32 * c + r] : 1.f) * L.sc1;
+            rs[c] = (RAW ? s_rs0[32 * c + r] : 1.f) * L_sc1;
             S1[c] = S2[c] = 0.f;
         }
 #pragma unroll
@@ -323,18 +403,25 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(s_cst + kHidden + nb);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
+                    float sv[CT];
 #pragma unroll
                     for (int c = 0; c < CT; ++c) {
                         float v = acc[rti][c][4 * g4 + e];
                         if constexpr (RAW) v = fmaf(-mu[c], ws[e], v);
-                        const float sv = silu_f(fmaf(rs[c], v, bb[e]));
-                        acc[rti][c][4 * g4 + e] = sv;
-                        S1[c] += sv;
-                        S2[c] = fmaf(sv, sv, S2[c]);
+                        sv[c] = silu_f(fmaf(rs[c], v, bb[e]));
                     }
-                    // bound live ranges: at 128-row tiles the accumulators alone are 128 VGPRs, and 16
-                    // SiLU chains in flight pushed ~40 of them into scratch (each reload then waits
-                    // behind s_waitcnt vmcnt(0)); 8 chains at a time (4 at CT = 4) fit
+                    // CT independent SiLU chains per group, and the group pinned where it is written: pure
+                    // arithmetic is free to move across sched_barrier at IR level - without the empty asm
+                    // the compiler ran one chain per group and left the other 3*32 in one block at the end
+                    // (serial dependent VALU, transcendental hazards exposed, spills)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) asm volatile("" : "+v"(sv[c]));
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        acc[rti][c][4 * g4 + e] = sv[c];
+                        S1[c] += sv[c];
+                        S2[c] = fmaf(sv[c], sv[c], S2[c]);
+                    }
                     if (CT >= 4 || (e & 1)) __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -348,12 +435,12 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
         }
     }
 
+    PSTAMP(4)
     // ---- fc2 / fc3, G column tiles at a time ---------------------------------------
     float* bufT1 = s_red + 2 * NWV * ROWS;  // [NWV][64] x4: sum s2, sum s2^2, fc3 class 0 / 1 partials
     float* bufT2 = bufT1 + NWV * 64;
     float* bufP0 = bufT2 + NWV * 64;
     float* bufP1 = bufP0 + NWV * 64;
-    const gptr_u32x4 w2p = as_global(L.W2f) + (size_t)(RT * w) * 64 + lane;  // + ((part*32 + ks)*16 + rti)*64
     float mean1[CT], rstd1[CT];
     // fc2 weight fragments: two slots, refilled right after use.  The fragments do not depend on the
     // column tile, so the refills at the end of one pass wrap around to k-steps 0 and 1 and the next
@@ -364,7 +451,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
         for (int p = 0; p < NA; ++p)
 #pragma unroll
             for (int rti = 0; rti < RT; ++rti) {
-                const u32x4 v = w2p[((size_t)(p * 32 + ks) * 16 + rti) * 64];
+                const u32x4 v = buf_load16(rs_w2, lane16, ((unsigned)(p * 32 + ks) * 16u + w_frag0 + rti) << 10);
                 a2[slot][p][rti] = __builtin_bit_cast(half8, v);
             }
     };
@@ -406,7 +493,9 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc2[i][c][e] = 0.f;
 
+        PSTAMP(5 + 5 * g)
         __syncthreads();  // fragments (and, first time, the LN1 partial sums) of all waves are in LDS
+        PSTAMP(6 + 5 * g)
 
         if (g == 0) {
 #pragma unroll
@@ -421,45 +510,55 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                 mean1[c] = t1 * (1.0f / kHidden);
                 const float var = fmaxf(t2 * (1.0f / kHidden) - mean1[c] * mean1[c], 0.f);
                 rstd1[c] = 1.0f / sqrtf(var + kLnEps);
+                // one column tile's 2*NWV reads at a time (hoisted together they went to scratch)
+                asm volatile("" : "+v"(mean1[c]), "+v"(rstd1[c]));
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 
+        // exchange fragments of k-step ks+1 are read while the MFMAs of k-step ks run
+        half8 b2h[2][G], b2l[2][G];
+        auto b2_read = [&](int buf, int ks) {
+#pragma unroll
+            for (int c2 = 0; c2 < G; ++c2) {
+                const int fi = (ks * G + c2) * 64 + lane;
+                b2h[buf][c2] = *reinterpret_cast<const half8*>(s_ex + (size_t)fi * 16);
+                b2l[buf][c2] = *reinterpret_cast<const half8*>(s_ex + (size_t)(16 * 2 * G * 64 + fi) * 16);
+            }
+        };
+        b2_read(0, 0);
 #pragma unroll 1
         for (int ks2 = 0; ks2 < 32; ks2 += 2) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int ks = ks2 + u;
-                half8 b2h[G], b2l[G];
-#pragma unroll
-                for (int c2 = 0; c2 < G; ++c2) {
-                    const int fi = (ks * G + c2) * 64 + lane;
-                    b2h[c2] = *reinterpret_cast<const half8*>(s_ex + (size_t)fi * 16);
-                    b2l[c2] = *reinterpret_cast<const half8*>(s_ex + (size_t)(16 * 2 * G * 64 + fi) * 16);
-                }
+                b2_read(u ^ 1, (ks + 1) & 31);  // the last one wraps to k-step 0: valid bytes, never used
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int rti = 0; rti < RT; ++rti)
 #pragma unroll
                     for (int c2 = 0; c2 < G; ++c2) {
                         acc2[rti][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                            a2[u][0][rti], b2h[c2], acc2[rti][c2], 0, 0, 0);
+                            a2[u][0][rti], b2h[u][c2], acc2[rti][c2], 0, 0, 0);
                         acc2[rti][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                            a2[u][0][rti], b2l[c2], acc2[rti][c2], 0, 0, 0);
+                            a2[u][0][rti], b2l[u][c2], acc2[rti][c2], 0, 0, 0);
                         if constexpr (NA == 2)
                             acc2[rti][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                                a2[u][1][rti], b2h[c2], acc2[rti][c2], 0, 0, 0);
+                                a2[u][1][rti], b2h[u][c2], acc2[rti][c2], 0, 0, 0);
                     }
                 a2_load(u, (ks + 2) & 31);  // refill, wrapping to the next pass's first fragments: no branch
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 
+        PSTAMP(7 + 5 * g)
         // epilogue 2: LN1 fold, bias, SiLU, one-pass LN2 sums, fc3 partial dot products
         float T1[G], T2[G], P0[G], P1[G], m1[G], r1[G];
 #pragma unroll
         for (int c2 = 0; c2 < G; ++c2) {
             T1[c2] = T2[c2] = P0[c2] = P1[c2] = 0.f;
             m1[c2] = mean1[g * G + c2];
-            r1[c2] = rstd1[g * G + c2] * L.sc2;
+            r1[c2] = rstd1[g * G + c2] * L_sc2;
         }
 #pragma unroll
         for (int rti = 0; rti < RT; ++rti)
@@ -470,16 +569,27 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                 const f32x4 w2s = *reinterpret_cast<const f32x4*>(s_cst + 5 * kHidden + nb);
                 const f32x4 w30 = *reinterpret_cast<const f32x4*>(s_cst + 3 * kHidden + nb);
                 const f32x4 w31 = *reinterpret_cast<const f32x4*>(s_cst + 4 * kHidden + nb);
+                float sv[4][G];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int c2 = 0; c2 < G; ++c2) {
                         const float v = fmaf(-m1[c2], w2s[e], acc2[rti][c2][4 * g4 + e]);
-                        const float sv = silu_f(fmaf(r1[c2], v, bb[e]));
-                        T1[c2] += sv;
-                        T2[c2] = fmaf(sv, sv, T2[c2]);
-                        P0[c2] = fmaf(sv, w30[e], P0[c2]);
-                        P1[c2] = fmaf(sv, w31[e], P1[c2]);
+                        sv[e][c2] = silu_f(fmaf(r1[c2], v, bb[e]));
+                    }
+                // 4*G independent chains per group, pinned here (see epilogue 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int c2 = 0; c2 < G; ++c2) asm volatile("" : "+v"(sv[e][c2]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int c2 = 0; c2 < G; ++c2) {
+                        T1[c2] += sv[e][c2];
+                        T2[c2] = fmaf(sv[e][c2], sv[e][c2], T2[c2]);
+                        P0[c2] = fmaf(sv[e][c2], w30[e], P0[c2]);
+                        P1[c2] = fmaf(sv[e][c2], w31[e], P1[c2]);
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -493,6 +603,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                 bufP1[w * 64 + 32 * c2 + r] = q1;
             }
         }
+        PSTAMP(8 + 5 * g)
         __syncthreads();
         if (tid < 32 * G) {
             const int row = m0 + 32 * g * G + tid;
@@ -510,13 +621,21 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                 const float var2 = fmaxf(t2 * (1.0f / kHidden) - mean2 * mean2, 0.f);
                 const float rstd2 = 1.0f / sqrtf(var2 + kLnEps);
                 float2 o;
-                o.x = fmaf(rstd2, q0 - mean2 * L.w3sum[0], L.b3[0]);
-                o.y = fmaf(rstd2, q1 - mean2 * L.w3sum[1], L.b3[1]);
+                o.x = fmaf(rstd2, q0 - mean2 * L_w3sum[0], L_b3[0]);
+                o.y = fmaf(rstd2, q1 - mean2 * L_w3sum[1], L_b3[1]);
                 *reinterpret_cast<float2*>(a.logits + ((size_t)lrun * a.B + row) * 2) = o;
             }
         }
+        PSTAMP(9 + 5 * g)
     }
 }
+
+#ifdef PRAG_MM_DIAG
+extern "C" int prag_diag_prober_stamps(unsigned long long* out, int n) {
+    if (n > 3 * 8 * 32) n = 3 * 8 * 32;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pstamp), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -2;
+}
+#endif
 
 // ---------------------------------------------------------------------------
 // fp32 activations -> LayerNorm-0-normalised hi/lo fp16 terms (one wave per row)
@@ -961,12 +1080,13 @@ extern "C" int prag_prober_reserve(prag_prober_t* p, int max_B) {
 
 template <int NA, int NB, int CT, int NWV>
 static int launch_fused(const ProberArgs& a, int n_run, hipStream_t st, EventRing& prof) {
-    constexpr int G = (CT >= 2 && CT < 4) ? 2 : 1;
+    constexpr int G = fc2_group<CT, NWV>();
     constexpr int ROWS = 32 * CT;
     constexpr int XSTAGE = NB * ROWS * 128;
     constexpr int EXCH = 2 * 16 * 2 * G * 1024;
     constexpr int REGION_A = (2 * XSTAGE > EXCH) ? 2 * XSTAGE : EXCH;
     constexpr int LDS = REGION_A + (2 * NWV * ROWS + 4 * NWV * 64 + 2 * ROWS + 6 * kHidden) * (int)sizeof(float);
+    static_assert(LDS <= 160 * 1024, "workgroup LDS");
     auto kern = prober_fused_kernel<NA, NB, CT, NWV>;
     static LdsOptIn lds_opt_in;
     {
@@ -974,6 +1094,9 @@ static int launch_fused(const ProberArgs& a, int n_run, hipStream_t st, EventRin
         if (rc_ != PRAG_OK) return rc_;
     }
     ProberArgs b = a;
+#ifdef PRAG_MM_DIAG
+    b.stamps = getenv("PRAG_PROBER_STAMPS") ? atoi(getenv("PRAG_PROBER_STAMPS")) : 0;
+#endif
     b.n_tiles = (a.B + ROWS - 1) / ROWS;
     b.n_run = n_run;
     const int per_xcd = (b.n_tiles * n_run + 7) / 8;
