@@ -283,19 +283,21 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     const int col_b = (lane & 7) * 16;
     const int64_t row_bytes = d;
     const char* rows = reinterpret_cast<const char*>(a.rows8);
-    // three chunks (12 KiB per wave, 96 KiB per CU) in flight: at half the bytes per row the loop turns
-    // over twice as fast as the fp16 scan's, and with two it starved at 64 queries
-    u32x4 ldA[4], ldB[4], ldC[4];
+    // four chunks (16 KiB per wave, 128 KiB per CU) in flight: at half the bytes per row the loop turns
+    // over twice as fast as the fp16 scan's; with two it starved at 64 queries, the fourth is worth 0.8 %
+    // (2.936 -> 2.912 ms at 21 M rows, same box).  64 queries x 32-deep lists have no registers for it.
+    constexpr int NLD = (QT == 64 && KC == 32) ? 3 : 4;
+    u32x4 ld[NLD][4];
     // wave-uniform tile base (scalar registers) + a per-lane 32-bit offset: no 64-bit vector address
     // arithmetic and no per-row clamp in the loop - the shadow is allocated in multiples of 256 rows, so
     // the rows of the last, partial tile past N are readable (their scores are masked in the epilogue)
     int lane_off[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) lane_off[i] = st_doc[i] * d + col_b;
-    auto issue = [&](u32x4 (&ld)[4], int tile, int c) {
+    auto issue = [&](u32x4 (&ldr)[4], int tile, int c) {
         const char* base = rows + (int64_t)tile * (32 * row_bytes) + c * 128;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ld[i] = *reinterpret_cast<const u32x4*>(base + lane_off[i]);
+        for (int i = 0; i < 4; ++i) ldr[i] = *reinterpret_cast<const u32x4*>(base + lane_off[i]);
     };
     const int a_off = r * 128;
     const int a_sw = (r >> 1) & 7;
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     float m_s = 1.f, m_e = 0.f, m_x = 0.f;   // metadata of row (tile*32 + r), requested at the tile's first chunk
     int tiles_done = 0;
 
-    auto body = [&](u32x4 (&ld)[4]) {
+    auto body = [&](u32x4 (&ldr)[4]) {
         const int tile_cur = vtile(vt_cur);
         if (c_cur == 0) {
             const int64_t row = (int64_t)tile_cur * 32 + r;     // (arrays are padded to a multiple of 32 rows)
@@ -337,8 +339,8 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
             m_x = a.use_norm ? a.xnorm[row] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(s_st + st_dst[i]) = ld[i];
-        issue(ld, vtile(vt_nx), c_nx);
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(s_st + st_dst[i]) = ldr[i];
+        issue(ldr, vtile(vt_nx), c_nx);
         advance(vt_nx, c_nx);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {               // 4 k-steps of 32 elements per 128-byte chunk
@@ -485,20 +487,19 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     };
 
     if (n_my > 0) {
-        issue(ldA, vtile(vt_nx), c_nx);
-        advance(vt_nx, c_nx);
-        issue(ldB, vtile(vt_nx), c_nx);
-        advance(vt_nx, c_nx);
-        issue(ldC, vtile(vt_nx), c_nx);
-        advance(vt_nx, c_nx);
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            issue(ld[u], vtile(vt_nx), c_nx);
+            advance(vt_nx, c_nx);
+        }
         // (`redo` grows during the first tiles only, long before the loop bound is reached - or, on a
         // shard of a few tiles, up to n_my: every tile is then visited twice)
-        for (int it = 0; it < (n_my + redo) * NCH; it += 3) {
-            body(ldA);
-            if (it + 1 >= (n_my + redo) * NCH) break;
-            body(ldB);
-            if (it + 2 >= (n_my + redo) * NCH) break;
-            body(ldC);
+        for (int it = 0; it < (n_my + redo) * NCH; it += NLD) {
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                if (u > 0 && it + u >= (n_my + redo) * NCH) break;
+                body(ld[u]);
+            }
         }
     }
     __syncthreads();
