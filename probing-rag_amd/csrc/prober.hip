@@ -381,19 +381,25 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     __syncthreads();  // stats visible; every wave is done with the staging ring
     PSTAMP(3)
 
-    // ---- epilogue 1: LN0 fold, bias, SiLU, one-pass LN1 sums ---------------------------
+    // ---- after fc1: epilogue 1 (LN0 fold, bias, SiLU, LN1 sums), fc2, epilogue 2, fc3 -----------
     // LayerNorm-1 is NOT applied element-wise: fc2 consumes the raw SiLU outputs and
     // its epilogue applies  rstd1*(W2~ s - mean1*rowsum(W2~)) + b2~  (same algebra as LN0).
     float* bufS1 = s_red;               // [NWV][ROWS] partial sums of s
     float* bufS2 = s_red + NWV * ROWS;  // [NWV][ROWS] partial sums of s*s
-    {
+    float* setT0 = s_red + 2 * NWV * ROWS;  // [4][NWV][64]: sum s2, sum s2^2, fc3 class 0 / 1 partials
+    float* setT1 = s_red;                   // second set of the same (128-row tiles, once bufS is dead)
+
+    // epilogue 1 on column tiles [c0, c0 + nc): SiLU in place, partial LN1 sums -> bufS
+    auto ep1_cols = [&](const int c0, const int nc) {
         float mu[CT], rs[CT], S1[CT], S2[CT];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            mu[c] = RAW ? s_mu0[32 * c + r] : 0.f;
-            rs[c] = (RAW ? s_rs0[32 * c + r] : 1.f) * L_sc1;
-            S1[c] = S2[c] = 0.f;
-        }
+        for (int c = 0; c < CT; ++c)
+            if (c >= c0 && c < c0 + nc) {
+                mu[c] = RAW ? s_mu0[32 * c + r] : 0.f;
+                rs[c] = (RAW ? s_rs0[32 * c + r] : 1.f) * L_sc1;
+                S1[c] = S2[c] = 0.f;
+            }
+        const int epg = nc >= 4 ? 1 : nc == 2 ? 2 : 4;   // rows of the accumulator per group: 4 chains
 #pragma unroll
         for (int rti = 0; rti < RT; ++rti)
 #pragma unroll
@@ -402,50 +408,77 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                 const f32x4 ws = *reinterpret_cast<const f32x4*>(s_cst + nb);
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(s_cst + kHidden + nb);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float sv[CT];
+                for (int e0 = 0; e0 < 4; e0 += epg) {
+                    float sv[4][CT];
 #pragma unroll
-                    for (int c = 0; c < CT; ++c) {
-                        float v = acc[rti][c][4 * g4 + e];
-                        if constexpr (RAW) v = fmaf(-mu[c], ws[e], v);
-                        sv[c] = silu_f(fmaf(rs[c], v, bb[e]));
-                    }
-                    // CT independent SiLU chains per group, and the group pinned where it is written: pure
-                    // arithmetic is free to move across sched_barrier at IR level - without the empty asm
-                    // the compiler ran one chain per group and left the other 3*32 in one block at the end
-                    // (serial dependent VALU, transcendental hazards exposed, spills)
+                    for (int e = e0; e < e0 + epg; ++e)
 #pragma unroll
-                    for (int c = 0; c < CT; ++c) asm volatile("" : "+v"(sv[c]));
+                        for (int c = 0; c < CT; ++c)
+                            if (c >= c0 && c < c0 + nc) {
+                                float v = acc[rti][c][4 * g4 + e];
+                                if constexpr (RAW) v = fmaf(-mu[c], ws[e], v);
+                                sv[e][c] = silu_f(fmaf(rs[c], v, bb[e]));
+                            }
+                    // four independent SiLU chains per group, and the group pinned where it is written:
+                    // pure arithmetic is free to move across sched_barrier at IR level - without the empty
+                    // asm the compiler ran one chain per group and left the other 3*32 in one block at the
+                    // end (serial dependent VALU, transcendental hazards exposed, spills)
 #pragma unroll
-                    for (int c = 0; c < CT; ++c) {
-                        acc[rti][c][4 * g4 + e] = sv[c];
-                        S1[c] += sv[c];
-                        S2[c] = fmaf(sv[c], sv[c], S2[c]);
-                    }
-                    if (CT >= 4 || (e & 1)) __builtin_amdgcn_sched_barrier(0);
+                    for (int e = e0; e < e0 + epg; ++e)
+#pragma unroll
+                        for (int c = 0; c < CT; ++c)
+                            if (c >= c0 && c < c0 + nc) asm volatile("" : "+v"(sv[e][c]));
+#pragma unroll
+                    for (int e = e0; e < e0 + epg; ++e)
+#pragma unroll
+                        for (int c = 0; c < CT; ++c)
+                            if (c >= c0 && c < c0 + nc) {
+                                acc[rti][c][4 * g4 + e] = sv[e][c];
+                                S1[c] += sv[e][c];
+                                S2[c] = fmaf(sv[e][c], sv[e][c], S2[c]);
+                            }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const float t1 = xor32(S1[c]), t2 = xor32(S2[c]);
-            if (hh == 0) {
-                bufS1[w * ROWS + 32 * c + r] = t1;
-                bufS2[w * ROWS + 32 * c + r] = t2;
+        for (int c = 0; c < CT; ++c)
+            if (c >= c0 && c < c0 + nc) {
+                const float t1 = xor32(S1[c]), t2 = xor32(S2[c]);
+                if (hh == 0) {
+                    bufS1[w * ROWS + 32 * c + r] = t1;
+                    bufS2[w * ROWS + 32 * c + r] = t2;
+                }
             }
-        }
-    }
+    };
 
-    PSTAMP(4)
-    // ---- fc2 / fc3, G column tiles at a time ---------------------------------------
-    float* bufT1 = s_red + 2 * NWV * ROWS;  // [NWV][64] x4: sum s2, sum s2^2, fc3 class 0 / 1 partials
-    float* bufT2 = bufT1 + NWV * 64;
-    float* bufP0 = bufT2 + NWV * 64;
-    float* bufP1 = bufP0 + NWV * 64;
+    // LN1 statistics of column tiles [c0, c0 + nc) from the partial sums of all waves
     float mean1[CT], rstd1[CT];
-    // fc2 weight fragments: two slots, refilled right after use.  The fragments do not depend on the
-    // column tile, so the refills at the end of one pass wrap around to k-steps 0 and 1 and the next
-    // pass starts with its first fragments already in registers (no exposed load latency per pass).
-    half8 a2[2][NA][RT];
+    auto mean_cols = [&](const int c0, const int nc) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+            if (c >= c0 && c < c0 + nc) {
+                const int m = 32 * c + r;
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < NWV; ++ww) {
+                    t1 += bufS1[ww * ROWS + m];
+                    t2 += bufS2[ww * ROWS + m];
+                }
+                mean1[c] = t1 * (1.0f / kHidden);
+                const float var = fmaxf(t2 * (1.0f / kHidden) - mean1[c] * mean1[c], 0.f);
+                rstd1[c] = 1.0f / sqrtf(var + kLnEps);
+                // one column tile's 2*NWV reads at a time (hoisted together they went to scratch)
+                asm volatile("" : "+v"(mean1[c]), "+v"(rstd1[c]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+
+    // fc2 weight fragments: A2S slots, refilled right after use (four where a wave may run the k loop
+    // alone on its SIMD: at 256 cycles per k-step two slots are only 512 cycles of prefetch).  The
+    // fragments do not depend on the column tile, so the refills at the end of one pass wrap around to
+    // the first k-steps and the next pass starts with them already in registers.
+    constexpr int A2S = (NG == 2 && ROWS == 128 && NA == 1) ? 4 : 2;
+    half8 a2[A2S][NA][RT];
     auto a2_load = [&](int slot, int ks) {
 #pragma unroll
         for (int p = 0; p < NA; ++p)
@@ -455,14 +488,9 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                 a2[slot][p][rti] = __builtin_bit_cast(half8, v);
             }
     };
-    a2_load(0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    a2_load(1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        if (g > 0) __syncthreads();  // previous pass finished reading the exchange area / T buffers
-        // publish this wave's SiLU outputs as ready-made B fragments (hi + lo halves, RTZ split)
+
+    // publish this wave's SiLU outputs of pass g as ready-made B fragments (hi + lo halves, RTZ split)
+    auto publish = [&](const int g) {
 #pragma unroll
         for (int rti = 0; rti < RT; ++rti)
 #pragma unroll
@@ -484,39 +512,19 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                     *reinterpret_cast<u32x4*>(s_ex + (size_t)(16 * 2 * G * 64 + fi) * 16) = lo;
                     __builtin_amdgcn_sched_barrier(0);
                 }
+    };
 
-        f32x16 acc2[RT][G];
+    auto zero2 = [&](f32x16 (&acc2)[RT][G]) {
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int c = 0; c < G; ++c)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc2[i][c][e] = 0.f;
+    };
 
-        PSTAMP(5 + 5 * g)
-        __syncthreads();  // fragments (and, first time, the LN1 partial sums) of all waves are in LDS
-        PSTAMP(6 + 5 * g)
-
-        if (g == 0) {
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const int m = 32 * c + r;
-                float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                for (int ww = 0; ww < NWV; ++ww) {
-                    t1 += bufS1[ww * ROWS + m];
-                    t2 += bufS2[ww * ROWS + m];
-                }
-                mean1[c] = t1 * (1.0f / kHidden);
-                const float var = fmaxf(t2 * (1.0f / kHidden) - mean1[c] * mean1[c], 0.f);
-                rstd1[c] = 1.0f / sqrtf(var + kLnEps);
-                // one column tile's 2*NWV reads at a time (hoisted together they went to scratch)
-                asm volatile("" : "+v"(mean1[c]), "+v"(rstd1[c]));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-
-        // exchange fragments of k-step ks+1 are read while the MFMAs of k-step ks run
+    // the fc2 k loop of one pass; exchange fragments of k-step ks+1 are read while the MFMAs of ks run
+    auto fc2_loop = [&](f32x16 (&acc2)[RT][G]) {
         half8 b2h[2][G], b2l[2][G];
         auto b2_read = [&](int buf, int ks) {
 #pragma unroll
@@ -528,31 +536,46 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
         };
         b2_read(0, 0);
 #pragma unroll 1
-        for (int ks2 = 0; ks2 < 32; ks2 += 2) {
+        for (int ks2 = 0; ks2 < 32; ks2 += A2S) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < A2S; ++u) {
                 const int ks = ks2 + u;
-                b2_read(u ^ 1, (ks + 1) & 31);  // the last one wraps to k-step 0: valid bytes, never used
-                __builtin_amdgcn_sched_barrier(0);
+                b2_read((u & 1) ^ 1, (ks + 1) & 31);  // the last one wraps to k-step 0: valid bytes, never used
 #pragma unroll
                 for (int rti = 0; rti < RT; ++rti)
 #pragma unroll
                     for (int c2 = 0; c2 < G; ++c2) {
                         acc2[rti][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                            a2[u][0][rti], b2h[u][c2], acc2[rti][c2], 0, 0, 0);
+                            a2[u][0][rti], b2h[u & 1][c2], acc2[rti][c2], 0, 0, 0);
                         acc2[rti][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                            a2[u][0][rti], b2l[u][c2], acc2[rti][c2], 0, 0, 0);
+                            a2[u][0][rti], b2l[u & 1][c2], acc2[rti][c2], 0, 0, 0);
                         if constexpr (NA == 2)
                             acc2[rti][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                                a2[u][1][rti], b2h[u][c2], acc2[rti][c2], 0, 0, 0);
+                                a2[u][1][rti], b2h[u & 1][c2], acc2[rti][c2], 0, 0, 0);
                     }
-                a2_load(u, (ks + 2) & 31);  // refill, wrapping to the next pass's first fragments: no branch
+                a2_load(u, (ks + A2S) & 31);  // refill, wrapping to the next pass's first fragments: no branch
+                // one LDS read / one weight load in the shadow of each MFMA: a wave that has the SIMD to
+                // itself (the other one is in its VALU phase) then keeps the pipe at one MFMA per 32 cycles
+                if constexpr (NA == 1) {
+#pragma unroll
+                    for (int i = 0; i < 2 * G; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                    }
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * RT * G - 2 * G - RT, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+    };
 
-        PSTAMP(7 + 5 * g)
-        // epilogue 2: LN1 fold, bias, SiLU, one-pass LN2 sums, fc3 partial dot products
+    // epilogue 2 of pass g: LN1 fold, bias, SiLU, one-pass LN2 sums, fc3 partial dot products -> set
+    auto ep2 = [&](const int g, f32x16 (&acc2)[RT][G], float* set) {
         float T1[G], T2[G], P0[G], P1[G], m1[G], r1[G];
 #pragma unroll
         for (int c2 = 0; c2 < G; ++c2) {
@@ -597,36 +620,107 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
         for (int c2 = 0; c2 < G; ++c2) {
             const float t1 = xor32(T1[c2]), t2 = xor32(T2[c2]), q0 = xor32(P0[c2]), q1 = xor32(P1[c2]);
             if (hh == 0) {
-                bufT1[w * 64 + 32 * c2 + r] = t1;
-                bufT2[w * 64 + 32 * c2 + r] = t2;
-                bufP0[w * 64 + 32 * c2 + r] = q0;
-                bufP1[w * 64 + 32 * c2 + r] = q1;
+                set[(0 * NWV + w) * 64 + 32 * c2 + r] = t1;
+                set[(1 * NWV + w) * 64 + 32 * c2 + r] = t2;
+                set[(2 * NWV + w) * 64 + 32 * c2 + r] = q0;
+                set[(3 * NWV + w) * 64 + 32 * c2 + r] = q1;
             }
         }
-        PSTAMP(8 + 5 * g)
-        __syncthreads();
-        if (tid < 32 * G) {
-            const int row = m0 + 32 * g * G + tid;
-            if (row < a.B) {
-                float t1 = 0.f, t2 = 0.f, q0 = 0.f, q1 = 0.f;
+    };
+
+    // logits of row (32*G*g + i) from the cross-wave sums of a set:
+    // logits = W3~ . LN2(s2) + b3~ = rstd2 * (W3~.s2 - mean2 * rowsum(W3~)) + b3~
+    auto logits_row = [&](const int g, const int i, const float* set) {
+        const int row = m0 + 32 * g * G + i;
+        if (row < a.B) {
+            float t1 = 0.f, t2 = 0.f, q0 = 0.f, q1 = 0.f;
 #pragma unroll
-                for (int ww = 0; ww < NWV; ++ww) {
-                    t1 += bufT1[ww * 64 + tid];
-                    t2 += bufT2[ww * 64 + tid];
-                    q0 += bufP0[ww * 64 + tid];
-                    q1 += bufP1[ww * 64 + tid];
-                }
-                // logits = W3~ . LN2(s2) + b3~ = rstd2 * (W3~.s2 - mean2 * rowsum(W3~)) + b3~
-                const float mean2 = t1 * (1.0f / kHidden);
-                const float var2 = fmaxf(t2 * (1.0f / kHidden) - mean2 * mean2, 0.f);
-                const float rstd2 = 1.0f / sqrtf(var2 + kLnEps);
-                float2 o;
-                o.x = fmaf(rstd2, q0 - mean2 * L_w3sum[0], L_b3[0]);
-                o.y = fmaf(rstd2, q1 - mean2 * L_w3sum[1], L_b3[1]);
-                *reinterpret_cast<float2*>(a.logits + ((size_t)lrun * a.B + row) * 2) = o;
+            for (int ww = 0; ww < NWV; ++ww) {
+                t1 += set[(0 * NWV + ww) * 64 + i];
+                t2 += set[(1 * NWV + ww) * 64 + i];
+                q0 += set[(2 * NWV + ww) * 64 + i];
+                q1 += set[(3 * NWV + ww) * 64 + i];
             }
+            const float mean2 = t1 * (1.0f / kHidden);
+            const float var2 = fmaxf(t2 * (1.0f / kHidden) - mean2 * mean2, 0.f);
+            const float rstd2 = 1.0f / sqrtf(var2 + kLnEps);
+            float2 o;
+            o.x = fmaf(rstd2, q0 - mean2 * L_w3sum[0], L_b3[0]);
+            o.y = fmaf(rstd2, q1 - mean2 * L_w3sum[1], L_b3[1]);
+            *reinterpret_cast<float2*>(a.logits + ((size_t)lrun * a.B + row) * 2) = o;
         }
-        PSTAMP(9 + 5 * g)
+    };
+
+    if constexpr (NG == 2 && ROWS == 128) {
+        // Two fc2 passes, and the two waves of every SIMD (w and w + NWV/2) take the VALU phase and the
+        // MFMA phase of a pass in opposite orders: while one runs the k loop of pass 0 the other applies
+        // epilogue 1 to the column tiles of pass 1, and epilogue 2 of pass 0 runs beside the k loop of
+        // pass 1.  (In one order for everybody the matrix pipe idles through every epilogue.)
+        f32x16 acc2a[RT][G], acc2b[RT][G];
+        const bool loop_first = w >= NWV / 2;
+        ep1_cols(0, G);
+        PSTAMP(4)
+#pragma unroll
+        for (int u = 0; u < A2S; ++u) {
+            a2_load(u, u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        publish(0);
+        zero2(acc2a);
+        PSTAMP(5)
+        __syncthreads();   // fragments and the LN1 partial sums of pass 0 are in LDS
+        mean_cols(0, G);
+        PSTAMP(6)
+        if (loop_first) {
+            __builtin_amdgcn_s_setprio(2);   // finish the k loop first: the other wave then has the pipe alone
+            fc2_loop(acc2a);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        ep1_cols(G, G);
+        if (!loop_first) fc2_loop(acc2a);
+        PSTAMP(7)
+        __syncthreads();   // every wave is done with the exchange area; LN1 partial sums of pass 1 are in LDS
+        publish(1);
+        zero2(acc2b);
+        __syncthreads();
+        mean_cols(G, G);
+        __syncthreads();   // bufS is dead from here on: its bytes become the second set of cross-wave sums
+        PSTAMP(8)
+        if (!loop_first) {
+            __builtin_amdgcn_s_setprio(2);
+            fc2_loop(acc2b);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        ep2(0, acc2a, setT0);
+        if (loop_first) fc2_loop(acc2b);
+        PSTAMP(9)
+        ep2(1, acc2b, setT1);
+        PSTAMP(10)
+        __syncthreads();
+        if (tid < 64) logits_row(0, tid, setT0);
+        else if (tid < 128) logits_row(1, tid - 64, setT1);
+        PSTAMP(11)
+    } else {
+        ep1_cols(0, CT);
+        PSTAMP(4)
+        a2_load(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        a2_load(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g > 0) __syncthreads();  // previous pass finished reading the exchange area / the sums
+            publish(g);
+            f32x16 acc2[RT][G];
+            zero2(acc2);
+            __syncthreads();  // fragments (and, first time, the LN1 partial sums) of all waves are in LDS
+            if (g == 0) mean_cols(0, CT);
+            fc2_loop(acc2);
+            ep2(g, acc2, setT0);
+            __syncthreads();
+            if (tid < 32 * G) logits_row(g, tid, setT0);
+        }
+        PSTAMP(11)
     }
 }
 

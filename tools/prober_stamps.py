@@ -32,14 +32,17 @@ fn = lib.prag_diag_prober_stamps
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert fn(buf, len(buf)) == 0
 s = np.frombuffer(buf, dtype=np.uint64).astype(np.int64).reshape(3, 8, 32)
-names = ["prologue", "fc1 loop", "stats+sync", "epilogue 1"]
-NG = 2   # fc2 passes of the 128-row tile (two column tiles each)
-for g in range(NG):
-    names += [f"p{g} publish", f"p{g} sync", f"p{g} fc2 loop", f"p{g} epilogue 2", f"p{g} sync+logits"]
+names = ["prologue", "fc1 loop", "stats+sync", "epilogue 1 (cols 0,1)", "publish 0", "sync + LN1 stats",
+         "pass 0: k loop | epilogue 1 (cols 2,3)", "sync, publish 1, sync, stats, sync",
+         "pass 1: k loop | epilogue 2 (pass 0)", "epilogue 2 (pass 1)", "sync + logits"]
+LAST = len(names)
 tick = 0.01   # s_memtime ticks once per shader cycle: phases are printed in units of 100 cycles
 for sel in range(3):
     t0 = s[sel, :, 0].min()
-    print(f"workgroup {sel}: total {(s[sel, :, 4 + 5 * NG].max() - t0) * tick:7.2f} x100 cycles")
+    print(f"workgroup {sel}: total {(s[sel, :, LAST].max() - t0) * tick:7.2f} x100 cycles")
     for i, nm in enumerate(names):
         d = (s[sel, :, i + 1] - s[sel, :, i]) * tick
-        print(f"   {nm:18s} {d.mean():7.2f} c  (waves {d.min():6.2f} .. {d.max():6.2f})   ends at {((s[sel, :, i + 1].max()) - t0) * tick:7.2f}")
+        print(f"   {nm:40s} {d.mean():7.2f} c  (waves {d.min():6.2f} .. {d.max():6.2f})   ends at {((s[sel, :, i + 1].max()) - t0) * tick:7.2f}")
+if os.environ.get("PRAG_STAMPS_PER_WAVE"):
+    for i, nm in enumerate(names):
+        print(f"   {nm:40s} per wave:", " ".join(f"{v * tick:7.1f}" for v in (s[1, :, i + 1] - s[1, :, i])))
