@@ -105,6 +105,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 // raw 16-byte payloads: an ext-vector (HIP's uint4 struct copies defeat SROA -> scratch)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 

@@ -52,6 +52,7 @@ constexpr float kLnEps = 1e-5f;
 struct LayerDev {
     const u32x4* W1f;    // [NA][d/16][16 row tiles][64 lanes] x 16 B
     const u32x4* W2f;    // [NA][32 k steps][16 row tiles][64 lanes] x 16 B
+    const u32x4* W2q;    // fp16-weight mode: fp8 (e4m3) copy for the lo term, [8 k blocks][16 row tiles][2][64 lanes] x 16 B
     const float* wsum1;  // [512] row sums of the packed (scaled) W1
     const float* b1;     // [512] b1 + W1 . ln0_b
     const float* b2;     // [512] b2 + W2 . ln1_b
@@ -148,6 +149,23 @@ constexpr int fc2_group() {
     return (CT >= 2 && !(CT == 4 && NWV == 4)) ? 2 : 1;
 }
 
+// fc2's second activation term (the low 11 bits of the SiLU outputs) in fp8: v_mfma_f32_32x32x64_f8f6f4 does
+// the 512-wide contraction in a quarter of the k-steps at half the rate (64 cycles each), i.e. in half the
+// matrix-pipe time of the fp16 term; |lo| <= 2^-10 |s|, so 3 mantissa bits on it and on its copy of W2 leave
+// ~2^-15 of relative error per product (the hi term is rounded to nearest here, so |lo| <= 2^-12 |s|).
+// fp16-weight mode only; every tile shape uses it, so a row's logits do not depend on the batch it is in.
+// Two row tiles of a wave make exactly one 32-byte operand per lane: k block kb = hidden units 64kb..64kb+63.
+template <int NA, int NWV>
+constexpr bool fc2_lo8() {
+    return NA == 1;
+}
+constexpr int kLoShift = 13;   // lo is scaled by 2^13 before the fp8 conversion (and W2's copy by 2^-13)
+template <int NA, int NWV, int G>
+constexpr int exch_bytes() {
+    return fc2_lo8<NA, NWV>() ? (16 * 2 * G + 8 * G * 2) * 1024     // hi fragments + fp8 lo operands
+                              : 2 * 16 * 2 * G * 1024;            // hi/lo x 16 row tiles x 2 k-steps x G tiles
+}
+
 template <int NA, int NB, int CT, int NWV>
 __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberArgs a) {
     constexpr int NT = 64 * NWV;        // threads
@@ -158,7 +176,9 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     constexpr int ROWS = 32 * CT;
     constexpr int XPART = ROWS * 128;            // bytes of one staged part (64 halves per row)
     constexpr int XSTAGE = NB * XPART;
-    constexpr int EXCH = 2 * 16 * 2 * G * 1024;  // hi/lo x 16 row tiles x 2 k-steps x G tiles
+    constexpr bool LO8 = fc2_lo8<NA, NWV>();
+    static_assert(!LO8 || RT % 2 == 0, "two row tiles per fp8 operand");
+    constexpr int EXCH = exch_bytes<NA, NWV, G>();
     constexpr int REGION_A = (2 * XSTAGE > EXCH) ? 2 * XSTAGE : EXCH;
     constexpr int NPASS = (256 * CT + NT - 1) / NT;  // 16-B pieces per thread per staged part
 
@@ -187,6 +207,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     // the layer record, read once before anything is stored (scalar loads) and pinned to SGPRs
     const __amdgpu_buffer_rsrc_t rs_w1 = make_rsrc(uniform_p(L.W1f), (size_t)NA * a.d * 1024);
     const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(uniform_p(L.W2f), (size_t)NA * 32 * 16 * 1024);
+    const __amdgpu_buffer_rsrc_t rs_w2q = make_rsrc(uniform_p(L.W2q), LO8 ? (size_t)8 * 16 * 2048 : 0);
     const float L_sc1 = uniform_f(L.sc1), L_sc2 = uniform_f(L.sc2);
     const float L_b3[2] = {uniform_f(L.b3[0]), uniform_f(L.b3[1])};
     const float L_w3sum[2] = {uniform_f(L.w3sum[0]), uniform_f(L.w3sum[1])};
@@ -479,6 +500,20 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     // the first k-steps and the next pass starts with them already in registers.
     constexpr int A2S = (NG == 2 && ROWS == 128 && NA == 1) ? 4 : 2;
     half8 a2[A2S][NA][RT];
+    // fp8 copy of this wave's W2 rows for the lo term: two slots of one k block (64 hidden units) each
+    i32x8 q2[2][RT];
+    auto q2_load = [&](int slot, int kb) {
+        if constexpr (LO8) {
+#pragma unroll
+            for (int rti = 0; rti < RT; ++rti) {
+                const unsigned frag = ((unsigned)kb * 16u + w_frag0 + rti) << 11;
+                const u32x4 v0 = buf_load16(rs_w2q, lane16, frag);
+                const u32x4 v1 = buf_load16(rs_w2q, lane16, frag + 1024u);
+                q2[slot][rti] = i32x8{(int)v0[0], (int)v0[1], (int)v0[2], (int)v0[3],
+                                      (int)v1[0], (int)v1[1], (int)v1[2], (int)v1[3]};
+            }
+        }
+    };
     auto a2_load = [&](int slot, int ks) {
 #pragma unroll
         for (int p = 0; p < NA; ++p)
@@ -494,24 +529,52 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
 #pragma unroll
         for (int rti = 0; rti < RT; ++rti)
 #pragma unroll
-            for (int s2i = 0; s2i < 2; ++s2i)
+            for (int c2 = 0; c2 < G; ++c2) {
+                const int c = g * G + c2;
+                u32x4 lo8;   // LO8: this row tile's 16 lo values as fp8, byte e of the lane's operand half rti
 #pragma unroll
-                for (int c2 = 0; c2 < G; ++c2) {
-                    const int c = g * G + c2;
+                for (int s2i = 0; s2i < 2; ++s2i) {
                     u32x4 hi, lo;
+                    float lq[8];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float v0 = acc[rti][c][8 * s2i + 2 * j], v1 = acc[rti][c][8 * s2i + 2 * j + 1];
-                        const auto h01 = __builtin_amdgcn_cvt_pkrtz(v0, v1);
-                        const auto l01 = __builtin_amdgcn_cvt_pkrtz(v0 - (float)h01[0], v1 - (float)h01[1]);
+                        half2_t h01;
+                        if constexpr (LO8) {   // nearest (v_cvt_pk_f16_f32): halves |lo|
+                            typedef float float2_t __attribute__((ext_vector_type(2)));
+                            h01 = __builtin_convertvector(float2_t{v0, v1}, half2_t);
+                        } else {
+                            h01 = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+                        }
                         hi[j] = __builtin_bit_cast(unsigned int, h01);
-                        lo[j] = __builtin_bit_cast(unsigned int, l01);
+                        if constexpr (LO8) {
+                            // (v - hi) * 2^13, clamped to the e4m3 range (an overflow converts to NaN)
+                            const float kS = (float)(1 << kLoShift);
+                            lq[2 * j] = __builtin_amdgcn_fmed3f(fmaf(v0, kS, -kS * (float)h01[0]), -448.f, 448.f);
+                            lq[2 * j + 1] = __builtin_amdgcn_fmed3f(fmaf(v1, kS, -kS * (float)h01[1]), -448.f, 448.f);
+                        } else {
+                            const auto l01 = __builtin_amdgcn_cvt_pkrtz(v0 - (float)h01[0], v1 - (float)h01[1]);
+                            lo[j] = __builtin_bit_cast(unsigned int, l01);
+                        }
+                    }
+                    if constexpr (LO8) {
+#pragma unroll
+                        for (int dd = 0; dd < 2; ++dd) {
+                            int wd = 0;
+                            wd = __builtin_amdgcn_cvt_pk_fp8_f32(lq[4 * dd], lq[4 * dd + 1], wd, false);
+                            wd = __builtin_amdgcn_cvt_pk_fp8_f32(lq[4 * dd + 2], lq[4 * dd + 3], wd, true);
+                            lo8[2 * s2i + dd] = (unsigned)wd;
+                        }
                     }
                     const int fi = (((RT * w + rti) * 2 + s2i) * G + c2) * 64 + lane;
                     *reinterpret_cast<u32x4*>(s_ex + (size_t)fi * 16) = hi;
-                    *reinterpret_cast<u32x4*>(s_ex + (size_t)(16 * 2 * G * 64 + fi) * 16) = lo;
-                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!LO8) *reinterpret_cast<u32x4*>(s_ex + (size_t)(16 * 2 * G * 64 + fi) * 16) = lo;
                 }
+                if constexpr (LO8)   // [k block][c2][half][lane] x 16 B behind the hi fragments
+                    *reinterpret_cast<u32x4*>(s_ex + (size_t)16 * 2 * G * 1024 +
+                                              (size_t)(((((RT / 2) * w + (rti >> 1)) * G + c2) * 2 + (rti & 1)) * 64 + lane) * 16) = lo8;
+                __builtin_amdgcn_sched_barrier(0);
+            }
     };
 
     auto zero2 = [&](f32x16 (&acc2)[RT][G]) {
@@ -525,18 +588,18 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
 
     // the fc2 k loop of one pass; exchange fragments of k-step ks+1 are read while the MFMAs of ks run
     auto fc2_loop = [&](f32x16 (&acc2)[RT][G]) {
-        half8 b2h[2][G], b2l[2][G];
+        half8 b2h[2][G], b2l[LO8 ? 1 : 2][LO8 ? 1 : G];
         auto b2_read = [&](int buf, int ks) {
 #pragma unroll
             for (int c2 = 0; c2 < G; ++c2) {
                 const int fi = (ks * G + c2) * 64 + lane;
                 b2h[buf][c2] = *reinterpret_cast<const half8*>(s_ex + (size_t)fi * 16);
-                b2l[buf][c2] = *reinterpret_cast<const half8*>(s_ex + (size_t)(16 * 2 * G * 64 + fi) * 16);
+                if constexpr (!LO8)
+                    b2l[buf][c2] = *reinterpret_cast<const half8*>(s_ex + (size_t)(16 * 2 * G * 64 + fi) * 16);
             }
         };
         b2_read(0, 0);
-#pragma unroll 1
-        for (int ks2 = 0; ks2 < 32; ks2 += A2S) {
+        auto hi_iter = [&](const int ks2) {
 #pragma unroll
             for (int u = 0; u < A2S; ++u) {
                 const int ks = ks2 + u;
@@ -547,8 +610,9 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                     for (int c2 = 0; c2 < G; ++c2) {
                         acc2[rti][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
                             a2[u][0][rti], b2h[u & 1][c2], acc2[rti][c2], 0, 0, 0);
-                        acc2[rti][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                            a2[u][0][rti], b2l[u & 1][c2], acc2[rti][c2], 0, 0, 0);
+                        if constexpr (!LO8)
+                            acc2[rti][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                a2[u][0][rti], b2l[u & 1][c2], acc2[rti][c2], 0, 0, 0);
                         if constexpr (NA == 2)
                             acc2[rti][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
                                 a2[u][1][rti], b2h[u & 1][c2], acc2[rti][c2], 0, 0, 0);
@@ -557,20 +621,61 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                 // one LDS read / one weight load in the shadow of each MFMA: a wave that has the SIMD to
                 // itself (the other one is in its VALU phase) then keeps the pipe at one MFMA per 32 cycles
                 if constexpr (NA == 1) {
+                    constexpr int n_ds = LO8 ? G : 2 * G, n_mf = LO8 ? RT * G : 2 * RT * G;
+                    constexpr int n_pair = n_ds < n_mf ? n_ds : n_mf;
 #pragma unroll
-                    for (int i = 0; i < 2 * G; ++i) {
+                    for (int i = 0; i < n_pair; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
                     }
+                    constexpr int n_vm = (n_mf - n_pair) < RT ? (n_mf - n_pair) : RT;
 #pragma unroll
-                    for (int i = 0; i < RT; ++i) {
+                    for (int i = 0; i < n_vm; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * RT * G - 2 * G - RT, 0);
+                    if constexpr (n_mf - n_pair - n_vm > 0)
+                        __builtin_amdgcn_sched_group_barrier(0x008, n_mf - n_pair - n_vm, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        if constexpr (LO8) {
+#pragma unroll 1
+            for (int ks2 = 0; ks2 < 32 - A2S; ks2 += A2S) hi_iter(ks2);
+            q2_load(0, 0);   // the lo term's first weight blocks, one iteration before they are used
+            q2_load(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            hi_iter(32 - A2S);
+            // lo term: eight k blocks of 64 hidden units (one per pair of published row tiles), fp8 x fp8
+            const char* s_lo = s_ex + (size_t)16 * 2 * G * 1024;
+            i32x8 bq[2][G];
+            auto bq_read = [&](int buf, int kb) {
+#pragma unroll
+                for (int c2 = 0; c2 < G; ++c2) {
+                    const char* pz = s_lo + (size_t)(((kb * G + c2) * 2) * 64 + lane) * 16;
+                    const u32x4 v0 = *reinterpret_cast<const u32x4*>(pz);
+                    const u32x4 v1 = *reinterpret_cast<const u32x4*>(pz + 1024);
+                    bq[buf][c2] = i32x8{(int)v0[0], (int)v0[1], (int)v0[2], (int)v0[3],
+                                        (int)v1[0], (int)v1[1], (int)v1[2], (int)v1[3]};
+                }
+            };
+            bq_read(0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                if (kb + 1 < 8) bq_read((kb & 1) ^ 1, kb + 1);
+#pragma unroll
+                for (int rti = 0; rti < RT; ++rti)
+#pragma unroll
+                    for (int c2 = 0; c2 < G; ++c2)
+                        acc2[rti][c2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                            q2[kb & 1][rti], bq[kb & 1][c2], acc2[rti][c2], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                if (kb + 2 < 8) q2_load(kb & 1, kb + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll 1
+            for (int ks2 = 0; ks2 < 32; ks2 += A2S) hi_iter(ks2);
         }
     };
 
@@ -959,6 +1064,42 @@ static void pack_fragments(const std::vector<double>& Ws, int K, int n_steps, in
             }
 }
 
+// OCP fp8 e4m3 (no infinities, max 448), round to nearest even, saturating: what v_cvt_pk_fp8_f32 produces
+static unsigned char to_e4m3(double v) {
+    const unsigned char sgn = std::signbit(v) ? 0x80 : 0x00;
+    double a = std::fabs(v);
+    if (!(a == a)) return 0x7f;
+    if (a >= 448.0) return sgn | 0x7e;
+    if (a < std::ldexp(1.0, -6)) return sgn | (unsigned char)std::nearbyint(a * 512.0);   // subnormals: k * 2^-9 (8 = 2^-6)
+    int e;
+    (void)std::frexp(a, &e);
+    int E = e - 1;                                                  // a = 1.xxx * 2^E
+    int q = (int)std::nearbyint(std::ldexp(a, 3 - E)) - 8;          // 3 mantissa bits
+    if (q == 8) {
+        q = 0;
+        ++E;
+    }
+    const int code = ((E + 7) << 3) | q;
+    return sgn | (unsigned char)(code > 0x7e ? 0x7e : code);
+}
+
+// fp8 copy of the (scaled) fc2 matrix for the lo term: [8 k blocks][16 row tiles][2 halves][64 lanes][16 B].
+// Byte j of half `hf` of lane (row r, lane half h) holds hidden unit 32*(2*kb + hf) + 8*(j>>2) + 4*h + (j&3):
+// the order in which a wave's two accumulator tiles sit in its lanes (see `publish`).
+static void pack_w2q(const std::vector<double>& Ws, std::vector<unsigned char>& out) {
+    out.assign((size_t)8 * 16 * 2 * 64 * 16, 0);
+    for (int kb = 0; kb < 8; ++kb)
+        for (int rt = 0; rt < 16; ++rt)
+            for (int hf = 0; hf < 2; ++hf)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 16; ++j) {
+                        const int row = 32 * rt + (lane & 31), h = lane >> 5;
+                        const int col = 32 * (2 * kb + hf) + 8 * (j >> 2) + 4 * h + (j & 3);
+                        out[((((size_t)kb * 16 + rt) * 2 + hf) * 64 + lane) * 16 + j] =
+                            to_e4m3(std::ldexp(Ws[(size_t)row * kHidden + col], -kLoShift));
+                    }
+}
+
 template <typename T>
 static int upload(prag_prober* p, const std::vector<T>& v, const T** out) {
     void* dptr = nullptr;
@@ -1104,6 +1245,14 @@ extern "C" int prag_prober_load_layer(prag_prober_t* p, int li, const float* ln0
     L.W2f = reinterpret_cast<const u32x4*>(dW2);
     if ((rc = upload(p, b2e, &L.b2)) != PRAG_OK) return rc;
     L.sc2 = (float)std::ldexp(1.0, -e2);
+    L.W2q = nullptr;
+    if (p->na == 1) {
+        std::vector<unsigned char> q8;
+        pack_w2q(W2g, q8);
+        const unsigned char* dq = nullptr;
+        if ((rc = upload(p, q8, &dq)) != PRAG_OK) return rc;
+        L.W2q = reinterpret_cast<const u32x4*>(dq);
+    }
 
     // ---- fc3: fp32 VALU, fold ln2 affine --------------------------------------
     std::vector<float> W3e((size_t)kClasses * H);
@@ -1177,7 +1326,7 @@ static int launch_fused(const ProberArgs& a, int n_run, hipStream_t st, EventRin
     constexpr int G = fc2_group<CT, NWV>();
     constexpr int ROWS = 32 * CT;
     constexpr int XSTAGE = NB * ROWS * 128;
-    constexpr int EXCH = 2 * 16 * 2 * G * 1024;
+    constexpr int EXCH = exch_bytes<NA, NWV, G>();
     constexpr int REGION_A = (2 * XSTAGE > EXCH) ? 2 * XSTAGE : EXCH;
     constexpr int LDS = REGION_A + (2 * NWV * ROWS + 4 * NWV * 64 + 2 * ROWS + 6 * kHidden) * (int)sizeof(float);
     static_assert(LDS <= 160 * 1024, "workgroup LDS");
