@@ -26,7 +26,10 @@
 //   * The fc1 accumulator tile has the hidden index in its registers and the batch row on its
 //     lane - exactly the B-operand layout of the next MFMA (k order permuted; W2 is
 //     pre-permuted to match), so SiLU runs lane-locally and fc2's operand crosses waves
-//     through LDS as ready-made 1 KiB fragments (hi + lo fp16 terms: ~22 bits).
+//     through LDS as ready-made fragments: an fp16 hi term plus a lo term (fp16 with fp32-parity
+//     weights; fp8 against an fp8 copy of W2 with fp16 weights - half the matrix-pipe time).
+//   * 128-row tiles run fc2 in two passes; the two waves of a SIMD take the VALU phase (SiLU
+//     epilogues) and the MFMA phase of a pass in opposite orders, so the pipe stays fed.
 //   * fc3 (512->2) partial dot products, the cross-wave reductions and the logits store finish
 //     the launch; a second tiny kernel does softmax / sum over layers / threshold in the
 //     reference's own order (deterministic, no float atomics).
