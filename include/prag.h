@@ -129,14 +129,14 @@ void prag_prober_destroy(prag_prober_t* p);
 /* Replaces `torch.sum(torch.concat(cache[name][1:], dim=1), dim=1)`
  * (exp_rag.py:385-386): acc[l, b, :] (+)= h[l, b, :] for one decode step, on
  * device, so hooks need no D2H copy.
- * acc_dev float32 [L,B,d]; h_dev element type h_dtype, same layout; if
+ * acc_dev float32 [L,B,d]; h_dev element type h_dtype (PRAG_F32 / PRAG_F16 / PRAG_BF16), same layout; if
  * `assign` != 0 the accumulator is overwritten instead of added to. */
 int prag_pool_accumulate(float* acc_dev, const void* h_dev, int h_dtype, int64_t n_elems,
                          int assign, void* stream);
 
 /* Replaces input_tensor_method1 + per-sample mean (train.py:153-162, 202-205;
  * utils.py:134-143, 184-186): out[b,:] = mean over the last pred_lens[b]
- * positions of acts[b] ([B,T,d], element type dtype).  out float32 [B,d];
+ * positions of acts[b] ([B,T,d], element type dtype: PRAG_F32 / PRAG_F16 / PRAG_BF16).  out float32 [B,d];
  * pred_lens_dev int64 [B].  scale_mean=0 gives the inference-time sum pool. */
 int prag_pool_ragged(const void* acts_dev, int dtype, int B, int T, int d,
                      const int64_t* pred_lens_dev, int scale_mean, float* out_dev, void* stream);

@@ -969,9 +969,11 @@ __global__ __launch_bounds__(256) void pool_accumulate_kernel(float* __restrict_
         f32x4 v;
         if constexpr (sizeof(T) == 4) {
             v = *reinterpret_cast<const f32x4*>(h + i);
-        } else {
+        } else if constexpr (std::is_same<T, _Float16>::value) {
             const half4 hv = *reinterpret_cast<const half4*>(h + i);
             v = {(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+        } else {   // bf16 bits
+            v = load4_as_f32(h + i);
         }
         f32x4* dst = reinterpret_cast<f32x4*>(acc + i);
         *dst = assign ? v : (*dst + v);
@@ -994,9 +996,11 @@ __global__ __launch_bounds__(256) void pool_ragged_kernel(const T* __restrict__ 
     for (int64_t t = 0; t < n; ++t) {
         if constexpr (sizeof(T) == 4) {
             s += *reinterpret_cast<const f32x4*>(base + t * d);
-        } else {
+        } else if constexpr (std::is_same<T, _Float16>::value) {
             const half4 hv = *reinterpret_cast<const half4*>(base + t * d);
             s += f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+        } else {   // bf16 bits
+            s += load4_as_f32(base + t * d);
         }
     }
     if (scale_mean && n > 0) s = s / (float)n;
@@ -1528,16 +1532,20 @@ extern "C" int prag_pool_accumulate(float* acc_dev, const void* h_dev, int h_dty
     PRAG_REQUIRE(acc_dev && h_dev, PRAG_EINVAL, "prag_pool_accumulate: NULL device pointer");
     PRAG_REQUIRE(n_elems >= 0 && n_elems % 4 == 0, PRAG_EINVAL, "n_elems=%lld must be a multiple of 4",
                  (long long)n_elems);
-    PRAG_REQUIRE(h_dtype == PRAG_F32 || h_dtype == PRAG_F16, PRAG_EINVAL, "h_dtype=%d", h_dtype);
+    PRAG_REQUIRE(h_dtype == PRAG_F32 || h_dtype == PRAG_F16 || h_dtype == PRAG_BF16, PRAG_EINVAL, "h_dtype=%d",
+                 h_dtype);
     if (n_elems == 0) return PRAG_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int blocks = (int)std::min<int64_t>((n_elems / 4 + 255) / 256, 2048);
     if (h_dtype == PRAG_F32)
         hipLaunchKernelGGL(pool_accumulate_kernel<float>, dim3(blocks), dim3(256), 0, st, acc_dev,
                            reinterpret_cast<const float*>(h_dev), n_elems, assign);
-    else
+    else if (h_dtype == PRAG_F16)
         hipLaunchKernelGGL(pool_accumulate_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, acc_dev,
                            reinterpret_cast<const _Float16*>(h_dev), n_elems, assign);
+    else
+        hipLaunchKernelGGL(pool_accumulate_kernel<unsigned short>, dim3(blocks), dim3(256), 0, st, acc_dev,
+                           reinterpret_cast<const unsigned short*>(h_dev), n_elems, assign);
     PRAG_LAUNCH_CHECK();
     return PRAG_OK;
 }
@@ -1567,15 +1575,19 @@ extern "C" int prag_pool_ragged(const void* acts_dev, int dtype, int B, int T, i
                                 void* stream) {
     PRAG_REQUIRE(acts_dev && pred_lens_dev && out_dev, PRAG_EINVAL, "prag_pool_ragged: NULL device pointer");
     PRAG_REQUIRE(B >= 1 && T >= 1 && d >= 4 && d % 4 == 0, PRAG_EINVAL, "B=%d T=%d d=%d", B, T, d);
-    PRAG_REQUIRE(dtype == PRAG_F32 || dtype == PRAG_F16, PRAG_EINVAL, "dtype=%d", dtype);
+    PRAG_REQUIRE(dtype == PRAG_F32 || dtype == PRAG_F16 || dtype == PRAG_BF16, PRAG_EINVAL, "dtype=%d", dtype);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((d / 4 + 255) / 256, B);
     if (dtype == PRAG_F32)
         hipLaunchKernelGGL(pool_ragged_kernel<float>, grid, dim3(256), 0, st,
                            reinterpret_cast<const float*>(acts_dev), T, d, pred_lens_dev, scale_mean, out_dev);
-    else
+    else if (dtype == PRAG_F16)
         hipLaunchKernelGGL(pool_ragged_kernel<_Float16>, grid, dim3(256), 0, st,
                            reinterpret_cast<const _Float16*>(acts_dev), T, d, pred_lens_dev, scale_mean,
+                           out_dev);
+    else
+        hipLaunchKernelGGL(pool_ragged_kernel<unsigned short>, grid, dim3(256), 0, st,
+                           reinterpret_cast<const unsigned short*>(acts_dev), T, d, pred_lens_dev, scale_mean,
                            out_dev);
     PRAG_LAUNCH_CHECK();
     return PRAG_OK;

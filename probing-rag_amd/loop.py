@@ -43,12 +43,12 @@ class HiddenStatePool:
         if n == 0:
             return              # element 0 = the prompt pass, skipped by cache[name][1:]
         a = activations.detach()
-        if a.dtype not in (torch.float32, torch.float16):
+        if a.dtype not in (torch.float32, torch.float16, torch.bfloat16):
             a = a.float()
         a = a.contiguous()
         Bt, T, d = a.shape
         dst = self.acc[slot]
-        dt = _lib.PRAG_F32 if a.dtype == torch.float32 else _lib.PRAG_F16
+        dt = {torch.float32: _lib.PRAG_F32, torch.float16: _lib.PRAG_F16, torch.bfloat16: _lib.PRAG_BF16}[a.dtype]
         st = _lib.current_stream_ptr(a.device)
         with torch.cuda.device(a.device):
             if T == 1:
@@ -75,14 +75,15 @@ def pool_ragged(acts, pred_lens, mean: bool = True):
     import torch
     _lib.require_gpu()
     acts = acts.contiguous()
-    if acts.dtype not in (torch.float32, torch.float16):
+    if acts.dtype not in (torch.float32, torch.float16, torch.bfloat16):
         acts = acts.float()
     B, T, d = acts.shape
     lens = torch.as_tensor(pred_lens, dtype=torch.int64, device=acts.device).contiguous()
     out = torch.empty((B, d), dtype=torch.float32, device=acts.device)
     with torch.cuda.device(acts.device):
         _lib.check(_lib.lib().prag_pool_ragged(ctypes.c_void_p(acts.data_ptr()),
-                                               _lib.PRAG_F32 if acts.dtype == torch.float32 else _lib.PRAG_F16,
+                                               {torch.float32: _lib.PRAG_F32, torch.float16: _lib.PRAG_F16,
+                                                torch.bfloat16: _lib.PRAG_BF16}[acts.dtype],
                                                B, T, d, ctypes.c_void_p(lens.data_ptr()), 1 if mean else 0,
                                                ctypes.c_void_p(out.data_ptr()), _lib.current_stream_ptr(acts.device)))
     return out

@@ -201,6 +201,31 @@ def test_bf16_activations_and_masked_mean_pool(torch_cuda):
         np.testing.assert_allclose(got, want, atol=tol, rtol=0)
 
 
+def test_bf16_hidden_states_pool_without_a_conversion_pass(torch_cuda):
+    """Gemma's hidden states are bf16: the hook accumulator and the ragged pool read them as they are
+    (bf16 -> f32 is exact, sums are f32 in position order), so the result equals the pool of the
+    same values held in float32."""
+    torch = torch_cuda
+    import probing_rag_amd as pra
+    rng = np.random.default_rng(11)
+    acts = torch.from_numpy(rng.standard_normal((3, 13, 256)).astype(np.float32)).cuda().bfloat16()
+    lens = [13, 4, 1]
+    for mean in (True, False):
+        got = pra.pool_ragged(acts, lens, mean=mean).cpu().numpy()
+        want = pra.pool_ragged(acts.float(), lens, mean=mean).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+    pool16, pool32 = pra.HiddenStatePool(1, 256, batch=3), pra.HiddenStatePool(1, 256, batch=3)
+    pool16.observe(0, acts)            # prompt pass (skipped)
+    pool32.observe(0, acts.float())
+    for t in range(5):
+        step = acts[:, t:t + 1].contiguous()
+        pool16.observe(0, step)
+        pool32.observe(0, step.float())
+    pool16.observe(0, acts)            # a later pass without KV cache: all of its positions
+    pool32.observe(0, acts.float())
+    np.testing.assert_array_equal(pool16.pooled().cpu().numpy(), pool32.pooled().cpu().numpy())
+
+
 def test_method_2_eval_matches_reference_golden(torch_cuda, golden):
     """train.py's evaluation forward (ragged mean pool -> prober -> double-softmax CE -> acc)."""
     torch = torch_cuda
