@@ -579,6 +579,7 @@ struct GatherArgs {
     int* part_id;
     uint32_t* ovf;          // [B] set when a region overflowed (or the id stage did)
     CertArgs cert;          // flag list for the exact fallback
+    int dbg;                // timing experiments only (PRAG_SHADOW_DBG bits 32 / 64 / 128; results are WRONG)
 };
 
 template <bool F32>
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
         s_rc[i] = (int)min(c, (uint32_t)a.cap);
     }
     __syncthreads();
-    for (int base = 0; base < nreg * a.cap; base += 8 * kShThreads) {
+    for (int base = 0; base < ((a.dbg & 128) ? 0 : nreg * a.cap); base += 8 * kShThreads) {
         int2 ev[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {          // all loads of the batch in flight before the first use
@@ -635,9 +636,13 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
         }
     }
     __syncthreads();
-    const int n_ids = min(s_n, kShIds);
+    const int n_ids = (a.dbg & 32) ? 0 : min(s_n, kShIds);
     if (s_over && tid == 0 && atomicExch(a.ovf + b, 1u) == 0u) cert_flag(a.cert, b);   // exact scan recomputes b
     // ---- exact scores, 16 lanes per candidate row -------------------------------------------------
+    // (45 of the kernel's 58 us at the 8-GPU shard size and 64 queries, tools/gather_probe.py: ~600
+    // candidates per slice, one dependent row fetch per step of 32.  The rows in flight per CU are bounded
+    // by registers - 4 workgroups x 32 rows x 1.5 KB now; 2 or 4 rows per lane group cost as many resident
+    // workgroups as they add rows, tried and dropped)
     for (int i0 = 0; i0 < n_ids; i0 += 32) {
         const int ci = i0 + w * 4 + slot;
         const bool have = ci < n_ids;
@@ -695,7 +700,7 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
             if (c > kShCap - 256) sh_cut(tk, a.k);
         }
     }
-    sh_cut(tk, a.k);
+    if (!(a.dbg & 64)) sh_cut(tk, a.k);
     const int64_t o = ((int64_t)b * kShSplit + blockIdx.x) * a.k;
     for (int j = tid; j < a.k; j += kShThreads) {
         const bool ok = j < tk.cnt;
@@ -835,6 +840,7 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         g.part_id = s.part_id;
         g.ovf = s.ovf;
         g.cert = s.cert;
+        g.dbg = a.dbg;
         if (s.store.store_f32)
             hipLaunchKernelGGL(shadow_gather_kernel<true>, dim3(kShSplit, nq), dim3(kShThreads), 0, st, g);
         else
