@@ -89,6 +89,34 @@ def test_reduced_precision_modes_against_oracle_on_same_operands(torch_cuda, gol
     np.testing.assert_allclose(logits, golden[f"{case['name']}/logits"], atol=2e-2, rtol=0)
 
 
+@pytest.mark.parametrize("B", [5, 70, 200, 600])
+def test_fp16_weight_mode_lo_term_under_stress(torch_cuda, B):
+    """The fp16-weight mode carries the low bits of fc2's input as fp8 against an fp8 copy of W2.  Weights
+    with a wide dynamic range (a few rows and columns 100x the rest, many tiny entries), large fc1 outputs
+    (|SiLU| up to ~50: the lo term reaches its clamp region only far beyond that) and every tile shape
+    (B = 5 ... 600 takes the 32-, 64- and 128-row kernels) stay inside the 1e-4 contract against the
+    float64 oracle on the same operands."""
+    torch = torch_cuda
+    import probing_rag_amd as pra
+    d = 1024
+    rng = np.random.default_rng(B)
+    st = cases.synth_state(77, d)
+    w2 = st["fc2.weight"].copy()
+    w2[rng.integers(0, 512, 6)] *= 100.0
+    w2[:, rng.integers(0, 512, 6)] *= 100.0
+    w2[rng.random(w2.shape) < 0.3] *= 1e-3
+    st["fc2.weight"] = w2.astype(np.float32)
+    st["fc1.weight"] = (st["fc1.weight"] * 8.0).astype(np.float32)      # large pre-activations
+    ens = pra.HipProberEnsemble(1, d, 2, weights="f16")
+    ens.load_layer(0, st)
+    x = (rng.standard_normal((1, B, d)) * 3.0).astype(np.float32)
+    xd = torch.from_numpy(x).cuda().half()
+    got = ens.forward(xd).cpu().numpy()
+    want = _oracle_effective(ens, xd.float().cpu().numpy())
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+
+
 def test_state_dict_contract(torch_cuda):
     import probing_rag_amd as pra
     p = pra.HipProber(2048, 2)
