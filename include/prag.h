@@ -47,7 +47,9 @@ extern "C" {
 #define PRAG_BF16 2   /* activations only (hidden states of a bf16 LM); handled like PRAG_F32 */
 
 /* weight precision of a prober handle */
-#define PRAG_W_F16 1   /* weights rounded to 11 significant bits (one fp16 MFMA term)   */
+#define PRAG_W_F16 1   /* weights rounded to 11 significant bits (one fp16 MFMA term); fc2's low
+                        * activation bits meet an fp8 copy of W2: logits within ~2e-5 of float64 on the
+                        * same operands (PRAG_W_F32: ~2e-6)                                             */
 #define PRAG_W_F32 0   /* weights kept to ~22 bits as hi+lo fp16 terms (fp32 parity)    */
 
 /* similarity metrics of the flat index */
