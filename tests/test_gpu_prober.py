@@ -117,6 +117,26 @@ def test_fp16_weight_mode_lo_term_under_stress(torch_cuda, B):
     np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
 
 
+@pytest.mark.parametrize("d", [128, 192, 320, 1600, 2304, 3584, 5120])
+def test_odd_model_widths_all_tile_shapes(torch_cuda, d):
+    """d_model only has to be a multiple of 64: two K steps (128), odd numbers of K steps (192, 320, 1600),
+    Gemma-2 / Qwen / Llama widths - every tile shape (B = 3 ... 300), both weight modes, fp16 and fp32
+    activations, against the float64 oracle on the weights the kernel holds."""
+    torch = torch_cuda
+    import probing_rag_amd as pra
+    rng = np.random.default_rng(d)
+    for weights in ("f16", "f32"):
+        ens = pra.HipProberEnsemble(2, d, 2, weights=weights)
+        for l in range(2):
+            ens.load_layer(l, cases.synth_state(300 + l, d))
+        for B in (3, 40, 130, 300):
+            x = rng.standard_normal((2, B, d)).astype(np.float32)
+            for xd in (torch.from_numpy(x).cuda().half(), torch.from_numpy(x).cuda()):
+                got = ens.forward(xd).cpu().numpy()
+                want = _oracle_effective(ens, xd.float().cpu().numpy())
+                np.testing.assert_allclose(got, want, atol=TOL, rtol=0, err_msg=f"d={d} B={B} w={weights} x={xd.dtype}")
+
+
 def test_state_dict_contract(torch_cuda):
     import probing_rag_amd as pra
     p = pra.HipProber(2048, 2)
