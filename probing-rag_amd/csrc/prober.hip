@@ -377,6 +377,24 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                             afr[sub][1][rti], bfr[cb][0][c], acc[rti][c], 0, 0, 0);
                 }
             a_load(sub, s16n + sub);  // refill this slot for the next K step
+            if constexpr (NA == 1 && NB == 1) {
+                // one fragment read / one weight load in the shadow of each MFMA instead of a block of them
+                // after the MFMAs (tools/micro/fc1_loop.hip: 2781 -> 2653 cycles per K step)
+                constexpr int n_mf = RT * CT, n_ds = CT < n_mf ? CT : n_mf;
+                if (sub < 3) {
+#pragma unroll
+                    for (int i = 0; i < n_ds; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                    }
+                }
+                constexpr int n_vm = (n_mf - n_ds) < RT ? (n_mf - n_ds) : RT;
+#pragma unroll
+                for (int i = 0; i < n_vm; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // VMEM read
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);  // keep sub-steps apart: caps live fragments (no spills)
         }
     }

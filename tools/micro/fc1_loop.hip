@@ -9,6 +9,7 @@
 //   bit 5: global loads addressed as uniform base (SGPR pair) + 32-bit lane offset instead of 64-bit lane pointers
 //   bit 6: global loads as buffer_load_dwordx4 (resource + lane offset VGPR + SGPR offset): no address VALU
 //   bit 7: LayerNorm-0 sums taken from the staging registers instead (16 v_dot2c per K step, no extra LDS read)
+//   bit 8: one LDS read / one weight load placed in the shadow of each MFMA (sched_group_barrier)
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/micro/fc1_loop.hip -o tools/micro/fc1_loop
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -168,6 +169,19 @@ __global__ __launch_bounds__(512, 2) void fc1_loop(const u32x4* __restrict__ W, 
                 for (int c = 0; c < CT; ++c)
                     acc[rti][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[sub][rti], bfr[cb][c], acc[rti][c], 0, 0, 0);
             if constexpr (MODE & 2) a_load(sub, s16n + sub);
+            if constexpr (MODE & 256) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -208,9 +222,9 @@ static void run(const u32x4* W, const _Float16* x, int d, float* out, unsigned l
         if ((double)v > mx) mx = (double)v;
     }
     const int T = d / 64;
-    printf("mode %3d [%s%s%s%s%s%s%s%s] grid %3d: %7.1f us per launch | loop cycles per K step: mean %6.0f max %6.0f (64 MFMAs per SIMD: floor 2048)\n",
+    printf("mode %3d [%s%s%s%s%s%s%s%s%s] grid %3d: %7.1f us per launch | loop cycles per K step: mean %6.0f max %6.0f (64 MFMAs per SIMD: floor 2048)\n",
            MODE, MODE & 1 ? "lds " : "", MODE & 2 ? "wts " : "", MODE & 4 ? "stage " : "", MODE & 8 ? "barrier " : "",
-           MODE & 16 ? "stats " : "", MODE & 32 ? "saddr " : "", MODE & 64 ? "buffer " : "", MODE & 128 ? "stats-from-staging" : "", grid, ms * 1e3 / n, sum / h.size() / T, mx / T);
+           MODE & 16 ? "stats " : "", MODE & 32 ? "saddr " : "", MODE & 64 ? "buffer " : "", MODE & 128 ? "stats-from-staging " : "", MODE & 256 ? "interleaved" : "", grid, ms * 1e3 / n, sum / h.size() / T, mx / T);
 }
 
 int main(int argc, char** argv) {
@@ -245,5 +259,6 @@ int main(int argc, char** argv) {
     run<79>(W, x, d, out, cyc, grid);
     run<95>(W, x, d, out, cyc, grid);
     run<207>(W, x, d, out, cyc, grid);
+    run<463>(W, x, d, out, cyc, grid);
     return 0;
 }
