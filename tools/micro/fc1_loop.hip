@@ -10,6 +10,8 @@
 //   bit 6: global loads as buffer_load_dwordx4 (resource + lane offset VGPR + SGPR offset): no address VALU
 //   bit 7: LayerNorm-0 sums taken from the staging registers instead (16 v_dot2c per K step, no extra LDS read)
 //   bit 8: one LDS read / one weight load placed in the shadow of each MFMA (sched_group_barrier)
+//   bit 9: (with bits 7, 8) no branch around the sums (last K step peeled) and sums / staging stores / staging
+//          loads of a K step placed in the MFMA shadows of its first sub-step
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/micro/fc1_loop.hip -o tools/micro/fc1_loop
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -125,14 +127,19 @@ __global__ __launch_bounds__(512, 2) void fc1_loop(const u32x4* __restrict__ W, 
     b_read(s_x, 1, 1);
     unsigned long long t0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
-    for (int t = 0; t < T; ++t) {
+    auto kstep = [&](const int t, const bool sums) {
         if constexpr (MODE & 8) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
+        const char* xs = s_x + (t & 1) * XSTAGE;
+        const int s16n = 4 * (t + 1 < T ? t + 1 : T - 1);
+        if constexpr (MODE & 512) {
+            if constexpr (MODE & 1) b_read(xs, 0, 0);
+        }
         if constexpr (MODE & 4) {
             if constexpr (MODE & 128) {
-                if (t + 1 < T) {
+                if ((MODE & 512) ? sums : (t + 1 < T)) {
 #pragma unroll
                     for (int c = 0; c < NPASS; ++c)
 #pragma unroll
@@ -147,9 +154,9 @@ __global__ __launch_bounds__(512, 2) void fc1_loop(const u32x4* __restrict__ W, 
             x_store((t + 1) & 1);
             x_load(t + 2 < T ? t + 2 : T - 1);
         }
-        const char* xs = s_x + (t & 1) * XSTAGE;
-        const int s16n = 4 * (t + 1 < T ? t + 1 : T - 1);
-        if constexpr (MODE & 1) b_read(xs, 0, 0);
+        if constexpr (!(MODE & 512)) {
+            if constexpr (MODE & 1) b_read(xs, 0, 0);
+        }
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
             const int cb = sub & 1;
@@ -170,20 +177,50 @@ __global__ __launch_bounds__(512, 2) void fc1_loop(const u32x4* __restrict__ W, 
                     acc[rti][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[sub][rti], bfr[cb][c], acc[rti][c], 0, 0, 0);
             if constexpr (MODE & 2) a_load(sub, s16n + sub);
             if constexpr (MODE & 256) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                if ((MODE & 512) && sub == 0) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // first fragment of this sub-step
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    if (sums) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    for (int i = 0; i < 3; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (sums) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // staging store
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // staging load + weight refill
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    if constexpr (MODE & 512) {
+        for (int t = 0; t < T - 1; ++t) kstep(t, true);
+        kstep(T - 1, false);
+    } else {
+        for (int t = 0; t < T; ++t) kstep(t, false);
     }
     unsigned long long t1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
@@ -222,9 +259,9 @@ static void run(const u32x4* W, const _Float16* x, int d, float* out, unsigned l
         if ((double)v > mx) mx = (double)v;
     }
     const int T = d / 64;
-    printf("mode %3d [%s%s%s%s%s%s%s%s%s] grid %3d: %7.1f us per launch | loop cycles per K step: mean %6.0f max %6.0f (64 MFMAs per SIMD: floor 2048)\n",
+    printf("mode %3d [%s%s%s%s%s%s%s%s%s%s] grid %3d: %7.1f us per launch | loop cycles per K step: mean %6.0f max %6.0f (64 MFMAs per SIMD: floor 2048)\n",
            MODE, MODE & 1 ? "lds " : "", MODE & 2 ? "wts " : "", MODE & 4 ? "stage " : "", MODE & 8 ? "barrier " : "",
-           MODE & 16 ? "stats " : "", MODE & 32 ? "saddr " : "", MODE & 64 ? "buffer " : "", MODE & 128 ? "stats-from-staging " : "", MODE & 256 ? "interleaved" : "", grid, ms * 1e3 / n, sum / h.size() / T, mx / T);
+           MODE & 16 ? "stats " : "", MODE & 32 ? "saddr " : "", MODE & 64 ? "buffer " : "", MODE & 128 ? "stats-from-staging " : "", MODE & 256 ? "interleaved " : "", MODE & 512 ? "sums+staging in sub-step 0" : "", grid, ms * 1e3 / n, sum / h.size() / T, mx / T);
 }
 
 int main(int argc, char** argv) {
@@ -260,5 +297,6 @@ int main(int argc, char** argv) {
     run<95>(W, x, d, out, cyc, grid);
     run<207>(W, x, d, out, cyc, grid);
     run<463>(W, x, d, out, cyc, grid);
+    run<975>(W, x, d, out, cyc, grid);
     return 0;
 }
