@@ -71,6 +71,34 @@ __global__ __launch_bounds__(256) void k_rate(float* out, unsigned long long* cy
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+__global__ void k_cvt(const float* in, unsigned char* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * i + 1 < n) {
+        const int w = __builtin_amdgcn_cvt_pk_fp8_f32(in[2 * i], in[2 * i + 1], 0, false);
+        out[2 * i] = (unsigned char)(w & 0xff);
+        out[2 * i + 1] = (unsigned char)((w >> 8) & 0xff);
+    }
+}
+
+// the host-side conversion libprag uses for the fp8 copy of W2 (prober.hip: to_e4m3)
+static unsigned char to_e4m3(double v) {
+    const unsigned char sgn = std::signbit(v) ? 0x80 : 0x00;
+    double a = std::fabs(v);
+    if (!(a == a)) return 0x7f;
+    if (a >= 448.0) return sgn | 0x7e;
+    if (a < std::ldexp(1.0, -6)) return sgn | (unsigned char)std::nearbyint(a * 512.0);
+    int e;
+    (void)std::frexp(a, &e);
+    int E = e - 1;
+    int q = (int)std::nearbyint(std::ldexp(a, 3 - E)) - 8;
+    if (q == 8) {
+        q = 0;
+        ++E;
+    }
+    const int code = ((E + 7) << 3) | q;
+    return sgn | (unsigned char)(code > 0x7e ? 0x7e : code);
+}
+
 static float fp8_exact(int i) {  // values exactly representable in e4m3
     static const float tab[] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, -0.5f, -1.f, -2.f, 0.25f, -0.25f, 4.f, -3.f, 0.75f, -1.5f, 6.f};
     return tab[i & 15];
@@ -99,6 +127,37 @@ int main() {
             if (std::fabs(C16[lane * 16 + e] - ref) > 1e-3) ++bad16;
         }
     printf("fp8 32x32x64: %d of 1024 outputs differ from the host sum; f16 x4: %d differ\n", bad8, bad16);
+    {   // (4) v_cvt_pk_fp8_f32 against the host conversion, on magnitudes from the subnormals to the clamp
+        const int n = 1 << 16;
+        std::vector<float> h(n);
+        for (int i = 0; i < n; ++i) {
+            const double mag = std::ldexp(1.0 + (rand() % 4096) / 4096.0, (rand() % 22) - 12);   // 2^-12 .. 2^10
+            h[i] = (float)((rand() & 1) ? mag : -mag);
+        }
+        h[0] = 0.f; h[1] = 448.f; h[2] = 447.9f; h[3] = 464.f; h[4] = 1e-9f; h[5] = -0.f;
+        float* di; unsigned char* dq;
+        hipMalloc(&di, n * 4); hipMalloc(&dq, n);
+        hipMemcpy(di, h.data(), n * 4, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_cvt, dim3(n / 2 / 256), dim3(256), 0, 0, di, dq, n);
+        std::vector<unsigned char> q(n);
+        hipMemcpy(q.data(), dq, n, hipMemcpyDeviceToHost);
+        int bad = 0, shown = 0, over = 0, over_nan = 0;
+        for (int i = 0; i < n; ++i) {
+            const unsigned char w = to_e4m3((double)h[i]);
+            if (std::fabs(h[i]) >= 464.f) {      // beyond the largest value that rounds to 448: the device gives NaN
+                ++over;
+                over_nan += (q[i] & 0x7f) == 0x7f;
+                continue;
+            }
+            const bool same = w == q[i] || ((w & 0x7f) == 0 && (q[i] & 0x7f) == 0);   // +-0
+            if (!same) {
+                ++bad;
+                if (shown++ < 8) printf("   %g: device 0x%02x host 0x%02x\n", h[i], q[i], w);
+            }
+        }
+        printf("v_cvt_pk_fp8_f32 vs host to_e4m3: %d of %d in-range values differ; %d of %d out-of-range values convert to NaN "
+               "on the device (the kernel clamps first, the host saturates)\n", bad, n - over, over_nan, over);
+    }
     float* out;
     unsigned long long* cyc;
     hipMalloc(&out, 256 * 256 * 4);
