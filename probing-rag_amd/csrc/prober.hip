@@ -119,6 +119,10 @@ __device__ __forceinline__ gptr_f32 as_global(const float* p) { return (gptr_f32
 
 __device__ __forceinline__ float xor32(float v) { return v + __shfl_xor(v, 32, 64); }
 
+// 1/sqrt(v) for the LayerNorm scales inside the fused kernel: v_rsq_f32 (1 ulp) instead of the IEEE
+// sqrt + division sequence (~35 dependent VALU each, on the critical path between the fc2 phases)
+__device__ __forceinline__ float rsqrt_fast(float v) { return __builtin_amdgcn_rsqf(v); }
+
 // Streams with a uniform base go through buffer loads: resource in SGPRs, one loop-invariant 32-bit lane
 // offset in a VGPR, the moving part of the address in an SGPR.  (global_load with 64-bit lane pointers
 // needs a v_lshl_add_u64 per load and moves 512 B of addresses per instruction: in the fc1 loop that alone
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
             if ((tid & 7) == 0) {
                 const int row = (tid + c * NT) >> 3;
                 s_mu0[row] = mean;
-                s_rs0[row] = 1.0f / sqrtf(var + kLnEps);
+                s_rs0[row] = rsqrt_fast(var + kLnEps);
             }
         }
     }
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
                 }
                 mean1[c] = t1 * (1.0f / kHidden);
                 const float var = fmaxf(t2 * (1.0f / kHidden) - mean1[c] * mean1[c], 0.f);
-                rstd1[c] = 1.0f / sqrtf(var + kLnEps);
+                rstd1[c] = rsqrt_fast(var + kLnEps);
                 // one column tile's 2*NWV reads at a time (hoisted together they went to scratch)
                 asm volatile("" : "+v"(mean1[c]), "+v"(rstd1[c]));
                 __builtin_amdgcn_sched_barrier(0);
@@ -769,7 +773,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
             }
             const float mean2 = t1 * (1.0f / kHidden);
             const float var2 = fmaxf(t2 * (1.0f / kHidden) - mean2 * mean2, 0.f);
-            const float rstd2 = 1.0f / sqrtf(var2 + kLnEps);
+            const float rstd2 = rsqrt_fast(var2 + kLnEps);
             float2 o;
             o.x = fmaf(rstd2, q0 - mean2 * L_w3sum[0], L_b3[0]);
             o.y = fmaf(rstd2, q1 - mean2 * L_w3sum[1], L_b3[1]);
