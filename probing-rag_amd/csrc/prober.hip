@@ -226,14 +226,33 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     PSTAMP(0)
 #endif
 
-    // epilogue constants -> LDS once, so no epilogue ever waits on a global load
-    for (int i = tid; i < 6 * kHidden / 4; i += NT) {
-        const int arr = i / (kHidden / 4), o = (i % (kHidden / 4)) * 4;
-        const gptr_f32 src = as_global(arr == 0 ? L.wsum1 : arr == 1 ? L.b1 : arr == 2 ? L.b2
-                                       : arr == 5 ? L.w2sum : (L.W3 + (arr - 3) * kHidden));
-        typedef const __attribute__((address_space(1))) f32x4* gptr_f32x4;
-        *reinterpret_cast<f32x4*>(s_cst + arr * kHidden + o) = *(gptr_f32x4)(src + o);
-    }
+    // epilogue constants -> LDS once, so no epilogue ever waits on a global load.  The loads are issued
+    // right behind the first activation tile's and stored after the weight prologue (their latency used to
+    // sit in front of the first tile's: two dependent memory round trips before the first MFMA).
+    constexpr int NCST = (6 * kHidden / 4 + NT - 1) / NT;
+    f32x4 cst_v[NCST];
+    auto cst_load = [&]() {
+#pragma unroll
+        for (int u = 0; u < NCST; ++u) {
+            const int i = tid + u * NT;
+            const int ic = i < 6 * kHidden / 4 ? i : 6 * kHidden / 4 - 1;
+            const int arr = ic / (kHidden / 4), o = (ic % (kHidden / 4)) * 4;
+            const gptr_f32 src = as_global(arr == 0 ? L.wsum1 : arr == 1 ? L.b1 : arr == 2 ? L.b2
+                                           : arr == 5 ? L.w2sum : (L.W3 + (arr - 3) * kHidden));
+            typedef const __attribute__((address_space(1))) f32x4* gptr_f32x4;
+            cst_v[u] = *(gptr_f32x4)(src + o);
+        }
+    };
+    auto cst_store = [&]() {
+#pragma unroll
+        for (int u = 0; u < NCST; ++u) {
+            const int i = tid + u * NT;
+            if (i < 6 * kHidden / 4) {
+                const int arr = i / (kHidden / 4), o = (i % (kHidden / 4)) * 4;
+                *reinterpret_cast<f32x4*>(s_cst + arr * kHidden + o) = cst_v[u];
+            }
+        }
+    };
 
     // ---- activation staging: thread -> 16-B piece(s) of the [ROWS x 64] tile ----
     // (threads beyond the tile duplicate an in-range piece: no divergent loads)
@@ -326,6 +345,9 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     // (issue order mirrors the loop body - activations first, then the four weight
     // slots - so the counted vmcnt waits at the loop head hold on entry too)
     x_load(0);
+    __builtin_amdgcn_sched_barrier(0);
+    cst_load();
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (RAW) x_stats();
     x_store(0);
     x_load(1);
@@ -334,6 +356,8 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
         __builtin_amdgcn_sched_barrier(0);  // pin the issue order (see above)
         a_load(s, s);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    cst_store();
     __builtin_amdgcn_sched_barrier(0);
     PSTAMP(1)
 
