@@ -13,7 +13,7 @@
 //     v_mfma_f32_32x32x16_f16: the weight rows sit on the MFMA A operand, the batch rows on
 //     the B operand, so every wave owns 512/NWV hidden units for all of the tile's rows.
 //   * Weights are pre-packed at load time in MFMA-fragment-major order (one fully coalesced
-//     1 KiB global_load_dwordx4 per fragment per wave, straight to VGPRs - a wave's weight rows
+//     1 KiB buffer_load_dwordx4 per fragment per wave, straight to VGPRs - a wave's weight rows
 //     are not shared with the other waves, so an LDS round trip would be pure overhead).
 //     LayerNorm affines are folded into the following Linear at load time.
 //   * Activations (shared by all waves) are staged through LDS in full 128-B lines with an
@@ -21,7 +21,7 @@
 //     one raw s_barrier per 64-wide K step, fragments of the next sub-step prefetched.
 //   * No LayerNorm is applied element-wise.  fp16 activations are fed to the MFMA *raw*
 //     (exact) and LN0 becomes  rstd*(W~x - mu*rowsum(W~)) + b~  in the epilogue, with
-//     sum x / sum x^2 from v_dot2_f32_f16 on the staged fragments; LN1 and LN2 are folded the
+//     sum x / sum x^2 from v_dot2_f32_f16 on the staging registers; LN1 and LN2 are folded the
 //     same way into the fc2 / fc3 epilogues from one-pass sums of the SiLU outputs.
 //   * The fc1 accumulator tile has the hidden index in its registers and the batch row on its
 //     lane - exactly the B-operand layout of the next MFMA (k order permuted; W2 is
