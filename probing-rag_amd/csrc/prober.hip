@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     constexpr bool LO8 = fc2_lo8<NA, NWV>();
     static_assert(!LO8 || RT % 2 == 0, "two row tiles per fp8 operand");
     constexpr int EXCH = exch_bytes<NA, NWV, G>();
-    constexpr int REGION_A = (2 * XSTAGE > EXCH) ? 2 * XSTAGE : EXCH;
+    constexpr int REGION_A = (4 * XSTAGE > EXCH) ? 4 * XSTAGE : EXCH;   // four-stage activation ring | exchange area
     constexpr int NPASS = (256 * CT + NT - 1) / NT;  // 16-B pieces per thread per staged part
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -344,6 +344,10 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     // ---- prologue ---------------------------------------------------------------
     // (issue order mirrors the loop body - activations first, then the four weight
     // slots - so the counted vmcnt waits at the loop head hold on entry too)
+    // Activation tiles live in a four-stage ring and are stored TWO K steps before they are read, so one
+    // barrier per two K steps orders everything: tile t (stage t & 3) is written during K step t-2, the
+    // barrier in front of every even K step publishes the two tiles of the coming pair, and the stage a K
+    // step overwrites was last read two K steps - at least one barrier - earlier.
     x_load(0);
     __builtin_amdgcn_sched_barrier(0);
     cst_load();
@@ -351,6 +355,10 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     if constexpr (RAW) x_stats();
     x_store(0);
     x_load(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (RAW) x_stats();   // T >= 2
+    x_store(1);
+    x_load(2 < T ? 2 : T - 1);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         __builtin_amdgcn_sched_barrier(0);  // pin the issue order (see above)
@@ -361,18 +369,20 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     __builtin_amdgcn_sched_barrier(0);
     PSTAMP(1)
 
-    // ---- fc1 main loop: one barrier per 64-wide K step, no other control flow -----
+    // ---- fc1 main loop: one barrier per two 64-wide K steps ------------------------
     for (int t = 0; t < T; ++t) {
-        // LDS-only hand-off: drain this wave's LDS ops and meet at a raw barrier.
-        // (__syncthreads() also carries a fence that makes hipcc drain vmcnt to 0,
-        // which would serialise the weight prefetch every K step.)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if ((t & 1) == 0) {
+            // LDS-only hand-off: drain this wave's LDS ops and meet at a raw barrier.
+            // (__syncthreads() also carries a fence that makes hipcc drain vmcnt to 0,
+            // which would serialise the weight prefetch.)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         if constexpr (RAW)
-            if (t + 1 < T) x_stats();          // tile t+1; the tail's re-read of the last tile does not count
-        x_store((t + 1) & 1);                  // tile t+1 (loaded one step ago)
-        x_load(t + 2 < T ? t + 2 : T - 1);     // clamped: the tail re-reads the last tile
-        const char* xs = s_x + (t & 1) * XSTAGE;
+            if (t + 2 < T) x_stats();          // tile t+2; the tail's re-reads of the last tile do not count
+        x_store((t + 2) & 3);                  // tile t+2 (loaded one step ago)
+        x_load(t + 3 < T ? t + 3 : T - 1);     // clamped: the tail re-reads the last tile
+        const char* xs = s_x + (t & 3) * XSTAGE;
         const int s16n = 4 * (t + 1 < T ? t + 1 : T - 1);
         // B fragments of sub-step s+1 are read while the MFMAs of sub-step s run: only the first read
         // of a K step is exposed
@@ -1380,7 +1390,7 @@ static int launch_fused(const ProberArgs& a, int n_run, hipStream_t st, EventRin
     constexpr int ROWS = 32 * CT;
     constexpr int XSTAGE = NB * ROWS * 128;
     constexpr int EXCH = exch_bytes<NA, NWV, G>();
-    constexpr int REGION_A = (2 * XSTAGE > EXCH) ? 2 * XSTAGE : EXCH;
+    constexpr int REGION_A = (4 * XSTAGE > EXCH) ? 4 * XSTAGE : EXCH;
     constexpr int LDS = REGION_A + (2 * NWV * ROWS + 4 * NWV * 64 + 2 * ROWS + 6 * kHidden) * (int)sizeof(float);
     static_assert(LDS <= 160 * 1024, "workgroup LDS");
     auto kern = prober_fused_kernel<NA, NB, CT, NWV>;

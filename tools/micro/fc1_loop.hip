@@ -12,6 +12,7 @@
 //   bit 8: one LDS read / one weight load placed in the shadow of each MFMA (sched_group_barrier)
 //   bit 9: (with bits 7, 8) no branch around the sums (last K step peeled) and sums / staging stores / staging
 //          loads of a K step placed in the MFMA shadows of its first sub-step
+//   bit 10: four-stage activation ring, staged two K steps ahead, ONE barrier per TWO K steps
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/micro/fc1_loop.hip -o tools/micro/fc1_loop
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -106,6 +107,8 @@ __global__ __launch_bounds__(512, 2) void fc1_loop(const u32x4* __restrict__ W, 
     x_load(0);
     x_store(0);
     x_store(1);
+    x_store(2);
+    x_store(3);
     x_load(1);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -129,10 +132,12 @@ __global__ __launch_bounds__(512, 2) void fc1_loop(const u32x4* __restrict__ W, 
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     auto kstep = [&](const int t, const bool sums) {
         if constexpr (MODE & 8) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (!(MODE & 1024) || (t & 1) == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
         }
-        const char* xs = s_x + (t & 1) * XSTAGE;
+        const char* xs = s_x + ((MODE & 1024) ? (t & 3) : (t & 1)) * XSTAGE;
         const int s16n = 4 * (t + 1 < T ? t + 1 : T - 1);
         if constexpr (MODE & 512) {
             if constexpr (MODE & 1) b_read(xs, 0, 0);
@@ -151,8 +156,8 @@ __global__ __launch_bounds__(512, 2) void fc1_loop(const u32x4* __restrict__ W, 
                         }
                 }
             }
-            x_store((t + 1) & 1);
-            x_load(t + 2 < T ? t + 2 : T - 1);
+            x_store((MODE & 1024) ? ((t + 2) & 3) : ((t + 1) & 1));
+            x_load(t + 3 < T ? t + 3 : T - 1);
         }
         if constexpr (!(MODE & 512)) {
             if constexpr (MODE & 1) b_read(xs, 0, 0);
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void fc1_loop(const u32x4* __restrict__ W, 
 
 template <int MODE>
 static void run(const u32x4* W, const _Float16* x, int d, float* out, unsigned long long* cyc, int grid) {
-    const int lds = 2 * XSTAGE;
+    const int lds = 4 * XSTAGE;
     hipFuncSetAttribute((const void*)fc1_loop<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t a, b;
     hipEventCreate(&a);
@@ -259,9 +264,9 @@ static void run(const u32x4* W, const _Float16* x, int d, float* out, unsigned l
         if ((double)v > mx) mx = (double)v;
     }
     const int T = d / 64;
-    printf("mode %3d [%s%s%s%s%s%s%s%s%s%s] grid %3d: %7.1f us per launch | loop cycles per K step: mean %6.0f max %6.0f (64 MFMAs per SIMD: floor 2048)\n",
+    printf("mode %4d [%s%s%s%s%s%s%s%s%s%s%s] grid %3d: %7.1f us per launch | loop cycles per K step: mean %6.0f max %6.0f (64 MFMAs per SIMD: floor 2048)\n",
            MODE, MODE & 1 ? "lds " : "", MODE & 2 ? "wts " : "", MODE & 4 ? "stage " : "", MODE & 8 ? "barrier " : "",
-           MODE & 16 ? "stats " : "", MODE & 32 ? "saddr " : "", MODE & 64 ? "buffer " : "", MODE & 128 ? "stats-from-staging " : "", MODE & 256 ? "interleaved " : "", MODE & 512 ? "sums+staging in sub-step 0" : "", grid, ms * 1e3 / n, sum / h.size() / T, mx / T);
+           MODE & 16 ? "stats " : "", MODE & 32 ? "saddr " : "", MODE & 64 ? "buffer " : "", MODE & 128 ? "stats-from-staging " : "", MODE & 256 ? "interleaved " : "", MODE & 512 ? "sums+staging in sub-step 0 " : "", MODE & 1024 ? "4-stage ring, barrier every 2nd K step" : "", grid, ms * 1e3 / n, sum / h.size() / T, mx / T);
 }
 
 int main(int argc, char** argv) {
@@ -298,5 +303,6 @@ int main(int argc, char** argv) {
     run<207>(W, x, d, out, cyc, grid);
     run<463>(W, x, d, out, cyc, grid);
     run<975>(W, x, d, out, cyc, grid);
+    run<1487>(W, x, d, out, cyc, grid);
     return 0;
 }
