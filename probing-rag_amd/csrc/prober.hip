@@ -166,6 +166,9 @@ template <int NA, int NWV>
 constexpr bool fc2_lo8() {
     return NA == 1;
 }
+// fc1's activation ring: tile t sits in stage t % kRing and is written kAhead K steps before it is read, so
+// one barrier per kAhead K steps orders everything (see the prologue of the kernel)
+constexpr int kRing = 4, kAhead = kRing / 2;
 constexpr int kLoShift = 13;   // lo is scaled by 2^13 before the fp8 conversion (and W2's copy by 2^-13)
 template <int NA, int NWV, int G>
 constexpr int exch_bytes() {
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     constexpr bool LO8 = fc2_lo8<NA, NWV>();
     static_assert(!LO8 || RT % 2 == 0, "two row tiles per fp8 operand");
     constexpr int EXCH = exch_bytes<NA, NWV, G>();
-    constexpr int REGION_A = (4 * XSTAGE > EXCH) ? 4 * XSTAGE : EXCH;   // four-stage activation ring | exchange area
+    constexpr int REGION_A = (kRing * XSTAGE > EXCH) ? kRing * XSTAGE : EXCH;   // activation ring | exchange area
     constexpr int NPASS = (256 * CT + NT - 1) / NT;  // 16-B pieces per thread per staged part
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -284,19 +287,21 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
     }
 
     u32x4 xreg[NB][NPASS];
-    auto x_load = [&](int t) {
+    auto x_load_r = [&](u32x4 (&xr)[NB][NPASS], int t) {
 #pragma unroll
         for (int p = 0; p < NB; ++p)
 #pragma unroll
-            for (int c = 0; c < NPASS; ++c) xreg[p][c] = buf_load16(rs_x[p], x_off[c], (unsigned)t * 128u);
+            for (int c = 0; c < NPASS; ++c) xr[p][c] = buf_load16(rs_x[p], x_off[c], (unsigned)t * 128u);
     };
-    auto x_store = [&](int stage) {
+    auto x_store_r = [&](u32x4 (&xr)[NB][NPASS], int stage) {
 #pragma unroll
         for (int p = 0; p < NB; ++p)
 #pragma unroll
             for (int c = 0; c < NPASS; ++c)
-                *reinterpret_cast<u32x4*>(s_x + stage * XSTAGE + p * XPART + st_off[c]) = xreg[p][c];
+                *reinterpret_cast<u32x4*>(s_x + stage * XSTAGE + p * XPART + st_off[c]) = xr[p][c];
     };
+    auto x_load = [&](int t) { x_load_r(xreg, t); };
+    auto x_store = [&](int stage) { x_store_r(xreg, stage); };
 
     // ---- weight fragments: straight from global, 1 KiB per wave-load --------------
     const unsigned lane16 = lane * 16;
@@ -327,51 +332,58 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
 #pragma unroll
     for (int c = 0; c < NPASS; ++c) st_s[c] = st_q2[c] = 0.f;
     const half2_t kOnes2 = {(_Float16)1.f, (_Float16)1.f};
-    auto x_stats = [&]() {
+    auto x_stats_r = [&](u32x4 (&xr)[NB][NPASS]) {
         // LayerNorm-0 sums with v_dot2_f32_f16: products of halves are exact in f32,
         // accumulation is f32 (error ~1e-6 * (1 + mean^2/var) on the variance)
 #pragma unroll
         for (int c = 0; c < NPASS; ++c)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const unsigned int u = xreg[0][c][j];   // (bit_cast of the element lvalue itself reads element 0)
+                const unsigned int u = xr[0][c][j];   // (bit_cast of the element lvalue itself reads element 0)
                 const half2_t xv = __builtin_bit_cast(half2_t, u);
                 st_s[c] = __builtin_amdgcn_fdot2(xv, kOnes2, st_s[c], false);
                 st_q2[c] = __builtin_amdgcn_fdot2(xv, xv, st_q2[c], false);
             }
     };
+    auto x_stats = [&]() { x_stats_r(xreg); };
 
     // ---- prologue ---------------------------------------------------------------
     // (issue order mirrors the loop body - activations first, then the four weight
     // slots - so the counted vmcnt waits at the loop head hold on entry too)
-    // Activation tiles live in a four-stage ring and are stored TWO K steps before they are read, so one
-    // barrier per two K steps orders everything: tile t (stage t & 3) is written during K step t-2, the
-    // barrier in front of every even K step publishes the two tiles of the coming pair, and the stage a K
-    // step overwrites was last read two K steps - at least one barrier - earlier.
-    x_load(0);
-    __builtin_amdgcn_sched_barrier(0);
-    cst_load();
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (RAW) x_stats();
-    x_store(0);
-    x_load(1);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (RAW) x_stats();   // T >= 2
-    x_store(1);
-    x_load(2 < T ? 2 : T - 1);
+    // Activation tiles live in a kRing-stage ring and are stored kAhead K steps before they are read, so one
+    // barrier per kAhead K steps orders everything: tile t (stage t % kRing) is written during K step
+    // t - kAhead, the barrier in front of every kAhead-th K step publishes the tiles of the coming group, and
+    // the stage a K step overwrites was last read kAhead K steps - at least one barrier - earlier.
+    {
+        // every load of the prologue is issued before the first one is waited for: the first kAhead tiles,
+        // the epilogue constants, tile kAhead (the loop's staging registers) and the four weight slots
+        u32x4 xpro[kAhead][NB][NPASS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        __builtin_amdgcn_sched_barrier(0);  // pin the issue order (see above)
-        a_load(s, s);
+        for (int i = 0; i < kAhead; ++i) x_load_r(xpro[i], i < T ? i : T - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        cst_load();
+        __builtin_amdgcn_sched_barrier(0);
+        x_load(kAhead < T ? kAhead : T - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            __builtin_amdgcn_sched_barrier(0);  // pin the issue order (see above)
+            a_load(s, s);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) {
+            if constexpr (RAW)
+                if (i < T) x_stats_r(xpro[i]);
+            x_store_r(xpro[i], i);
+        }
+        cst_store();
+        __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    cst_store();
-    __builtin_amdgcn_sched_barrier(0);
     PSTAMP(1)
 
-    // ---- fc1 main loop: one barrier per two 64-wide K steps ------------------------
+    // ---- fc1 main loop: one barrier per kAhead 64-wide K steps ---------------------
     for (int t = 0; t < T; ++t) {
-        if ((t & 1) == 0) {
+        if ((t & (kAhead - 1)) == 0) {
             // LDS-only hand-off: drain this wave's LDS ops and meet at a raw barrier.
             // (__syncthreads() also carries a fence that makes hipcc drain vmcnt to 0,
             // which would serialise the weight prefetch.)
@@ -379,10 +391,10 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
             __builtin_amdgcn_s_barrier();
         }
         if constexpr (RAW)
-            if (t + 2 < T) x_stats();          // tile t+2; the tail's re-reads of the last tile do not count
-        x_store((t + 2) & 3);                  // tile t+2 (loaded one step ago)
-        x_load(t + 3 < T ? t + 3 : T - 1);     // clamped: the tail re-reads the last tile
-        const char* xs = s_x + (t & 3) * XSTAGE;
+            if (t + kAhead < T) x_stats();                 // tile t+kAhead; the tail's re-reads do not count
+        x_store((t + kAhead) & (kRing - 1));           // tile t+kAhead (loaded one step ago)
+        x_load(t + kAhead + 1 < T ? t + kAhead + 1 : T - 1);   // clamped: the tail re-reads the last tile
+        const char* xs = s_x + (t & (kRing - 1)) * XSTAGE;
         const int s16n = 4 * (t + 1 < T ? t + 1 : T - 1);
         // B fragments of sub-step s+1 are read while the MFMAs of sub-step s run: only the first read
         // of a K step is exposed
@@ -1390,7 +1402,7 @@ static int launch_fused(const ProberArgs& a, int n_run, hipStream_t st, EventRin
     constexpr int ROWS = 32 * CT;
     constexpr int XSTAGE = NB * ROWS * 128;
     constexpr int EXCH = exch_bytes<NA, NWV, G>();
-    constexpr int REGION_A = (4 * XSTAGE > EXCH) ? 4 * XSTAGE : EXCH;
+    constexpr int REGION_A = (kRing * XSTAGE > EXCH) ? kRing * XSTAGE : EXCH;
     constexpr int LDS = REGION_A + (2 * NWV * ROWS + 4 * NWV * 64 + 2 * ROWS + 6 * kHidden) * (int)sizeof(float);
     static_assert(LDS <= 160 * 1024, "workgroup LDS");
     auto kern = prober_fused_kernel<NA, NB, CT, NWV>;

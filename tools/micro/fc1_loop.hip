@@ -13,6 +13,7 @@
 //   bit 9: (with bits 7, 8) no branch around the sums (last K step peeled) and sums / staging stores / staging
 //          loads of a K step placed in the MFMA shadows of its first sub-step
 //   bit 10: four-stage activation ring, staged two K steps ahead, ONE barrier per TWO K steps
+//   bit 11: (with bit 10) eight stages, four K steps ahead, one barrier per FOUR K steps
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/micro/fc1_loop.hip -o tools/micro/fc1_loop
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -109,6 +110,10 @@ __global__ __launch_bounds__(512, 2) void fc1_loop(const u32x4* __restrict__ W, 
     x_store(1);
     x_store(2);
     x_store(3);
+    x_store(4);
+    x_store(5);
+    x_store(6);
+    x_store(7);
     x_load(1);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -132,12 +137,12 @@ __global__ __launch_bounds__(512, 2) void fc1_loop(const u32x4* __restrict__ W, 
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     auto kstep = [&](const int t, const bool sums) {
         if constexpr (MODE & 8) {
-            if (!(MODE & 1024) || (t & 1) == 0) {
+            if (!(MODE & 1024) || (t & ((MODE & 2048) ? 3 : 1)) == 0) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
         }
-        const char* xs = s_x + ((MODE & 1024) ? (t & 3) : (t & 1)) * XSTAGE;
+        const char* xs = s_x + ((MODE & 2048) ? (t & 7) : (MODE & 1024) ? (t & 3) : (t & 1)) * XSTAGE;
         const int s16n = 4 * (t + 1 < T ? t + 1 : T - 1);
         if constexpr (MODE & 512) {
             if constexpr (MODE & 1) b_read(xs, 0, 0);
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void fc1_loop(const u32x4* __restrict__ W, 
                         }
                 }
             }
-            x_store((MODE & 1024) ? ((t + 2) & 3) : ((t + 1) & 1));
+            x_store((MODE & 2048) ? ((t + 4) & 7) : (MODE & 1024) ? ((t + 2) & 3) : ((t + 1) & 1));
             x_load(t + 3 < T ? t + 3 : T - 1);
         }
         if constexpr (!(MODE & 512)) {
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void fc1_loop(const u32x4* __restrict__ W, 
 
 template <int MODE>
 static void run(const u32x4* W, const _Float16* x, int d, float* out, unsigned long long* cyc, int grid) {
-    const int lds = 4 * XSTAGE;
+    const int lds = 8 * XSTAGE;
     hipFuncSetAttribute((const void*)fc1_loop<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t a, b;
     hipEventCreate(&a);
@@ -304,5 +309,6 @@ int main(int argc, char** argv) {
     run<463>(W, x, d, out, cyc, grid);
     run<975>(W, x, d, out, cyc, grid);
     run<1487>(W, x, d, out, cyc, grid);
+    run<3535>(W, x, d, out, cyc, grid);
     return 0;
 }
