@@ -192,7 +192,7 @@ struct ShadowStore {
     const void* rows;        // the stored rows (exact scores come from these)
     int store_f32;
     int d;
-    signed char* rows8;      // [cap][d]
+    signed char* rows8;      // [cap/32][d/128][32][128]: 8-bit rows, chunk-major inside 32-row tiles
     float* sscale;           // [cap] s_i
     float* serr;             // [cap] e_i = ||x_i - s_i x^_i||, rounded up
     uint32_t* err_max;       // float bits of max_i e_i (diagnostic)

@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256) void shadow_build_kernel(const void* __restric
         const float v = get(c);
         float qv = rintf(v / s);
         qv = fminf(fmaxf(qv, -127.f), 127.f);
-        rows8[i * d + c] = (signed char)(int)qv;
+        // chunk-major inside a 32-row tile: [tile][128-byte chunk][row in tile][128] - the 4 KiB a wave stages
+        // per step are contiguous
+        rows8[(i >> 5) * (32 * (int64_t)d) + (int64_t)(c >> 7) * 4096 + (i & 31) * 128 + (c & 127)] = (signed char)(int)qv;
         const double df = (double)v - (double)s * (double)qv;
         err2 = fma(df, df, err2);
     }
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void shadow_prep_kernel(const float* __restric
 // the scan
 // ---------------------------------------------------------------------------
 struct Scan8Args {
-    const signed char* rows8;   // [N][d]
+    const signed char* rows8;   // [N/32][d/128][32][128]: chunk-major inside 32-row tiles
     const float* sscale;        // [roundup(N,32)]
     const float* serr;
     const float* xnorm;
@@ -293,9 +295,9 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     // the rows of the last, partial tile past N are readable (their scores are masked in the epilogue)
     int lane_off[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lane_off[i] = st_doc[i] * d + col_b;
+    for (int i = 0; i < 4; ++i) lane_off[i] = st_doc[i] * 128 + col_b;
     auto issue = [&](u32x4 (&ldr)[4], int tile, int c) {
-        const char* base = rows + (int64_t)tile * (32 * row_bytes) + c * 128;
+        const char* base = rows + (int64_t)tile * (32 * row_bytes) + c * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ldr[i] = *reinterpret_cast<const u32x4*>(base + lane_off[i]);
     };
