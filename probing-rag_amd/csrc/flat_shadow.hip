@@ -285,10 +285,11 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     const int col_b = (lane & 7) * 16;
     const int64_t row_bytes = d;
     const char* rows = reinterpret_cast<const char*>(a.rows8);
-    // four chunks (16 KiB per wave, 128 KiB per CU) in flight: at half the bytes per row the loop turns
-    // over twice as fast as the fp16 scan's; with two it starved at 64 queries, the fourth is worth 0.8 %
-    // (2.936 -> 2.912 ms at 21 M rows, same box).  64 queries x 32-deep lists have no registers for it.
-    constexpr int NLD = (QT == 64 && KC == 32) ? 3 : 4;
+    // chunks in flight per wave (4 KiB each): four for 32-query tiles, five for 64-query tiles (20 KiB per
+    // wave, 160 KiB per CU) - with the chunk-major row layout the fifth is worth 2-3 % at 64 queries (2.875 ->
+    // 2.827 ms at 21 M rows, same box, alternating runs) and nothing at 32 or 1; with two the loop starved.
+    // 64 queries x 32-deep lists have no registers beyond three.
+    constexpr int NLD = QT == 64 ? (KC == 32 ? 3 : 5) : 4;
     u32x4 ld[NLD][4];
     // wave-uniform tile base (scalar registers) + a per-lane 32-bit offset: no 64-bit vector address
     // arithmetic and no per-row clamp in the loop - the shadow is allocated in multiples of 256 rows, so
