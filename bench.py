@@ -15,7 +15,8 @@ Total work is fixed as GPUs are added ("strong"): the 21M rows and the 4096
 gate rows are split across ranks.
 
   python bench.py                      # 1 GPU
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+  python bench.py --gpus N             # starts its own torch.distributed.run child (one rank per GPU, RCCL)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N     # same thing
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects
   roofline      dominant kernel of the headline step (scan8 - or scan_topk with --shadow 0 -, HBM-bound),
@@ -33,6 +34,8 @@ Other sizes are parity/diagnostic cases, e.g. BASELINE config 3:
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -47,7 +50,7 @@ MFMA_F16_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA
 D_MODEL, D_EMB, N_LAYERS = 2048, 768, 6
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -69,7 +72,7 @@ def parse():
                          "n_cu-16 workgroups); 0: one stream; -1 (default): overlap only on shards below 8 M "
                          "rows, where the scan is short enough for the gate to matter (measured both ways)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -213,29 +216,67 @@ def variant_record(torch, ix, q, k, store, metric, n_local, shadow=0):
     return rec
 
 
-def main():
-    args = parse()
+def launch_command(n_gpus, argv, port=None):
+    """The one-rank-per-GPU launch of this file: the command the driver documents, on a free local port."""
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start `torch.distributed.run` as a fresh CHILD
+    process - before torch is imported or any HIP call is made here, and never by exec (a process that has
+    touched the GPU must not be replaced) - let its output through and return its exit code.
+    Returns None when this process is itself a rank (WORLD_SIZE set) or N == 1."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    assert "torch" not in sys.modules, "the launcher must not have imported torch"
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = launch_command(args.gpus, argv)
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    rc = self_launch(args, argv)
+    if rc is not None:
+        raise SystemExit(rc)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: using the launcher's world size",
+              file=sys.stderr, flush=True)
         args.gpus = world
-    n_dev = torch.cuda.device_count()
-    dev_index = local_rank % max(1, n_dev)   # (several ranks per GPU only in the gloo smoke mode below)
+    n_dev = torch.cuda.device_count()            # does not initialise the GPU
+    # RCCL ("nccl") is the product path.  PRAG_BENCH_BACKEND=gloo exists only to exercise the
+    # multi-rank control flow on a box with fewer GPUs than ranks (collectives staged via host,
+    # several ranks share a device).
+    backend = os.environ.get("PRAG_BENCH_BACKEND", "nccl") if world > 1 else "none"
+    if world > 1 and backend == "nccl" and n_dev < world:
+        raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, {n_dev} visible "
+                         f"(PRAG_BENCH_BACKEND=gloo runs the rank logic on fewer)")
+    dev_index = local_rank % max(1, n_dev)
     torch.cuda.set_device(dev_index)
+    rank_devices = [dev_index]
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # RCCL ("nccl") is the product path.  PRAG_BENCH_BACKEND=gloo exists only to exercise the
-        # multi-rank control flow on a box with fewer GPUs than ranks (collectives staged via host).
-        backend = os.environ.get("PRAG_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
+        backend = dist.get_backend()
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, dev_index)
 
     import probing_rag_amd as pra
     from probing_rag_amd.synth import random_prober_state, synth_rows
@@ -385,7 +426,8 @@ def main():
     out = {
         "metric": "probe-decisions/sec + query*doc scores/sec/GPU (value = query*doc scores/sec, whole job)",
         "value": value, "unit": "query*doc scores/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": backend,
+        "rank_devices": rank_devices, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": ("i8 shadow scan (MFMA i8, i32 accumulate) over f16 rows; f64 exact rerank of the filter's survivors"
                   if scan_kernel == "scan8_kernel" else "f16 (MFMA, f32 accumulate; f64 rerank + exactness certificate)"),
