@@ -1343,8 +1343,14 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
         ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // Performance-only switches (every setting returns the exact result): PRAG_SCAN_MM=0 never takes the
+    // MFMA-tiled scan, PRAG_PREPASS, PRAG_SHADOW.  The switches that trade exactness for a timing
+    // experiment (certificate off, tiled-scan overflow left unrepaired) exist only in `make diag`.
+    if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e) != 0;
+#ifdef PRAG_MM_DIAG
     if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e);
     if (const char* e = getenv("PRAG_CERT")) ix->cert_mode = atoi(e);
+#endif
     if (const char* e = getenv("PRAG_PREPASS")) ix->prepass_mode = atoi(e);
     if (const char* e = getenv("PRAG_SHADOW")) ix->shadow_mode = atoi(e);
     {
@@ -1890,7 +1896,9 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     // ---- two-level search through the 8-bit shadow (HBM-bound batches on large shards) --------------
     constexpr int64_t kShadowMinRows = 1 << 20;
     constexpr int kShadowCap = 128;
-    bool use_shadow = ix->shadow_mode && !exact_only && !use_mm && !use_qs && ix->ntotal > 0 &&
+    // (the shadow's eps constants read max ||x||^2 and its overflow path needs the exact scan: both exist
+    // only with the certificate on - a diag build with PRAG_CERT=0 scans the rows directly)
+    bool use_shadow = certify && ix->shadow_mode && !exact_only && !use_mm && !use_qs && ix->ntotal > 0 &&
                       (ix->shadow_mode >= 2 || (ix->ntotal >= kShadowMinRows && !ix->shadow_no_room)) &&
                       shadow_supported(ix->d, kc, k, B);
     if (use_shadow && ix->shadow_cap < ix->cap && ix->shadow_mode == 1) {

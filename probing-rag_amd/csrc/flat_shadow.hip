@@ -35,6 +35,15 @@ namespace prag {
 
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
+// Timing experiments that give WRONG results (warm-up off, nothing collected, gather stages off) exist only
+// in the `make diag` build (libprag_diag.so, -DPRAG_MM_DIAG); in libprag.so the knob is the constant 0 and
+// the environment is never read.
+#ifdef PRAG_MM_DIAG
+#define PRAG_SH_DBG(x) (x)
+#else
+#define PRAG_SH_DBG(x) 0
+#endif
+
 // ---------------------------------------------------------------------------
 // shadow build: one wave per row
 // ---------------------------------------------------------------------------
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     // virtual tile sequence of this wave: its n_my tiles, then the first `redo` of them again
     constexpr int kWarmMax = 16;
     int redo = 0;
-    bool warm = !(a.dbg & 1);
+    bool warm = !(PRAG_SH_DBG(a.dbg) & 1);
     auto vtile = [&](int vt) {
         int at = vt < n_my ? vt : vt - n_my;
         at = at < n_my ? at : n_my - 1;             // prefetch past the end: any valid tile
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
         if (c_cur == NCH - 1) {
             // ---- epilogue: 16 rows x this lane's queries ---------------------------------------
             const bool second = vt_cur >= n_my;     // second visit of a warm-up tile: filter only
-            const bool collect = (second || !warm) && !(a.dbg & 2);
+            const bool collect = (second || !warm) && !(PRAG_SH_DBG(a.dbg) & 2);
             if (hh == 0) {
                 s_meta[r] = m_s;
                 s_meta[32 + r] = m_e;
@@ -620,7 +629,7 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
         s_rc[i] = (int)min(c, (uint32_t)a.cap);
     }
     __syncthreads();
-    for (int base = 0; base < ((a.dbg & 128) ? 0 : nreg * a.cap); base += 8 * kShThreads) {
+    for (int base = 0; base < ((PRAG_SH_DBG(a.dbg) & 128) ? 0 : nreg * a.cap); base += 8 * kShThreads) {
         int2 ev[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {          // all loads of the batch in flight before the first use
@@ -639,7 +648,7 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
         }
     }
     __syncthreads();
-    const int n_ids = (a.dbg & 32) ? 0 : min(s_n, kShIds);
+    const int n_ids = (PRAG_SH_DBG(a.dbg) & 32) ? 0 : min(s_n, kShIds);
     if (s_over && tid == 0 && atomicExch(a.ovf + b, 1u) == 0u) cert_flag(a.cert, b);   // exact scan recomputes b
     // ---- exact scores, 16 lanes per candidate row -------------------------------------------------
     // (45 of the kernel's 58 us at the 8-GPU shard size and 64 queries, tools/gather_probe.py: ~600
@@ -703,7 +712,7 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
             if (c > kShCap - 256) sh_cut(tk, a.k);
         }
     }
-    if (!(a.dbg & 64)) sh_cut(tk, a.k);
+    if (!(PRAG_SH_DBG(a.dbg) & 64)) sh_cut(tk, a.k);
     const int64_t o = ((int64_t)b * kShSplit + blockIdx.x) * a.k;
     for (int j = tid; j < a.k; j += kShThreads) {
         const bool ok = j < tk.cnt;
@@ -815,8 +824,12 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         a.cand = reinterpret_cast<int2*>(s.cand);
         a.ccnt = s.ccnt;
         a.cap = s.cap;
+#ifdef PRAG_MM_DIAG
         static const int dbg_env = getenv("PRAG_SHADOW_DBG") ? atoi(getenv("PRAG_SHADOW_DBG")) : 0;
         a.dbg = dbg_env;
+#else
+        a.dbg = 0;
+#endif
         int rc;
         if (QT == 64)
             rc = s.kc == 8 ? launch_scan8<64, 8>(a, grid, st, prof)

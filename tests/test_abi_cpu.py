@@ -63,3 +63,18 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "prag_oracle" not in src and "oracle_np import" not in src, f
+
+
+def test_product_library_has_no_result_corrupting_knobs():
+    """Environment switches that trade exactness for a timing experiment (certificate off, tiled-scan
+    overflow unrepaired, shadow stages off) exist only in the `make diag` build: the product library
+    must not even contain their names."""
+    from probing_rag_amd import _lib
+    _lib.build()
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"PRAG_CERT", b"PRAG_SHADOW_DBG", b"PRAG_MM_ABLATE", b"PRAG_MM_CLOCK", b"PRAG_PROBER_STAMPS"):
+        assert name not in blob, name
+    # PRAG_SCAN_MM stays as a performance switch (0 = never the MFMA-tiled scan); its value is reduced to
+    # a boolean in the product build, so "2" (overflow unrepaired) cannot be selected
+    src = open(os.path.join(_lib.CSRC, "flat_index.hip")).read()
+    assert 'ix->mm_mode = atoi(e) != 0;' in src
