@@ -79,8 +79,9 @@ def test_c4_one_shard_of_the_21m_corpus(store, metric):
 
 
 def test_c4_full_corpus_equals_its_eight_shards():
-    """21 M x 768 fp16 on one GPU, cosine top-10, B_q = 1000 (MFMA-tiled scan), 32 and 1 (per-lane
-    lists): properties at full size, and unsharded == 8 row shards + (score, id) merge, bit for bit."""
+    """21 M x 768 fp16 on one GPU, cosine top-10, B_q = 1000 (MFMA-tiled scan), 64 (the bench line's
+    shape: 64-query tiles, one int8 query term, five chunks in flight), 32 and 1 (per-lane lists):
+    properties at full size, and unsharded == 8 row shards + (score, id) merge, bit for bit."""
     import torch
     import probing_rag_amd as pra
     k = 10
@@ -89,12 +90,13 @@ def test_c4_full_corpus_equals_its_eight_shards():
     Q, planted = _queries(whole, FULL, 1000)
     qd = torch.from_numpy(Q).cuda()
     out = {}
-    for B in (1000, 32, 1):
+    for B in (1000, 64, 32, 1):
         Dm, I = whole.search(qd[:B], k)
         out[B] = (Dm, I)
         _properties(Dm.cpu().numpy(), I.cpu().numpy(), FULL, k, False, planted[:B])
         assert whole.last_exact_fallbacks() <= max(1, B // 50)
     assert torch.equal(out[32][1], out[1000][1][:32]) and torch.equal(out[1][1], out[1000][1][:1])
+    assert torch.equal(out[64][1], out[1000][1][:64]) and torch.allclose(out[64][0], out[1000][0][:64], rtol=1e-6, atol=0)
     D2, I2 = whole.search(qd, k)                                   # idempotent
     assert torch.equal(I2, out[1000][1]) and torch.allclose(D2, out[1000][0], rtol=1e-6, atol=0)
     # planted rows: the score the search reports is the exact cosine to the stored row
@@ -112,12 +114,61 @@ def test_c4_full_corpus_equals_its_eight_shards():
         s = pra.HipFlatIndex(D, "cos", "f16", capacity=hi - lo)
         s.add_synthetic(42, lo, hi - lo)
         shards.append(s)
-    for B in (1000, 32):
+    for B in (1000, 64, 32):
         Ds, Is = pra.search_shards_on_one_gpu(shards, qd[:B], k, "cos")
         assert torch.equal(Is, out[B][1]) and torch.allclose(Ds, out[B][0], rtol=1e-6, atol=0)
     for s in shards:
         s.close()
     whole.close()
+
+
+def _chunked_oracle(ix, n_rows, Qsel, k, mid, chunk=1_000_000):
+    """The C oracle's float64 brute force over ALL rows of `ix` without a host copy of the corpus: the
+    stored rows are streamed back in `chunk`-row pieces, each searched with its global id offset, and the
+    per-chunk lists are merged by (score, id) (oracle_np.merge_topk) - the definition applied to the rows
+    the index actually holds."""
+    Ds, Is = [], []
+    for lo in range(0, n_rows, chunk):
+        xs = ix.reconstruct_n(lo, min(chunk, n_rows - lo))
+        d_, i_ = oracle_c.flat_search(xs, Qsel, k, mid, id_offset=lo)
+        Ds.append(d_)
+        Is.append(i_)
+        del xs
+    return onp.merge_topk(Ds, Is, k, onp.METRIC_L2 if mid == onp.METRIC_L2 else onp.METRIC_IP)
+
+
+@pytest.mark.parametrize("store,metric,k", [("f16", "cos", 10), ("f32", "l2", 5)])
+def test_c4_headline_shape_against_the_oracle_over_all_21m_rows(store, metric, k):
+    """True config-4 parity for the shape bench.py times: 64 queries x 21 M rows (two-level shadow search,
+    64-query tiles) - 6 of the 64 queries (planted and unplanted) are checked against the C oracle's float64
+    brute force over EVERY stored row, streamed in 1 M-row chunks; ids bit-exact, scores to 1e-4.  The
+    float32/L2 case is the reference's own index type (make_indexer.py:449-450) at the same batch shape."""
+    import torch
+    import probing_rag_amd as pra
+    mid = {"cos": onp.METRIC_COS, "l2": onp.METRIC_L2}[metric]
+    ix = pra.HipFlatIndex(D, metric, store, capacity=FULL)
+    ix.add_synthetic(42, 0, FULL)
+    Q, planted = _queries(ix, FULL, 64)
+    qd = torch.from_numpy(Q).cuda()
+    Dm, I = ix.search(qd, k)
+    assert ix.last_exact_fallbacks() <= 1
+    Dm, I = Dm.cpu().numpy(), I.cpu().numpy()
+    _properties(Dm, I, FULL, k, metric == "l2", planted)
+    pick = [0, 5, 15, 16, 40, 63]
+    D0, I0 = _chunked_oracle(ix, FULL, Q[pick], k, mid)
+    assert np.array_equal(I[pick], I0)
+    if metric == "l2":
+        np.testing.assert_allclose(Dm[pick], D0, rtol=1e-4, atol=0)
+    else:
+        np.testing.assert_allclose(Dm[pick], D0, atol=1e-4, rtol=0)
+    # the same rows scanned directly (no shadow) give the same answer, and so does one query alone
+    ix.set_shadow(0)
+    Dd, Id = ix.search(qd, k)
+    assert np.array_equal(Id.cpu().numpy(), I) and np.allclose(Dd.cpu().numpy(), Dm, rtol=1e-6, atol=0)
+    ix.set_shadow(1)
+    D1, I1 = ix.search(qd[16:17], k)
+    assert np.array_equal(I1.cpu().numpy()[0], I[16])
+    ix.close()
 
 
 def test_c4_reference_call_on_the_full_float32_corpus():
