@@ -263,8 +263,9 @@ int prag_index_set_candidate_depth(prag_index_t* ix, int depth);
  * certified and went through the exact float64 scan.  Synchronises `stream`. */
 int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out);
 
-/* Two-level exact search: keep an 8-bit shadow of the stored rows (+d bytes per row, built on the
- * device at the next search) and scan IT for batches of <= 64 queries (d a multiple of 128, <= 1024,
+/* Two-level exact search: keep an 8-bit shadow of the stored rows (+d+8 bytes per row, built on the
+ * device as rows are added - `prag_index_add*` extend it before they return, so no search pays for
+ * the build) and scan IT for batches of <= 64 queries (d a multiple of 128, <= 1024,
  * k <= 26): half the bytes of fp16 storage, a quarter of float32.  Results do not change: a
  * proof-carrying filter (Cauchy-Schwarz bound on the quantisation error of every row) keeps each row
  * that can still belong to the top k, the survivors are scored in float64 from the stored rows, and a
@@ -272,6 +273,14 @@ int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out);
  * mode 0 = off (the stored rows are scanned directly), 1 = shards of >= 2^20 rows when the device has
  * room for the shadow next to the rows (the default), 2 = any size. */
 int prag_index_set_shadow(prag_index_t* ix, int mode);
+
+/* Bring every derived structure of the index up to date with its rows on `stream` (the 8-bit shadow
+ * when the current mode and shard size call for one, max ||x||^2 for the exactness bounds), so that
+ * the first search after a mode change does not pay for it.  `prag_index_add*` already do this; the
+ * call is needed only after `prag_index_set_shadow` switched the shadow on for rows that were added
+ * while it was off.  (faiss has no counterpart: IndexFlat::add, make_indexer.py:455, is the whole
+ * build.) */
+int prag_index_prepare(prag_index_t* ix, void* stream);
 
 /* Cap the number of workgroups (= CUs) the scan kernels occupy; 0 = all CUs.  The scan is
  * HBM-bound, so leaving a few CUs free lets an independent kernel on another stream (e.g. the

@@ -1324,6 +1324,84 @@ static int ensure_capacity(prag_index* ix, int64_t want) {
     return PRAG_OK;
 }
 
+// ---- 8-bit shadow maintenance ---------------------------------------------------------------------
+constexpr int64_t kShadowMinRows = 1 << 20;
+
+// Does this index keep a shadow at its current size / mode?  (mode 1: shards of >= 2^20 rows when the
+// device has room for d + 8 more bytes per row with 2 GB to spare; mode 2: any size)
+static bool shadow_wanted(prag_index* ix) {
+    if (!ix->shadow_mode || ix->ntotal == 0 || !shadow_store_supported(ix->d)) return false;
+    if (ix->shadow_mode >= 2) return true;
+    if (ix->ntotal < kShadowMinRows || ix->shadow_no_room) return false;
+    if (ix->shadow_cap < ix->cap) {
+        size_t free_b = 0, total_b = 0;
+        const size_t have = ix->rows8 ? (size_t)ix->shadow_cap * (ix->d + 8) : 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
+            free_b + have < (size_t)ix->cap * (ix->d + 8) + ((size_t)2 << 30)) {
+            ix->shadow_no_room = true;
+            return false;
+        }
+    }
+    return true;
+}
+
+// Bring the shadow up to date with the stored rows (allocation follows the row capacity; rows added since
+// the last call are quantised; the max ||x||^2 word the shadow's error constants read is refreshed).
+// Called at the end of every add (so that no search pays for it), from prag_index_prepare, and - a no-op
+// then - from the search itself.
+static int shadow_ensure(prag_index* ix, hipStream_t st) {
+    if (ix->xn_max_rows < ix->ntotal) {  // rows added since the last refresh
+        const int blocks = (int)std::min<int64_t>(1024, (ix->ntotal - ix->xn_max_rows + 255) / 256);
+        hipLaunchKernelGGL(xnorm_max_kernel, dim3(blocks), dim3(256), 0, st, ix->xnorm, ix->xn_max_rows, ix->ntotal,
+                           ix->cert_words + 1);
+        PRAG_LAUNCH_CHECK();
+        ix->xn_max_rows = ix->ntotal;
+    }
+    if (!shadow_wanted(ix)) return PRAG_OK;
+    if (ix->shadow_cap < ix->cap) {    // (re)allocate with the rows; rebuilt from row 0
+        PRAG_HIP(hipStreamSynchronize(st));   // a search may still be reading the old shadow on this stream
+        for (void* p : {(void*)ix->rows8, (void*)ix->sscale, (void*)ix->serr})
+            if (p) (void)hipFree(p);
+        ix->rows8 = nullptr; ix->sscale = nullptr; ix->serr = nullptr; ix->shadow_cap = 0; ix->shadow_rows = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&ix->rows8), (size_t)ix->cap * ix->d);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ix->sscale), (size_t)ix->cap * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ix->serr), (size_t)ix->cap * sizeof(float));
+        if (e == hipSuccess && !ix->shadow_err_max) {
+            e = hipMalloc(reinterpret_cast<void**>(&ix->shadow_err_max), sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemsetAsync(ix->shadow_err_max, 0, sizeof(uint32_t), st);
+        }
+        if (e != hipSuccess) {   // nothing half-allocated is left behind; rows are scanned directly from now on
+            for (void* p : {(void*)ix->rows8, (void*)ix->sscale, (void*)ix->serr})
+                if (p) (void)hipFree(p);
+            ix->rows8 = nullptr; ix->sscale = nullptr; ix->serr = nullptr;
+            (void)hipGetLastError();
+            if (ix->shadow_mode == 1) { ix->shadow_no_room = true; return PRAG_OK; }
+            set_error("prag_index: allocating the 8-bit shadow failed: %s", hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? PRAG_ENOMEM : PRAG_EHIP;
+        }
+        ix->shadow_cap = ix->cap;
+    }
+    if (ix->shadow_rows < ix->ntotal) {
+        ShadowStore ss;
+        ss.rows = ix->rows;
+        ss.store_f32 = ix->store == PRAG_F32;
+        ss.d = ix->d;
+        ss.rows8 = ix->rows8;
+        ss.sscale = ix->sscale;
+        ss.serr = ix->serr;
+        ss.err_max = ix->shadow_err_max;
+        const int rc = shadow_build(ss, ix->shadow_rows, ix->ntotal, st);
+        if (rc != PRAG_OK) return rc;
+        ix->shadow_rows = ix->ntotal;
+    }
+    return PRAG_OK;
+}
+
+extern "C" int prag_index_prepare(prag_index_t* ix, void* stream) {
+    PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
+    return shadow_ensure(ix, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int store_dtype,
                                  int64_t capacity_rows) {
     PRAG_REQUIRE(out != nullptr, PRAG_EINVAL, "prag_index_create: out is NULL");
@@ -1405,9 +1483,10 @@ extern "C" int prag_index_add(prag_index_t* ix, const float* x, int64_t n, int s
         // on the caller's stream: x may still be in flight there (an encoder's output)
         rc = launch_add(ix, x, false, 0, 0, n, st);
         if (rc != PRAG_OK) return rc;
-        PRAG_HIP(hipStreamSynchronize(st));
         ix->ntotal += n;
-        return PRAG_OK;
+        rc = shadow_ensure(ix, st);
+        PRAG_HIP(hipStreamSynchronize(st));
+        return rc;
     }
     // host rows: stream through a bounded device staging buffer
     const int64_t chunk = std::min<int64_t>(n, std::max<int64_t>(1, (64ll << 20) / ((int64_t)ix->d * 4)));
@@ -1428,7 +1507,9 @@ extern "C" int prag_index_add(prag_index_t* ix, const float* x, int64_t n, int s
         ix->ntotal += m;
     }
     (void)hipFree(stage);
-    return PRAG_OK;
+    rc = shadow_ensure(ix, st);
+    PRAG_HIP(hipStreamSynchronize(st));
+    return rc;
 }
 
 extern "C" int prag_index_add_synthetic(prag_index_t* ix, uint32_t seed, int64_t row0, int64_t n) {
@@ -1440,9 +1521,10 @@ extern "C" int prag_index_add_synthetic(prag_index_t* ix, uint32_t seed, int64_t
     if (rc != PRAG_OK) return rc;
     rc = launch_add(ix, nullptr, true, seed, row0, n, nullptr);
     if (rc != PRAG_OK) return rc;
-    PRAG_HIP(hipDeviceSynchronize());
     ix->ntotal += n;
-    return PRAG_OK;
+    rc = shadow_ensure(ix, nullptr);
+    PRAG_HIP(hipDeviceSynchronize());
+    return rc;
 }
 
 extern "C" int64_t prag_index_ntotal(const prag_index_t* ix) { return ix ? ix->ntotal : -1; }
@@ -1854,13 +1936,10 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
             PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->ex_id), need * sizeof(int)));
             ix->ex_entries = need;
         }
-        if (ix->xn_max_rows < ix->ntotal) {  // rows added since the last search
-            const int blocks = (int)std::min<int64_t>(1024, (ix->ntotal - ix->xn_max_rows + 255) / 256);
-            hipLaunchKernelGGL(xnorm_max_kernel, dim3(blocks), dim3(256), 0, st, ix->xnorm, ix->xn_max_rows, ix->ntotal,
-                               ix->cert_words + 1);
-            PRAG_LAUNCH_CHECK();
-            ix->xn_max_rows = ix->ntotal;
-        }
+    }
+    {   // max ||x||^2 and the shadow are kept up to date by add / prepare: a no-op unless set_shadow changed the mode
+        const int rc = shadow_ensure(ix, st);
+        if (rc != PRAG_OK) return rc;
     }
     CertArgs cert;
     cert.qinfo = ix->qinfo;
@@ -1894,39 +1973,14 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     PRAG_LAUNCH_CHECK();
 
     // ---- two-level search through the 8-bit shadow (HBM-bound batches on large shards) --------------
-    constexpr int64_t kShadowMinRows = 1 << 20;
     constexpr int kShadowCap = 128;
     // (the shadow's eps constants read max ||x||^2 and its overflow path needs the exact scan: both exist
     // only with the certificate on - a diag build with PRAG_CERT=0 scans the rows directly)
-    bool use_shadow = certify && ix->shadow_mode && !exact_only && !use_mm && !use_qs && ix->ntotal > 0 &&
-                      (ix->shadow_mode >= 2 || (ix->ntotal >= kShadowMinRows && !ix->shadow_no_room)) &&
-                      shadow_supported(ix->d, kc, k, B);
-    if (use_shadow && ix->shadow_cap < ix->cap && ix->shadow_mode == 1) {
-        // automatic mode: only when the shadow (d + 8 bytes per row) fits with 2 GB to spare
-        size_t free_b = 0, total_b = 0;
-        const size_t have = ix->rows8 ? (size_t)ix->shadow_cap * (ix->d + 8) : 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
-            free_b + have < (size_t)ix->cap * (ix->d + 8) + ((size_t)2 << 30)) {
-            ix->shadow_no_room = true;
-            use_shadow = false;
-        }
-    }
+    const bool use_shadow = certify && !exact_only && !use_mm && !use_qs && ix->ntotal > 0 && ix->rows8 != nullptr &&
+                            ix->shadow_rows == ix->ntotal && shadow_wanted(ix) && shadow_supported(ix->d, kc, k, B);
     bool reranked = false;
     if (use_shadow) {
         int rc = PRAG_OK;
-        if (ix->shadow_cap < ix->cap) {    // (re)allocate with the rows; rebuilt from row 0
-            for (void* p : {(void*)ix->rows8, (void*)ix->sscale, (void*)ix->serr})
-                if (p) (void)hipFree(p);
-            ix->rows8 = nullptr; ix->sscale = nullptr; ix->serr = nullptr; ix->shadow_cap = 0; ix->shadow_rows = 0;
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->rows8), (size_t)ix->cap * ix->d));
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sscale), (size_t)ix->cap * sizeof(float)));
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->serr), (size_t)ix->cap * sizeof(float)));
-            if (!ix->shadow_err_max) {
-                PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->shadow_err_max), sizeof(uint32_t)));
-                PRAG_HIP(hipMemsetAsync(ix->shadow_err_max, 0, sizeof(uint32_t), st));
-            }
-            ix->shadow_cap = ix->cap;
-        }
         ShadowSearch ss;
         ss.store.rows = ix->rows;
         ss.store.store_f32 = ix->store == PRAG_F32;
@@ -1935,11 +1989,6 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         ss.store.sscale = ix->sscale;
         ss.store.serr = ix->serr;
         ss.store.err_max = ix->shadow_err_max;
-        if (ix->shadow_rows < ix->ntotal) {
-            rc = shadow_build(ss.store, ix->shadow_rows, ix->ntotal, st);
-            if (rc != PRAG_OK) return rc;
-            ix->shadow_rows = ix->ntotal;
-        }
         const int BpadS = (B + 63) / 64 * 64;
         if (BpadS > ix->sh_q_cap) {
             for (void* p : {(void*)ix->sh_q8, ix->sh_sq, (void*)ix->sh_slots, (void*)ix->sh_ovf})

@@ -224,6 +224,7 @@ struct ShadowSearch {
     uint32_t* ovf;           // [Bpad]
     CertArgs cert;           // flag list: queries whose candidate regions overflowed go to the exact scan
 };
+bool shadow_store_supported(int d);
 bool shadow_supported(int d, int kc, int k, int B);
 size_t shadow_slot_words();
 size_t shadow_q_bytes();

@@ -59,12 +59,13 @@ class HipFlatIndex:
 
     def add(self, x):
         import torch
+        if isinstance(x, torch.Tensor) and x.is_cuda and x.device != self.device:
+            x = x.to(self.device)          # rows on another GPU: the kernels run on the index's device
         ptr, n, is_dev, keep = self._rows_arg(x)
-        # on the caller's current stream: device rows (an encoder's output, a .float() copy made in
-        # _rows_arg) may still be in flight there
-        dev = keep.device if is_dev else self.device
-        with torch.cuda.device(dev):
-            _lib.check(_lib.lib().prag_index_add(self._h, ptr, n, is_dev, _lib.current_stream_ptr(dev)))
+        # on the caller's current stream of the INDEX's device: device rows (an encoder's output, a
+        # .float() copy made in _rows_arg) may still be in flight there
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().prag_index_add(self._h, ptr, n, is_dev, _lib.current_stream_ptr(self.device)))
         del keep
 
     def add_synthetic(self, seed: int, row0: int, n: int):
@@ -288,7 +289,17 @@ def _ix_set_shadow(self, mode=1):
     _lib.check(_lib.lib().prag_index_set_shadow(self._h, int(mode)))
 
 
+def _ix_prepare(self):
+    """Build whatever the current mode derives from the rows (the 8-bit shadow) now, on the current
+    stream, instead of inside the next search.  ``add`` already does this; needed only after
+    ``set_shadow`` switched the shadow on for rows added while it was off."""
+    import torch
+    with torch.cuda.device(self.device):
+        _lib.check(_lib.lib().prag_index_prepare(self._h, _lib.current_stream_ptr(self.device)))
+
+
 HipFlatIndex.set_shadow = _ix_set_shadow
+HipFlatIndex.prepare = _ix_prepare
 HipFlatIndex.set_candidate_depth = _ix_set_candidate_depth
 HipFlatIndex.last_exact_fallbacks = _ix_last_exact_fallbacks
 
