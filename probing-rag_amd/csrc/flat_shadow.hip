@@ -239,6 +239,16 @@ struct Scan8Args {
 constexpr int kShadowEpochs = 9;                    // bound slots refreshed after tiles 1, 2, 4, ..., 256
 constexpr int kShadowSlotWords = kShadowEpochs * 32;
 
+// staging buffers (4 KiB each, 16 VGPRs) of the compile-time-d scan: as many as the chunks of a row when the
+// register file allows (d = 768: 6 = 24 KiB per wave in flight), else half of them
+template <int QT, int KC, int NCHS>
+constexpr int kScan8Nld() {
+    if (QT == 64 && KC == 32) return NCHS == 6 ? 3 : 2;      // 64 list registers: less room
+    if (NCHS == 6) return 6;
+    if (NCHS == 8) return 4;
+    return NCHS <= 4 ? NCHS : NCHS / 2;
+}
+
 template <int KC>
 struct KeyList {   // sorted KC smallest keys (no ids: the lists only feed the bound)
     float k[KC];
@@ -259,7 +269,13 @@ struct KeyList {   // sorted KC smallest keys (no ids: the lists only feed the b
     }
 };
 
-template <int QT, int KC>
+// NCHS > 0: the row length is known at compile time (d = 128 NCHS) and the chunks of a tile are unrolled -
+// the metadata of a tile is requested NCHS staged chunks before its epilogue reads it and every staging
+// buffer is refilled at a fixed distance from its use, so the compiler keeps COUNTED vmcnt waits.  (With the
+// chunk index a run-time value - NCHS = 0, any d - it has to assume that a tile is one chunk long: it waited
+// for everything but the newest chunk in every epilogue and for vmcnt(0) at the head of every batch of NLD
+// chunks, i.e. the five chunks "in flight" were drained once per batch.)
+template <int QT, int KC, int NCHS = 0>
 __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NQ = QT / 32;
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int d = a.d;
+    const int d = NCHS > 0 ? NCHS * 128 : a.d;
     const int NCH = d >> 7;                       // 128-byte chunks per row
     const int qstride = a.qstride;
     char* s_qa = smem;
@@ -341,28 +357,31 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
         st_doc[i] = doc;
         st_dst[i] = doc * 128 + ((q ^ ((doc >> 1) & 7)) << 4);
     }
-    const int col_b = (lane & 7) * 16;
     const int64_t row_bytes = d;
     const char* rows = reinterpret_cast<const char*>(a.rows8);
     // chunks in flight per wave (4 KiB each): four for 32-query tiles, five for 64-query tiles (20 KiB per
     // wave, 160 KiB per CU) - with the chunk-major row layout the fifth is worth 2-3 % at 64 queries (2.875 ->
     // 2.827 ms at 21 M rows, same box, alternating runs) and nothing at 32 or 1; with two the loop starved.
     // 64 queries x 32-deep lists have no registers beyond three.
-    constexpr int NLD = QT == 64 ? (KC == 32 ? 3 : 5) : 4;
+    constexpr int NLD = NCHS > 0 ? kScan8Nld<QT, KC, NCHS>() : (QT == 64 ? (KC == 32 ? 3 : 5) : 4);
     u32x4 ld[NLD][4];
     // wave-uniform tile base (scalar registers) + a per-lane 32-bit offset: no 64-bit vector address
     // arithmetic and no per-row clamp in the loop - the shadow is allocated in multiples of 256 rows, so
     // the rows of the last, partial tile past N are readable (their scores are masked in the epilogue)
-    int lane_off[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) lane_off[i] = st_doc[i] * 128 + col_b;
+    // (lane -> byte (8 i + lane / 8) * 128 + (lane % 8) * 16 = 1024 i + 16 lane of the chunk: one unsigned 32-bit lane
+    // offset on a scalar base, the four pieces at immediate offsets)
+    const uint32_t lane16 = (uint32_t)lane * 16u;
     auto issue = [&](u32x4 (&ldr)[4], int tile, int c) {
         const char* base = rows + (int64_t)tile * (32 * row_bytes) + c * 4096;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ldr[i] = *reinterpret_cast<const u32x4*>(base + lane_off[i]);
+        for (int i = 0; i < 4; ++i) ldr[i] = *reinterpret_cast<const u32x4*>(base + lane16 + 1024 * i);
     };
     const int a_off = r * 128;
     const int a_sw = (r >> 1) & 7;
+    const int xq0 = (r ^ hh) & 15;                  // (32 t does not reach the low four bits)
+    int q_base[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) q_base[t] = (32 * t + r) * qstride;
 
     i32x16 acc1[NQ], acc2[TERMS == 2 ? NQ : 1];
 #pragma unroll
@@ -392,26 +411,33 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     float m_s = 1.f, m_e = 0.f, m_x = 0.f;   // metadata of row (tile*32 + r), requested at the tile's first chunk
     int tiles_done = 0;
 
-    auto body = [&](u32x4 (&ldr)[4]) {
-        const int tile_cur = vtile(vt_cur);
-        if (c_cur == 0) {
-            const int64_t row = (int64_t)tile_cur * 32 + r;     // (arrays are padded to a multiple of 32 rows)
-            m_s = a.sscale[row];
-            m_e = a.serr[row];
-            m_x = a.use_norm ? a.xnorm[row] : 0.f;
-        }
+    auto load_meta = [&](int tile) {
+        const int64_t row = (int64_t)tile * 32 + r;     // (arrays are padded to a multiple of 32 rows)
+        m_s = a.sscale[row];
+        m_e = a.serr[row];
+        m_x = a.use_norm ? a.xnorm[row] : 0.f;
+    };
+    // stage one 4-KiB chunk (32 rows x 128 bytes), refill its registers with chunk (tile_nx, c_nx), 4 k-steps
+    auto chunk_step = [&](u32x4 (&ldr)[4], int c, int tile_nx, int c_nx) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(s_st + st_dst[i]) = ldr[i];
-        issue(ldr, vtile(vt_nx), c_nx);
-        advance(vt_nx, c_nx);
+        issue(ldr, tile_nx, c_nx);
+        // the refill stays HERE: left alone, the scheduler sinks the loads of all unrolled chunks to the end of
+        // the tile (one burst, waited for at once) and the prefetch distance is gone
+        if constexpr (NCHS > 0) __builtin_amdgcn_sched_barrier(0);
+        // query-fragment slot of k-step piece P = 8 c + 2 s + hh in row qrow = 32 t + r:
+        //   (P & ~15) | ((P ^ qrow) & 15)  =  (P & ~15) | (((8 c + 2 s) & 15) ^ xq),  xq = (r ^ hh) & 15
+        // recomputed per chunk from an opaque copy of xq - hoisted out of the loop these are 4 NCH registers
+        int xq = xq0;
+        if constexpr (NCHS > 0) asm volatile("" : "+v"(xq));
 #pragma unroll
         for (int s = 0; s < 4; ++s) {               // 4 k-steps of 32 elements per 128-byte chunk
             const i32x4 av = *reinterpret_cast<const i32x4*>(s_st + a_off + (((2 * s + hh) ^ a_sw) << 4));
-            const int P = c_cur * 8 + 2 * s + hh;
+            const int P0 = c * 8 + 2 * s;           // (bit 0 = hh lives in xq)
+            const int q_sw = ((P0 & ~15) | (((P0 & 15) ^ xq))) << 4;
 #pragma unroll
             for (int t = 0; t < NQ; ++t) {
-                const int qrow = 32 * t + r;
-                const int q_addr = qrow * qstride + (((P & ~15) | ((P ^ qrow) & 15)) << 4);
+                const int q_addr = q_base[t] + q_sw;
                 const i32x4 b1 = *reinterpret_cast<const i32x4*>(s_qa + q_addr);
                 acc1[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b1, acc1[t], 0, 0, 0);
                 if constexpr (TERMS == 2) {
@@ -420,9 +446,11 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                 }
             }
         }
-        if (c_cur == NCH - 1) {
+    };
+    // ---- epilogue of a tile: 16 rows x this lane's queries ----------------------------------------
+    auto epilogue = [&](int tile_cur, bool second) {   // second visit of a warm-up tile: filter only
+        {
             // ---- epilogue: 16 rows x this lane's queries ---------------------------------------
-            const bool second = vt_cur >= n_my;     // second visit of a warm-up tile: filter only
             const bool collect = (second || !warm) && !(PRAG_SH_DBG(a.dbg) & 2);
             if (hh == 0) {
                 s_meta[r] = m_s;
@@ -545,10 +573,38 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                 }
             }
         }
+    };
+    auto body = [&](u32x4 (&ldr)[4]) {    // run-time chunk index (NCHS == 0)
+        const int tile_cur = vtile(vt_cur);
+        if (c_cur == 0) load_meta(tile_cur);
+        chunk_step(ldr, c_cur, vtile(vt_nx), c_nx);
+        advance(vt_nx, c_nx);
+        if (c_cur == NCH - 1) epilogue(tile_cur, vt_cur >= n_my);
         advance(vt_cur, c_cur);
     };
 
-    if (n_my > 0) {
+    if constexpr (NCHS > 0) {
+        if (n_my > 0) {
+            static_assert(NCHS % NLD == 0, "staging buffers rotate with the chunks of a tile");
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                issue(ld[u], vtile(0), u);
+                __builtin_amdgcn_sched_barrier(0);   // in this order: the waits in the loop count on it
+            }
+            // (`redo` grows during the first tiles only, long before the loop bound is reached - or, on a
+            // shard of a few tiles, up to n_my: every tile is then visited twice)
+            for (int vt = 0; vt < n_my + redo; ++vt) {
+                const int tile_cur = vtile(vt), tile_next = vtile(vt + 1);
+                load_meta(tile_cur);         // NCHS refills older than its use in the epilogue
+#pragma unroll
+                for (int c = 0; c < NCHS; ++c) {
+                    const int cn = c + NLD;  // the chunk this buffer holds next
+                    chunk_step(ld[c % NLD], c, cn < NCHS ? tile_cur : tile_next, cn < NCHS ? cn : cn - NCHS);
+                }
+                epilogue(tile_cur, vt >= n_my);
+            }
+        }
+    } else if (n_my > 0) {
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             issue(ld[u], vtile(vt_nx), c_nx);
@@ -836,10 +892,10 @@ size_t shadow_slot_words() { return kShadowSlotWords; }
 size_t shadow_q_bytes() { return sizeof(ShadowQ); }
 int shadow_split() { return kShSplit; }
 
-template <int QT, int KC>
+template <int QT, int KC, int NCHS>
 static int launch_scan8(const Scan8Args& a, int grid, hipStream_t st, EventRing& prof) {
     const int lds = 2 * QT * a.qstride + 8 * 4096 + 8 * 384 + 3 * QT * 4 + 64;   // (+ slot_ok, arrival words)
-    auto kern = scan8_kernel<QT, KC>;
+    auto kern = scan8_kernel<QT, KC, NCHS>;
     static LdsOptIn lds_opt_in;
     {
         const int rc_ = lds_opt_in.ensure(reinterpret_cast<const void*>(kern), 160 * 1024);
@@ -850,6 +906,17 @@ static int launch_scan8(const Scan8Args& a, int grid, hipStream_t st, EventRing&
     prof.end(st);
     PRAG_LAUNCH_CHECK();
     return PRAG_OK;
+}
+
+// d = 512 / 768 / 1024 take the compile-time-d loop; any other multiple of 128 the run-time one
+template <int QT, int KC>
+static int dispatch_scan8_d(const Scan8Args& a, int grid, hipStream_t st, EventRing& prof) {
+    switch (a.d) {
+        case 512: return launch_scan8<QT, KC, 4>(a, grid, st, prof);
+        case 768: return launch_scan8<QT, KC, 6>(a, grid, st, prof);
+        case 1024: return launch_scan8<QT, KC, 8>(a, grid, st, prof);
+        default: return launch_scan8<QT, KC, 0>(a, grid, st, prof);
+    }
 }
 
 int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
@@ -891,11 +958,11 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
 #endif
         int rc;
         if (QT == 64)
-            rc = s.kc == 8 ? launch_scan8<64, 8>(a, grid, st, prof)
-                           : s.kc == 16 ? launch_scan8<64, 16>(a, grid, st, prof) : launch_scan8<64, 32>(a, grid, st, prof);
+            rc = s.kc == 8 ? dispatch_scan8_d<64, 8>(a, grid, st, prof)
+                           : s.kc == 16 ? dispatch_scan8_d<64, 16>(a, grid, st, prof) : dispatch_scan8_d<64, 32>(a, grid, st, prof);
         else
-            rc = s.kc == 8 ? launch_scan8<32, 8>(a, grid, st, prof)
-                           : s.kc == 16 ? launch_scan8<32, 16>(a, grid, st, prof) : launch_scan8<32, 32>(a, grid, st, prof);
+            rc = s.kc == 8 ? dispatch_scan8_d<32, 8>(a, grid, st, prof)
+                           : s.kc == 16 ? dispatch_scan8_d<32, 16>(a, grid, st, prof) : dispatch_scan8_d<32, 32>(a, grid, st, prof);
         if (rc != PRAG_OK) return rc;
         const int nq = std::min(QT, s.B - p0);
         GatherArgs g;
