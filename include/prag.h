@@ -178,7 +178,9 @@ int prag_trainer_load(prag_trainer_t* t, const float* ln0_w, const float* ln0_b,
  * x_dev float32 [B,d_model] (per-sample mean of the last pred_len hidden states, see
  * prag_pool_ragged), labels_dev int32 [B].  Optional device outputs of the forward pass:
  * loss_dev (1 float: CrossEntropyLoss applied to the softmax probabilities, train.py:149-150)
- * and probs_dev float32 [B,n_classes].  All work is enqueued on `stream`. */
+ * and probs_dev float32 [B,n_classes].  All work is enqueued on `stream`.
+ * In eval mode (prag_trainer_set_training(t, 0)) the call is the forward pass only: parameters,
+ * optimiser state, learning rate and step counter are left untouched. */
 int prag_trainer_step(prag_trainer_t* t, const float* x_dev, const int32_t* labels_dev, int B, float* loss_dev,
                       float* probs_dev, void* stream);
 
@@ -187,7 +189,8 @@ int prag_trainer_export(prag_trainer_t* t, float* ln0_w, float* ln0_b, float* W1
                         float* ln1_b, float* W2, float* b2, float* ln2_w, float* ln2_b, float* W3, float* b3);
 
 /* `probe.train()` / `probe.eval()` (train.py:255-257, 299): with training == 0 the dropout of the
- * following steps is the identity.  Handles start in training mode. */
+ * following steps is the identity and prag_trainer_step stops after the forward pass.  Handles start in
+ * training mode. */
 int prag_trainer_set_training(prag_trainer_t* t, int training);
 
 /* Learning rate the next step will use (`optim.param_groups[0]['lr']`), steps taken so far. */

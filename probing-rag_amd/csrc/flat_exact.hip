@@ -10,9 +10,9 @@
 //   keeps the rows that can still reach its top k in an LDS buffer (threshold filter against the
 //   k-th best (score, id) so far; the buffer is sorted and cut to k when it fills) and writes its k
 //   best.  HBM-bound like the list scan: one extra pass over the shard per flagged query.
-// exact_merge_kernel: one workgroup per flagged query folds the per-workgroup lists the same way and
-//   writes D (float32 rounding of the float64 score) / I (row id + offset), faiss padding.
-// Both kernels read the flag count first and return at once when it is zero (the common case).
+//   The last workgroup to finish a query folds the per-workgroup lists the same way and writes D (float32
+//   rounding of the float64 score) / I (row id + offset), faiss padding.
+// The kernel reads the flag count first and returns at once when it is zero (the common case): one ~3 us launch.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -99,6 +99,7 @@ struct ExactArgs {
     int64_t id_offset;
     float* D;
     int64_t* I;
+    uint32_t* done;   // [f_cap] workgroups that have written their list of flag slot f (zero between searches)
 };
 
 template <int CTRL>
@@ -114,10 +115,39 @@ __device__ __forceinline__ double dpp_add16_f64(double v) {
     return v;
 }
 
+// fold the n_lists per-workgroup lists of flag slot `fs` (query b) and write D / I; all threads of the block
+__device__ __forceinline__ void exact_merge_lists(const ExactArgs& a, ExTopK& tk, int fs, int b) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    ex_init(tk);
+    __syncthreads();
+    const int64_t total = (int64_t)a.n_lists * a.k;
+    const int64_t o = (int64_t)fs * total;
+    for (int64_t base = 0; base < total; base += kExThreads) {
+        const int64_t i = base + tid;
+        if (i < total) {
+            const int id = a.part_id[o + i];
+            if (id != 0x7fffffff) ex_push(tk, a.part_key[o + i], id);
+        }
+        __syncthreads();
+        const int c = tk.cnt;
+        __syncthreads();
+        if (c > kExCap - kExThreads) ex_cut(tk, a.k);
+    }
+    ex_cut(tk, a.k);
+    for (int j = tid; j < a.k; j += kExThreads) {
+        const bool ok = j < tk.cnt;
+        const double sc = ok ? unsortable_f64(a.metric_l2 ? tk.key[j] : ~tk.key[j]) : 0.0;
+        a.D[(int64_t)b * a.k + j] = ok ? (float)sc : (a.metric_l2 ? FLT_MAX : -FLT_MAX);
+        a.I[(int64_t)b * a.k + j] = ok ? (int64_t)tk.id[j] + a.id_offset : -1;
+    }
+}
+
 template <bool F32>
 __global__ __launch_bounds__(kExThreads) void exact_scan_kernel(ExactArgs a) {
     __shared__ ExTopK tk;
     __shared__ __attribute__((aligned(16))) float s_q[1536];
+    __shared__ int s_last;
     const uint32_t nf = *a.n_flag;
     if ((uint32_t)a.f0 >= nf) return;
     const int f1 = (int)std::min<uint32_t>(nf, (uint32_t)(a.f0 + a.f_cap));
@@ -201,37 +231,18 @@ __global__ __launch_bounds__(kExThreads) void exact_scan_kernel(ExactArgs a) {
             a.part_key[o + j] = ok ? tk.key[j] : ~0ull;
             a.part_id[o + j] = ok ? tk.id[j] : 0x7fffffff;
         }
-    }
-}
-
-__global__ __launch_bounds__(kExThreads) void exact_merge_kernel(ExactArgs a) {
-    __shared__ ExTopK tk;
-    const uint32_t nf = *a.n_flag;
-    const int f = a.f0 + blockIdx.x;
-    if ((uint32_t)f >= nf) return;
-    const int b = a.flag_list[f];
-    const int tid = threadIdx.x;
-    ex_init(tk);
-    __syncthreads();
-    const int64_t total = (int64_t)a.n_lists * a.k;
-    const int64_t o = (int64_t)blockIdx.x * total;
-    for (int64_t base = 0; base < total; base += kExThreads) {
-        const int64_t i = base + tid;
-        if (i < total) {
-            const int id = a.part_id[o + i];
-            if (id != 0x7fffffff) ex_push(tk, a.part_key[o + i], id);
+        // the LAST workgroup to finish this query folds the per-workgroup lists (one launch instead of two:
+        // with no query flagged the whole exact path is a single early-exit launch).  Only flagged queries get
+        // here, so the device-scope fences (L2 write-back / invalidate across XCDs) cost nothing otherwise.
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(a.done + (f - a.f0), 1u) == gridDim.x - 1 ? 1 : 0;
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            exact_merge_lists(a, tk, f - a.f0, b);
+            if (tid == 0) a.done[f - a.f0] = 0u;
         }
-        __syncthreads();
-        const int c = tk.cnt;
-        __syncthreads();
-        if (c > kExCap - kExThreads) ex_cut(tk, a.k);
-    }
-    ex_cut(tk, a.k);
-    for (int j = tid; j < a.k; j += kExThreads) {
-        const bool ok = j < tk.cnt;
-        const double sc = ok ? unsortable_f64(a.metric_l2 ? tk.key[j] : ~tk.key[j]) : 0.0;
-        a.D[(int64_t)b * a.k + j] = ok ? (float)sc : (a.metric_l2 ? FLT_MAX : -FLT_MAX);
-        a.I[(int64_t)b * a.k + j] = ok ? (int64_t)tk.id[j] + a.id_offset : -1;
     }
 }
 
@@ -256,14 +267,13 @@ int exact_run(const ExactRun& r, hipStream_t st) {
     a.id_offset = r.id_offset;
     a.D = r.D;
     a.I = r.I;
+    a.done = r.done;
     for (int f0 = 0; f0 < r.B; f0 += r.f_cap) {
         a.f0 = f0;
         if (r.store_f32)
             hipLaunchKernelGGL(exact_scan_kernel<true>, dim3(r.grid), dim3(kExThreads), 0, st, a);
         else
             hipLaunchKernelGGL(exact_scan_kernel<false>, dim3(r.grid), dim3(kExThreads), 0, st, a);
-        PRAG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(exact_merge_kernel, dim3(std::min(r.f_cap, r.B - f0)), dim3(kExThreads), 0, st, a);
         PRAG_LAUNCH_CHECK();
     }
     return PRAG_OK;

@@ -114,10 +114,20 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
                                                           uint32_t mm_first_rows, float* __restrict__ qinfo,
                                                           double* __restrict__ qn2, uint32_t* __restrict__ n_flag,
                                                           int* __restrict__ flag_list, int flag_all,
-                                                          uint32_t* __restrict__ g_slot) {
+                                                          uint32_t* __restrict__ g_slot, ShadowPrep sp) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= Bpad) return;
+    // blockIdx.y > 0 (two-level search only): this wave scores slice blockIdx.y - 1 of the shadow's sample
+    // against its query and writes one bound slot; everything else is the work of the y == 0 wave
+    const bool sampler = blockIdx.y > 0;
+    __shared__ __attribute__((aligned(16))) signed char s_q8[4][1024];
+    if (sampler && b >= B) {
+        const f32x4 zero[6] = {};
+        shadow_prebound_wave(sp, b, d, false, (int)blockIdx.y - 1, zero, lane, s_q8[threadIdx.x >> 6]);
+        return;
+    }
+    if (!sampler) {
     // certificate bookkeeping: the flag list starts empty (or holds every query when the search goes
     // straight to the exact scan)
     if (b == 0 && lane == 0) *n_flag = flag_all ? (uint32_t)B : 0u;
@@ -135,7 +145,12 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
             *reinterpret_cast<half4*>(q16 + (int64_t)b * d + c) = half4{0, 0, 0, 0};
             *reinterpret_cast<half4*>(q16lo + (int64_t)b * d + c) = half4{0, 0, 0, 0};
         }
+        if (sp.q8a) {
+            const f32x4 zero[6] = {};
+            shadow_prep_wave(sp, b, d, false, zero, lane);
+        }
         return;
+    }
     }
     const float* s = q + (int64_t)b * d;
     // d is a multiple of 64: 4 consecutive elements per lane per step, at most 6 steps (d <= 1536)
@@ -175,9 +190,12 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
                 r1 = fma(e1, e1, r1);
                 r2 = fma(e2, e2, r2);
             }
-            *reinterpret_cast<f32x4*>(q32 + (int64_t)b * d + c) = o;
-            *reinterpret_cast<half4*>(q16 + (int64_t)b * d + c) = h;
-            *reinterpret_cast<half4*>(q16lo + (int64_t)b * d + c) = lo;
+            if (!sampler) {
+                *reinterpret_cast<f32x4*>(q32 + (int64_t)b * d + c) = o;
+                *reinterpret_cast<half4*>(q16 + (int64_t)b * d + c) = h;
+                *reinterpret_cast<half4*>(q16lo + (int64_t)b * d + c) = lo;
+            }
+            v[it] = o;             // the query as the rerank uses it: what the 8-bit terms below approximate
         }
     }
 #pragma unroll
@@ -185,6 +203,10 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
         n2 += __shfl_xor(n2, o, 64);
         r1 += __shfl_xor(r1, o, 64);
         r2 += __shfl_xor(r2, o, 64);
+    }
+    if (sampler) {
+        shadow_prebound_wave(sp, b, d, true, (int)blockIdx.y - 1, v, lane, s_q8[threadIdx.x >> 6]);
+        return;
     }
     if (lane == 0) {
         qn2[b] = n2;
@@ -194,6 +216,7 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
         qinfo[4 * b + 2] = (float)(sqrt(r2) * (1.0 + 1e-6));
         qinfo[4 * b + 3] = 0.f;
     }
+    if (sp.q8a) shadow_prep_wave(sp, b, d, true, v, lane);
 }
 
 // max_i ||x_i||^2 over rows [row0, row1) folded into *out (float bits; non-negative floats order like
@@ -1269,6 +1292,8 @@ struct prag_index {
     unsigned long long* ex_key = nullptr;
     int* ex_id = nullptr;
     size_t ex_entries = 0;
+    uint32_t* ex_done = nullptr;  // [ex_done_cap] arrival counters of the exact scan's list merge
+    int ex_done_cap = 0;
     // 8-bit shadow (flat_shadow.hip): 0 off, 1 (default) on for shards >= kShadowMinRows when the device has
     // room for it, 2 on at any size
     int shadow_mode = 1;
@@ -1936,6 +1961,13 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
             PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->ex_id), need * sizeof(int)));
             ix->ex_entries = need;
         }
+        if (ex_fcap > ix->ex_done_cap) {
+            if (ix->ex_done) (void)hipFree(ix->ex_done);
+            ix->ex_done = nullptr; ix->ex_done_cap = 0;
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->ex_done), (size_t)ex_fcap * sizeof(uint32_t)));
+            PRAG_HIP(hipMemsetAsync(ix->ex_done, 0, (size_t)ex_fcap * sizeof(uint32_t), st));
+            ix->ex_done_cap = ex_fcap;
+        }
     }
     {   // max ||x||^2 and the shadow are kept up to date by add / prepare: a no-op unless set_shadow changed the mode
         const int rc = shadow_ensure(ix, st);
@@ -1965,30 +1997,14 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
             cert.c_row = cert.c_abs = cert.c_acc = -1e30f;
         }
     }
-    hipLaunchKernelGGL(prep_queries_kernel, dim3((Bpad + 3) / 4), dim3(256), 0, st, q_dev, B, Bpad, ix->d,
-                       ix->metric == PRAG_METRIC_COS ? 1 : 0, ix->q32, ix->q16, ix->q16lo, ix->g_tau,
-                       use_mm ? ix->mm_cnt : nullptr, ix->mm_ovf,
-                       (uint32_t)std::min<int64_t>(ix->ntotal, kMmFirstSeg), ix->qinfo, ix->qn2, flag_word,
-                       ix->flag_list, exact_only && ix->ntotal > 0 ? 1 : 0, ix->g_slot);
-    PRAG_LAUNCH_CHECK();
-
     // ---- two-level search through the 8-bit shadow (HBM-bound batches on large shards) --------------
     constexpr int kShadowCap = 128;
     // (the shadow's eps constants read max ||x||^2 and its overflow path needs the exact scan: both exist
     // only with the certificate on - a diag build with PRAG_CERT=0 scans the rows directly)
     const bool use_shadow = certify && !exact_only && !use_mm && !use_qs && ix->ntotal > 0 && ix->rows8 != nullptr &&
                             ix->shadow_rows == ix->ntotal && shadow_wanted(ix) && shadow_supported(ix->d, kc, k, B);
-    bool reranked = false;
-    if (use_shadow) {
-        int rc = PRAG_OK;
-        ShadowSearch ss;
-        ss.store.rows = ix->rows;
-        ss.store.store_f32 = ix->store == PRAG_F32;
-        ss.store.d = ix->d;
-        ss.store.rows8 = ix->rows8;
-        ss.store.sscale = ix->sscale;
-        ss.store.serr = ix->serr;
-        ss.store.err_max = ix->shadow_err_max;
+    ShadowPrep sprep{};
+    if (use_shadow) {   // workspace of the two-level search; its query terms come out of prep_queries_kernel
         const int BpadS = (B + 63) / 64 * 64;
         if (BpadS > ix->sh_q_cap) {
             for (void* p : {(void*)ix->sh_q8, ix->sh_sq, (void*)ix->sh_slots, (void*)ix->sh_ovf})
@@ -1997,7 +2013,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
             PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_q8), (size_t)2 * BpadS * ix->d));
             PRAG_HIP(hipMalloc(&ix->sh_sq, (size_t)BpadS * shadow_q_bytes()));
             PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_slots), (size_t)BpadS * shadow_slot_words() * sizeof(uint32_t)));
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_ovf), (size_t)BpadS * sizeof(uint32_t)));
+            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_ovf), (size_t)2 * BpadS * sizeof(uint32_t)));   // + arrival counters
             ix->sh_q_cap = BpadS;
         }
         if (!ix->sh_cand) {
@@ -2013,6 +2029,41 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
             PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_pid), pe * sizeof(int)));
             ix->sh_part_entries = pe;
         }
+        sprep.q8a = ix->sh_q8;
+        sprep.q8b = ix->sh_q8 + (size_t)ix->sh_q_cap * ix->d;
+        sprep.sq = reinterpret_cast<ShadowQ*>(ix->sh_sq);
+        sprep.slots = ix->sh_slots;
+        sprep.ovf = ix->sh_ovf;
+        sprep.done = ix->sh_ovf + ix->sh_q_cap;
+        sprep.xn_max = ix->cert_words + 1;
+        sprep.alpha = metric_l2 ? -2.0f : -1.0f;
+        // sample for the pre-bound: kShadowSampleSlices x kShadowSampleTiles whole tiles spread over the shard
+        sprep.rows8 = ix->rows8;
+        sprep.sscale = ix->sscale;
+        sprep.serr = ix->serr;
+        sprep.xnorm = metric_l2 ? ix->xnorm : nullptr;
+        const int64_t whole_tiles = ix->ntotal / 32;
+        sprep.sample_stride = whole_tiles / (kShadowSampleSlices * kShadowSampleTiles);   // 0: shard too small
+    }
+    hipLaunchKernelGGL(prep_queries_kernel, dim3((Bpad + 3) / 4, use_shadow ? 1 + kShadowSampleSlices : 1), dim3(256), 0,
+                       st, q_dev, B, Bpad, ix->d,
+                       ix->metric == PRAG_METRIC_COS ? 1 : 0, ix->q32, ix->q16, ix->q16lo, ix->g_tau,
+                       use_mm ? ix->mm_cnt : nullptr, ix->mm_ovf,
+                       (uint32_t)std::min<int64_t>(ix->ntotal, kMmFirstSeg), ix->qinfo, ix->qn2, flag_word,
+                       ix->flag_list, exact_only && ix->ntotal > 0 ? 1 : 0, ix->g_slot, sprep);
+    PRAG_LAUNCH_CHECK();
+
+    bool reranked = false;
+    if (use_shadow) {
+        int rc = PRAG_OK;
+        ShadowSearch ss;
+        ss.store.rows = ix->rows;
+        ss.store.store_f32 = ix->store == PRAG_F32;
+        ss.store.d = ix->d;
+        ss.store.rows8 = ix->rows8;
+        ss.store.sscale = ix->sscale;
+        ss.store.serr = ix->serr;
+        ss.store.err_max = ix->shadow_err_max;
         ss.xnorm = ix->xnorm;
         ss.N = ix->ntotal;
         ss.d = ix->d;
@@ -2041,6 +2092,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         ss.part_key = ix->sh_pkey;
         ss.part_id = ix->sh_pid;
         ss.ovf = ix->sh_ovf;
+        ss.done = ix->sh_ovf + ix->sh_q_cap;
         ss.cert = cert;
         rc = shadow_search(ss, st, ix->prof);
         if (rc != PRAG_OK) return rc;
@@ -2158,6 +2210,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     er.part_id = ix->ex_id;
     er.f_cap = ex_fcap;
     er.grid = ex_grid;
+    er.done = ix->ex_done;
     const bool may_flag = certify && ix->ntotal > 0;
     if (io_is_device) {
         ix->last_flagged = -1;
@@ -2300,7 +2353,7 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
                     ix->io_q, ix->io_res, ix->mm_cnt, ix->mm_ovf, ix->mm_ckey, ix->mm_cidx,
                     ix->mm_wcnt, ix->mm_wkey, ix->mm_widx, ix->rows16, ix->qinfo, ix->qn2, ix->flag_list, ix->g_slot,
                     ix->cert_words, ix->ex_key, ix->ex_id, ix->rows8, ix->sscale, ix->serr, ix->shadow_err_max, ix->sh_q8,
-                    ix->sh_sq, ix->sh_slots, ix->sh_ovf, ix->sh_cand, ix->sh_ccnt, ix->sh_pkey, ix->sh_pid};
+                    ix->sh_sq, ix->sh_slots, ix->sh_ovf, ix->sh_cand, ix->sh_ccnt, ix->sh_pkey, ix->sh_pid, ix->ex_done};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ix->io_q_host) (void)hipHostFree(ix->io_q_host);

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <float.h>
 #include <stdint.h>
 
 #include "prag_common.h"
@@ -180,14 +181,192 @@ struct ExactRun {
     int* part_id;
     int f_cap;              // flagged queries one round can hold
     int grid;               // workgroups of the scan
+    uint32_t* done;         // [f_cap] zero-initialised arrival counters (the kernel leaves them zero)
 };
 size_t exact_part_entries(int f_cap, int grid, int k);
-// Enqueue ceil(B / f_cap) rounds of {exact scan, merge}; every launch exits at once when no query is flagged.
+// Enqueue ceil(B / f_cap) launches of the exact scan (list merge folded in); each exits at once when no query is flagged.
 int exact_run(const ExactRun& r, hipStream_t st);
 
 // ---------------------------------------------------------------------------
 // 8-bit shadow, two-level exact search (flat_shadow.hip)
 // ---------------------------------------------------------------------------
+struct ShadowQ {     // per query, consumed by the scan
+    float kscale;    // alpha * sq : key = xnorm_i + kscale * s_i * (acc1 + acc2 / 128)
+    float A2, C2;    // two query terms:  eps_i = A e_i + C,  A = |alpha| ||q~||, C = |alpha| rq max||x|| + rounding slack
+    float A1, C1;    // first term only (64-query tiles)
+    float pad[3];
+};
+// Bound slots of the two-level scan, per query: kShadowEpochs epochs x 32 slots filled inside the scan launch
+// (after tiles 1, 2, 4, ..., 256) and one more "epoch" filled BEFORE it by prep_queries_kernel from a sample of
+// the shard (below).
+constexpr int kShadowEpochs = 9;
+constexpr int kShadowPreEpoch = kShadowEpochs;                 // index of the sample slots
+constexpr int kShadowSlotWords = (kShadowEpochs + 1) * 32;
+constexpr int kShadowSampleSlices = 32;                        // one slot each
+constexpr int kShadowSampleTiles = 4;                          // 32-row tiles per slice: 4096 sample rows
+
+// what prep_queries_kernel writes for the two-level search (q8a == nullptr: nothing)
+struct ShadowPrep {
+    signed char* q8a;        // [Bpad][d]
+    signed char* q8b;
+    ShadowQ* sq;             // [Bpad]
+    uint32_t* slots;         // [Bpad][kShadowSlotWords]
+    uint32_t* ovf;           // [Bpad]
+    uint32_t* done;          // [Bpad] arrival counters of the gather's list merge
+    const uint32_t* xn_max;  // bits of max ||x||^2
+    float alpha;
+    // sample for the pre-bound (sample_stride == 0: none, the slots of the pre-epoch stay +inf)
+    const signed char* rows8;
+    const float* sscale;
+    const float* serr;
+    const float* xnorm;      // nullptr unless L2
+    int64_t sample_stride;   // in tiles: slice s, j-th tile = (s * kShadowSampleTiles + j) * sample_stride
+};
+
+#ifdef __HIPCC__
+struct ShadowTerms {         // what one wave derives from its query
+    float s1;
+    double n1, r1, n2, r2;   // ||q~||^2 and ||q - q~||^2 with one / both int8 terms
+};
+// One wave, one query: v[it] holds elements [4 lane + 256 it, +4) of the query as the rerank will use it (zero
+// past d).  Two int8 terms q ~ s1 (q1 + q2 / 128) - written to qa / qb (global or LDS) when non-null - and the
+// residual norms of both truncations (float64).
+__device__ __forceinline__ ShadowTerms shadow_terms_wave(int d, const f32x4 (&v)[6], int lane, signed char* qa,
+                                                         signed char* qb) {
+    float mx = 0.f;
+#pragma unroll
+    for (int it = 0; it < 6; ++it)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(v[it][e]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    ShadowTerms t;
+    t.s1 = mx > 0.f ? mx / 127.0f : 1.0f;
+    const float s1 = t.s1, s2 = s1 * (1.0f / 128.0f);          // exact (power of two)
+    double r2 = 0.0, n2 = 0.0, r1 = 0.0, n1 = 0.0;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < d) {
+            uint32_t wa = 0, wb = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = v[it][e];
+                const float a = fminf(fmaxf(rintf(x / s1), -127.f), 127.f);
+                const float rem = x - s1 * a;
+                const float bq = fminf(fmaxf(rintf(rem / s2), -127.f), 127.f);
+                wa |= ((uint32_t)(int)a & 0xFFu) << (8 * e);
+                wb |= ((uint32_t)(int)bq & 0xFFu) << (8 * e);
+                const double qt = (double)s1 * (double)a + (double)s2 * (double)bq;
+                const double df = (double)x - qt;
+                r2 = fma(df, df, r2);
+                n2 = fma(qt, qt, n2);
+                const double q1 = (double)s1 * (double)a, d1 = (double)x - q1;
+                r1 = fma(d1, d1, r1);
+                n1 = fma(q1, q1, n1);
+            }
+            if (qa) *reinterpret_cast<uint32_t*>(qa + c) = wa;
+            if (qb) *reinterpret_cast<uint32_t*>(qb + c) = wb;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        r2 += __shfl_xor(r2, o, 64);
+        n2 += __shfl_xor(n2, o, 64);
+        r1 += __shfl_xor(r1, o, 64);
+        n1 += __shfl_xor(n1, o, 64);
+    }
+    t.n1 = n1; t.r1 = r1; t.n2 = n2; t.r2 = r2;
+    return t;
+}
+// constants of eps_i = A e_i + C (every lane computes the same values)
+__device__ __forceinline__ ShadowQ shadow_consts(const ShadowTerms& t, float alpha, const uint32_t* xn_max) {
+    const double aa = fabs((double)alpha);
+    const double xn = (double)__uint_as_float(*xn_max) * (1.0 + 1e-6);
+    const double nx = sqrt(xn);
+    ShadowQ o;
+    o.kscale = alpha * t.s1;
+    // eps = A e_i + C;  C = query residual against the largest row + float32 roundings of key / eps
+    auto consts = [&](double nq, double rq, float& A, float& C) {
+        A = (float)(aa * nq * (1.0 + 1e-5)) + FLT_MIN;
+        C = (float)((aa * rq * nx + 1e-6 * (xn + 2.0 * aa * (nq + rq) * nx)) * (1.0 + 1e-5)) + FLT_MIN;
+    };
+    consts(sqrt(t.n2), sqrt(t.r2), o.A2, o.C2);
+    consts(sqrt(t.n1), sqrt(t.r1), o.A1, o.C1);
+    o.pad[0] = o.pad[1] = o.pad[2] = 0.f;
+    return o;
+}
+// The wave that owns query b in prep_queries_kernel (`real` false: a padding row - zeros, constants 0).
+__device__ __forceinline__ void shadow_prep_wave(const ShadowPrep& p, int b, int d, bool real, const f32x4 (&v)[6],
+                                                 int lane) {
+    // (the sample slots of the pre-epoch belong to the sampling waves)
+    for (int w = lane; w < kShadowEpochs * 32; w += 64) p.slots[(int64_t)b * kShadowSlotWords + w] = kSortablePosInf;
+    if (lane == 0) {
+        p.ovf[b] = 0u;
+        p.done[b] = 0u;
+    }
+    if (!real) {
+        for (int c = lane * 4; c < d; c += 256) {
+            *reinterpret_cast<uint32_t*>(p.q8a + (int64_t)b * d + c) = 0u;
+            *reinterpret_cast<uint32_t*>(p.q8b + (int64_t)b * d + c) = 0u;
+        }
+        if (lane == 0) p.sq[b] = ShadowQ{0.f, 0.f, 0.f, 0.f, 0.f, {0.f, 0.f, 0.f}};
+        return;
+    }
+    const ShadowTerms t = shadow_terms_wave(d, v, lane, p.q8a + (int64_t)b * d, p.q8b + (int64_t)b * d);
+    if (lane == 0) p.sq[b] = shadow_consts(t, p.alpha, p.xn_max);
+}
+// Pre-bound: slice `slice` of the sample - kShadowSampleTiles 32-row tiles of the shadow, spread over the shard -
+// scored against the FIRST int8 term of query b by this wave (v_dot4_i32_i8: exact integers, the scan's own
+// selection score), slot = min over the slice of key + a eps >= the exact key of that row.  The slices are
+// disjoint, so the k'-th smallest slot bounds the k'-th best exact key of the shard: the scan starts with a bound
+// near the 0.4 % quantile instead of +inf - no warm-up tiles to visit twice, no flood of early candidates.
+// q8_lds: 1024 bytes of this wave's LDS.
+__device__ __forceinline__ void shadow_prebound_wave(const ShadowPrep& p, int b, int d, bool real, int slice,
+                                                     const f32x4 (&v)[6], int lane, signed char* q8_lds) {
+    uint32_t* slot = p.slots + (int64_t)b * kShadowSlotWords + kShadowPreEpoch * 32 + slice;
+    if (!real || p.sample_stride == 0) {
+        if (lane == 0) *slot = kSortablePosInf;
+        return;
+    }
+    const ShadowTerms t = shadow_terms_wave(d, v, lane, q8_lds, nullptr);
+    const ShadowQ c = shadow_consts(t, p.alpha, p.xn_max);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int nch = d >> 7;
+    const int piece = lane & 7, rsub = lane >> 3;
+    float best = INFINITY;
+    for (int j = 0; j < kShadowSampleTiles; ++j) {
+        const int64_t tile = ((int64_t)slice * kShadowSampleTiles + j) * p.sample_stride;
+        const signed char* base = p.rows8 + tile * (32 * (int64_t)d) + lane * 16;
+        int acc[4] = {0, 0, 0, 0};
+        for (int ch = 0; ch < nch; ++ch) {
+            const i32x4 qv = *reinterpret_cast<const i32x4*>(q8_lds + ch * 128 + piece * 16);
+            i32x4 x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const i32x4*>(base + ch * 4096 + i * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) acc[i] = __builtin_amdgcn_sdot4(x[i][w], qv[w], acc[i], false);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) acc[i] += __shfl_xor(acc[i], o, 64);
+            const int64_t row = tile * 32 + 8 * i + rsub;       // (whole tiles below N only)
+            const float rs = p.sscale[row], re = p.serr[row], rx = p.xnorm ? p.xnorm[row] : 0.f;
+            const float mid = fmaf(c.kscale * rs, (float)acc[i], rx);
+            const float eps = fmaf(c.A1, re, c.C1);
+            best = fminf(best, mid + eps);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = fminf(best, __shfl_xor(best, o, 64));
+    if (lane == 0) *slot = sortable_u32(best);
+}
+#endif
+
 struct ShadowStore {
     const void* rows;        // the stored rows (exact scores come from these)
     int store_f32;
@@ -222,6 +401,7 @@ struct ShadowSearch {
     unsigned long long* part_key;   // [Bpad][shadow_split()][k]
     int* part_id;
     uint32_t* ovf;           // [Bpad]
+    uint32_t* done;          // [Bpad]
     CertArgs cert;           // flag list: queries whose candidate regions overflowed go to the exact scan
 };
 bool shadow_store_supported(int d);

@@ -35,6 +35,7 @@ namespace prag {
 
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
+
 // Timing experiments that give WRONG results (warm-up off, nothing collected, gather stages off) exist only
 // in the `make diag` build (libprag_diag.so, -DPRAG_MM_DIAG); in libprag.so the knob is the constant 0 and
 // the environment is never read.
@@ -136,81 +137,10 @@ __global__ __launch_bounds__(256) void shadow_build_kernel(const void* __restric
 }
 
 // ---------------------------------------------------------------------------
-// query terms + per-query constants (after prep_queries_kernel wrote q32 / qinfo)
+// query terms + per-query constants
 // ---------------------------------------------------------------------------
-struct ShadowQ {     // per query, consumed by the scan
-    float kscale;    // alpha * sq : key = xnorm_i + kscale * s_i * (acc1 + acc2 / 128)
-    float A2, C2;    // two query terms:  eps_i = A e_i + C,  A = |alpha| ||q~||, C = |alpha| rq max||x|| + rounding slack
-    float A1, C1;    // first term only (64-query tiles: the matrix pipe has no room for the second)
-    float pad[3];
-};
-
-__global__ __launch_bounds__(256) void shadow_prep_kernel(const float* __restrict__ q32, int B, int Bpad, int d,
-                                                         float alpha, const uint32_t* __restrict__ xn_max,
-                                                         signed char* __restrict__ q8a, signed char* __restrict__ q8b,
-                                                         ShadowQ* __restrict__ sq_out, uint32_t* __restrict__ slots,
-                                                         int slot_words, uint32_t* __restrict__ ovf) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= Bpad) return;
-    for (int w = lane; w < slot_words; w += 64) slots[(int64_t)b * slot_words + w] = kSortablePosInf;
-    if (lane == 0) ovf[b] = 0u;
-    if (b >= B) {
-        for (int c = lane; c < d; c += 64) {
-            q8a[(int64_t)b * d + c] = 0;
-            q8b[(int64_t)b * d + c] = 0;
-        }
-        if (lane == 0) sq_out[b] = ShadowQ{0.f, 0.f, 0.f, 0.f, 0.f, {0.f, 0.f, 0.f}};
-        return;
-    }
-    const float* q = q32 + (int64_t)b * d;
-    float mx = 0.f;
-    for (int c = lane; c < d; c += 64) mx = fmaxf(mx, fabsf(q[c]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    const float s1 = mx > 0.f ? mx / 127.0f : 1.0f;
-    const float s2 = s1 * (1.0f / 128.0f);          // exact (power of two)
-    double r2 = 0.0, n2 = 0.0, r1 = 0.0, n1 = 0.0;
-    for (int c = lane; c < d; c += 64) {
-        const float v = q[c];
-        float a = fminf(fmaxf(rintf(v / s1), -127.f), 127.f);
-        const float rem = v - s1 * a;
-        float bq = fminf(fmaxf(rintf(rem / s2), -127.f), 127.f);
-        q8a[(int64_t)b * d + c] = (signed char)(int)a;
-        q8b[(int64_t)b * d + c] = (signed char)(int)bq;
-        const double qt = (double)s1 * (double)a + (double)s2 * (double)bq;
-        const double df = (double)v - qt;
-        r2 = fma(df, df, r2);
-        n2 = fma(qt, qt, n2);
-        const double q1 = (double)s1 * (double)a, d1 = (double)v - q1;
-        r1 = fma(d1, d1, r1);
-        n1 = fma(q1, q1, n1);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        r2 += __shfl_xor(r2, o, 64);
-        n2 += __shfl_xor(n2, o, 64);
-        r1 += __shfl_xor(r1, o, 64);
-        n1 += __shfl_xor(n1, o, 64);
-    }
-    if (lane == 0) {
-        const double aa = fabs((double)alpha);
-        const double xn = (double)__uint_as_float(*xn_max) * (1.0 + 1e-6);
-        const double nx = sqrt(xn);
-        ShadowQ o;
-        o.kscale = alpha * s1;
-        // eps = A e_i + C;  C = query residual against the largest row + float32 roundings of key / eps
-        auto consts = [&](double nq, double rq, float& A, float& C) {
-            A = (float)(aa * nq * (1.0 + 1e-5)) + FLT_MIN;
-            C = (float)((aa * rq * nx + 1e-6 * (xn + 2.0 * aa * (nq + rq) * nx)) * (1.0 + 1e-5)) + FLT_MIN;
-        };
-        consts(sqrt(n2), sqrt(r2), o.A2, o.C2);
-        consts(sqrt(n1), sqrt(r1), o.A1, o.C1);
-        o.pad[0] = o.pad[1] = o.pad[2] = 0.f;
-        sq_out[b] = o;
-    }
-}
-
+// (ShadowQ and the quantisation itself live in flat_internal.h: prep_queries_kernel runs them for the wave that
+// has the query in registers - one launch instead of two)
 // ---------------------------------------------------------------------------
 // the scan
 // ---------------------------------------------------------------------------
@@ -228,26 +158,18 @@ struct Scan8Args {
     int n_tiles;                // ceil(N / 32)
     int use_norm;               // L2: key includes ||x||^2
     uint32_t* g_tau;            // [QT] chip-wide bound (sortable), +inf at start, -inf for padding
-    uint32_t* g_slot;           // [QT][kShadowEpochs][32]
+    uint32_t* g_slot;           // [QT][kShadowEpochs + 1][32]
     int2* cand;                 // [grid][QT][cap]  (row id, bits of key - a eps)
-    uint32_t* ccnt;             // [grid][QT]
+    uint32_t* ccnt;             // [grid][QT]   (> cap: the region overflowed, the query goes to the exact scan)
     int cap;
+
     int dbg;                    // timing experiments only (PRAG_SHADOW_DBG; results are WRONG): bit 0 no warm-up
                                 // (no second visits), bit 1 nothing is collected
 };
 
-constexpr int kShadowEpochs = 9;                    // bound slots refreshed after tiles 1, 2, 4, ..., 256
-constexpr int kShadowSlotWords = kShadowEpochs * 32;
-
-// staging buffers (4 KiB each, 16 VGPRs) of the compile-time-d scan: as many as the chunks of a row when the
-// register file allows (d = 768: 6 = 24 KiB per wave in flight), else half of them
-template <int QT, int KC, int NCHS>
-constexpr int kScan8Nld() {
-    if (QT == 64 && KC == 32) return NCHS == 6 ? 3 : 2;      // 64 list registers: less room
-    if (NCHS == 6) return 6;
-    if (NCHS == 8) return 4;
-    return NCHS <= 4 ? NCHS : NCHS / 2;
-}
+// (kShadowEpochs = 9 in flat_internal.h: bound slots refreshed after tiles 1, 2, 4, ..., 256; per query
+// kShadowEpochs + 1 rows of 32 words, the last one the sample slots written by prep_queries_kernel)
+constexpr int kShadowSlotRows = kShadowEpochs + 1;
 
 template <int KC>
 struct KeyList {   // sorted KC smallest keys (no ids: the lists only feed the bound)
@@ -269,13 +191,17 @@ struct KeyList {   // sorted KC smallest keys (no ids: the lists only feed the b
     }
 };
 
-// NCHS > 0: the row length is known at compile time (d = 128 NCHS) and the chunks of a tile are unrolled -
-// the metadata of a tile is requested NCHS staged chunks before its epilogue reads it and every staging
-// buffer is refilled at a fixed distance from its use, so the compiler keeps COUNTED vmcnt waits.  (With the
-// chunk index a run-time value - NCHS = 0, any d - it has to assume that a tile is one chunk long: it waited
-// for everything but the newest chunk in every epilogue and for vmcnt(0) at the head of every batch of NLD
-// chunks, i.e. the five chunks "in flight" were drained once per batch.)
-template <int QT, int KC, int NCHS = 0>
+// 64-query tiles run the FIRST int8 query term only (32-query tiles both).  Both terms at 64 queries were built
+// in round 3 (32 more accumulator registers -> three staging buffers instead of five): it paid on shards of a
+// few million rows while the scan opened with a warm-up (0.50 vs 0.58 ms per search at 2.6 M rows); with the
+// sampled pre-bound the single term wins at every size (2.6 M rows: 0.477 vs 0.535 ms, 21 M: 2.8 vs 3.6).
+//
+// Tried in round 3 and dropped (same box, alternating runs): the row length as a template parameter with the
+// chunks of a tile unrolled - six staging buffers refilled at a fixed distance, COUNTED vmcnt waits in every
+// chunk instead of this loop's drain at the head of every batch of NLD chunks (2.87 vs 2.80 ms at 21 M rows,
+// 0.468 vs 0.418 ms at 2.6 M), and the same with the whole next tile requested in one 24-KiB burst (2.88 ms).
+// The prefetch structure is not what limits this loop.
+template <int QT, int KC>
 __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NQ = QT / 32;
@@ -286,24 +212,60 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int d = NCHS > 0 ? NCHS * 128 : a.d;
+    const int d = a.d;
     const int NCH = d >> 7;                       // 128-byte chunks per row
     const int qstride = a.qstride;
     char* s_qa = smem;
-    char* s_qb = smem + QT * qstride;
-    char* s_st = smem + 2 * QT * qstride + w * 4096;
-    float* s_meta = reinterpret_cast<float*>(smem + 2 * QT * qstride + 8 * 4096) + w * 96;   // [3][32] per wave
-    uint32_t* s_tau = reinterpret_cast<uint32_t*>(smem + 2 * QT * qstride + 8 * 4096 + 8 * 384);
+    char* s_qb = smem + QT * qstride;           // (second term: 32-query tiles only)
+    const int planes_b = TERMS * QT * qstride;
+    char* s_st = smem + planes_b + w * 4096;
+    float* s_meta = reinterpret_cast<float*>(smem + planes_b + 8 * 4096) + w * 96;   // [3][32] per wave
+    uint32_t* s_tau = reinterpret_cast<uint32_t*>(smem + planes_b + 8 * 4096 + 8 * 384);
     uint32_t* s_best = s_tau + QT;
     uint32_t* s_ccnt = s_best + QT;
     uint32_t* s_slot_ok = s_ccnt + QT;     // set once a poll found every query's slot bound finite
-    uint32_t* s_arrive = s_slot_ok + 1;    // waves that have fed epoch 0
-    if (tid < QT) {
-        s_tau[tid] = a.g_tau[tid];
-        s_best[tid] = 0xFFFFFFFFu;
-        s_ccnt[tid] = 0u;
-    }
+    uint32_t* s_arrive = s_slot_ok + 1;    // waves that have fed epoch 0 (kShadowEpochs words)
+    uint32_t* s_pre = s_arrive + kShadowEpochs + 1;   // [QT] the sampled pre-bound of every query
     if (tid <= kShadowEpochs) s_slot_ok[tid] = 0u;   // the flag and the arrival counters behind it
+    // ---- the bound the search starts with: the KC-th smallest of the 32 sample slots prep_queries_kernel filled.
+    // The slices are disjoint row sets, so KC (>= k) rows have exact keys at or below it.  (The MAX over the slots
+    // is valid too but has a bad tail - one slice without a good row loosens the bound of that query - and a loose
+    // start floods the candidate regions of the first tiles: one query in a few searches overflowed a region.)
+    {
+        uint32_t* s_ps = reinterpret_cast<uint32_t*>(smem + planes_b);       // [QT][32] in the (still unused) stages
+        for (int i = tid; i < QT * 32; i += 512)
+            s_ps[i] = a.g_slot[((i >> 5) * kShadowSlotRows + kShadowPreEpoch) * 32 + (i & 31)];
+        __syncthreads();
+        if (tid < QT * 8) {                 // 8 threads per query, 4 slots each: rank by counting
+            const int q = tid >> 3;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = (tid & 7) * 4 + u;
+                const uint32_t v = s_ps[q * 32 + i];
+                int rank = 0;
+                for (int j = 0; j < 32; ++j) {
+                    const uint32_t x = s_ps[q * 32 + j];
+                    rank += (x < v || (x == v && j < i)) ? 1 : 0;
+                }
+                if (rank == KC - 1) s_pre[q] = v;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < 64) {      // wave 0
+        uint32_t t0 = kSortableNegInf;
+        bool missing = false;
+        if (tid < QT) {
+            t0 = a.g_tau[tid];
+            const uint32_t m = s_pre[tid];
+            missing = m == kSortablePosInf && t0 != kSortableNegInf;   // (padding queries do not count)
+            s_tau[tid] = m < t0 ? m : t0;
+            s_best[tid] = 0xFFFFFFFFu;
+            s_ccnt[tid] = 0u;
+        }
+        // every query has a finite bound: no warm-up (nothing to visit twice)
+        if (__builtin_amdgcn_ballot_w64(missing) == 0 && tid == 0) *s_slot_ok = 1u;
+    }
     // ---- query tiles -> LDS (swizzled 16-B pieces, as the fp16 scan) -----------------------------
     {
         const int ppr = d >> 4;
@@ -363,7 +325,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     // wave, 160 KiB per CU) - with the chunk-major row layout the fifth is worth 2-3 % at 64 queries (2.875 ->
     // 2.827 ms at 21 M rows, same box, alternating runs) and nothing at 32 or 1; with two the loop starved.
     // 64 queries x 32-deep lists have no registers beyond three.
-    constexpr int NLD = NCHS > 0 ? kScan8Nld<QT, KC, NCHS>() : (QT == 64 ? (KC == 32 ? 3 : 5) : 4);
+    constexpr int NLD = QT == 64 ? (KC == 32 ? 3 : 5) : 4;
     u32x4 ld[NLD][4];
     // wave-uniform tile base (scalar registers) + a per-lane 32-bit offset: no 64-bit vector address
     // arithmetic and no per-row clamp in the loop - the shadow is allocated in multiples of 256 rows, so
@@ -395,7 +357,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     // virtual tile sequence of this wave: its n_my tiles, then the first `redo` of them again
     constexpr int kWarmMax = 16;
     int redo = 0;
-    bool warm = !(PRAG_SH_DBG(a.dbg) & 1);
+    bool warm = !(PRAG_SH_DBG(a.dbg) & 1) && *s_slot_ok == 0u;   // (read after the barrier below the query tiles)
     auto vtile = [&](int vt) {
         int at = vt < n_my ? vt : vt - n_my;
         at = at < n_my ? at : n_my - 1;             // prefetch past the end: any valid tile
@@ -421,15 +383,12 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     auto chunk_step = [&](u32x4 (&ldr)[4], int c, int tile_nx, int c_nx) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(s_st + st_dst[i]) = ldr[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (staged by some lanes, read as fragments by others)
+        __builtin_amdgcn_wave_barrier();
         issue(ldr, tile_nx, c_nx);
-        // the refill stays HERE: left alone, the scheduler sinks the loads of all unrolled chunks to the end of
-        // the tile (one burst, waited for at once) and the prefetch distance is gone
-        if constexpr (NCHS > 0) __builtin_amdgcn_sched_barrier(0);
         // query-fragment slot of k-step piece P = 8 c + 2 s + hh in row qrow = 32 t + r:
         //   (P & ~15) | ((P ^ qrow) & 15)  =  (P & ~15) | (((8 c + 2 s) & 15) ^ xq),  xq = (r ^ hh) & 15
-        // recomputed per chunk from an opaque copy of xq - hoisted out of the loop these are 4 NCH registers
-        int xq = xq0;
-        if constexpr (NCHS > 0) asm volatile("" : "+v"(xq));
+        const int xq = xq0;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {               // 4 k-steps of 32 elements per 128-byte chunk
             const i32x4 av = *reinterpret_cast<const i32x4*>(s_st + a_off + (((2 * s + hh) ^ a_sw) << 4));
@@ -457,6 +416,10 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                 s_meta[32 + r] = m_e;
                 s_meta[64 + r] = m_x;
             }
+            // same-wave exchange through LDS: DS operations of a wave complete in order; the fence keeps the
+            // compiler from moving the reads above the stores
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             const int64_t doc0 = (int64_t)tile_cur * 32;
             float tau[NQ];
 #pragma unroll
@@ -479,6 +442,11 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                         if (!second) top[t].push(valid ? mid + eps : INFINITY, tau[t]);
                         const float lo = mid - eps;
                         if (collect && valid && lo <= tau[t]) {     // cannot be excluded: candidate
+                            // appended HERE, at each of the 32 sites.  Round 3 measured the alternatives on one
+                            // box (21 M rows, 64 queries): all candidates through a per-lane pending list in LDS
+                            // and one copy of the append code behind the unrolled part 2.90 ms vs 2.82; an else
+                            // branch at every site that sends what a full region cannot take to a per-workgroup
+                            // overflow pool 3.34 - 3.44 ms.  A region that overflows flags its query instead.
                             const uint32_t slot = atomicAdd(&s_ccnt[32 * t + r], 1u);
                             if (slot < (uint32_t)a.cap)
                                 a.cand[((int64_t)blockIdx.x * QT + 32 * t + r) * a.cap + slot] =
@@ -521,7 +489,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                         if ((int)old + 1 == n_active && lane < QT) {
                             const uint32_t v = s_best[lane];
                             if (v != 0xFFFFFFFFu)
-                                (void)__hip_atomic_fetch_min(a.g_slot + (lane * kShadowEpochs + 0) * 32 + (blockIdx.x % KC), v,
+                                (void)__hip_atomic_fetch_min(a.g_slot + (lane * kShadowSlotRows + 0) * 32 + (blockIdx.x % KC), v,
                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
@@ -535,7 +503,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                         const int epoch = 31 - __builtin_clz(tm);
                         const uint32_t v = s_best[lane];
                         if (v != 0xFFFFFFFFu)
-                            (void)__hip_atomic_fetch_min(a.g_slot + (lane * kShadowEpochs + epoch) * 32 + (blockIdx.x % KC), v,
+                            (void)__hip_atomic_fetch_min(a.g_slot + (lane * kShadowSlotRows + epoch) * 32 + (blockIdx.x % KC), v,
                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     // polls 2 and 3 tiles after an epoch was fed (epoch 0 also after 1), waves take turns
@@ -545,7 +513,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                         if (tp >= 1 && (tp & (tp - 1)) == 0 && tp <= (1 << (kShadowEpochs - 1)) && (i >= 0 || tp == 1)) {
                             const int epoch = 31 - __builtin_clz(tp);
                             if (w == ((2 * epoch + i + 5) & 7) && lane < QT) {
-                                const uint32_t* sl = a.g_slot + (lane * kShadowEpochs + epoch) * 32;
+                                const uint32_t* sl = a.g_slot + (lane * kShadowSlotRows + epoch) * 32;
                                 uint32_t m = 0u;
 #pragma unroll
                                 for (int s2 = 0; s2 < KC; ++s2) {
@@ -574,7 +542,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
             }
         }
     };
-    auto body = [&](u32x4 (&ldr)[4]) {    // run-time chunk index (NCHS == 0)
+    auto body = [&](u32x4 (&ldr)[4]) {
         const int tile_cur = vtile(vt_cur);
         if (c_cur == 0) load_meta(tile_cur);
         chunk_step(ldr, c_cur, vtile(vt_nx), c_nx);
@@ -583,28 +551,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
         advance(vt_cur, c_cur);
     };
 
-    if constexpr (NCHS > 0) {
-        if (n_my > 0) {
-            static_assert(NCHS % NLD == 0, "staging buffers rotate with the chunks of a tile");
-#pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                issue(ld[u], vtile(0), u);
-                __builtin_amdgcn_sched_barrier(0);   // in this order: the waits in the loop count on it
-            }
-            // (`redo` grows during the first tiles only, long before the loop bound is reached - or, on a
-            // shard of a few tiles, up to n_my: every tile is then visited twice)
-            for (int vt = 0; vt < n_my + redo; ++vt) {
-                const int tile_cur = vtile(vt), tile_next = vtile(vt + 1);
-                load_meta(tile_cur);         // NCHS refills older than its use in the epilogue
-#pragma unroll
-                for (int c = 0; c < NCHS; ++c) {
-                    const int cn = c + NLD;  // the chunk this buffer holds next
-                    chunk_step(ld[c % NLD], c, cn < NCHS ? tile_cur : tile_next, cn < NCHS ? cn : cn - NCHS);
-                }
-                epilogue(tile_cur, vt >= n_my);
-            }
-        }
-    } else if (n_my > 0) {
+    if (n_my > 0) {
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             issue(ld[u], vtile(vt_nx), c_nx);
@@ -695,6 +642,10 @@ struct GatherArgs {
     int k;
     unsigned long long* part_key;   // [B][kShSplit][k]
     int* part_id;
+    uint32_t* done;         // [B] slices of the query that have published their list (zeroed by prep_queries_kernel)
+    int64_t id_offset;
+    float* D;               // [B][k] results (written by the last slice of every query)
+    int64_t* I;
     uint32_t* ovf;          // [B] set when a region overflowed (or the id stage did)
     CertArgs cert;          // flag list for the exact fallback
     int dbg;                // timing experiments only (PRAG_SHADOW_DBG bits 32 / 64 / 128; results are WRONG)
@@ -819,42 +770,47 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
         }
     }
     if (!(PRAG_SH_DBG(a.dbg) & 64)) sh_cut(tk, a.k);
+    // ---- publish this slice's list; the LAST slice of the query ranks the kShSplit lists and writes D / I --------
+    // (one launch instead of gather + merge.  The lists cross XCDs - whose L2s are not coherent with each other -
+    // as relaxed device-scope atomics: written through, read around the local L2.  A release / acquire fence pair
+    // here would write back and invalidate the whole L2 of every one of the 1024 blocks: measured 524 -> 782 us
+    // per search in round 2.)
     const int64_t o = ((int64_t)b * kShSplit + blockIdx.x) * a.k;
     for (int j = tid; j < a.k; j += kShThreads) {
         const bool ok = j < tk.cnt;
-        a.part_key[o + j] = ok ? tk.key[j] : ~0ull;
-        a.part_id[o + j] = ok ? tk.id[j] : 0x7fffffff;
+        __hip_atomic_store(a.part_key + o + j, ok ? tk.key[j] : ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.part_id + o + j, ok ? tk.id[j] : 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-}
-
-// merge of the kShSplit partial lists of every query -> D / I   (k <= 32: one wave's worth of entries)
-__global__ __launch_bounds__(256) void shadow_merge_kernel(const unsigned long long* __restrict__ part_key,
-                                                          const int* __restrict__ part_id, int k, int metric_l2,
-                                                          int64_t id_offset, float* __restrict__ D,
-                                                          int64_t* __restrict__ I) {
-    __shared__ unsigned long long s_key[kShSplit * 32];
-    __shared__ int s_id[kShSplit * 32];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int n = kShSplit * k;
-    for (int i = tid; i < n; i += 256) {
-        s_key[i] = part_key[(int64_t)b * n + i];
-        s_id[i] = part_id[(int64_t)b * n + i];
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the stores above have reached the coherence point
+    __syncthreads();
+    if (tid == 0)
+        s_n = __hip_atomic_fetch_add(a.done + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)kShSplit - 1 ? 1 : 0;
+    __syncthreads();
+    if (!s_n) return;
+    // k <= 32: kShSplit * k <= 512 entries, ranked by counting
+    unsigned long long* m_key = tk.key;        // (the block's own list is published: its LDS is free)
+    int* m_id = tk.id;
+    const int n = kShSplit * a.k;
+    __syncthreads();
+    for (int i = tid; i < n; i += kShThreads) {
+        m_key[i] = __hip_atomic_load(a.part_key + (int64_t)b * n + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        m_id[i] = __hip_atomic_load(a.part_id + (int64_t)b * n + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-        const unsigned long long kv = s_key[i];
-        const int iv = s_id[i];
+    for (int i = tid; i < n; i += kShThreads) {
+        const unsigned long long kv = m_key[i];
+        const int iv = m_id[i];
         int rank = 0;
         for (int j = 0; j < n; ++j) {
-            const unsigned long long kj = s_key[j];
-            const int ij = s_id[j];
+            const unsigned long long kj = m_key[j];
+            const int ij = m_id[j];
             rank += (kj < kv) || (kj == kv && (ij < iv || (ij == iv && j < i)));
         }
-        if (rank < k) {
+        if (rank < a.k) {
             const bool ok = iv != 0x7fffffff;
-            const double sc = ok ? unsortable_f64(metric_l2 ? kv : ~kv) : 0.0;
-            D[(int64_t)b * k + rank] = ok ? (float)sc : (metric_l2 ? FLT_MAX : -FLT_MAX);
-            I[(int64_t)b * k + rank] = ok ? (int64_t)iv + id_offset : -1;
+            const double sc = ok ? unsortable_f64(a.metric_l2 ? kv : ~kv) : 0.0;
+            a.D[(int64_t)b * a.k + rank] = ok ? (float)sc : (a.metric_l2 ? FLT_MAX : -FLT_MAX);
+            a.I[(int64_t)b * a.k + rank] = ok ? (int64_t)iv + a.id_offset : -1;
         }
     }
 }
@@ -892,10 +848,16 @@ size_t shadow_slot_words() { return kShadowSlotWords; }
 size_t shadow_q_bytes() { return sizeof(ShadowQ); }
 int shadow_split() { return kShSplit; }
 
-template <int QT, int KC, int NCHS>
+// LDS of the scan: query planes (both terms for 32-query tiles), one 4-KiB stage and 384 B of row metadata per
+// wave, bounds / counters
+static int scan8_lds_bytes(int QT, int qstride) {
+    return (QT == 32 ? 2 : 1) * QT * qstride + 8 * 4096 + 8 * 384 + 4 * QT * 4 + 64;
+}
+
+template <int QT, int KC>
 static int launch_scan8(const Scan8Args& a, int grid, hipStream_t st, EventRing& prof) {
-    const int lds = 2 * QT * a.qstride + 8 * 4096 + 8 * 384 + 3 * QT * 4 + 64;   // (+ slot_ok, arrival words)
-    auto kern = scan8_kernel<QT, KC, NCHS>;
+    const int lds = scan8_lds_bytes(QT, a.qstride);
+    auto kern = scan8_kernel<QT, KC>;
     static LdsOptIn lds_opt_in;
     {
         const int rc_ = lds_opt_in.ensure(reinterpret_cast<const void*>(kern), 160 * 1024);
@@ -908,29 +870,17 @@ static int launch_scan8(const Scan8Args& a, int grid, hipStream_t st, EventRing&
     return PRAG_OK;
 }
 
-// d = 512 / 768 / 1024 take the compile-time-d loop; any other multiple of 128 the run-time one
-template <int QT, int KC>
-static int dispatch_scan8_d(const Scan8Args& a, int grid, hipStream_t st, EventRing& prof) {
-    switch (a.d) {
-        case 512: return launch_scan8<QT, KC, 4>(a, grid, st, prof);
-        case 768: return launch_scan8<QT, KC, 6>(a, grid, st, prof);
-        case 1024: return launch_scan8<QT, KC, 8>(a, grid, st, prof);
-        default: return launch_scan8<QT, KC, 0>(a, grid, st, prof);
-    }
-}
-
 int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
     const int qstride = (s.d + 255) / 256 * 256;
-    const bool wide = s.qt_max >= 64 && s.B > 32 && 2 * 64 * qstride + 8 * 4096 + 8 * 384 + 3 * 64 * 4 + 64 <= 160 * 1024;
+    const bool wide = s.qt_max >= 64 && s.B > 32 && scan8_lds_bytes(64, qstride) <= 160 * 1024;
     const int QT = wide ? 64 : 32;
     const int Bpad = (s.B + QT - 1) / QT * QT;
     PRAG_REQUIRE(Bpad <= s.Bpad_ws, PRAG_EUNSUPPORTED, "internal: shadow workspace too small");
     const int n_tiles = (int)((s.N + 31) / 32);
     const int grid = std::max(1, std::min(s.max_wg, (n_tiles + 7) / 8));
     PRAG_REQUIRE(grid <= s.wg_slots, PRAG_EUNSUPPORTED, "internal: shadow candidate regions too few");
-    hipLaunchKernelGGL(shadow_prep_kernel, dim3((Bpad + 3) / 4), dim3(256), 0, st, s.q32, s.B, Bpad, s.d, s.alpha, s.xn_max,
-                       s.q8a, s.q8b, reinterpret_cast<ShadowQ*>(s.sq), s.slots, (int)kShadowSlotWords, s.ovf);
-    PRAG_LAUNCH_CHECK();
+    PRAG_REQUIRE(grid <= 128 * kShSplit, PRAG_EUNSUPPORTED, "internal: more scan workgroups than the gather's slices hold");
+    // (query terms, per-query constants, bound slots and overflow words were written by prep_queries_kernel)
     for (int p0 = 0; p0 < Bpad; p0 += QT) {
         Scan8Args a;
         a.rows8 = s.store.rows8;
@@ -958,11 +908,11 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
 #endif
         int rc;
         if (QT == 64)
-            rc = s.kc == 8 ? dispatch_scan8_d<64, 8>(a, grid, st, prof)
-                           : s.kc == 16 ? dispatch_scan8_d<64, 16>(a, grid, st, prof) : dispatch_scan8_d<64, 32>(a, grid, st, prof);
+            rc = s.kc == 8 ? launch_scan8<64, 8>(a, grid, st, prof)
+                           : s.kc == 16 ? launch_scan8<64, 16>(a, grid, st, prof) : launch_scan8<64, 32>(a, grid, st, prof);
         else
-            rc = s.kc == 8 ? dispatch_scan8_d<32, 8>(a, grid, st, prof)
-                           : s.kc == 16 ? dispatch_scan8_d<32, 16>(a, grid, st, prof) : dispatch_scan8_d<32, 32>(a, grid, st, prof);
+            rc = s.kc == 8 ? launch_scan8<32, 8>(a, grid, st, prof)
+                           : s.kc == 16 ? launch_scan8<32, 16>(a, grid, st, prof) : launch_scan8<32, 32>(a, grid, st, prof);
         if (rc != PRAG_OK) return rc;
         const int nq = std::min(QT, s.B - p0);
         GatherArgs g;
@@ -980,6 +930,10 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         g.k = s.k;
         g.part_key = s.part_key;
         g.part_id = s.part_id;
+        g.done = s.done;
+        g.id_offset = s.id_offset;
+        g.D = s.D;
+        g.I = s.I;
         g.ovf = s.ovf;
         g.cert = s.cert;
         g.dbg = a.dbg;
@@ -989,9 +943,6 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
             hipLaunchKernelGGL(shadow_gather_kernel<false>, dim3(kShSplit, nq), dim3(kShThreads), 0, st, g);
         PRAG_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(shadow_merge_kernel, dim3(s.B), dim3(256), 0, st, s.part_key, s.part_id, s.k, s.metric_l2,
-                       s.id_offset, s.D, s.I);
-    PRAG_LAUNCH_CHECK();
     return PRAG_OK;
 }
 

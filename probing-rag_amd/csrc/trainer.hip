@@ -486,6 +486,9 @@ extern "C" int prag_trainer_step(prag_trainer_t* t, const float* x_dev, const in
     hipLaunchKernelGGL(tr_loss_kernel, dim3(1), dim3(256), 0, st, t->z, labels_dev, B, C, t->probs, t->dz, t->loss);
     if (loss_dev) PRAG_HIP(hipMemcpyAsync(loss_dev, t->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
     if (probs_dev) PRAG_HIP(hipMemcpyAsync(probs_dev, t->probs, (size_t)B * C * sizeof(float), hipMemcpyDeviceToDevice, st));
+    // eval mode (`probe.eval()`, train.py:299): the reference's validation pass is a forward only - no backward,
+    // no optimiser step, no scheduler step; a validation loop written against step() must not train on the dev set
+    if (!t->training) return PRAG_OK;
     // ---- backward (activations first: every weight is still the pre-step value) ----
     const size_t part_lds = 16 * 8 * 64 * sizeof(float);
     hipLaunchKernelGGL(tr_fc_backward_input_kernel, dim3(H / 64), dim3(1024), 8 * C * sizeof(float) + part_lds, st, t->dz,

@@ -66,7 +66,8 @@ class HipProberTrainer:
         return {k: torch.from_numpy(a) for k, a in zip(STATE_KEYS, arrs)}
 
     def train(self, mode: bool = True):
-        """``probe.train()`` / ``probe.eval()``: in eval mode the dropout of ``step`` is the identity."""
+        """``probe.train()`` / ``probe.eval()``: in eval mode the dropout of ``step`` is the identity and
+        ``step`` is forward-only."""
         self.training = bool(mode)
         _lib.check(_lib.lib().prag_trainer_set_training(self._h, 1 if mode else 0))
         return self
@@ -88,7 +89,9 @@ class HipProberTrainer:
 
     def step(self, x, labels):
         """One optimiser step on pooled states x [B,d_model] (cuda float32) and labels [B].
-        Returns (loss 0-d cuda tensor, probs [B,num_classes] cuda) of the forward pass."""
+        Returns (loss 0-d cuda tensor, probs [B,num_classes] cuda) of the forward pass.
+        In eval mode (``probe.eval()``, train.py:299) only the forward pass runs: no backward, no
+        AdamW / scheduler step - a validation loop cannot train on the dev set."""
         import torch
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
         if x.dim() != 2 or x.shape[1] != self.d_model:

@@ -146,6 +146,12 @@ def test_labels_are_validated_and_eval_mode_disables_dropout():
     want = np.exp(want - want.max(1, keepdims=True))
     want /= want.sum(1, keepdims=True)
     np.testing.assert_allclose(probs.cpu().numpy(), want, atol=2e-5, rtol=0)
+    # ... and it is a forward pass ONLY (the reference validates under `probe.eval()`, train.py:299): no
+    # optimiser / scheduler step, parameters bit-identical
+    assert tr.steps == 0 and tr.lr == pra.HipProberTrainer(d, 2, seed=5).lr
+    sd = tr.state_dict()
+    for k in onp.STATE_KEYS:
+        assert np.array_equal(sd[k].numpy(), np.asarray(st[k], np.float32)), k
     # back in train mode the masks are applied again (p = 0.1 changes the forward)
     tr2 = pra.HipProberTrainer(d, 2, seed=5).load_state_dict(st)
     _, p_train = tr2.train().step(x, labels)
