@@ -122,11 +122,11 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
     // against its query and writes one bound slot; everything else is the work of the y == 0 wave
     const bool sampler = blockIdx.y > 0;
     __shared__ __attribute__((aligned(16))) signed char s_q8[4][1024];
-    if (sampler && b >= B) {
-        const f32x4 zero[6] = {};
-        shadow_prebound_wave(sp, b, d, false, (int)blockIdx.y - 1, zero, lane, s_q8[threadIdx.x >> 6]);
+    if (sampler && (b >= B || sp.sample_stride == 0)) {
+        shadow_prebound_none(sp, b, (int)blockIdx.y - 1, lane);
         return;
     }
+    ShadowSample sm;
     if (!sampler) {
     // certificate bookkeeping: the flag list starts empty (or holds every query when the search goes
     // straight to the exact scan)
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
         r2 += __shfl_xor(r2, o, 64);
     }
     if (sampler) {
-        shadow_prebound_wave(sp, b, d, true, (int)blockIdx.y - 1, v, lane, s_q8[threadIdx.x >> 6]);
+        shadow_prebound_wave(sp, b, d, (int)blockIdx.y - 1, v, lane, s_q8[threadIdx.x >> 6], sm);
         return;
     }
     if (lane == 0) {
@@ -2044,8 +2044,15 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         sprep.xnorm = metric_l2 ? ix->xnorm : nullptr;
         const int64_t whole_tiles = ix->ntotal / 32;
         sprep.sample_stride = whole_tiles / (kShadowSampleSlices * kShadowSampleTiles);   // 0: shard too small
+        // The sampled bound is used for batches of <= 32 queries (kernel trace at 2.6 M rows: the sampling waves
+        // take the prep kernel from 7 to 19 us and the scan from 399 to 376 us; at 64 queries - one query term,
+        // twice the error band - the candidates of the loosely bounded first tiles cost the scan and the gather
+        // what the warm-up's second visits cost: prep +13 us, gather +6 us, scan +-0, and one query in a few
+        // searches overflowed a region).  PRAG_SHADOW_SAMPLE=0|1 forces it off / on for A/B runs (exact either way).
+        static const int sample_env = getenv("PRAG_SHADOW_SAMPLE") ? atoi(getenv("PRAG_SHADOW_SAMPLE")) : -1;
+        if (sample_env == 0 || (sample_env < 0 && B > 32)) sprep.sample_stride = 0;
     }
-    hipLaunchKernelGGL(prep_queries_kernel, dim3((Bpad + 3) / 4, use_shadow ? 1 + kShadowSampleSlices : 1), dim3(256), 0,
+    hipLaunchKernelGGL(prep_queries_kernel, dim3((Bpad + 3) / 4, sprep.sample_stride > 0 ? 1 + kShadowSampleSlices : 1), dim3(256), 0,
                        st, q_dev, B, Bpad, ix->d,
                        ix->metric == PRAG_METRIC_COS ? 1 : 0, ix->q32, ix->q16, ix->q16lo, ix->g_tau,
                        use_mm ? ix->mm_cnt : nullptr, ix->mm_ovf,

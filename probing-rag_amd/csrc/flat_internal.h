@@ -299,8 +299,9 @@ __device__ __forceinline__ ShadowQ shadow_consts(const ShadowTerms& t, float alp
 // The wave that owns query b in prep_queries_kernel (`real` false: a padding row - zeros, constants 0).
 __device__ __forceinline__ void shadow_prep_wave(const ShadowPrep& p, int b, int d, bool real, const f32x4 (&v)[6],
                                                  int lane) {
-    // (the sample slots of the pre-epoch belong to the sampling waves)
-    for (int w = lane; w < kShadowEpochs * 32; w += 64) p.slots[(int64_t)b * kShadowSlotWords + w] = kSortablePosInf;
+    // (the sample slots of the pre-epoch belong to the sampling waves - when there are any)
+    const int n_init = p.sample_stride > 0 ? kShadowEpochs * 32 : kShadowSlotWords;
+    for (int w = lane; w < n_init; w += 64) p.slots[(int64_t)b * kShadowSlotWords + w] = kSortablePosInf;
     if (lane == 0) {
         p.ovf[b] = 0u;
         p.done[b] = 0u;
@@ -322,43 +323,89 @@ __device__ __forceinline__ void shadow_prep_wave(const ShadowPrep& p, int b, int
 // disjoint, so the k'-th smallest slot bounds the k'-th best exact key of the shard: the scan starts with a bound
 // near the 0.4 % quantile instead of +inf - no warm-up tiles to visit twice, no flood of early candidates.
 // q8_lds: 1024 bytes of this wave's LDS.
-__device__ __forceinline__ void shadow_prebound_wave(const ShadowPrep& p, int b, int d, bool real, int slice,
-                                                     const f32x4 (&v)[6], int lane, signed char* q8_lds) {
-    uint32_t* slot = p.slots + (int64_t)b * kShadowSlotWords + kShadowPreEpoch * 32 + slice;
-    if (!real || p.sample_stride == 0) {
-        if (lane == 0) *slot = kSortablePosInf;
-        return;
+constexpr int kShadowSampleRing = 4;
+struct ShadowSample {        // what a sampling wave requests before it even looks at its query
+    i32x4 ring[kShadowSampleRing][4];
+    float rs[4], re[4], rx[4];     // scale, error bound, ||x||^2 of the tile being scored (4 rows per lane group)
+};
+__device__ __forceinline__ void shadow_sample_meta(const ShadowPrep& p, int slice, int j, int lane, ShadowSample& sm) {
+    const int jc = j < kShadowSampleTiles ? j : kShadowSampleTiles - 1;
+    const int64_t tile = ((int64_t)slice * kShadowSampleTiles + jc) * p.sample_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t row = tile * 32 + 8 * i + (lane >> 3);       // (whole tiles below N only)
+        sm.rs[i] = p.sscale[row];
+        sm.re[i] = p.serr[row];
+        sm.rx[i] = p.xnorm ? p.xnorm[row] : 0.f;
     }
+}
+__device__ __forceinline__ const signed char* shadow_sample_chunk(const ShadowPrep& p, int d, int slice, int lane, int sidx) {
+    const int nch = d >> 7, total = kShadowSampleTiles * nch;
+    const int sc = sidx < total ? sidx : total - 1;
+    const int j = sc / nch, ch = sc - j * nch;
+    const int64_t tile = ((int64_t)slice * kShadowSampleTiles + j) * p.sample_stride;
+    return p.rows8 + tile * (32 * (int64_t)d) + ch * 4096 + lane * 16;
+}
+// The sample tiles are cold (the scan of the previous search has been through every cache since) and scattered
+// over the shard: a ring of chunks is requested at once, right after the query has been quantised.  (Requesting
+// it BEFORE the float64 work on the query was tried: the ring's registers are then live across that work, the
+// kernel needs > 168 VGPRs or spills - and 64 queries x 33 waves only fit the chip in one round at 3 waves per SIMD.)
+__device__ __forceinline__ void shadow_sample_issue(const ShadowPrep& p, int d, int slice, int lane, ShadowSample& sm) {
+#pragma unroll
+    for (int u = 0; u < kShadowSampleRing; ++u) {
+        const signed char* src = shadow_sample_chunk(p, d, slice, lane, u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sm.ring[u][i] = *reinterpret_cast<const i32x4*>(src + i * 1024);
+    }
+    shadow_sample_meta(p, slice, 0, lane, sm);
+}
+__device__ __forceinline__ void shadow_prebound_none(const ShadowPrep& p, int b, int slice, int lane) {
+    if (lane == 0) p.slots[(int64_t)b * kShadowSlotWords + kShadowPreEpoch * 32 + slice] = kSortablePosInf;
+}
+__device__ __forceinline__ void shadow_prebound_wave(const ShadowPrep& p, int b, int d, int slice, const f32x4 (&v)[6],
+                                                     int lane, signed char* q8_lds, ShadowSample& sm) {
+    uint32_t* slot = p.slots + (int64_t)b * kShadowSlotWords + kShadowPreEpoch * 32 + slice;
     const ShadowTerms t = shadow_terms_wave(d, v, lane, q8_lds, nullptr);
     const ShadowQ c = shadow_consts(t, p.alpha, p.xn_max);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    shadow_sample_issue(p, d, slice, lane, sm);
     const int nch = d >> 7;
-    const int piece = lane & 7, rsub = lane >> 3;
+    const int piece = lane & 7;
     float best = INFINITY;
-    for (int j = 0; j < kShadowSampleTiles; ++j) {
-        const int64_t tile = ((int64_t)slice * kShadowSampleTiles + j) * p.sample_stride;
-        const signed char* base = p.rows8 + tile * (32 * (int64_t)d) + lane * 16;
-        int acc[4] = {0, 0, 0, 0};
-        for (int ch = 0; ch < nch; ++ch) {
-            const i32x4 qv = *reinterpret_cast<const i32x4*>(q8_lds + ch * 128 + piece * 16);
-            i32x4 x[4];
+    // the slice as one stream of 4-KiB chunks (tile-major, chunk-minor), a ring of them in flight
+    constexpr int kRing = kShadowSampleRing;
+    const int total = kShadowSampleTiles * nch;
+    int acc[4] = {0, 0, 0, 0};
+    int ch = 0, j = 0;
+    for (int s0 = 0; s0 < total; s0 += kRing) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const i32x4*>(base + ch * 4096 + i * 1024);
+        for (int u = 0; u < kRing; ++u) {
+            if (s0 + u < total) {
+                const i32x4 qv = *reinterpret_cast<const i32x4*>(q8_lds + ch * 128 + piece * 16);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int w = 0; w < 4; ++w) acc[i] = __builtin_amdgcn_sdot4(x[i][w], qv[w], acc[i], false);
-        }
+                    for (int w = 0; w < 4; ++w) acc[i] = __builtin_amdgcn_sdot4(sm.ring[u][i][w], qv[w], acc[i], false);
+                const signed char* src = shadow_sample_chunk(p, d, slice, lane, s0 + u + kRing);   // (clamped: a harmless re-read)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 4; ++i) sm.ring[u][i] = *reinterpret_cast<const i32x4*>(src + i * 1024);
+                if (++ch == nch) {       // tile finished: 8 lanes share a row
+                    ch = 0;
 #pragma unroll
-            for (int o = 1; o < 8; o <<= 1) acc[i] += __shfl_xor(acc[i], o, 64);
-            const int64_t row = tile * 32 + 8 * i + rsub;       // (whole tiles below N only)
-            const float rs = p.sscale[row], re = p.serr[row], rx = p.xnorm ? p.xnorm[row] : 0.f;
-            const float mid = fmaf(c.kscale * rs, (float)acc[i], rx);
-            const float eps = fmaf(c.A1, re, c.C1);
-            best = fminf(best, mid + eps);
+                    for (int i = 0; i < 4; ++i) {
+                        int a = acc[i];
+#pragma unroll
+                        for (int o = 1; o < 8; o <<= 1) a += __shfl_xor(a, o, 64);
+                        acc[i] = 0;
+                        const float mid = fmaf(c.kscale * sm.rs[i], (float)a, sm.rx[i]);
+                        const float eps = fmaf(c.A1, sm.re[i], c.C1);
+                        best = fminf(best, mid + eps);
+                    }
+                    ++j;
+                    shadow_sample_meta(p, slice, j, lane, sm);     // (of the next tile: nch chunks ahead of its use)
+                }
+            }
         }
     }
 #pragma unroll

@@ -669,23 +669,24 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
         tk.bound = ~0ull;
         tk.cnt = 0;
     }
-    for (int c = tid; c < d; c += kShThreads) s_q[c] = a.q32[(int64_t)b * d + c];
-    __syncthreads();
     // ---- stage this slice's candidate ids: only those the FINAL bound of the scan still admits -----
     // (rows were collected against the bound of their time; key - a eps > final bound >= k-th best exact
     // key means the row is provably not among the k best)
+    // One memory round trip brings the query, the final bound and the region counts of the slice, a second one
+    // every filled slot of every region (instead of a count -> entries chain per region).
     const float tau_final = unsortable_f32(a.g_tau[qi]);
     const int per = (a.n_wg + kShSplit - 1) / kShSplit;
     const int wg0 = blockIdx.x * per, wg1 = min(a.n_wg, wg0 + per);
-    // two dependent memory steps for the whole slice (region counts, then every filled slot at once)
-    // instead of a count -> entries chain per region
     const int nreg = wg1 - wg0;
+    bool over_l = false;
     for (int i = tid; i < nreg; i += kShThreads) {
         const uint32_t c = a.ccnt[(int64_t)(wg0 + i) * a.QT + qi];
-        if (c > (uint32_t)a.cap) s_over = 1;
+        over_l |= c > (uint32_t)a.cap;
         s_rc[i] = (int)min(c, (uint32_t)a.cap);
     }
+    for (int c = tid; c < d; c += kShThreads) s_q[c] = a.q32[(int64_t)b * d + c];
     __syncthreads();
+    if (over_l) s_over = 1;
     for (int base = 0; base < ((PRAG_SH_DBG(a.dbg) & 128) ? 0 : nreg * a.cap); base += 8 * kShThreads) {
         int2 ev[8];
 #pragma unroll
