@@ -28,6 +28,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   cpu_baseline  (1 GPU) BASELINE config 1 (128 states x 6 probers; 128 queries x 10k docs L2 top-5)
                 and the reference's batch-1 call shape, torch-cpu and the C restatement, on this
                 box's host cores
+`python bench.py --e2e [--gpus N]` times BASELINE config 5 instead (bench_e2e.py): the retrieve-decide loop around a
+Gemma-2B-shaped decoder, HIP path next to the reference's data path; its own JSON line, never the default.
 Other sizes are parity/diagnostic cases, e.g. BASELINE config 3:
   python bench.py --queries 1000 --docs 1000000      # MFMA-tiled scan, roofline.bound = "mfma"
 """
@@ -72,6 +74,16 @@ def parse(argv=None):
                          "n_cu-16 workgroups); 0: one stream; -1 (default): overlap only on shards below 8 M "
                          "rows, where the scan is short enough for the gate to matter (measured both ways)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
+    # BASELINE config 5 as a timed run (not part of the default line): see bench_e2e.py
+    ap.add_argument("--e2e", action="store_true",
+                    help="time the retrieve-decide loop around a Gemma-2B-shaped random-weight decoder: HIP path vs the "
+                         "reference's data path (hooks with .cpu(), eager probers, Python gate, CPU flat scan)")
+    ap.add_argument("--e2e-queries", type=int, default=64)
+    ap.add_argument("--e2e-new-tokens", type=int, default=16)
+    ap.add_argument("--e2e-prompt-len", type=int, default=64)
+    ap.add_argument("--e2e-theta", type=float, default=0.0)
+    ap.add_argument("--e2e-cpu-docs", type=int, default=200_000,
+                    help="rows of the sub-corpus the reference-style path scans on the CPU")
     return ap.parse_args(argv)
 
 
@@ -309,6 +321,17 @@ def main(argv=None):
 
     import probing_rag_amd as pra
     from probing_rag_amd.synth import random_prober_state, synth_rows
+
+    if args.e2e:
+        import bench_e2e
+        out = bench_e2e.run(args, pra, torch, dist, world, rank, dev_index)
+        if rank == 0:
+            out.update({"rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": backend,
+                        "rank_devices": rank_devices})
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     d_model, d_emb, L = D_MODEL, D_EMB, N_LAYERS
     # ---- corpus shard (generated on device by the counter-based generator of add_synthetic)
