@@ -1998,7 +1998,11 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         }
     }
     // ---- two-level search through the 8-bit shadow (HBM-bound batches on large shards) --------------
-    constexpr int kShadowCap = 128;
+    // candidates per (scan workgroup, query) region: 64 MB at 256 workgroups x 64 queries.  128 (round 2) sent
+    // every query of a corpus with contiguous clusters to the exact scan (104 ms per search against 1.1 ms for
+    // the direct scan: whole tiles of a loosely bounded query's look-alikes arrive at once); 512 holds them
+    // (0.77 ms) and costs nothing on the i.i.d. corpus (same box: 2.84 / 2.85 / 2.84 ms at 128 / 256 / 512)
+    constexpr int kShadowCap = 512;
     // (the shadow's eps constants read max ||x||^2 and its overflow path needs the exact scan: both exist
     // only with the certificate on - a diag build with PRAG_CERT=0 scans the rows directly)
     const bool use_shadow = certify && !exact_only && !use_mm && !use_qs && ix->ntotal > 0 && ix->rows8 != nullptr &&

@@ -297,7 +297,12 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     __syncthreads();
 
     const int nW = gridDim.x * 8;
-    const int gw = blockIdx.x * 8 + w;
+    // tile t belongs to workgroup t mod grid (wave (t / grid) mod 8): CONSECUTIVE tiles go to different
+    // workgroups, so a run of similar rows (a corpus in article order: 1024 contiguous near-duplicates are 32
+    // tiles) spreads over 32 candidate regions instead of filling the regions of 4 workgroups (measured on such
+    // a corpus with the wave-major map: all 64 queries overflowed into the exact scan, 104 ms per search
+    // against 1.1 ms for the direct scan)
+    const int gw = w * (int)gridDim.x + (int)blockIdx.x;
     const int n_my = gw < a.n_tiles ? (a.n_tiles - gw + nW - 1) / nW : 0;
 
     KeyList<KC> top[NQ];
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                         // pass the filter (2.6 M-row shard: scan 474 -> 412 us).  Doing the same for the
                         // later epochs, with a third poll each, made the whole scan 8 % SLOWER (3.12 ->
                         // 3.38 ms at 21 M rows; the extra in-loop polls, presumably their vmcnt(0)).
-                        const int n_active = min(8, max(0, a.n_tiles - (int)blockIdx.x * 8));
+                        const int n_active = min(8, max(0, (a.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x));   // waves of this workgroup that own a tile
                         uint32_t old = 0;
                         if (lane == 0) old = atomicAdd(s_arrive, 1u);
                         old = (uint32_t)__shfl((int)old, 0, 64);

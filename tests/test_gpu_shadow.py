@@ -138,3 +138,31 @@ def test_shadow_equals_the_direct_scan_on_clustered_rows(seed):
         D0, I0 = oracle_c.flat_search(_stored(X, metric, store), Q[:6], k, metric)
         _check(out[(2, 64)][0][:6], out[(2, 64)][1][:6], D0, I0, metric)
         ix.close()
+
+
+def test_contiguous_clusters_stay_on_the_two_level_path():
+    """A corpus in 'article order' - 1024 contiguous rows around each centre, cosine ~0.9 to it - with
+    queries next to centres: thousands of rows sit inside the shadow's error band, and a loosely bounded
+    query sees whole tiles of look-alikes at once.  Results must equal the direct scan bit for bit, and the
+    candidate regions must hold (round 2's 128-slot regions and wave-major tile map sent all 64 queries to
+    the exact float64 scan: 104 ms per search against 1.1 ms for the direct scan)."""
+    import torch
+    import probing_rag_amd as pra
+    d, n_rows, n_centres, sigma, B, k = 768, 1 << 20, 1024, 0.0175, 64, 10
+    g = torch.Generator(device="cuda").manual_seed(11)
+    centres = torch.nn.functional.normalize(torch.randn((n_centres, d), generator=g, device="cuda"), dim=1)
+    ix = pra.HipFlatIndex(d, "cos", "f16", capacity=n_rows)
+    for lo in range(0, n_rows, 1 << 18):
+        idx = (torch.arange(lo, lo + (1 << 18), device="cuda") * n_centres) // n_rows
+        ix.add(centres[idx] + sigma * torch.randn((1 << 18, d), generator=g, device="cuda"))
+    q = centres[torch.randint(0, n_centres, (B,), generator=g, device="cuda")] + \
+        0.5 * sigma * torch.randn((B, d), generator=g, device="cuda")
+    ix.set_shadow(0)
+    D0, I0 = ix.search(q, k)
+    ix.set_shadow(2)
+    ix.prepare()
+    for nq in (64, 32, 1):
+        D1, I1 = ix.search(q[:nq], k)
+        assert torch.equal(I1, I0[:nq]) and torch.allclose(D1, D0[:nq], rtol=1e-6, atol=0)
+        assert ix.last_exact_fallbacks() <= nq // 16
+    ix.close()
