@@ -208,6 +208,8 @@ def scan_model(B, k, store, metric, n_local, shadow):
     (+4 B of ||x||^2 per row for L2; the 8-bit shadow carries 8 B of scale and error bound per row)."""
     if B > 128:
         return "scan_mm_kernel", None, 1
+    if B > 64 and shadow and k <= 12 and n_local >= (1 << 20):     # one pass with 128-query tiles
+        return "scan8_kernel", n_local * (D_EMB + 8) + (n_local * 4 if metric == "l2" else 0), 1
     if B > 64 and store == "f16":
         return "scan_qs_kernel", n_local * D_EMB * 2 + (n_local * 4 if metric == "l2" else 0), 1 + (B - 1) // 128
     if shadow and k <= 26 and n_local >= (1 << 20):
@@ -564,7 +566,8 @@ def main(argv=None):
                     variant_record(torch, local, q, args.k, "f16", "cos", n_local, 0)
                 for B in (1, 32, 1000):
                     variants[f"f16_cos_k{args.k}_q{B}"] = variant_record(torch, local, qv[:B], args.k, "f16", "cos", n_local, 0)
-                for B in (1, 32):
+                variants[f"f16_cos_k{args.k}_q128"] = variant_record(torch, local, qv[:128], args.k, "f16", "cos", n_local, 0)
+                for B in (1, 32, 128):
                     variants[f"f16_cos_k{args.k}_q{B}_shadow"] = variant_record(torch, local, qv[:B], args.k, "f16", "cos", n_local, 1)
                 local.set_shadow(1 if args.shadow else 0)
             # the reference's literal call: IndexFlatL2 (float32 rows), one query, k = 5

@@ -1349,6 +1349,37 @@ static int ensure_capacity(prag_index* ix, int64_t want) {
     return PRAG_OK;
 }
 
+// Grow-only device workspaces.  Every buffer of a group is released and nulled, then all are allocated; if an
+// allocation fails the ones already made are released again.  The caller zeroes the group's capacity before
+// the call and sets it after success, so a failed search never leaves a freed pointer behind a non-zero
+// capacity, nor a half-allocated group.  (hipFree synchronises the device: growth is rare by design.)
+struct WsItem {
+    void** ptr;
+    size_t bytes;
+};
+static int ws_regrow(std::initializer_list<WsItem> items) {
+    for (const WsItem& it : items) {
+        if (*it.ptr) (void)hipFree(*it.ptr);
+        *it.ptr = nullptr;
+    }
+    for (const WsItem& it : items) {
+        const hipError_t e = hipMalloc(it.ptr, it.bytes);
+        if (e != hipSuccess) {
+            *it.ptr = nullptr;
+            for (const WsItem& j : items) {
+                if (*j.ptr) (void)hipFree(*j.ptr);
+                *j.ptr = nullptr;
+            }
+            (void)hipGetLastError();
+            set_error("prag_index: workspace of %zu bytes: %s", it.bytes, hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? PRAG_ENOMEM : PRAG_EHIP;
+        }
+    }
+    return PRAG_OK;
+}
+template <typename T>
+static void** vpp(T** p) { return reinterpret_cast<void**>(p); }
+
 // ---- 8-bit shadow maintenance ---------------------------------------------------------------------
 constexpr int64_t kShadowMinRows = 1 << 20;
 
@@ -1709,9 +1740,9 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
     if (ix->store == PRAG_F32) {
         // candidate selection runs on an fp16 copy of the rows (what the list kernels do on the fly)
         if (ix->rows16_cap < ix->cap) {
-            if (ix->rows16) (void)hipFree(ix->rows16);
-            ix->rows16 = nullptr; ix->rows16_cap = 0; ix->rows16_n = -1;
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->rows16), (size_t)ix->cap * ix->d * sizeof(_Float16)));
+            ix->rows16_cap = 0; ix->rows16_n = -1;
+            const int rc_ws = ws_regrow({{vpp(&ix->rows16), (size_t)ix->cap * ix->d * sizeof(_Float16)}});
+            if (rc_ws != PRAG_OK) return rc_ws;
             ix->rows16_cap = ix->cap;
         }
         if (ix->rows16_n != ix->ntotal) {
@@ -1773,11 +1804,9 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
     const int64_t part_stride = (int64_t)fb_grid * fq * kc;
     const size_t fb_need = (size_t)n_groups * part_stride;
     if (fb_need > ix->part_cap) {
-        if (ix->part_key) (void)hipFree(ix->part_key);
-        if (ix->part_idx) (void)hipFree(ix->part_idx);
-        ix->part_key = nullptr; ix->part_idx = nullptr; ix->part_cap = 0;
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->part_key), fb_need * sizeof(float)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->part_idx), fb_need * sizeof(int)));
+        ix->part_cap = 0;
+        const int rc_ws = ws_regrow({{vpp(&ix->part_key), fb_need * sizeof(float)}, {vpp(&ix->part_idx), fb_need * sizeof(int)}});
+        if (rc_ws != PRAG_OK) return rc_ws;
         ix->part_cap = fb_need;
     }
     ScanArgs a;
@@ -1856,31 +1885,27 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     // > 128 queries: the contraction bounds the search -> MFMA-tiled scan, 256 queries per tile
     const bool use_mm = !exact_only && ix->ntotal > 0 && mm_supported(ix->d, PRAG_F16, kc) &&
                         ((B > 128 && ix->mm_mode) || kc > 32);
-    const bool use_qs = !exact_only && !use_mm && B > 64 && qs_supported(ix->d, ix->store, kc);  // 128 queries per corpus pass
-    const int QT = use_mm ? 256 : use_qs ? 128 : ((B > 32 && wide_ok) ? 64 : 32);
+    // 65..128 queries: one pass over the 8-bit shadow with 128-query tiles when the index keeps one ...
+    const bool shadow128 = !exact_only && !use_mm && B > 64 && B <= 128 && ix->cert_mode != 0 && ix->ntotal > 0 &&
+                           ix->rows8 != nullptr && ix->shadow_rows == ix->ntotal && shadow_wanted(ix) &&
+                           shadow_supported(ix->d, kc, k, B) && shadow_tile128_ok(ix->d, kc);
+    // ... else the query-stationary kernel over the fp16 rows (128 queries per corpus pass)
+    const bool use_qs = !exact_only && !use_mm && !shadow128 && B > 64 && qs_supported(ix->d, ix->store, kc);
+    const int QT = use_mm ? 256 : (use_qs || shadow128) ? 128 : ((B > 32 && wide_ok) ? 64 : 32);
     // <= 32 queries (the reference's call shape): high-precision selection, if two query tiles fit LDS
     const bool use_hp = ix->hp_mode && QT == 32 && 2 * 32 * qstride + 8 * 4096 + 32 * 12 <= 160 * 1024;
     const int Bpad = (B + QT - 1) / QT * QT;
     if (Bpad > ix->q_cap) {
-        if (ix->q32) (void)hipFree(ix->q32);
-        if (ix->q16) (void)hipFree(ix->q16);
-        if (ix->q16lo) (void)hipFree(ix->q16lo);
-        if (ix->g_tau) (void)hipFree(ix->g_tau);
-        if (ix->g_slot) (void)hipFree(ix->g_slot);
-        ix->g_slot = nullptr;
-        if (ix->qinfo) (void)hipFree(ix->qinfo);
-        if (ix->qn2) (void)hipFree(ix->qn2);
-        if (ix->flag_list) (void)hipFree(ix->flag_list);
-        ix->q32 = nullptr; ix->q16 = nullptr; ix->q16lo = nullptr; ix->g_tau = nullptr; ix->q_cap = 0;
-        ix->qinfo = nullptr; ix->qn2 = nullptr; ix->flag_list = nullptr;
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->qinfo), (size_t)Bpad * 4 * sizeof(float)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->qn2), (size_t)Bpad * sizeof(double)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->flag_list), (size_t)Bpad * sizeof(int)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->q32), (size_t)Bpad * ix->d * sizeof(float)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->q16), (size_t)Bpad * ix->d * sizeof(_Float16)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->q16lo), (size_t)Bpad * ix->d * sizeof(_Float16)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->g_tau), (size_t)Bpad * sizeof(uint32_t)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->g_slot), (size_t)Bpad * kSlotWords * sizeof(uint32_t)));
+        ix->q_cap = 0;
+        const int rc_ws = ws_regrow({{vpp(&ix->qinfo), (size_t)Bpad * 4 * sizeof(float)},
+                                     {vpp(&ix->qn2), (size_t)Bpad * sizeof(double)},
+                                     {vpp(&ix->flag_list), (size_t)Bpad * sizeof(int)},
+                                     {vpp(&ix->q32), (size_t)Bpad * ix->d * sizeof(float)},
+                                     {vpp(&ix->q16), (size_t)Bpad * ix->d * sizeof(_Float16)},
+                                     {vpp(&ix->q16lo), (size_t)Bpad * ix->d * sizeof(_Float16)},
+                                     {vpp(&ix->g_tau), (size_t)Bpad * sizeof(uint32_t)},
+                                     {vpp(&ix->g_slot), (size_t)Bpad * kSlotWords * sizeof(uint32_t)}});
+        if (rc_ws != PRAG_OK) return rc_ws;
         ix->q_cap = Bpad;
     }
     const int n_tiles = (int)((ix->ntotal + 31) / 32);
@@ -1891,18 +1916,16 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     // (the pre-pass may use up to 64 workgroups; the tiled scan sizes its own fallback lists)
     const size_t part_need = use_mm ? 0 : (size_t)std::max(grid, 64) * QT * kc;
     if (part_need > ix->part_cap) {
-        if (ix->part_key) (void)hipFree(ix->part_key);
-        if (ix->part_idx) (void)hipFree(ix->part_idx);
-        ix->part_key = nullptr; ix->part_idx = nullptr; ix->part_cap = 0;
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->part_key), part_need * sizeof(float)));
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->part_idx), part_need * sizeof(int)));
+        ix->part_cap = 0;
+        const int rc_ws = ws_regrow({{vpp(&ix->part_key), part_need * sizeof(float)}, {vpp(&ix->part_idx), part_need * sizeof(int)}});
+        if (rc_ws != PRAG_OK) return rc_ws;
         ix->part_cap = part_need;
     }
     const size_t cand_need = (size_t)Bpad * kc;
     if (cand_need > ix->cand_cap) {
-        if (ix->cand) (void)hipFree(ix->cand);
-        ix->cand = nullptr; ix->cand_cap = 0;
-        PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->cand), cand_need * sizeof(int)));
+        ix->cand_cap = 0;
+        const int rc_ws = ws_regrow({{vpp(&ix->cand), cand_need * sizeof(int)}});
+        if (rc_ws != PRAG_OK) return rc_ws;
         ix->cand_cap = cand_need;
     }
 
@@ -1912,34 +1935,25 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     const int mm_chunk = kc > 32 ? 256 : std::min(Bpad, kMmMaxQueries);
     const int mm_cap_wg = kc > 32 ? 512 : kMmCapWg;
     if (use_mm) {
-        auto regrow = [&](void** ptr, size_t bytes) -> int {
-            if (*ptr) (void)hipFree(*ptr);
-            *ptr = nullptr;
-            PRAG_HIP(hipMalloc(ptr, bytes));
-            return PRAG_OK;
-        };
-        int rc_ws = PRAG_OK;
         if (Bpad > ix->mm_q_cap) {
             ix->mm_q_cap = 0;
-            rc_ws = regrow(reinterpret_cast<void**>(&ix->mm_cnt), (size_t)Bpad * sizeof(uint32_t));
-            if (rc_ws == PRAG_OK) rc_ws = regrow(reinterpret_cast<void**>(&ix->mm_ovf), ((size_t)Bpad + 1) * sizeof(uint32_t));
+            const int rc_ws = ws_regrow({{vpp(&ix->mm_cnt), (size_t)Bpad * sizeof(uint32_t)},
+                                         {vpp(&ix->mm_ovf), ((size_t)Bpad + 1) * sizeof(uint32_t)}});
             if (rc_ws != PRAG_OK) return rc_ws;
             ix->mm_q_cap = Bpad;
         }
         const size_t c_need = (size_t)std::max(mm_chunk, ix->n_cu) * std::max<size_t>(kMmCapQ, ix->n_cu);
         if ((size_t)mm_chunk * kMmCapQ > ix->mm_c_entries || (size_t)ix->n_cu * mm_chunk > ix->mm_c_entries) {
             ix->mm_c_entries = 0;
-            rc_ws = regrow(reinterpret_cast<void**>(&ix->mm_ckey), c_need * sizeof(float));
-            if (rc_ws == PRAG_OK) rc_ws = regrow(reinterpret_cast<void**>(&ix->mm_cidx), c_need * sizeof(int));
-            if (rc_ws == PRAG_OK) rc_ws = regrow(reinterpret_cast<void**>(&ix->mm_wcnt), c_need * sizeof(uint32_t));
+            const int rc_ws = ws_regrow({{vpp(&ix->mm_ckey), c_need * sizeof(float)}, {vpp(&ix->mm_cidx), c_need * sizeof(int)},
+                                         {vpp(&ix->mm_wcnt), c_need * sizeof(uint32_t)}});
             if (rc_ws != PRAG_OK) return rc_ws;
             ix->mm_c_entries = c_need;
         }
         const size_t w_need = (size_t)ix->n_cu * mm_chunk * mm_cap_wg;
         if (w_need > ix->mm_w_entries) {
             ix->mm_w_entries = 0;
-            rc_ws = regrow(reinterpret_cast<void**>(&ix->mm_wkey), w_need * sizeof(float));
-            if (rc_ws == PRAG_OK) rc_ws = regrow(reinterpret_cast<void**>(&ix->mm_widx), w_need * sizeof(int));
+            const int rc_ws = ws_regrow({{vpp(&ix->mm_wkey), w_need * sizeof(float)}, {vpp(&ix->mm_widx), w_need * sizeof(int)}});
             if (rc_ws != PRAG_OK) return rc_ws;
             ix->mm_w_entries = w_need;
         }
@@ -1954,17 +1968,15 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     if (certify && ix->ntotal > 0) {
         const size_t need = exact_part_entries(ex_fcap, ex_grid, k);
         if (need > ix->ex_entries) {
-            if (ix->ex_key) (void)hipFree(ix->ex_key);
-            if (ix->ex_id) (void)hipFree(ix->ex_id);
-            ix->ex_key = nullptr; ix->ex_id = nullptr; ix->ex_entries = 0;
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->ex_key), need * sizeof(unsigned long long)));
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->ex_id), need * sizeof(int)));
+            ix->ex_entries = 0;
+            const int rc_ws = ws_regrow({{vpp(&ix->ex_key), need * sizeof(unsigned long long)}, {vpp(&ix->ex_id), need * sizeof(int)}});
+            if (rc_ws != PRAG_OK) return rc_ws;
             ix->ex_entries = need;
         }
         if (ex_fcap > ix->ex_done_cap) {
-            if (ix->ex_done) (void)hipFree(ix->ex_done);
-            ix->ex_done = nullptr; ix->ex_done_cap = 0;
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->ex_done), (size_t)ex_fcap * sizeof(uint32_t)));
+            ix->ex_done_cap = 0;
+            const int rc_ws = ws_regrow({{vpp(&ix->ex_done), (size_t)ex_fcap * sizeof(uint32_t)}});
+            if (rc_ws != PRAG_OK) return rc_ws;
             PRAG_HIP(hipMemsetAsync(ix->ex_done, 0, (size_t)ex_fcap * sizeof(uint32_t), st));
             ix->ex_done_cap = ex_fcap;
         }
@@ -2011,26 +2023,24 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     if (use_shadow) {   // workspace of the two-level search; its query terms come out of prep_queries_kernel
         const int BpadS = (B + 63) / 64 * 64;
         if (BpadS > ix->sh_q_cap) {
-            for (void* p : {(void*)ix->sh_q8, ix->sh_sq, (void*)ix->sh_slots, (void*)ix->sh_ovf})
-                if (p) (void)hipFree(p);
-            ix->sh_q8 = nullptr; ix->sh_sq = nullptr; ix->sh_slots = nullptr; ix->sh_ovf = nullptr; ix->sh_q_cap = 0;
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_q8), (size_t)2 * BpadS * ix->d));
-            PRAG_HIP(hipMalloc(&ix->sh_sq, (size_t)BpadS * shadow_q_bytes()));
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_slots), (size_t)BpadS * shadow_slot_words() * sizeof(uint32_t)));
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_ovf), (size_t)2 * BpadS * sizeof(uint32_t)));   // + arrival counters
+            ix->sh_q_cap = 0;
+            const int rc_ws = ws_regrow({{vpp(&ix->sh_q8), (size_t)2 * BpadS * ix->d},
+                                         {&ix->sh_sq, (size_t)BpadS * shadow_q_bytes()},
+                                         {vpp(&ix->sh_slots), (size_t)BpadS * shadow_slot_words() * sizeof(uint32_t)},
+                                         {vpp(&ix->sh_ovf), (size_t)2 * BpadS * sizeof(uint32_t)}});   // + arrival counters
+            if (rc_ws != PRAG_OK) return rc_ws;
             ix->sh_q_cap = BpadS;
         }
-        if (!ix->sh_cand) {
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_cand), (size_t)ix->n_cu * 64 * kShadowCap * 2 * sizeof(int)));
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_ccnt), (size_t)ix->n_cu * 64 * sizeof(uint32_t)));
+        if (!ix->sh_cand || !ix->sh_ccnt) {
+            const int rc_ws = ws_regrow({{vpp(&ix->sh_cand), (size_t)ix->n_cu * 64 * kShadowCap * 2 * sizeof(int)},
+                                         {vpp(&ix->sh_ccnt), (size_t)ix->n_cu * 128 * sizeof(uint32_t)}});   // (128-query tiles)
+            if (rc_ws != PRAG_OK) return rc_ws;
         }
         const size_t pe = (size_t)BpadS * shadow_split() * k;
         if (pe > ix->sh_part_entries) {
-            if (ix->sh_pkey) (void)hipFree(ix->sh_pkey);
-            if (ix->sh_pid) (void)hipFree(ix->sh_pid);
-            ix->sh_pkey = nullptr; ix->sh_pid = nullptr; ix->sh_part_entries = 0;
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_pkey), pe * sizeof(unsigned long long)));
-            PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&ix->sh_pid), pe * sizeof(int)));
+            ix->sh_part_entries = 0;
+            const int rc_ws = ws_regrow({{vpp(&ix->sh_pkey), pe * sizeof(unsigned long long)}, {vpp(&ix->sh_pid), pe * sizeof(int)}});
+            if (rc_ws != PRAG_OK) return rc_ws;
             ix->sh_part_entries = pe;
         }
         sprep.q8a = ix->sh_q8;

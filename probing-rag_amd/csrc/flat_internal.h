@@ -432,7 +432,7 @@ struct ShadowSearch {
     const float* q32;        // [B][d] as the rerank uses them
     const uint32_t* xn_max;
     int B, Bpad_ws, k, kc;
-    int qt_max;              // query-tile height the caller padded for (32 or 64)
+    int qt_max;              // query-tile height the caller padded for (32, 64 or 128)
     int64_t id_offset;
     float* D;
     int64_t* I;
@@ -452,6 +452,7 @@ struct ShadowSearch {
     CertArgs cert;           // flag list: queries whose candidate regions overflowed go to the exact scan
 };
 bool shadow_store_supported(int d);
+bool shadow_tile128_ok(int d, int kc);
 bool shadow_supported(int d, int kc, int k, int B);
 size_t shadow_slot_words();
 size_t shadow_q_bytes();

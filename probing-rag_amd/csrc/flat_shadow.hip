@@ -36,6 +36,7 @@ namespace prag {
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 
+
 // Timing experiments that give WRONG results (warm-up off, nothing collected, gather stages off) exist only
 // in the `make diag` build (libprag_diag.so, -DPRAG_MM_DIAG); in libprag.so the knob is the constant 0 and
 // the environment is never read.
@@ -201,18 +202,25 @@ struct KeyList {   // sorted KC smallest keys (no ids: the lists only feed the b
 // chunk instead of this loop's drain at the head of every batch of NLD chunks (2.87 vs 2.80 ms at 21 M rows,
 // 0.468 vs 0.418 ms at 2.6 M), and the same with the whole next tile requested in one 24-KiB burst (2.88 ms).
 // The prefetch structure is not what limits this loop.
-template <int QT, int KC>
+// LISTS false: no per-lane lists - a lane keeps only the best key_hi it has seen per query (what the bound slots
+// are fed with) and the bound comes from the slot epochs alone.  128-query tiles need it (4 x 16 list registers
+// on top of 64 accumulator registers do not fit).
+// NCHS > 0 (128-query tiles, d = 128 NCHS): the chunks of a tile are unrolled with ONE copy of the epilogue behind
+// them instead of one per staging buffer - the only form in which four query columns per lane fit the register
+// file.  (For 64-query tiles this loop form measured 2-3 % slower than the run-time one, see above.)
+template <int QT, int KC, bool LISTS = true, int NCHS = 0>
 __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NQ = QT / 32;
     // 32-query tiles carry the query as two int8 terms (the HBM-bound loop has matrix-pipe slack for the
     // second MFMA); 64-query tiles use the first term only and pay with a wider eps (more candidates)
     constexpr int TERMS = QT == 32 ? 2 : 1;
+    static_assert(QT == 32 || QT == 64 || QT == 128, "query tile");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int d = a.d;
+    const int d = NCHS > 0 ? NCHS * 128 : a.d;
     const int NCH = d >> 7;                       // 128-byte chunks per row
     const int qstride = a.qstride;
     char* s_qa = smem;
@@ -226,6 +234,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     uint32_t* s_slot_ok = s_ccnt + QT;     // set once a poll found every query's slot bound finite
     uint32_t* s_arrive = s_slot_ok + 1;    // waves that have fed epoch 0 (kShadowEpochs words)
     uint32_t* s_pre = s_arrive + kShadowEpochs + 1;   // [QT] the sampled pre-bound of every query
+    float* s_sqc = reinterpret_cast<float*>(s_pre + QT + 5);   // [QT][3] kscale, A, C (128-query tiles only)
     if (tid <= kShadowEpochs) s_slot_ok[tid] = 0u;   // the flag and the arrival counters behind it
     // ---- the bound the search starts with: the KC-th smallest of the 32 sample slots prep_queries_kernel filled.
     // The slices are disjoint row sets, so KC (>= k) rows have exact keys at or below it.  (The MAX over the slots
@@ -236,11 +245,11 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
         for (int i = tid; i < QT * 32; i += 512)
             s_ps[i] = a.g_slot[((i >> 5) * kShadowSlotRows + kShadowPreEpoch) * 32 + (i & 31)];
         __syncthreads();
-        if (tid < QT * 8) {                 // 8 threads per query, 4 slots each: rank by counting
-            const int q = tid >> 3;
+        for (int tt = tid; tt < QT * 8; tt += 512) {   // 8 threads per query, 4 slots each: rank by counting
+            const int q = tt >> 3;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = (tid & 7) * 4 + u;
+                const int i = (tt & 7) * 4 + u;
                 const uint32_t v = s_ps[q * 32 + i];
                 int rank = 0;
                 for (int j = 0; j < 32; ++j) {
@@ -252,16 +261,23 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
         }
         __syncthreads();
     }
-    if (tid < 64) {      // wave 0
-        uint32_t t0 = kSortableNegInf;
-        bool missing = false;
+    if constexpr (QT == 128) {
         if (tid < QT) {
-            t0 = a.g_tau[tid];
-            const uint32_t m = s_pre[tid];
-            missing = m == kSortablePosInf && t0 != kSortableNegInf;   // (padding queries do not count)
-            s_tau[tid] = m < t0 ? m : t0;
-            s_best[tid] = 0xFFFFFFFFu;
-            s_ccnt[tid] = 0u;
+            const ShadowQ sq_ = a.sq[tid];
+            s_sqc[3 * tid] = sq_.kscale;
+            s_sqc[3 * tid + 1] = sq_.A1;
+            s_sqc[3 * tid + 2] = sq_.C1;
+        }
+    }
+    if (tid < 64) {      // wave 0 (QT / 64 queries per lane)
+        bool missing = false;
+        for (int qq = tid; qq < QT; qq += 64) {
+            const uint32_t t0 = a.g_tau[qq];
+            const uint32_t m = s_pre[qq];
+            missing |= m == kSortablePosInf && t0 != kSortableNegInf;   // (padding queries do not count)
+            s_tau[qq] = m < t0 ? m : t0;
+            s_best[qq] = 0xFFFFFFFFu;
+            s_ccnt[qq] = 0u;
         }
         // every query has a finite bound: no warm-up (nothing to visit twice)
         if (__builtin_amdgcn_ballot_w64(missing) == 0 && tid == 0) *s_slot_ok = 1u;
@@ -305,15 +321,17 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     const int gw = w * (int)gridDim.x + (int)blockIdx.x;
     const int n_my = gw < a.n_tiles ? (a.n_tiles - gw + nW - 1) / nW : 0;
 
-    KeyList<KC> top[NQ];
-    float kscale[NQ], cA[NQ], cC[NQ];
+    KeyList<LISTS ? KC : 1> top[NQ];    // (LISTS false: k[0] = the lane's best key)
+    float kscale[QT == 128 ? 1 : NQ], cA[QT == 128 ? 1 : NQ], cC[QT == 128 ? 1 : NQ];
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
         top[t].init();
-        const ShadowQ s = a.sq[32 * t + r];
-        kscale[t] = s.kscale;
-        cA[t] = TERMS == 2 ? s.A2 : s.A1;
-        cC[t] = TERMS == 2 ? s.C2 : s.C1;
+        if constexpr (QT != 128) {
+            const ShadowQ s = a.sq[32 * t + r];
+            kscale[t] = s.kscale;
+            cA[t] = TERMS == 2 ? s.A2 : s.A1;
+            cC[t] = TERMS == 2 ? s.C2 : s.C1;
+        }
     }
 
     // staging geometry: 4 x 16-B loads per lane per 128-byte chunk of 32 rows
@@ -330,7 +348,8 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     // wave, 160 KiB per CU) - with the chunk-major row layout the fifth is worth 2-3 % at 64 queries (2.875 ->
     // 2.827 ms at 21 M rows, same box, alternating runs) and nothing at 32 or 1; with two the loop starved.
     // 64 queries x 32-deep lists have no registers beyond three.
-    constexpr int NLD = QT == 64 ? (KC == 32 ? 3 : 5) : 4;
+    constexpr int NLD = NCHS > 0 ? 2 :   // (128-query tiles: three spill 13 registers and measured no faster: 3.85 vs 3.79 ms)
+                         QT == 64 ? (KC == 32 ? 3 : 5) : 4;
     u32x4 ld[NLD][4];
     // wave-uniform tile base (scalar registers) + a per-lane 32-bit offset: no 64-bit vector address
     // arithmetic and no per-row clamp in the loop - the shadow is allocated in multiples of 256 rows, so
@@ -393,7 +412,9 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
         issue(ldr, tile_nx, c_nx);
         // query-fragment slot of k-step piece P = 8 c + 2 s + hh in row qrow = 32 t + r:
         //   (P & ~15) | ((P ^ qrow) & 15)  =  (P & ~15) | (((8 c + 2 s) & 15) ^ xq),  xq = (r ^ hh) & 15
-        const int xq = xq0;
+        int xq = xq0;
+        // (unrolled chunks: hoisted out of the tile loop these offsets would be 4 NCHS registers)
+        if constexpr (NCHS > 0) asm volatile("" : "+v"(xq));
 #pragma unroll
         for (int s = 0; s < 4; ++s) {               // 4 k-steps of 32 elements per 128-byte chunk
             const i32x4 av = *reinterpret_cast<const i32x4*>(s_st + a_off + (((2 * s + hh) ^ a_sw) << 4));
@@ -426,46 +447,70 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int64_t doc0 = (int64_t)tile_cur * 32;
+            // one (row, query) pair: list / best-key update, filter, append
+            auto pair = [&](int t, int ge, int64_t doc, float rs_e, float re_e, float rx_e, float ks, float cA_t, float cC_t,
+                            float tau_t) {
+                const bool valid = doc < a.N;
+                float dq = (float)acc1[t][ge];
+                if constexpr (TERMS == 2) dq = fmaf((float)acc2[t][ge], 1.0f / 128.0f, dq);
+                const float mid = fmaf(ks * rs_e, dq, rx_e);
+                const float eps = fmaf(cA_t, re_e, cC_t);
+                if (!second) {
+                    if constexpr (LISTS) top[t].push(valid ? mid + eps : INFINITY, tau_t);
+                    else top[t].k[0] = fminf(top[t].k[0], valid ? mid + eps : INFINITY);
+                }
+                const float lo = mid - eps;
+                if (collect && valid && lo <= tau_t) {     // cannot be excluded: candidate
+                    // appended HERE, at each of the sites.  Round 3 measured the alternatives on one box (21 M
+                    // rows, 64 queries): all candidates through a per-lane pending list in LDS and one copy of
+                    // the append code behind the unrolled part 2.90 ms vs 2.82; an else branch at every site
+                    // that sends what a full region cannot take to a per-workgroup overflow pool 3.34 - 3.44 ms.
+                    // A region that overflows flags its query instead.
+                    const uint32_t slot = atomicAdd(&s_ccnt[32 * t + r], 1u);
+                    if (slot < (uint32_t)a.cap)
+                        a.cand[((int64_t)blockIdx.x * QT + 32 * t + r) * a.cap + slot] = int2{(int)doc, (int)__float_as_uint(lo)};
+                }
+                acc1[t][ge] = 0;
+                if constexpr (TERMS == 2) acc2[t][ge] = 0;
+            };
             float tau[NQ];
+            if constexpr (QT == 128) {
+                // query tile outermost, its constants read from LDS: with four query columns per lane the
+                // row-major order below keeps 16 constants and the row metadata live at once and spills
 #pragma unroll
-            for (int t = 0; t < NQ; ++t) tau[t] = unsortable_f32(s_tau[32 * t + r]);
+                for (int t = 0; t < NQ; ++t) {
+                    tau[t] = unsortable_f32(s_tau[32 * t + r]);
+                    const float ks = s_sqc[3 * (32 * t + r)], cA_t = s_sqc[3 * (32 * t + r) + 1], cC_t = s_sqc[3 * (32 * t + r) + 2];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 rs = *reinterpret_cast<const f32x4*>(s_meta + 8 * g + 4 * hh);
-                const f32x4 re = *reinterpret_cast<const f32x4*>(s_meta + 32 + 8 * g + 4 * hh);
-                const f32x4 rx = *reinterpret_cast<const f32x4*>(s_meta + 64 + 8 * g + 4 * hh);
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 rs = *reinterpret_cast<const f32x4*>(s_meta + 8 * g + 4 * hh);
+                        const f32x4 re = *reinterpret_cast<const f32x4*>(s_meta + 32 + 8 * g + 4 * hh);
+                        const f32x4 rx = *reinterpret_cast<const f32x4*>(s_meta + 64 + 8 * g + 4 * hh);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int64_t doc = doc0 + 8 * g + 4 * hh + e;
-                    const bool valid = doc < a.N;
-#pragma unroll
-                    for (int t = 0; t < NQ; ++t) {
-                        float dq = (float)acc1[t][4 * g + e];
-                        if constexpr (TERMS == 2) dq = fmaf((float)acc2[t][4 * g + e], 1.0f / 128.0f, dq);
-                        const float mid = fmaf(kscale[t] * rs[e], dq, rx[e]);
-                        const float eps = fmaf(cA[t], re[e], cC[t]);
-                        if (!second) top[t].push(valid ? mid + eps : INFINITY, tau[t]);
-                        const float lo = mid - eps;
-                        if (collect && valid && lo <= tau[t]) {     // cannot be excluded: candidate
-                            // appended HERE, at each of the 32 sites.  Round 3 measured the alternatives on one
-                            // box (21 M rows, 64 queries): all candidates through a per-lane pending list in LDS
-                            // and one copy of the append code behind the unrolled part 2.90 ms vs 2.82; an else
-                            // branch at every site that sends what a full region cannot take to a per-workgroup
-                            // overflow pool 3.34 - 3.44 ms.  A region that overflows flags its query instead.
-                            const uint32_t slot = atomicAdd(&s_ccnt[32 * t + r], 1u);
-                            if (slot < (uint32_t)a.cap)
-                                a.cand[((int64_t)blockIdx.x * QT + 32 * t + r) * a.cap + slot] =
-                                    int2{(int)doc, (int)__float_as_uint(lo)};
-                        }
-                        acc1[t][4 * g + e] = 0;
-                        if constexpr (TERMS == 2) acc2[t][4 * g + e] = 0;
+                        for (int e = 0; e < 4; ++e)
+                            pair(t, 4 * g + e, doc0 + 8 * g + 4 * hh + e, rs[e], re[e], rx[e], ks, cA_t, cC_t, tau[t]);
                     }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) tau[t] = unsortable_f32(s_tau[32 * t + r]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 rs = *reinterpret_cast<const f32x4*>(s_meta + 8 * g + 4 * hh);
+                    const f32x4 re = *reinterpret_cast<const f32x4*>(s_meta + 32 + 8 * g + 4 * hh);
+                    const f32x4 rx = *reinterpret_cast<const f32x4*>(s_meta + 64 + 8 * g + 4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int t = 0; t < NQ; ++t)
+                            pair(t, 4 * g + e, doc0 + 8 * g + 4 * hh + e, rs[e], re[e], rx[e], kscale[t], cA[t], cC[t], tau[t]);
                 }
             }
             if (!second) {
 #pragma unroll
                 for (int t = 0; t < NQ; ++t)
-                    if (top[t].k[KC - 1] < tau[t]) atomicMin(&s_tau[32 * t + r], sortable_u32(top[t].k[KC - 1]));
+                    if constexpr (LISTS)
+                        if (top[t].k[KC - 1] < tau[t]) atomicMin(&s_tau[32 * t + r], sortable_u32(top[t].k[KC - 1]));
                 ++tiles_done;
                 if (warm) {
                     ++redo;
@@ -491,11 +536,13 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                         uint32_t old = 0;
                         if (lane == 0) old = atomicAdd(s_arrive, 1u);
                         old = (uint32_t)__shfl((int)old, 0, 64);
-                        if ((int)old + 1 == n_active && lane < QT) {
-                            const uint32_t v = s_best[lane];
-                            if (v != 0xFFFFFFFFu)
-                                (void)__hip_atomic_fetch_min(a.g_slot + (lane * kShadowSlotRows + 0) * 32 + (blockIdx.x % KC), v,
-                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((int)old + 1 == n_active) {
+                            for (int qq = lane; qq < QT; qq += 64) {
+                                const uint32_t v = s_best[qq];
+                                if (v != 0xFFFFFFFFu)
+                                    (void)__hip_atomic_fetch_min(a.g_slot + (qq * kShadowSlotRows + 0) * 32 + (blockIdx.x % KC), v,
+                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                         }
                     }
                 }
@@ -504,12 +551,14 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                     // warm-up then ends on a weaker bound and the early tiles flood the candidate regions,
                     // 0.53 -> 0.57 ms on a 2.6 M-row shard - hence the last-arriver rule above)
                     const int tm = tiles_done - 1;          // published one tile after the lists fed s_best
-                    if (w == 0 && tm >= 1 && (tm & (tm - 1)) == 0 && tm <= (1 << (kShadowEpochs - 1)) && lane < QT) {
+                    if (w == 0 && tm >= 1 && (tm & (tm - 1)) == 0 && tm <= (1 << (kShadowEpochs - 1))) {
                         const int epoch = 31 - __builtin_clz(tm);
-                        const uint32_t v = s_best[lane];
-                        if (v != 0xFFFFFFFFu)
-                            (void)__hip_atomic_fetch_min(a.g_slot + (lane * kShadowSlotRows + epoch) * 32 + (blockIdx.x % KC), v,
-                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int qq = lane; qq < QT; qq += 64) {
+                            const uint32_t v = s_best[qq];
+                            if (v != 0xFFFFFFFFu)
+                                (void)__hip_atomic_fetch_min(a.g_slot + (qq * kShadowSlotRows + epoch) * 32 + (blockIdx.x % KC), v,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
                     // polls 2 and 3 tiles after an epoch was fed (epoch 0 also after 1), waves take turns
 #pragma unroll
@@ -517,17 +566,20 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                         const int tp = tiles_done - 2 - i;
                         if (tp >= 1 && (tp & (tp - 1)) == 0 && tp <= (1 << (kShadowEpochs - 1)) && (i >= 0 || tp == 1)) {
                             const int epoch = 31 - __builtin_clz(tp);
-                            if (w == ((2 * epoch + i + 5) & 7) && lane < QT) {
-                                const uint32_t* sl = a.g_slot + (lane * kShadowSlotRows + epoch) * 32;
-                                uint32_t m = 0u;
+                            if (w == ((2 * epoch + i + 5) & 7)) {
+                                bool missing = false;
+                                for (int qq = lane; qq < QT; qq += 64) {
+                                    const uint32_t* sl = a.g_slot + (qq * kShadowSlotRows + epoch) * 32;
+                                    uint32_t m = 0u;
 #pragma unroll
-                                for (int s2 = 0; s2 < KC; ++s2) {
-                                    const uint32_t v = __hip_atomic_load(sl + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    m = v > m ? v : m;
+                                    for (int s2 = 0; s2 < KC; ++s2) {
+                                        const uint32_t v = __hip_atomic_load(sl + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        m = v > m ? v : m;
+                                    }
+                                    if (m < s_tau[qq]) atomicMin(&s_tau[qq], m);
+                                    // padding queries (bound -inf) never get slot values: they do not count
+                                    missing |= m == kSortablePosInf && s_tau[qq] != kSortableNegInf;
                                 }
-                                if (m < s_tau[lane]) atomicMin(&s_tau[lane], m);
-                                // padding queries (bound -inf) never get slot values: they do not count
-                                const bool missing = m == kSortablePosInf && s_tau[lane] != kSortableNegInf;
                                 if (__builtin_amdgcn_ballot_w64(missing) == 0 && lane == 0) *s_slot_ok = 1u;
                             }
                         }
@@ -556,7 +608,27 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
         advance(vt_cur, c_cur);
     };
 
-    if (n_my > 0) {
+    if constexpr (NCHS > 0) {
+        static_assert(NCHS == 0 || NCHS % NLD == 0, "staging buffers rotate with the chunks of a tile");
+        if (n_my > 0) {
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                issue(ld[u], vtile(0), u);
+                __builtin_amdgcn_sched_barrier(0);   // in this order: the counted waits in the loop rely on it
+            }
+            for (int vt = 0; vt < n_my + redo; ++vt) {
+                const int tile_cur = vtile(vt), tile_next = vtile(vt + 1);
+                load_meta(tile_cur);         // NCHS refills older than its use in the epilogue
+#pragma unroll
+                for (int c = 0; c < NCHS; ++c) {
+                    const int cn = c + NLD;  // the chunk this buffer holds next
+                    chunk_step(ld[c % NLD], c, cn < NCHS ? tile_cur : tile_next, cn < NCHS ? cn : cn - NCHS);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                epilogue(tile_cur, vt >= n_my);
+            }
+        }
+    } else if (n_my > 0) {
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             issue(ld[u], vtile(vt_nx), c_nx);
@@ -824,7 +896,17 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+// LDS of the scan: query planes (both terms for 32-query tiles), one 4-KiB stage and 384 B of row metadata per
+// wave, bounds / counters
+static int scan8_lds_bytes(int QT, int qstride) {
+    return (QT == 32 ? 2 : 1) * QT * qstride + 8 * 4096 + 8 * 384 + 4 * QT * 4 + 64 + (QT == 128 ? 3 * QT * 4 + 64 : 0);
+}
+
 bool shadow_store_supported(int d) { return d % 128 == 0 && d <= 1024; }
+// 128-query tiles: the query plane (one int8 term) + stages must fit LDS; lists up to 16 deep
+bool shadow_tile128_ok(int d, int kc) {
+    return (d == 768 || d == 512) && kc <= 16 && scan8_lds_bytes(128, (d + 255) / 256 * 256) <= 160 * 1024;
+}
 bool shadow_supported(int d, int kc, int k, int B) {
     return shadow_store_supported(d) && (kc == 8 || kc == 16 || kc == 32) && k <= 32 && B >= 1;
 }
@@ -854,16 +936,10 @@ size_t shadow_slot_words() { return kShadowSlotWords; }
 size_t shadow_q_bytes() { return sizeof(ShadowQ); }
 int shadow_split() { return kShSplit; }
 
-// LDS of the scan: query planes (both terms for 32-query tiles), one 4-KiB stage and 384 B of row metadata per
-// wave, bounds / counters
-static int scan8_lds_bytes(int QT, int qstride) {
-    return (QT == 32 ? 2 : 1) * QT * qstride + 8 * 4096 + 8 * 384 + 4 * QT * 4 + 64;
-}
-
-template <int QT, int KC>
+template <int QT, int KC, bool LISTS = true, int NCHS = 0>
 static int launch_scan8(const Scan8Args& a, int grid, hipStream_t st, EventRing& prof) {
     const int lds = scan8_lds_bytes(QT, a.qstride);
-    auto kern = scan8_kernel<QT, KC>;
+    auto kern = scan8_kernel<QT, KC, LISTS, NCHS>;
     static LdsOptIn lds_opt_in;
     {
         const int rc_ = lds_opt_in.ensure(reinterpret_cast<const void*>(kern), 160 * 1024);
@@ -879,7 +955,11 @@ static int launch_scan8(const Scan8Args& a, int grid, hipStream_t st, EventRing&
 int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
     const int qstride = (s.d + 255) / 256 * 256;
     const bool wide = s.qt_max >= 64 && s.B > 32 && scan8_lds_bytes(64, qstride) <= 160 * 1024;
-    const int QT = wide ? 64 : 32;
+    // 65..128 queries in ONE pass over the shadow (128-query tiles, list-less, lists up to 16 deep)
+    const bool wide128 = s.qt_max >= 128 && s.B > 64 && shadow_tile128_ok(s.d, s.kc);
+    const int QT = wide128 ? 128 : wide ? 64 : 32;
+    // the candidate store is sized for 64 queries x s.cap slots per workgroup: 128-query tiles get half the slots
+    const int cap = QT == 128 ? s.cap / 2 : s.cap;
     const int Bpad = (s.B + QT - 1) / QT * QT;
     PRAG_REQUIRE(Bpad <= s.Bpad_ws, PRAG_EUNSUPPORTED, "internal: shadow workspace too small");
     const int n_tiles = (int)((s.N + 31) / 32);
@@ -905,7 +985,7 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         a.g_slot = s.slots + (size_t)p0 * kShadowSlotWords;
         a.cand = reinterpret_cast<int2*>(s.cand);
         a.ccnt = s.ccnt;
-        a.cap = s.cap;
+        a.cap = cap;
 #ifdef PRAG_MM_DIAG
         static const int dbg_env = getenv("PRAG_SHADOW_DBG") ? atoi(getenv("PRAG_SHADOW_DBG")) : 0;
         a.dbg = dbg_env;
@@ -913,7 +993,12 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         a.dbg = 0;
 #endif
         int rc;
-        if (QT == 64)
+        if (QT == 128)
+            rc = s.d == 768 ? (s.kc == 8 ? launch_scan8<128, 8, false, 6>(a, grid, st, prof)
+                                         : launch_scan8<128, 16, false, 6>(a, grid, st, prof))
+                            : (s.kc == 8 ? launch_scan8<128, 8, false, 4>(a, grid, st, prof)
+                                         : launch_scan8<128, 16, false, 4>(a, grid, st, prof));
+        else if (QT == 64)
             rc = s.kc == 8 ? launch_scan8<64, 8>(a, grid, st, prof)
                            : s.kc == 16 ? launch_scan8<64, 16>(a, grid, st, prof) : launch_scan8<64, 32>(a, grid, st, prof);
         else
@@ -931,7 +1016,7 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         g.g_tau = s.g_tau + p0;
         g.n_wg = grid;
         g.QT = QT;
-        g.cap = s.cap;
+        g.cap = cap;
         g.q0 = p0;
         g.k = s.k;
         g.part_key = s.part_key;

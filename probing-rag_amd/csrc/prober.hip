@@ -1102,6 +1102,7 @@ struct prag_prober {
     _Float16* ws_h = nullptr;  // [L][maxB][d] hi / lo workspace for fp32 activations
     _Float16* ws_l = nullptr;
     int64_t ws_rows = 0;
+    int n_cu = 256;            // compute units of the device the handle lives on (tile-height choice)
     EventRing prof;
 };
 
@@ -1208,6 +1209,13 @@ extern "C" int prag_prober_create(prag_prober_t** out, int n_layers, int d_model
     p->allocs.resize(n_layers);
     p->h_small.resize(n_layers);
     if (const char* ev = getenv("PRAG_PROBER_SMALL")) p->small_mode = atoi(ev);
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            prop.multiProcessorCount > 0)
+            p->n_cu = prop.multiProcessorCount;
+    }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_layers), sizeof(LayerDev) * n_layers);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_small), sizeof(SmallLayer) * n_layers);
     if (e == hipSuccess)
@@ -1425,10 +1433,10 @@ static int launch_fused(const ProberArgs& a, int n_run, hipStream_t st, EventRin
     return PRAG_OK;
 }
 
-static int pick_ct(int B, int n_run, int max_ct) {
+static int pick_ct(int B, int n_run, int max_ct, int n_cu) {
     // smallest tile that still fills the chip: more workgroups pull weights in parallel
     int ct = 1;
-    while (ct < max_ct && (int64_t)((B + 32 * ct - 1) / (32 * ct)) * n_run > 256) ct *= 2;
+    while (ct < max_ct && (int64_t)((B + 32 * ct - 1) / (32 * ct)) * n_run > n_cu) ct *= 2;
     return ct;
 }
 
@@ -1514,7 +1522,7 @@ static int forward_impl(prag_prober_t* p, const void* x_dev, int x_dtype, int64_
         nb = 2;
     }
     const int max_ct = (p->na == 1 && nb == 1) ? 4 : 2;
-    int ct = pick_ct(B, n_run, max_ct);
+    int ct = pick_ct(B, n_run, max_ct, p->n_cu);
     static const int ct_force = getenv("PRAG_PROBER_CT") ? atoi(getenv("PRAG_PROBER_CT")) : 0;  // tuning knob
     if (ct_force == 1 || ct_force == 2 || (ct_force == 4 && max_ct >= 4)) ct = ct_force;
 #define PRAG_DISPATCH(NA_, NB_)                                                      \

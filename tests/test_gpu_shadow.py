@@ -166,3 +166,34 @@ def test_contiguous_clusters_stay_on_the_two_level_path():
         assert torch.equal(I1, I0[:nq]) and torch.allclose(D1, D0[:nq], rtol=1e-6, atol=0)
         assert ix.last_exact_fallbacks() <= nq // 16
     ix.close()
+
+
+@pytest.mark.parametrize("store", ["f16", "f32"])
+@pytest.mark.parametrize("metric", METRICS)
+@pytest.mark.parametrize("N,B,k,d", [(40_000, 128, 10, 768), (9_001, 65, 5, 768), (20_000, 100, 12, 512),
+                                     (300, 77, 10, 768)])
+def test_128_query_tiles_match_definition(metric, store, N, B, k, d):
+    """65..128 queries take ONE pass over the shadow with 128-query tiles (list-less scan8, bound from the
+    slot epochs alone): results are the float64 definition's bit for bit, duplicates and planted rows included."""
+    import probing_rag_amd as pra
+    X = onp.synth_rows(42, 0, N, d)
+    X[N // 2] = X[3]
+    X[N - 1] = X[3]
+    Q = onp.synth_rows(7, 0, B, d)
+    Q[0] = X[3]
+    Q[B - 1] = X[N // 3] + np.float32(0.01) * Q[B - 1]
+    ix = pra.HipFlatIndex(d, metric, store)
+    ix.set_shadow(2)
+    ix.add(X)
+    D, I = ix.search(Q, k)
+    D0, I0 = oracle_c.flat_search(_stored(X, metric, store), Q, k, metric)
+    _check(D, I, D0, I0, metric)
+    # the same queries through 64-query tiles (two passes) and directly over the stored rows: identical
+    import torch
+    qd = torch.from_numpy(Q).cuda()
+    Da, Ia = ix.search(qd[:64], k)
+    assert np.array_equal(Ia.cpu().numpy(), I[:64])
+    ix.set_shadow(0)
+    Db, Ib = ix.search(qd, k)
+    assert np.array_equal(Ib.cpu().numpy(), I)
+    ix.close()
