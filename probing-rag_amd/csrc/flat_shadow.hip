@@ -204,7 +204,8 @@ struct KeyList {   // sorted KC smallest keys (no ids: the lists only feed the b
 // The prefetch structure is not what limits this loop.
 // LISTS false: no per-lane lists - a lane keeps only the best key_hi it has seen per query (what the bound slots
 // are fed with) and the bound comes from the slot epochs alone.  128-query tiles need it (4 x 16 list registers
-// on top of 64 accumulator registers do not fit).
+// on top of 64 accumulator registers do not fit); at 64 queries it was measured and is no faster (21 M rows:
+// 2.82 - 2.89 vs 2.81 - 2.85 ms; 2.6 M rows: 0.449 - 0.460 vs 0.425 - 0.441).
 // NCHS > 0 (128-query tiles, d = 128 NCHS): the chunks of a tile are unrolled with ONE copy of the epilogue behind
 // them instead of one per staging buffer - the only form in which four query columns per lane fit the register
 // file.  (For 64-query tiles this loop form measured 2-3 % slower than the run-time one, see above.)
