@@ -246,6 +246,12 @@ __global__ __launch_bounds__(kExThreads) void exact_scan_kernel(ExactArgs a) {
     }
 }
 
+
+// Tried in round 3 and dropped: a batched form that takes up to 8 flagged queries through one pass over the rows
+// (rows loaded once per step, queries in LDS, one threshold list per query).  The scan is bound by float64 issue,
+// not by HBM (8 M x 640 fp16 rows: 2.6 ms per query = 3.9 TB/s): four flagged queries cost 10.2 ms batched against
+// 10.4 ms one by one, and ONE flagged query - the common case - 6.1 ms instead of 2.6 (74 KB of LDS leave one
+// workgroup per CU).
 size_t exact_part_entries(int f_cap, int grid, int k) { return (size_t)f_cap * grid * k; }
 
 int exact_run(const ExactRun& r, hipStream_t st) {

@@ -425,6 +425,31 @@ def test_large_k_on_dimensions_outside_the_tiled_scan(d, store, metric):
     assert ix.last_exact_fallbacks() == B
 
 
+@pytest.mark.parametrize("store,metric,k", [("f16", onp.METRIC_L2, 100), ("f32", onp.METRIC_COS, 128), ("f32", onp.METRIC_IP, 40),
+                                            ("f16", onp.METRIC_IP, 129)])
+def test_exact_scan_serves_many_flagged_queries(store, metric, k):
+    """21 queries straight to the exact float64 scan (list merge folded into the scan's last workgroup),
+    duplicates of one row asked for by three of them: results the definition's for every query."""
+    import probing_rag_amd as pra
+    N, d, B = 7000, 640, 21                       # d = 640 with k > 26: straight to the exact scan
+    X = onp.synth_rows(91, 0, N, d)
+    X[N - 1] = X[17]
+    X[N // 2] = X[17]
+    Q = onp.synth_rows(92, 0, B, d)
+    Q[0] = X[17]
+    Q[8] = X[17]
+    Q[20] = X[N // 2] * np.float32(1.0)
+    ix = pra.HipFlatIndex(d, metric, store)
+    ix.add(X)
+    D, I = ix.search(Q, k)
+    D0, I0 = onp.flat_search(_stored(X, metric, store), Q, k, metric)
+    _check(D, I, D0, I0, metric)
+    assert ix.last_exact_fallbacks() == B
+    import torch
+    D2, I2 = ix.search(torch.from_numpy(Q).cuda(), k)            # device i/o path: same kernel, no host round trip
+    assert np.array_equal(I2.cpu().numpy(), I0)
+
+
 @pytest.mark.parametrize("metric", [onp.METRIC_IP, onp.METRIC_L2])
 def test_large_k_candidate_overflow_is_recomputed_exactly(metric):
     """Deep lists (k > 26) have no per-lane-list fallback: rows ordered so that each beats all earlier
