@@ -791,6 +791,9 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
     __syncthreads();
     const int n_ids = (PRAG_SH_DBG(a.dbg) & 32) ? 0 : min(s_n, kShIds);
     if (s_over && tid == 0 && atomicExch(a.ovf + b, 1u) == 0u) cert_flag(a.cert, b);   // exact scan recomputes b
+    // (Round 3: a second-level filter here - both int8 query terms over the candidate's 8-bit row before its stored
+    // row is fetched, for the tiles whose scan used one term - was built and measured: search time unchanged at
+    // 21 M rows (2.972 vs 2.973 ms) and at 2.6 M (0.544 vs 0.541).  The gather is a latency chain, not a byte count.)
     // ---- exact scores, 16 lanes per candidate row -------------------------------------------------
     // (45 of the kernel's 58 us at the 8-GPU shard size and 64 queries, tools/gather_probe.py: ~600
     // candidates per slice, one dependent row fetch per step of 32.  The rows in flight per CU are bounded
