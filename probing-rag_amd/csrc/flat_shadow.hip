@@ -663,7 +663,9 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
 // ---------------------------------------------------------------------------
 constexpr int kShCap = 1024;
 constexpr int kShThreads = 512;
-constexpr int kShSplit = 16;     // workgroups per query (small LDS footprint: several per CU)
+constexpr int kShSplit = 16;     // workgroups per query (small LDS footprint: several per CU); measured in round 3,
+                                 // same box: 2 / 4 / 8 / 16 / 32 slices -> 0.645 / 0.575 / 0.513 / 0.522 / 0.540 ms per
+                                 // 64-query search at 2.6 M rows, 3.08 / 2.95 / 2.90 / 2.88 / 2.98 ms at 21 M
 constexpr int kShIds = 2048;     // candidate ids one workgroup stages in LDS (after the final-bound filter)
 
 struct ShTopK {
@@ -758,7 +760,8 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
     // One memory round trip brings the query, the final bound and the region counts of the slice, a second one
     // every filled slot of every region (instead of a count -> entries chain per region).
     const float tau_final = unsortable_f32(a.g_tau[qi]);
-    const int per = (a.n_wg + kShSplit - 1) / kShSplit;
+    const int nsplit = (int)gridDim.x;             // slices per query (<= kShSplit)
+    const int per = (a.n_wg + nsplit - 1) / nsplit;
     const int wg0 = blockIdx.x * per, wg1 = min(a.n_wg, wg0 + per);
     const int nreg = wg1 - wg0;
     bool over_l = false;
@@ -862,7 +865,7 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
     // as relaxed device-scope atomics: written through, read around the local L2.  A release / acquire fence pair
     // here would write back and invalidate the whole L2 of every one of the 1024 blocks: measured 524 -> 782 us
     // per search in round 2.)
-    const int64_t o = ((int64_t)b * kShSplit + blockIdx.x) * a.k;
+    const int64_t o = ((int64_t)b * nsplit + blockIdx.x) * a.k;
     for (int j = tid; j < a.k; j += kShThreads) {
         const bool ok = j < tk.cnt;
         __hip_atomic_store(a.part_key + o + j, ok ? tk.key[j] : ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -871,13 +874,13 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
     __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the stores above have reached the coherence point
     __syncthreads();
     if (tid == 0)
-        s_n = __hip_atomic_fetch_add(a.done + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)kShSplit - 1 ? 1 : 0;
+        s_n = __hip_atomic_fetch_add(a.done + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)nsplit - 1 ? 1 : 0;
     __syncthreads();
     if (!s_n) return;
     // k <= 32: kShSplit * k <= 512 entries, ranked by counting
     unsigned long long* m_key = tk.key;        // (the block's own list is published: its LDS is free)
     int* m_id = tk.id;
-    const int n = kShSplit * a.k;
+    const int n = nsplit * a.k;
     __syncthreads();
     for (int i = tid; i < n; i += kShThreads) {
         m_key[i] = __hip_atomic_load(a.part_key + (int64_t)b * n + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -974,7 +977,8 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
     const int n_tiles = (int)((s.N + 31) / 32);
     const int grid = std::max(1, std::min(s.max_wg, (n_tiles + 7) / 8));
     PRAG_REQUIRE(grid <= s.wg_slots, PRAG_EUNSUPPORTED, "internal: shadow candidate regions too few");
-    PRAG_REQUIRE(grid <= 128 * kShSplit, PRAG_EUNSUPPORTED, "internal: more scan workgroups than the gather's slices hold");
+    const int nsplit = kShSplit;
+    PRAG_REQUIRE(grid <= 128 * nsplit, PRAG_EUNSUPPORTED, "internal: more scan workgroups than the gather's slices hold");
     // (query terms, per-query constants, bound slots and overflow words were written by prep_queries_kernel)
     for (int p0 = 0; p0 < Bpad; p0 += QT) {
         Scan8Args a;
@@ -1038,9 +1042,9 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         g.cert = s.cert;
         g.dbg = a.dbg;
         if (s.store.store_f32)
-            hipLaunchKernelGGL(shadow_gather_kernel<true>, dim3(kShSplit, nq), dim3(kShThreads), 0, st, g);
+            hipLaunchKernelGGL(shadow_gather_kernel<true>, dim3(nsplit, nq), dim3(kShThreads), 0, st, g);
         else
-            hipLaunchKernelGGL(shadow_gather_kernel<false>, dim3(kShSplit, nq), dim3(kShThreads), 0, st, g);
+            hipLaunchKernelGGL(shadow_gather_kernel<false>, dim3(nsplit, nq), dim3(kShThreads), 0, st, g);
         PRAG_LAUNCH_CHECK();
     }
     return PRAG_OK;
