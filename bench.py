@@ -69,10 +69,11 @@ def parse(argv=None):
     ap.add_argument("--shadow", type=int, default=1,
                     help="1: two-level exact search through the 8-bit shadow of the rows (prag_index_set_shadow); "
                          "0: scan the stored rows themselves")
-    ap.add_argument("--overlap-gate", type=int, default=-1,
+    ap.add_argument("--overlap-gate", type=int, default=0,
                     help="1: run the gate on a second stream beside the HBM-bound scan (scan capped at "
-                         "n_cu-16 workgroups); 0: one stream; -1 (default): overlap only on shards below 8 M "
-                         "rows, where the scan is short enough for the gate to matter (measured both ways)")
+                         "n_cu-16 workgroups); 0 (default): one stream.  Round 3 measured both at the 8-GPU shard "
+                         "size with the 8-GPU gate share (2.6 M rows, 512 gate rows): 0.537 ms per pass on one "
+                         "stream, 0.542 overlapped (the scan loses to the gate what the gate's latency saves)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     # BASELINE config 5 as a timed run (not part of the default line): see bench_e2e.py
     ap.add_argument("--e2e", action="store_true",
@@ -366,8 +367,6 @@ def main(argv=None):
     # ---- corpus shard (generated on device by the counter-based generator of add_synthetic)
     lo, hi = pra.partition_rows(args.docs, world, rank)
     n_local = hi - lo
-    if args.overlap_gate < 0:
-        args.overlap_gate = 1 if n_local < (8 << 20) else 0
     index = pra.ShardedFlatIndex(d_emb, args.metric, args.store, capacity=n_local)
     index.add_synthetic_local(42, lo, n_local)
     index.sync()
