@@ -355,7 +355,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     // 2.827 ms at 21 M rows, same box, alternating runs) and nothing at 32 or 1; with two the loop starved.
     // 64 queries x 32-deep lists have no registers beyond three.
     constexpr int NLD = NCHS > 0 ? 2 :   // (128-query tiles: three spill 13 registers and measured no faster: 3.85 vs 3.79 ms)
-                         QT == 64 ? (KC == 32 ? 3 : 5) : 4;
+                         QT == 64 ? (KC == 32 ? 3 : 5) : 4;   // (six at 64 queries fit - 253 VGPRs - and are slower: 2.92 vs 2.89 ms)
     u32x4 ld[NLD][4];
     // wave-uniform tile base (scalar registers) + a per-lane 32-bit offset: no 64-bit vector address
     // arithmetic and no per-row clamp in the loop - the shadow is allocated in multiples of 256 rows, so
