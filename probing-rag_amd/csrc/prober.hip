@@ -565,11 +565,13 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
             }
     };
 
-    // fc2 weight fragments: A2S slots, refilled right after use (four where a wave may run the k loop
-    // alone on its SIMD: at 256 cycles per k-step two slots are only 512 cycles of prefetch).  The
-    // fragments do not depend on the column tile, so the refills at the end of one pass wrap around to
-    // the first k-steps and the next pass starts with them already in registers.
-    constexpr int A2S = (NG == 2 && ROWS == 128 && NA == 1) ? 4 : 2;
+    // fc2 weight fragments: two slots, refilled right after use.  The fragments do not depend on the column
+    // tile, so the refills at the end of one pass wrap around to the first k-steps and the next pass starts with
+    // them already in registers.  (Round 2 gave the 128-row fp16 variant four slots - a wave that runs the k loop
+    // alone on its SIMD has only 512 cycles of prefetch with two - at the price of 21 spilled registers / 84 B of
+    // scratch; round 3 measured both on one box: back to back 85.4 vs 86.7 us, behind a cache flush 101.4 vs
+    // 98.4 us, in `bench.py` 95.5-96.5 vs 96.2 us.  Two slots: 255 VGPRs, no scratch.)
+    constexpr int A2S = 2;
     half8 a2[A2S][NA][RT];
     // fp8 copy of this wave's W2 rows for the lo term: two slots of one k block (64 hidden units) each
     i32x8 q2[2][RT];
