@@ -1309,6 +1309,7 @@ struct prag_index {
     uint32_t* sh_ovf = nullptr;
     int sh_q_cap = 0;
     int* sh_cand = nullptr;
+    int sh_cand_qt = 0;          // query-tile height the candidate store is sized for (64 or 128)
     uint32_t* sh_ccnt = nullptr;
     unsigned long long* sh_pkey = nullptr;
     int* sh_pid = nullptr;
@@ -2031,10 +2032,13 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
             if (rc_ws != PRAG_OK) return rc_ws;
             ix->sh_q_cap = BpadS;
         }
-        if (!ix->sh_cand || !ix->sh_ccnt) {
-            const int rc_ws = ws_regrow({{vpp(&ix->sh_cand), (size_t)ix->n_cu * 64 * kShadowCap * 2 * sizeof(int)},
-                                         {vpp(&ix->sh_ccnt), (size_t)ix->n_cu * 128 * sizeof(uint32_t)}});   // (128-query tiles)
+        const int cand_qt = QT == 128 ? 128 : 64;     // regions of kShadowCap slots for every query of a tile
+        if (!ix->sh_cand || !ix->sh_ccnt || ix->sh_cand_qt < cand_qt) {
+            ix->sh_cand_qt = 0;
+            const int rc_ws = ws_regrow({{vpp(&ix->sh_cand), (size_t)ix->n_cu * cand_qt * kShadowCap * 2 * sizeof(int)},
+                                         {vpp(&ix->sh_ccnt), (size_t)ix->n_cu * 128 * sizeof(uint32_t)}});
             if (rc_ws != PRAG_OK) return rc_ws;
+            ix->sh_cand_qt = cand_qt;
         }
         const size_t pe = (size_t)BpadS * shadow_split() * k;
         if (pe > ix->sh_part_entries) {
@@ -2064,7 +2068,12 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
         // what the warm-up's second visits cost: prep +13 us, gather +6 us, scan +-0, and one query in a few
         // searches overflowed a region).  PRAG_SHADOW_SAMPLE=0|1 forces it off / on for A/B runs (exact either way).
         static const int sample_env = getenv("PRAG_SHADOW_SAMPLE") ? atoi(getenv("PRAG_SHADOW_SAMPLE")) : -1;
-        if (sample_env == 0 || (sample_env < 0 && B > 32)) sprep.sample_stride = 0;
+        // ... and on shards so small that a wave owns fewer than 6 tiles: the chip-wide bound reaches a wave
+        // through the slot epochs it polls after its 2nd and 3rd tile, so without a starting bound such a wave
+        // filters against its own lists only and nearly every row passes (65 537 rows, 64 queries: every query
+        // overflowed the gather's staging and went to the exact scan; found by tools/fuzz_shadow.py)
+        const bool few_tiles = n_tiles < 48 * cu_budget;
+        if (sample_env == 0 || (sample_env < 0 && B > 32 && !few_tiles)) sprep.sample_stride = 0;
     }
     hipLaunchKernelGGL(prep_queries_kernel, dim3((Bpad + 3) / 4, sprep.sample_stride > 0 ? 1 + kShadowSampleSlices : 1), dim3(256), 0,
                        st, q_dev, B, Bpad, ix->d,

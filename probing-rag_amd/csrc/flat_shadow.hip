@@ -666,7 +666,7 @@ constexpr int kShThreads = 512;
 constexpr int kShSplit = 16;     // workgroups per query (small LDS footprint: several per CU); measured in round 3,
                                  // same box: 2 / 4 / 8 / 16 / 32 slices -> 0.645 / 0.575 / 0.513 / 0.522 / 0.540 ms per
                                  // 64-query search at 2.6 M rows, 3.08 / 2.95 / 2.90 / 2.88 / 2.98 ms at 21 M
-constexpr int kShIds = 2048;     // candidate ids one workgroup stages in LDS (after the final-bound filter)
+constexpr int kShIds = 4096;     // candidate ids one workgroup stages in LDS (after the final-bound filter)
 
 struct ShTopK {
     unsigned long long key[kShCap];
@@ -970,8 +970,9 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
     // 65..128 queries in ONE pass over the shadow (128-query tiles, list-less, lists up to 16 deep)
     const bool wide128 = s.qt_max >= 128 && s.B > 64 && shadow_tile128_ok(s.d, s.kc);
     const int QT = wide128 ? 128 : wide ? 64 : 32;
-    // the candidate store is sized for 64 queries x s.cap slots per workgroup: 128-query tiles get half the slots
-    const int cap = QT == 128 ? s.cap / 2 : s.cap;
+    // (the caller sizes the candidate store for the tile height: s.cap slots per (workgroup, query) either way -
+    // with half the slots the 128-query tiles overflowed on the contiguous-cluster corpus: 3 fallbacks, 5.7 ms)
+    const int cap = s.cap;
     const int Bpad = (s.B + QT - 1) / QT * QT;
     PRAG_REQUIRE(Bpad <= s.Bpad_ws, PRAG_EUNSUPPORTED, "internal: shadow workspace too small");
     const int n_tiles = (int)((s.N + 31) / 32);

@@ -1,0 +1,17 @@
+import sys
+sys.path.insert(0, "/root/repo")
+import torch, numpy as np
+import probing_rag_amd as pra
+g = torch.Generator(device="cuda").manual_seed(5)
+for store in ("f32", "f16"):
+  for metric in ("l2", "cos"):
+    for N in (33, 500, 4095, 4130, 20000, 65537, 300000):
+        for B in (1, 32, 64, 128):
+            d, k = 768, 10
+            X = torch.randn((N, d), generator=g, device="cuda")
+            Q = torch.randn((B, d), generator=g, device="cuda")
+            ix = pra.HipFlatIndex(d, metric, store); ix.set_shadow(2); ix.add(X)
+            ix.search(Q, k); fb = ix.last_exact_fallbacks()
+            if fb: print(store, metric, "N", N, "B", B, "fallbacks", fb, flush=True)
+            ix.close()
+print("done")

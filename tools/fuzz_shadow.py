@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the two-level search against the direct scan, both on the GPU (diagnostic):
+random (rows, queries, k, d, metric, storage, corpus structure); ids must be identical, scores equal to 1e-6
+relative.  python tools/fuzz_shadow.py [seconds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import probing_rag_amd as pra
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t0, n_case, n_fb = time.time(), 0, 0
+by = {}
+while time.time() - t0 < budget:
+    d = int(rng.choice([128, 256, 384, 512, 640, 768, 1024]))
+    N = int(rng.choice([1, 7, 33, 500, 4095, 4096, 4130, 20_000, 65_537, 300_000, 1_200_000], p=[.03, .03, .04, .1, .1, .1, .1, .2, .15, .1, .05]))
+    if N * d > 600_000_000:
+        N = 600_000_000 // d
+    B = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 96, 127, 128], p=[.15, .05, .05, .1, .1, .05, .15, .1, .05, .05, .15]))
+    k = int(rng.choice([1, 5, 10, 12, 13, 26]))
+    metric = str(rng.choice(["l2", "ip", "cos"]))
+    store = str(rng.choice(["f16", "f32"]))
+    kind = str(rng.choice(["iid", "clustered", "dups", "scaled"]))
+    g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
+    X = torch.randn((N, d), generator=g, device="cuda")
+    if kind == "clustered" and N >= 64:
+        nc = max(1, N // 257)
+        c = torch.randn((nc, d), generator=g, device="cuda")
+        X = c[(torch.arange(N, device="cuda") * nc) // N] + 0.02 * X
+    elif kind == "dups" and N >= 8:
+        X[N // 2:] = X[: N - N // 2].clone()
+    elif kind == "scaled":
+        X = X * torch.exp(torch.randn((N, 1), generator=g, device="cuda"))
+    Q = torch.randn((B, d), generator=g, device="cuda")
+    if N >= 4:
+        Q[0] = X[N // 3]
+        Q[B - 1] = X[N - 1] + 0.01 * Q[B - 1]
+    ix = pra.HipFlatIndex(d, metric, store)
+    half = N // 2
+    ix.set_shadow(2)
+    if half:
+        ix.add(X[:half])
+    ix.add(X[half:])
+    D1, I1 = ix.search(Q, k)
+    fb = ix.last_exact_fallbacks()
+    ix.set_shadow(0)
+    D0, I0 = ix.search(Q, k)
+    ok = torch.equal(I0, I1) and torch.allclose(D0, D1, rtol=1e-6, atol=0)
+    n_case += 1
+    n_fb += fb
+    key = (kind, metric, store, 'N<5k' if N < 5000 else 'N<100k' if N < 100_000 else 'N>=100k', 'B<=32' if B <= 32 else 'B<=64' if B <= 64 else 'B<=128')
+    c = by.setdefault(key, [0, 0, 0])
+    c[0] += 1; c[1] += B; c[2] += fb
+    if not ok:
+        bad = (I0 != I1).nonzero()[:5].tolist()
+        print(f"MISMATCH d={d} N={N} B={B} k={k} {metric} {store} {kind}: first diffs {bad}", flush=True)
+        sys.exit(1)
+    ix.close()
+for key in sorted(by, key=lambda k: -by[k][2] / max(1, by[k][1]))[:25]:
+    c = by[key]
+    print(key, f"cases {c[0]} queries {c[1]} fallbacks {c[2]} = {c[2] / max(1, c[1]):.3f} per query")
+print(f"fuzz ok: {n_case} cases in {time.time() - t0:.0f} s, {n_fb} exact fallbacks in total", flush=True)
