@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Which (storage, metric, rows, queries) shapes send queries to the exact fallback with the two-level search forced
+on (diagnostic; i.i.d. rows: the expected output is just `done`)."""
 import sys
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import probing_rag_amd as pra
 g = torch.Generator(device="cuda").manual_seed(5)
