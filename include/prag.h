@@ -253,6 +253,20 @@ int prag_merge_topk(const float* D_parts_dev, const int64_t* I_parts_dev, int n_
 int prag_merge_topk_packed(const void* parts_dev, int64_t part_stride_bytes, int n_parts, int B, int k,
                            int metric, float* D_dev, int64_t* I_dev, void* stream);
 
+/* The same call and the same merge for results that cross shards ("tagged" ids).  Only float32 scores
+ * travel between shards, so two rows of different shards whose float64 scores round to the same float32
+ * would be ordered by id in the merge while an unsharded search (like the float64 definition the oracle
+ * states) orders them by the float64 value - at the k-th place that can even change
+ * which row is returned.  prag_index_search_tagged writes, above the low 40 bits of each global row id, 23
+ * order-preserving bits of the float32 residual score64 - (double)D; prag_merge_topk_packed_tagged
+ * compares (D, residual, id) and returns plain ids.  Global ids must be < 2^40.  Tagged ids are an
+ * exchange format: nothing else reads them.  (The reference has no counterpart: faiss-cpu, one process,
+ * exp_rag.py:248, 432.) */
+int prag_index_search_tagged(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D, int64_t* I,
+                             int io_is_device, void* stream);
+int prag_merge_topk_packed_tagged(const void* parts_dev, int64_t part_stride_bytes, int n_parts, int B, int k,
+                                  int metric, float* D_dev, int64_t* I_dev, void* stream);
+
 /* Read back stored rows [row0,row0+n) as float32 (what the scan sees). */
 int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n, float* out_host);
 

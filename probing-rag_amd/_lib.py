@@ -80,6 +80,8 @@ SIGNATURES = {
     "prag_index_search": (_I, [_P, _P, _I, _I, _L, _P, _P, _I, _P]),
     "prag_merge_topk": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "prag_merge_topk_packed": (_I, [_P, _L, _I, _I, _I, _I, _P, _P, _P]),
+    "prag_merge_topk_packed_tagged": (_I, [_P, _L, _I, _I, _I, _I, _P, _P, _P]),
+    "prag_index_search_tagged": (_I, [_P, _P, _I, _I, _L, _P, _P, _I, _P]),
     "prag_index_reconstruct": (_I, [_P, _L, _L, _P]),
     "prag_index_set_candidate_depth": (_I, [_P, _I]),
     "prag_index_last_fallbacks": (_I, [_P, _P, ctypes.POINTER(_I)]),

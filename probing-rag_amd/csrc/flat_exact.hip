@@ -100,6 +100,7 @@ struct ExactArgs {
     float* D;
     int64_t* I;
     uint32_t* done;   // [f_cap] workgroups that have written their list of flag slot f (zero between searches)
+    int tag_ids;
 };
 
 template <int CTRL>
@@ -139,7 +140,7 @@ __device__ __forceinline__ void exact_merge_lists(const ExactArgs& a, ExTopK& tk
         const bool ok = j < tk.cnt;
         const double sc = ok ? unsortable_f64(a.metric_l2 ? tk.key[j] : ~tk.key[j]) : 0.0;
         a.D[(int64_t)b * a.k + j] = ok ? (float)sc : (a.metric_l2 ? FLT_MAX : -FLT_MAX);
-        a.I[(int64_t)b * a.k + j] = ok ? (int64_t)tk.id[j] + a.id_offset : -1;
+        a.I[(int64_t)b * a.k + j] = ok ? tag_id((int64_t)tk.id[j] + a.id_offset, sc, a.tag_ids) : -1;
     }
 }
 
@@ -274,6 +275,7 @@ int exact_run(const ExactRun& r, hipStream_t st) {
     a.D = r.D;
     a.I = r.I;
     a.done = r.done;
+    a.tag_ids = r.tag_ids;
     for (int f0 = 0; f0 < r.B; f0 += r.f_cap) {
         a.f0 = f0;
         if (r.store_f32)

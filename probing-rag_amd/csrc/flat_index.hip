@@ -1029,7 +1029,7 @@ __device__ __forceinline__ void rerank_block(const void* __restrict__ rows, int 
         const bool ok = iv >= 0;
         if (rank < k) {
             Db[rank] = ok ? (float)sv : (metric_l2 ? FLT_MAX : -FLT_MAX);
-            Ib[rank] = ok ? (int64_t)iv + id_offset : -1;
+            Ib[rank] = ok ? tag_id((int64_t)iv + id_offset, sv, cert.tag_ids) : -1;
         }
         // exactness certificate (the k-th result's owner): can a row outside the candidates still
         // belong to the top k?  Fewer than k valid candidates = the list is not full = every row is in it.
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(1024) void rerank_sort_kernel(const void* __restric
         const bool ok = j < KC && s_key[j] != ~0ull;
         const double sc = ok ? unsortable_f64(metric_l2 ? s_key[j] : ~s_key[j]) : 0.0;
         D[(int64_t)b * k + j] = ok ? (float)sc : (metric_l2 ? FLT_MAX : -FLT_MAX);
-        I[(int64_t)b * k + j] = ok ? (int64_t)s_id[j] + id_offset : -1;
+        I[(int64_t)b * k + j] = ok ? tag_id((int64_t)s_id[j] + id_offset, sc, cert.tag_ids) : -1;
     }
     if (threadIdx.x == 0) {
         const bool full = k <= KC && s_key[k - 1] != ~0ull;
@@ -1170,10 +1170,11 @@ __global__ __launch_bounds__(1024) void merge_rerank_kernel(const float* __restr
 __global__ __launch_bounds__(64) void merge_shards_kernel(const float* __restrict__ Dp,
                                                          const int64_t* __restrict__ Ip, int64_t d_stride,
                                                          int64_t i_stride, int n_parts, int B,
-                                                         int k, int metric_l2, float* __restrict__ D,
+                                                         int k, int metric_l2, int tagged, float* __restrict__ D,
                                                          int64_t* __restrict__ I) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    const int64_t id_mask = tagged ? (int64_t)((1ull << kTagShift) - 1) : ~0ll;
     // every part is already ordered, so a head pointer per part is enough;
     // heads live in a bitmap-free form: re-scan from the stored head positions
     int head[64];
@@ -1181,21 +1182,25 @@ __global__ __launch_bounds__(64) void merge_shards_kernel(const float* __restric
     for (int j = 0; j < k; ++j) {
         int best = -1;
         float bd = 0.f;
-        int64_t bi = 0;
+        int64_t bi = 0, br = 0;
         for (int p = 0; p < n_parts; ++p) {
             if (head[p] >= k) continue;
             const int64_t o = (int64_t)b * k + head[p];
-            const int64_t id = Ip[p * i_stride + o];
-            if (id < 0) continue;  // padding sorts last
+            const int64_t raw = Ip[p * i_stride + o];
+            if (raw < 0) continue;  // padding sorts last
+            const int64_t id = raw & id_mask;
+            const int64_t rk = tagged ? (raw >> kTagShift) : 0;      // float32 residual of the float64 score (tag_id)
             const float dv = Dp[p * d_stride + o];
             bool take;
             if (best < 0) take = true;
             else if (dv != bd) take = metric_l2 ? (dv < bd) : (dv > bd);
+            else if (rk != br) take = metric_l2 ? (rk < br) : (rk > br);
             else take = id < bi;
             if (take) {
                 best = p;
                 bd = dv;
                 bi = id;
+                br = rk;
             }
         }
         if (best >= 0) {
@@ -1834,8 +1839,24 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
     return PRAG_OK;
 }
 
+static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D, int64_t* I,
+                             int io_is_device, void* stream, int tag_ids);
+
 extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D,
                                  int64_t* I, int io_is_device, void* stream) {
+    return index_search_impl(ix, q, B, k, id_offset, D, I, io_is_device, stream, 0);
+}
+
+extern "C" int prag_index_search_tagged(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D,
+                                        int64_t* I, int io_is_device, void* stream) {
+    PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
+    PRAG_REQUIRE(id_offset >= 0 && id_offset + ix->ntotal < (1ll << kTagShift), PRAG_EUNSUPPORTED,
+                 "tagged ids hold %d-bit global row ids", kTagShift);
+    return index_search_impl(ix, q, B, k, id_offset, D, I, io_is_device, stream, 1);
+}
+
+static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D, int64_t* I,
+                             int io_is_device, void* stream, int tag_ids) {
     PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
     PRAG_REQUIRE(B >= 0 && k >= 1, PRAG_EINVAL, "B=%d k=%d", B, k);
     if (B == 0) return PRAG_OK;
@@ -1995,6 +2016,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     cert.n_flag = flag_word;
     cert.flag_list = ix->flag_list;
     cert.force = nullptr;
+    cert.tag_ids = tag_ids;
     {
         // which operands the selection kernel rounds (flat_internal.h "Exactness certificate")
         const bool hp = !use_mm && !use_qs && use_hp;
@@ -2241,6 +2263,7 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
     er.f_cap = ex_fcap;
     er.grid = ex_grid;
     er.done = ix->ex_done;
+    er.tag_ids = tag_ids;
     const bool may_flag = certify && ix->ntotal > 0;
     if (io_is_device) {
         ix->last_flagged = -1;
@@ -2273,13 +2296,13 @@ extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k,
 }
 
 static int merge_topk_impl(const float* Dp, const int64_t* Ip, int64_t d_stride, int64_t i_stride, int n_parts,
-                           int B, int k, int metric, float* D_dev, int64_t* I_dev, void* stream) {
+                           int B, int k, int metric, float* D_dev, int64_t* I_dev, void* stream, int tagged = 0) {
     PRAG_REQUIRE(Dp && Ip && D_dev && I_dev, PRAG_EINVAL, "prag_merge_topk: NULL pointer");
     PRAG_REQUIRE(n_parts >= 1 && n_parts <= 64, PRAG_EINVAL, "n_parts=%d outside [1,64]", n_parts);
     PRAG_REQUIRE(B >= 0 && k >= 1, PRAG_EINVAL, "B=%d k=%d", B, k);
     if (B == 0) return PRAG_OK;
     hipLaunchKernelGGL(merge_shards_kernel, dim3((B + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
-                       Dp, Ip, d_stride, i_stride, n_parts, B, k, metric == PRAG_METRIC_L2 ? 1 : 0, D_dev, I_dev);
+                       Dp, Ip, d_stride, i_stride, n_parts, B, k, metric == PRAG_METRIC_L2 ? 1 : 0, tagged, D_dev, I_dev);
     PRAG_LAUNCH_CHECK();
     return PRAG_OK;
 }
@@ -2290,15 +2313,28 @@ extern "C" int prag_merge_topk(const float* D_parts_dev, const int64_t* I_parts_
                            I_dev, stream);
 }
 
+static int merge_packed_impl(const void* parts_dev, int64_t part_stride_bytes, int n_parts, int B, int k, int metric,
+                             float* D_dev, int64_t* I_dev, void* stream, int tagged);
+
 extern "C" int prag_merge_topk_packed(const void* parts_dev, int64_t part_stride_bytes, int n_parts, int B, int k,
                                       int metric, float* D_dev, int64_t* I_dev, void* stream) {
+    return merge_packed_impl(parts_dev, part_stride_bytes, n_parts, B, k, metric, D_dev, I_dev, stream, 0);
+}
+
+extern "C" int prag_merge_topk_packed_tagged(const void* parts_dev, int64_t part_stride_bytes, int n_parts, int B, int k,
+                                             int metric, float* D_dev, int64_t* I_dev, void* stream) {
+    return merge_packed_impl(parts_dev, part_stride_bytes, n_parts, B, k, metric, D_dev, I_dev, stream, 1);
+}
+
+static int merge_packed_impl(const void* parts_dev, int64_t part_stride_bytes, int n_parts, int B, int k, int metric,
+                             float* D_dev, int64_t* I_dev, void* stream, int tagged) {
     PRAG_REQUIRE(parts_dev != nullptr, PRAG_EINVAL, "prag_merge_topk_packed: NULL pointer");
     const int64_t i_off = ((int64_t)B * k * 4 + 7) / 8 * 8;  // I block starts 8-byte aligned after the D block
     PRAG_REQUIRE(part_stride_bytes >= i_off + (int64_t)B * k * 8 && part_stride_bytes % 8 == 0, PRAG_EINVAL,
                  "part_stride_bytes=%lld too small or not a multiple of 8", (long long)part_stride_bytes);
     const char* base = reinterpret_cast<const char*>(parts_dev);
     return merge_topk_impl(reinterpret_cast<const float*>(base), reinterpret_cast<const int64_t*>(base + i_off),
-                           part_stride_bytes / 4, part_stride_bytes / 8, n_parts, B, k, metric, D_dev, I_dev, stream);
+                           part_stride_bytes / 4, part_stride_bytes / 8, n_parts, B, k, metric, D_dev, I_dev, stream, tagged);
 }
 
 extern "C" int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n, float* out_host) {

@@ -129,6 +129,20 @@ __device__ __forceinline__ double unsortable_f64(unsigned long long u) {
 //     c_acc = d * n_chains * 2^-23: one rounding (RN or RZ) per product-accumulate, worst case
 //   key = -dot (IP, COS) -> eps = eps_dot ;  key = ||x||^2 - 2 dot (L2) -> eps = 2 eps_dot + 2^-22 (xn_max + 2 nq nx)
 // ---------------------------------------------------------------------------
+// Result ids as they travel between shards ("tagged"): only float32 scores D are exchanged, so two rows of
+// different shards whose float64 scores round to the same float32 would be ordered by id in the merge while an
+// unsharded search orders them by the float64 value.  A tagged id carries, above the 40 bits of the global row
+// id, the top 23 bits of the (order-preserving transform of the) float32 residual score64 - (double)D: the merge
+// compares (D, residual, id) and strips the tag.  Resolution ~2^-14 of the residual, i.e. ~2^-38 of the score.
+constexpr int kTagShift = 40;
+__device__ __forceinline__ int64_t tag_id(int64_t gid, double score, int tag) {
+    if (!tag) return gid;
+    const float d32 = (float)score;
+    const float r32 = (float)(score - (double)d32);
+    const unsigned long long rk = sortable_u32(r32) >> 9;      // 23 bits: the result stays non-negative
+    return (int64_t)((rk << kTagShift) | ((unsigned long long)gid & ((1ull << kTagShift) - 1)));
+}
+
 struct CertArgs {
     const float* qinfo;       // [B][4]: ||q||, ||q - q16||, ||q - q16 - q16lo||, unused  (rounded up)
     const double* qn2;        // [B] ||q||^2
@@ -138,6 +152,7 @@ struct CertArgs {
     uint32_t* n_flag;         // number of flagged queries (zeroed by prep_queries_kernel)
     int* flag_list;           // [B]
     const uint32_t* force;    // optional [B]: non-zero = flag regardless (deep-list overflow), or null
+    int tag_ids;              // 1: write tagged ids (prag_index_search_tagged)
 };
 
 __device__ __forceinline__ double cert_eps(const CertArgs& c, int b, int metric_l2) {
@@ -182,6 +197,7 @@ struct ExactRun {
     int f_cap;              // flagged queries one round can hold
     int grid;               // workgroups of the scan
     uint32_t* done;         // [f_cap] zero-initialised arrival counters (the kernel leaves them zero)
+    int tag_ids;
 };
 size_t exact_part_entries(int f_cap, int grid, int k);
 // Enqueue ceil(B / f_cap) launches of the exact scan (list merge folded in); each exits at once when no query is flagged.

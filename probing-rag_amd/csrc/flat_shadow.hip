@@ -900,7 +900,7 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
             const bool ok = iv != 0x7fffffff;
             const double sc = ok ? unsortable_f64(a.metric_l2 ? kv : ~kv) : 0.0;
             a.D[(int64_t)b * a.k + rank] = ok ? (float)sc : (a.metric_l2 ? FLT_MAX : -FLT_MAX);
-            a.I[(int64_t)b * a.k + rank] = ok ? (int64_t)iv + a.id_offset : -1;
+            a.I[(int64_t)b * a.k + rank] = ok ? tag_id((int64_t)iv + a.id_offset, sc, a.cert.tag_ids) : -1;
         }
     }
 }

@@ -75,11 +75,14 @@ class HipFlatIndex:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().prag_index_add_synthetic(self._h, int(seed) & 0xFFFFFFFF, int(row0), int(n)))
 
-    def search(self, x, k: int, id_offset: int = 0, out=None):
+    def search(self, x, k: int, id_offset: int = 0, out=None, tagged: bool = False):
         """-> (D float32 [B,k], I int64 [B,k]); -1 / +-FLT_MAX padded if ntotal < k.
-        ``out=(D, I)`` lets device callers supply the result tensors."""
+        ``out=(D, I)`` lets device callers supply the result tensors.  ``tagged=True`` (row-sharded search
+        only): I carries the float32 residual of every score above the row id, for
+        ``merge_topk_packed(..., tagged=True)`` - an exchange format, not ids."""
         import torch
         k = int(k)
+        fn = _lib.lib().prag_index_search_tagged if tagged else _lib.lib().prag_index_search
         if isinstance(x, torch.Tensor) and x.is_cuda:
             ptr, B, _, keep = self._rows_arg(x)
             if out is None:
@@ -88,19 +91,16 @@ class HipFlatIndex:
             else:
                 D, I = out
             with torch.cuda.device(self.device):
-                _lib.check(_lib.lib().prag_index_search(self._h, ptr, B, k, int(id_offset),
-                                                        ctypes.c_void_p(D.data_ptr()),
-                                                        ctypes.c_void_p(I.data_ptr()), 1,
-                                                        _lib.current_stream_ptr(x.device)))
+                _lib.check(fn(self._h, ptr, B, k, int(id_offset), ctypes.c_void_p(D.data_ptr()),
+                              ctypes.c_void_p(I.data_ptr()), 1, _lib.current_stream_ptr(x.device)))
             del keep
             return D, I
         ptr, B, _, keep = self._rows_arg(x)
         D = np.empty((B, k), np.float32)
         I = np.empty((B, k), np.int64)
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().prag_index_search(self._h, ptr, B, k, int(id_offset),
-                                                    ctypes.c_void_p(D.ctypes.data), ctypes.c_void_p(I.ctypes.data),
-                                                    0, _lib.current_stream_ptr(self.device)))
+            _lib.check(fn(self._h, ptr, B, k, int(id_offset), ctypes.c_void_p(D.ctypes.data),
+                          ctypes.c_void_p(I.ctypes.data), 0, _lib.current_stream_ptr(self.device)))
         del keep
         return D, I
 
@@ -151,15 +151,18 @@ def packed_views(buf_row, B: int, k: int, i_off: int):
     return D, I
 
 
-def merge_topk_packed(buf, B: int, k: int, metric) -> tuple:
-    """Merge the shards of a packed buffer [n_parts, stride] (after ONE all-gather)."""
+def merge_topk_packed(buf, B: int, k: int, metric, tagged: bool = False) -> tuple:
+    """Merge the shards of a packed buffer [n_parts, stride] (after ONE all-gather).  ``tagged``: the
+    buffer was written by ``search(..., tagged=True)`` - float32 ties across shards are then broken by the
+    float64 scores, as in an unsharded search."""
     import torch
     _lib.require_gpu()
     P, stride = buf.shape
     D = torch.empty((B, k), dtype=torch.float32, device=buf.device)
     I = torch.empty((B, k), dtype=torch.int64, device=buf.device)
     with torch.cuda.device(buf.device):
-        _lib.check(_lib.lib().prag_merge_topk_packed(ctypes.c_void_p(buf.data_ptr()), stride, P, B, k,
+        fn = _lib.lib().prag_merge_topk_packed_tagged if tagged else _lib.lib().prag_merge_topk_packed
+        _lib.check(fn(ctypes.c_void_p(buf.data_ptr()), stride, P, B, k,
                                                      _lib.metric_id(metric), ctypes.c_void_p(D.data_ptr()),
                                                      ctypes.c_void_p(I.data_ptr()), _lib.current_stream_ptr(buf.device)))
     return D, I

@@ -70,12 +70,14 @@ class HipEngine:
                 self._ws.clear()
             self._ws[key] = ws
         buf, (D, I), gathered = ws
-        self.index.search(q, k, id_offset=id_offset, out=(D, I))
+        # ids tagged with the float32 residual of their float64 score: float32 ties ACROSS shards are then broken
+        # by the float64 values in the merge, as an unsharded search breaks them
+        self.index.search(q, k, id_offset=id_offset, out=(D, I), tagged=True)
         return buf, D, I, gathered
 
     def merge_packed(self, gathered, B, k, metric):
         from .index import merge_topk_packed
-        return merge_topk_packed(gathered, B, k, metric)
+        return merge_topk_packed(gathered, B, k, metric, tagged=True)
 
 
 class ShardedFlatIndex:
@@ -159,9 +161,9 @@ def search_shards_on_one_gpu(shards, q, k: int, metric, packed: bool = True):
     if packed:
         buf, stride, i_off = packed_result_buffer(B, k, q.device, n_parts=len(shards))
         for p, ix in enumerate(shards):
-            ix.search(q, k, id_offset=off, out=packed_views(buf[p], B, k, i_off))
+            ix.search(q, k, id_offset=off, out=packed_views(buf[p], B, k, i_off), tagged=True)
             off += ix.ntotal
-        return merge_topk_packed(buf, B, k, metric)
+        return merge_topk_packed(buf, B, k, metric, tagged=True)
     Ds, Is = [], []
     for ix in shards:
         D, I = ix.search(q, k, id_offset=off)

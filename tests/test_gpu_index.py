@@ -541,3 +541,42 @@ def test_add_waits_for_rows_produced_on_the_callers_stream():
         ix.add(rows)
     got = ix.reconstruct_n(n - 2000, 2000)
     assert np.array_equal(got, X)
+
+
+def test_float32_tie_across_shards_is_broken_by_the_float64_scores():
+    """Two rows in DIFFERENT shards whose float64 squared distances differ (64 vs 64 + 2.4e-7) but round to
+    the same float32: an unsharded search ranks them by the float64 value (the definition: oracle_np.flat_search),
+    and so must the row-sharded one - shards exchange tagged ids (prag_index_search_tagged) for that.  With
+    plain ids the merge can only order the pair by id and returns the wrong row at k = 1."""
+    import torch
+    import probing_rag_amd as pra
+    d, n = 64, 600
+    X = onp.synth_rows(3, 0, n, d) * np.float32(4.0)                      # far away from the origin
+    X[10] = 1.0
+    X[10, 5] = np.float32(1.0) + np.float32(2.0 ** -23)                   # ||x||^2 = 64 + 2^-22 + 2^-46
+    X[500] = 1.0                                                          # ||x||^2 = 64 exactly: the true nearest
+    Q = np.zeros((3, d), np.float32)
+    Q[1] = onp.synth_rows(4, 0, 1, d)[0]
+    Q[2] = X[77]
+    D0, I0 = onp.flat_search(X, Q, 2, onp.METRIC_L2)
+    assert I0[0].tolist() == [500, 10] and D0[0, 0] == D0[0, 1] == np.float32(64.0)
+    qd = torch.from_numpy(Q).cuda()
+    whole = pra.IndexFlatL2(d)
+    whole.add(X)
+    for k in (1, 2):
+        Dw, Iw = whole.search(qd, k)
+        assert np.array_equal(Iw.cpu().numpy(), I0[:, :k])
+        shards = []
+        for lo, hi in ((0, 300), (300, 600)):
+            sh = pra.IndexFlatL2(d)
+            sh.add(X[lo:hi])
+            shards.append(sh)
+        Ds, Is = pra.search_shards_on_one_gpu(shards, qd, k, "l2")
+        assert torch.equal(Is, Iw) and torch.equal(Ds, Dw)
+        # the plain-id exchange (prag_merge_topk on float32 scores alone) cannot tell the pair apart
+        Dp, Ip = pra.search_shards_on_one_gpu(shards, qd, k, "l2", packed=False)
+        if k == 1:
+            assert int(Ip[0, 0]) == 10 and float(Dp[0, 0]) == 64.0
+        for sh in shards:
+            sh.close()
+    whole.close()

@@ -47,17 +47,44 @@ while time.time() - t0 < budget:
     ix.set_shadow(0)
     D0, I0 = ix.search(Q, k)
     ok = torch.equal(I0, I1) and torch.allclose(D0, D1, rtol=1e-6, atol=0)
+    if ok and N >= 3 and rng.random() < 0.15:
+        # the same rows as 2-3 row shards with the two-level search forced on, searched shard by shard with global
+        # ids and merged (the multi-GPU data path minus the collective): must equal the unsharded answer
+        cuts = sorted(set([0, N] + [int(x) for x in rng.integers(1, N, size=int(rng.integers(1, 3)))]))
+        shards = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            sh = pra.HipFlatIndex(d, metric, store)
+            sh.set_shadow(2)
+            sh.add(X[lo:hi])
+            shards.append(sh)
+        Ds, Is = pra.search_shards_on_one_gpu(shards, Q, k, metric)
+        # (ids cross shards tagged with the float32 residual of their float64 score - prag_index_search_tagged -
+        # so even a float32 tie across shards comes out in the unsharded order)
+        ok = torch.equal(Ds, D0) and torch.equal(Is, I0)
+        for sh in shards:
+            sh.close()
+        n_sharded = globals().get("n_sharded", 0) + 1
+        globals()["n_sharded"] = n_sharded
     n_case += 1
+    if 'Is' in dir() and ok:
+        del Is
     n_fb += fb
     key = (kind, metric, store, 'N<5k' if N < 5000 else 'N<100k' if N < 100_000 else 'N>=100k', 'B<=32' if B <= 32 else 'B<=64' if B <= 64 else 'B<=128')
     c = by.setdefault(key, [0, 0, 0])
     c[0] += 1; c[1] += B; c[2] += fb
     if not ok:
         bad = (I0 != I1).nonzero()[:5].tolist()
-        print(f"MISMATCH d={d} N={N} B={B} k={k} {metric} {store} {kind}: first diffs {bad}", flush=True)
+        print(f"MISMATCH d={d} N={N} B={B} k={k} {metric} {store} {kind}: two-level vs direct id diffs {bad}, "
+              f"max |dD| {float((D0 - D1).abs().max()):.3e} (fallbacks {fb})", flush=True)
+        if "Is" in dir():
+            bs = (Is != I0).nonzero()[:5].tolist()
+            print(f"  sharded sub-case: cuts {cuts}, id diffs {bs}, max |dD| {float((Ds - D0).abs().max()):.3e}", flush=True)
+            for b_, j_ in bs[:3]:
+                print("   ", b_, j_, "whole", int(I0[b_, j_]), float(D0[b_, j_]), "sharded", int(Is[b_, j_]), float(Ds[b_, j_]), flush=True)
         sys.exit(1)
     ix.close()
 for key in sorted(by, key=lambda k: -by[k][2] / max(1, by[k][1]))[:25]:
     c = by[key]
     print(key, f"cases {c[0]} queries {c[1]} fallbacks {c[2]} = {c[2] / max(1, c[1]):.3f} per query")
+print(f"sharded sub-cases: {globals().get('n_sharded', 0)}")
 print(f"fuzz ok: {n_case} cases in {time.time() - t0:.0f} s, {n_fb} exact fallbacks in total", flush=True)
