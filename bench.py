@@ -49,6 +49,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA
+MFMA_I8_PEAK_TOP = 5000.0  # int8 MFMA: 2x the bf16 rate per clock (MI355X_MICROARCH.md, MFMA table)
+MM8_MIN_ROWS = 4 << 20     # prag_index_search takes the int8 tiles (> 128 queries, shadow kept) from this shard size on
 D_MODEL, D_EMB, N_LAYERS = 2048, 768, 6
 
 
@@ -243,9 +245,15 @@ def variant_record(torch, ix, q, k, store, metric, n_local, shadow=0):
            "exact_fallbacks_last_search": fb}
     if tiled:   # MFMA-bound: price the whole search (all segments, compactions, rerank) against the matrix peak
         tf = 2.0 * B * n_local * D_EMB / (ms_search * 1e-3) / 1e12
-        rec.update({"kernel": "scan_mm_kernel (whole search)", "bound": "mfma", "achieved": tf,
-                    "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TF,
+        i8 = bool(shadow) and ix.last_tiled8() >= 0
+        rec.update({"kernel": ("scan_mm_kernel<int8 tiles over the 8-bit shadow> (whole search)" if i8
+                               else "scan_mm_kernel (whole search)"), "bound": "mfma", "achieved": tf,
+                    "peak": MFMA_I8_PEAK_TOP if i8 else MFMA_F16_PEAK_TF, "unit": "Top/s" if i8 else "TFLOP/s",
+                    "frac": tf / (MFMA_I8_PEAK_TOP if i8 else MFMA_F16_PEAK_TF),
+                    "frac_of_f16_peak": tf / MFMA_F16_PEAK_TF,
                     "largest_segment_ms": float(np.mean(kern_ms)) if kern_ms else None})
+        if i8:
+            rec["int8_tier_failed_last_search"] = ix.last_tiled8()
     else:
         kms = float(np.mean(kern_ms)) if kern_ms else float("nan")
         gbs = alg_bytes / (kms * 1e-3) / 1e9
@@ -485,10 +493,16 @@ def main(argv=None):
     achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
     mm_tf = mm_flops = rows_last = None
     if tiled:
-        # the profiled launch is the last corpus segment (segments: 2048 rows, then x16)
+        # the profiled launch is the last corpus segment (segments: 2048 rows, then x16 on the fp16 tiles;
+        # the int8 tiles keep 256 candidates per query and grow by 1 + 32 CUs / (256 x query blocks), at most 16)
+        i8_tiles = local.last_tiled8() >= 0
+        growth = 16
+        if i8_tiles:
+            n_qb = min((args.queries + 255) // 256 * 256, 1024) // 256
+            growth = max(2, min(16, 1 + 32 * n_cu // (256 * n_qb), 1 + 3000 // 256))
         seg0 = 2048
-        while seg0 * 16 < n_local:
-            seg0 *= 16
+        while seg0 * growth < n_local:
+            seg0 *= growth
         rows_last = n_local - seg0 if n_local > 2048 else n_local
         mm_flops = 2.0 * args.queries * rows_last * d_emb
         mm_tf = mm_flops / (scan_avg_ms * 1e-3) / 1e12
@@ -531,8 +545,10 @@ def main(argv=None):
         "exact_fallbacks_last_search": fallbacks,
         "recall_at_k_vs_oracle": recall, "topk_ids_bit_exact_vs_oracle": exact_order,
         "recall_sample": f"{min(16, args.queries)} queries x {n_sub} docs, float64 C oracle",
-        "roofline": ({"bound": "mfma", "kernel": "scan_mm_kernel", "achieved": mm_tf, "peak": MFMA_F16_PEAK_TF,
-                      "unit": "TFLOP/s", "frac": mm_tf / MFMA_F16_PEAK_TF, "traffic": None,
+        "roofline": ({"bound": "mfma", "kernel": "scan_mm_kernel<int8 tiles>" if i8_tiles else "scan_mm_kernel",
+                      "achieved": mm_tf, "peak": MFMA_I8_PEAK_TOP if i8_tiles else MFMA_F16_PEAK_TF,
+                      "unit": "Top/s" if i8_tiles else "TFLOP/s",
+                      "frac": mm_tf / (MFMA_I8_PEAK_TOP if i8_tiles else MFMA_F16_PEAK_TF), "traffic": None,
                       "algorithmic_flops_per_launch": mm_flops, "rows_in_launch": rows_last,
                       "avg_launch_ms": scan_avg_ms, "launches_per_pass": launches} if tiled else
                      {"bound": "hbm", "kernel": scan_kernel,
@@ -568,6 +584,8 @@ def main(argv=None):
                 variants[f"f16_cos_k{args.k}_q128"] = variant_record(torch, local, qv[:128], args.k, "f16", "cos", n_local, 0)
                 for B in (1, 32, 128):
                     variants[f"f16_cos_k{args.k}_q{B}_shadow"] = variant_record(torch, local, qv[:B], args.k, "f16", "cos", n_local, 1)
+                if n_local >= MM8_MIN_ROWS:     # > 128 queries with the shadow kept: int8 tiles first, fp16 tiles if a query fails
+                    variants[f"f16_cos_k{args.k}_q1000_shadow"] = variant_record(torch, local, qv, args.k, "f16", "cos", n_local, 1)
                 local.set_shadow(1 if args.shadow else 0)
             # the reference's literal call: IndexFlatL2 (float32 rows), one query, k = 5
             # (make_indexer.py:449-450, utils.py:378-380, exp_rag.py:432)

@@ -280,6 +280,15 @@ int prag_index_set_candidate_depth(prag_index_t* ix, int depth);
  * certified and went through the exact float64 scan.  Synchronises `stream`. */
 int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out);
 
+/* Measurement hook: batches of > 128 queries on an index that keeps the 8-bit shadow (below) select their
+ * candidates on int8 matrix tiles over the shadow first (256 candidates per query, the shadow's error bound
+ * in the certificate) and repeat the whole batch on the fp16 tiles when any query fails that certificate
+ * (the one place a device-io search waits for its stream: a 4-byte read-back between the tiers).
+ * *n_failed_out = queries of the most recent search that failed the 8-bit certificate (0: the first tier
+ * answered), -1 if that search did not take the 8-bit tiles.  Reference call: utils.py:378-380
+ * (batch_topk_sim -> IndexFlat.search); results are the definition's either way. */
+int prag_index_last_tiled8(prag_index_t* ix, int* n_failed_out);
+
 /* Two-level exact search: keep an 8-bit shadow of the stored rows (+d+8 bytes per row, built on the
  * device as rows are added - `prag_index_add*` extend it before they return, so no search pays for
  * the build) and scan IT for batches of <= 64 queries (d a multiple of 128, <= 1024,

@@ -85,6 +85,7 @@ SIGNATURES = {
     "prag_index_reconstruct": (_I, [_P, _L, _L, _P]),
     "prag_index_set_candidate_depth": (_I, [_P, _I]),
     "prag_index_last_fallbacks": (_I, [_P, _P, ctypes.POINTER(_I)]),
+    "prag_index_last_tiled8": (_I, [_P, ctypes.POINTER(_I)]),
     "prag_index_set_shadow": (_I, [_P, _I]),
     "prag_index_prepare": (_I, [_P, _P]),
     "prag_index_set_scan_workgroups": (_I, [_P, _I]),

@@ -1273,6 +1273,19 @@ struct prag_index {
     size_t mm_w_entries = 0;      // entries of mm_wkey / mm_widx
     size_t mm_c_entries = 0;      // entries of mm_ckey / mm_cidx, mm_wcnt words
     int mm_mode = 1;   // 0 = never take the MFMA-tiled path (PRAG_SCAN_MM=0)
+    // 8-bit selection for the MFMA-tiled scan (> 128 queries on an index that keeps a shadow): int8 MFMA over the
+    // shadow, kMm8Kc candidates per query, the shadow's error bound in the certificate; a search in which any
+    // query fails that certificate is repeated on the fp16 tiles (PRAG_MM8=0: fp16 tiles only)
+    int mm8_mode = 1;
+    // ... on shards of at least this many rows (shadow mode 2 = "any size": no minimum).  Measured, 1000 queries x
+    // 768: 1 M rows 2.10 ms against 1.71 on the fp16 tiles - the 256-deep lists cost 0.49 ms of compaction sorts
+    // and 0.14 ms of rerank, and with the bound of a segment coming from <= 166 k rows one score in 650 survives
+    // the filter, so the int8 scan itself gains only 7 % -; 21 M rows 19.4 ms against 28.7 (0.76 ns per row and
+    // 1000 queries in the last segment against 1.34)
+    int64_t mm8_min_rows = 4ll << 20;
+    float* mm_kq = nullptr;            // [mm_q_cap] key scale of every query
+    uint32_t* tier_word_host = nullptr;   // pinned: flag count read back between the two tiers (device-io searches)
+    int mm8_last_failed = -1;             // queries of the last 8-bit tiled search that failed its certificate (-1: none ran)
     // fp32 indexes: fp16 copy of the rows for the tiled scan's candidate selection (built on the
     // first search with > 128 queries, dropped by add; the rerank always reads the fp32 rows)
     _Float16* rows16 = nullptr;
@@ -1491,6 +1504,8 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
     if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e);
     if (const char* e = getenv("PRAG_CERT")) ix->cert_mode = atoi(e);
 #endif
+    if (const char* e = getenv("PRAG_MM8")) ix->mm8_mode = atoi(e) != 0;
+    if (const char* e = getenv("PRAG_MM8_MIN_ROWS")) ix->mm8_min_rows = atoll(e);
     if (const char* e = getenv("PRAG_PREPASS")) ix->prepass_mode = atoi(e);
     if (const char* e = getenv("PRAG_SHADOW")) ix->shadow_mode = atoi(e);
     {
@@ -1740,10 +1755,10 @@ static int launch_merge_rerank(int kc, bool f32, const float* pk, const int* pi,
 // device-flagged fallback through the per-lane-list kernel for queries whose candidate store
 // overflowed.  Leaves the candidate ids in ix->cand.
 static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, int n_tiles, int cu_budget,
-                        int chunk, int cap_wg, hipStream_t st) {
+                        int chunk, int cap_wg, hipStream_t st, bool i8) {
     const int metric_l2 = ix->metric == PRAG_METRIC_L2;
     const _Float16* rows16 = reinterpret_cast<const _Float16*>(ix->rows);
-    if (ix->store == PRAG_F32) {
+    if (ix->store == PRAG_F32 && !i8) {
         // candidate selection runs on an fp16 copy of the rows (what the list kernels do on the fly)
         if (ix->rows16_cap < ix->cap) {
             ix->rows16_cap = 0; ix->rows16_n = -1;
@@ -1780,7 +1795,7 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
     // per-workgroup regions (64 per query) and the compaction's staging buffer (4096)
     {
         const int n_qb = std::min(Bpad, chunk) / 256;
-        const int g_wg = 1 + 16 * cu_budget / std::max(1, kc * n_qb);
+        const int g_wg = 1 + (cap_wg / 4) * cu_budget / std::max(1, kc * n_qb);
         const int g_lds = 1 + 3000 / kc;
         m.growth = std::max(2, std::min(16, std::min(g_wg, g_lds)));
     }
@@ -1789,6 +1804,13 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
         m.B = std::min(B - c0, chunk);
         m.Bpad = std::min(Bpad - c0, chunk);
         m.q16 = ix->q16 + (size_t)c0 * ix->d;
+        if (i8) {
+            m.i8 = 1;
+            m.rows8 = ix->rows8;
+            m.sscale = ix->sscale;
+            m.q8 = ix->sh_q8 + (size_t)c0 * ix->d;     // first int8 term of the queries
+            m.kq = ix->mm_kq + c0;
+        }
         m.tau = ix->g_tau + c0;
         m.cand = ix->cand + (size_t)c0 * kc;
         m.cnt = ix->mm_cnt + c0;
@@ -1840,7 +1862,14 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
 }
 
 static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D, int64_t* I,
-                             int io_is_device, void* stream, int tag_ids);
+                             int io_is_device, void* stream, int tag_ids, bool allow_mm8 = true);
+
+// candidates per query of the 8-bit tiled selection: the certificate needs the KC-th selection key to clear the
+// k-th exact key by the shadow's error bound (~0.55 sigma of the score distribution on 768 Gaussian elements with
+// the worst row's residual): rank ~110 at 1 M and at 21 M rows for k = 10; 256 leaves 0.2 sigma of margin
+constexpr int kMm8Kc = 256;
+constexpr int kMm8CapWg = 128;    // survivors one workgroup can hold per query and segment
+constexpr int kMm8Chunk = 1024;   // queries per mm_run call
 
 extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D,
                                  int64_t* I, int io_is_device, void* stream) {
@@ -1856,7 +1885,7 @@ extern "C" int prag_index_search_tagged(prag_index_t* ix, const float* q, int B,
 }
 
 static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D, int64_t* I,
-                             int io_is_device, void* stream, int tag_ids) {
+                             int io_is_device, void* stream, int tag_ids, bool allow_mm8) {
     PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
     PRAG_REQUIRE(B >= 0 && k >= 1, PRAG_EINVAL, "B=%d k=%d", B, k);
     if (B == 0) return PRAG_OK;
@@ -1871,6 +1900,14 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     const bool exact_only = kc > 32 && !mm_supported(ix->d, PRAG_F16, kc);
     if (exact_only) kc = 32;  // (sizes the unused candidate workspace)
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // > 128 queries on an index that keeps an up-to-date shadow: first tier = int8 tiles over the shadow with a
+    // deep candidate list; any query that fails the (much wider) certificate sends the search to the fp16 tiles
+    const bool use_mm8 = allow_mm8 && ix->mm8_mode && ix->mm_mode && !exact_only && kc <= 32 && B > 128 && ix->ntotal > 0 &&
+                         (ix->shadow_mode >= 2 || ix->ntotal >= ix->mm8_min_rows) &&
+                         ix->cert_mode != 0 && ix->rows8 != nullptr && ix->shadow_rows == ix->ntotal && shadow_wanted(ix) &&
+                         mm8_supported(ix->d, kMm8Kc) && mm_supported(ix->d, PRAG_F16, kMm8Kc) && k <= kMm8Kc / 8;
+    if (use_mm8) kc = kMm8Kc;
+    else if (allow_mm8) ix->mm8_last_failed = -1;
 
     // ---- host i/o staging -----------------------------------------------------
     const float* q_dev = q;
@@ -1954,12 +1991,13 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     // queries per mm_run call and survivors one workgroup can hold per query and segment.  Deep lists
     // (k > 26) yield up to KC/8 survivors per 256-row tile right after the first segment: they get
     // 512 slots and 256-query chunks.
-    const int mm_chunk = kc > 32 ? 256 : std::min(Bpad, kMmMaxQueries);
-    const int mm_cap_wg = kc > 32 ? 512 : kMmCapWg;
+    const int mm_chunk = use_mm8 ? std::min(Bpad, kMm8Chunk) : kc > 32 ? 256 : std::min(Bpad, kMmMaxQueries);
+    const int mm_cap_wg = use_mm8 ? kMm8CapWg : kc > 32 ? 512 : kMmCapWg;
     if (use_mm) {
         if (Bpad > ix->mm_q_cap) {
             ix->mm_q_cap = 0;
             const int rc_ws = ws_regrow({{vpp(&ix->mm_cnt), (size_t)Bpad * sizeof(uint32_t)},
+                                         {vpp(&ix->mm_kq), (size_t)Bpad * sizeof(float)},
                                          {vpp(&ix->mm_ovf), ((size_t)Bpad + 1) * sizeof(uint32_t)}});
             if (rc_ws != PRAG_OK) return rc_ws;
             ix->mm_q_cap = Bpad;
@@ -2017,6 +2055,8 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     cert.flag_list = ix->flag_list;
     cert.force = nullptr;
     cert.tag_ids = tag_ids;
+    cert.sq8 = nullptr;        // (set below, once the query workspace of the 8-bit selection exists)
+    cert.e_max = ix->shadow_err_max;
     {
         // which operands the selection kernel rounds (flat_internal.h "Exactness certificate")
         const bool hp = !use_mm && !use_qs && use_hp;
@@ -2043,8 +2083,8 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     const bool use_shadow = certify && !exact_only && !use_mm && !use_qs && ix->ntotal > 0 && ix->rows8 != nullptr &&
                             ix->shadow_rows == ix->ntotal && shadow_wanted(ix) && shadow_supported(ix->d, kc, k, B);
     ShadowPrep sprep{};
-    if (use_shadow) {   // workspace of the two-level search; its query terms come out of prep_queries_kernel
-        const int BpadS = (B + 63) / 64 * 64;
+    if (use_shadow || use_mm8) {   // workspace of the two-level search; its query terms come out of prep_queries_kernel
+        const int BpadS = use_mm8 ? Bpad : (B + 63) / 64 * 64;
         if (BpadS > ix->sh_q_cap) {
             ix->sh_q_cap = 0;
             const int rc_ws = ws_regrow({{vpp(&ix->sh_q8), (size_t)2 * BpadS * ix->d},
@@ -2055,7 +2095,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
             ix->sh_q_cap = BpadS;
         }
         const int cand_qt = QT == 128 ? 128 : 64;     // regions of kShadowCap slots for every query of a tile
-        if (!ix->sh_cand || !ix->sh_ccnt || ix->sh_cand_qt < cand_qt) {
+        if (use_shadow && (!ix->sh_cand || !ix->sh_ccnt || ix->sh_cand_qt < cand_qt)) {
             ix->sh_cand_qt = 0;
             const int rc_ws = ws_regrow({{vpp(&ix->sh_cand), (size_t)ix->n_cu * cand_qt * kShadowCap * 2 * sizeof(int)},
                                          {vpp(&ix->sh_ccnt), (size_t)ix->n_cu * 128 * sizeof(uint32_t)}});
@@ -2063,7 +2103,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
             ix->sh_cand_qt = cand_qt;
         }
         const size_t pe = (size_t)BpadS * shadow_split() * k;
-        if (pe > ix->sh_part_entries) {
+        if (use_shadow && pe > ix->sh_part_entries) {
             ix->sh_part_entries = 0;
             const int rc_ws = ws_regrow({{vpp(&ix->sh_pkey), pe * sizeof(unsigned long long)}, {vpp(&ix->sh_pid), pe * sizeof(int)}});
             if (rc_ws != PRAG_OK) return rc_ws;
@@ -2096,6 +2136,11 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         // overflowed the gather's staging and went to the exact scan; found by tools/fuzz_shadow.py)
         const bool few_tiles = n_tiles < 48 * cu_budget;
         if (sample_env == 0 || (sample_env < 0 && B > 32 && !few_tiles)) sprep.sample_stride = 0;
+        if (use_mm8) {   // the tiled scan wants the first int8 term, the key scales as one array, and no sample
+            sprep.sample_stride = 0;
+            sprep.kq = ix->mm_kq;
+            cert.sq8 = reinterpret_cast<const ShadowQ*>(ix->sh_sq);
+        }
     }
     hipLaunchKernelGGL(prep_queries_kernel, dim3((Bpad + 3) / 4, sprep.sample_stride > 0 ? 1 + kShadowSampleSlices : 1), dim3(256), 0,
                        st, q_dev, B, Bpad, ix->d,
@@ -2152,7 +2197,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     } else if (ix->ntotal == 0 || exact_only) {
         PRAG_HIP(hipMemsetAsync(ix->cand, 0xFF, cand_need * sizeof(int), st));  // all -1
     } else if (use_mm) {
-        const int rc = search_tiled(ix, B, Bpad, kc, qstride, n_tiles, cu_budget, mm_chunk, mm_cap_wg, st);
+        const int rc = search_tiled(ix, B, Bpad, kc, qstride, n_tiles, cu_budget, mm_chunk, mm_cap_wg, st, use_mm8);
         if (rc != PRAG_OK) return rc;
     } else {
         ScanArgs a;
@@ -2265,6 +2310,18 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     er.done = ix->ex_done;
     er.tag_ids = tag_ids;
     const bool may_flag = certify && ix->ntotal > 0;
+    if (use_mm8 && io_is_device) {
+        // tier decision: the flag count of the 8-bit selection comes back in one 4-byte transfer (the one place a
+        // device-io search waits for the stream: a > 128-query search is >= 0.1 ms of GPU time, the wait ~10 us);
+        // no flag -> done, otherwise the whole batch goes through the fp16 tiles (and their exact fallback)
+        if (!ix->tier_word_host) PRAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->tier_word_host), sizeof(uint32_t)));
+        PRAG_HIP(hipMemcpyAsync(ix->tier_word_host, flag_word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PRAG_HIP(hipStreamSynchronize(st));
+        ix->last_flagged = -1;
+        ix->mm8_last_failed = (int)*ix->tier_word_host;
+        if (*ix->tier_word_host == 0) return PRAG_OK;
+        return index_search_impl(ix, q_dev, B, k, id_offset, D_dev, I_dev, 1, stream, tag_ids, false);
+    }
     if (io_is_device) {
         ix->last_flagged = -1;
         if (may_flag) {
@@ -2284,7 +2341,17 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     uint32_t n_flag = 0;
     memcpy(&n_flag, ix->io_res_host + (size_t)B * k * 12, sizeof(n_flag));
     ix->last_flagged = (int)n_flag;
-    if (may_flag && n_flag > 0) {
+    if (use_mm8) ix->mm8_last_failed = (int)n_flag;
+    if (use_mm8 && n_flag > 0) {
+        // second tier: the staged queries through the fp16 tiles, results into the same staging block
+        const int rc = index_search_impl(ix, q_dev, B, k, id_offset, D_dev, I_dev, 1, stream, tag_ids, false);
+        if (rc != PRAG_OK) return rc;
+        rc_io = fetch();
+        if (rc_io != PRAG_OK) return rc_io;
+        uint32_t nf2 = 0;
+        PRAG_HIP(hipMemcpy(&nf2, ix->cert_words, sizeof(nf2), hipMemcpyDeviceToHost));
+        ix->last_flagged = (int)nf2;
+    } else if (may_flag && n_flag > 0) {
         const int rc = exact_run(er, st);
         if (rc != PRAG_OK) return rc;
         rc_io = fetch();
@@ -2377,6 +2444,12 @@ extern "C" int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_
     return PRAG_OK;
 }
 
+extern "C" int prag_index_last_tiled8(prag_index_t* ix, int* n_failed_out) {
+    PRAG_REQUIRE(ix != nullptr && n_failed_out != nullptr, PRAG_EINVAL, "prag_index_last_tiled8: NULL pointer");
+    *n_failed_out = ix->mm8_last_failed;
+    return PRAG_OK;
+}
+
 extern "C" int prag_index_set_candidate_depth(prag_index_t* ix, int depth) {
     PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
     PRAG_REQUIRE(depth == 0 || depth == 8 || depth == 16 || depth == 32, PRAG_EINVAL,
@@ -2416,7 +2489,7 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
     if (!ix) return;
     ix->prof.disable();
     void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->q16lo, ix->g_tau, ix->part_key, ix->part_idx, ix->cand,
-                    ix->io_q, ix->io_res, ix->mm_cnt, ix->mm_ovf, ix->mm_ckey, ix->mm_cidx,
+                    ix->io_q, ix->io_res, ix->mm_cnt, ix->mm_ovf, ix->mm_kq, ix->mm_ckey, ix->mm_cidx,
                     ix->mm_wcnt, ix->mm_wkey, ix->mm_widx, ix->rows16, ix->qinfo, ix->qn2, ix->flag_list, ix->g_slot,
                     ix->cert_words, ix->ex_key, ix->ex_id, ix->rows8, ix->sscale, ix->serr, ix->shadow_err_max, ix->sh_q8,
                     ix->sh_sq, ix->sh_slots, ix->sh_ovf, ix->sh_cand, ix->sh_ccnt, ix->sh_pkey, ix->sh_pid, ix->ex_done};
@@ -2424,5 +2497,6 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
         if (p) (void)hipFree(p);
     if (ix->io_q_host) (void)hipHostFree(ix->io_q_host);
     if (ix->io_res_host) (void)hipHostFree(ix->io_res_host);
+    if (ix->tier_word_host) (void)hipHostFree(ix->tier_word_host);
     delete ix;
 }

@@ -79,6 +79,13 @@ struct MmSearch {
     int wg_slots;           // workgroups the workspace was sized for
     int max_wg;             // workgroups the scan may occupy (<= wg_slots)
     int growth = 16;        // segment i+1 ends at growth x the end of segment i (2..16)
+    // 8-bit selection (i8 != 0): the rows' shadow and the first int8 term of the queries on the int8 MFMA
+    // (twice the fp16 rate); q16 / rows are not read.  key = xnorm + kq[b] * sscale[i] * (q8[b] . rows8[i])
+    int i8 = 0;
+    const signed char* rows8 = nullptr;   // [cap/32][d/128][32][128]
+    const float* sscale = nullptr;        // [cap]
+    const signed char* q8 = nullptr;      // [Bpad][d], zero rows past B
+    const float* kq = nullptr;            // [Bpad], 0 past B
 };
 
 constexpr int kMmFirstSeg = 2048;    // rows of the first segment (all of them become candidates); segments grow x16
@@ -143,6 +150,13 @@ __device__ __forceinline__ int64_t tag_id(int64_t gid, double score, int tag) {
     return (int64_t)((rk << kTagShift) | ((unsigned long long)gid & ((1ull << kTagShift) - 1)));
 }
 
+struct ShadowQ {     // per query, consumed by the scan
+    float kscale;    // alpha * sq : key = xnorm_i + kscale * s_i * (acc1 + acc2 / 128)
+    float A2, C2;    // two query terms:  eps_i = A e_i + C,  A = |alpha| ||q~||, C = |alpha| rq max||x|| + rounding slack
+    float A1, C1;    // first term only (64-query tiles)
+    float pad[3];
+};
+
 struct CertArgs {
     const float* qinfo;       // [B][4]: ||q||, ||q - q16||, ||q - q16 - q16lo||, unused  (rounded up)
     const double* qn2;        // [B] ||q||^2
@@ -153,9 +167,17 @@ struct CertArgs {
     int* flag_list;           // [B]
     const uint32_t* force;    // optional [B]: non-zero = flag regardless (deep-list overflow), or null
     int tag_ids;              // 1: write tagged ids (prag_index_search_tagged)
+    // 8-bit selection (MFMA-tiled scan over the shadow, first int8 query term): the selection key of row i is
+    // within A1 e_i + C1 of its exact key (ShadowQ, same bound as the two-level search), so eps = A1 max_i e_i + C1
+    const ShadowQ* sq8;       // [B] or null (fp16 selection: the model above)
+    const uint32_t* e_max;    // float bits of max_i e_i
 };
 
 __device__ __forceinline__ double cert_eps(const CertArgs& c, int b, int metric_l2) {
+    if (c.sq8) {   // (key units: |alpha| is inside A1 and C1)
+        const double em = (double)__uint_as_float(*c.e_max) * (1.0 + 1e-6);
+        return ((double)c.sq8[b].A1 * em + (double)c.sq8[b].C1) * 1.001;
+    }
     const double nq = (double)c.qinfo[4 * b + 0];
     const double rq = (double)c.qinfo[4 * b + c.rq_sel];
     const double xn = (double)__uint_as_float(*c.xn_max) * (1.0 + 1e-6);
@@ -206,12 +228,6 @@ int exact_run(const ExactRun& r, hipStream_t st);
 // ---------------------------------------------------------------------------
 // 8-bit shadow, two-level exact search (flat_shadow.hip)
 // ---------------------------------------------------------------------------
-struct ShadowQ {     // per query, consumed by the scan
-    float kscale;    // alpha * sq : key = xnorm_i + kscale * s_i * (acc1 + acc2 / 128)
-    float A2, C2;    // two query terms:  eps_i = A e_i + C,  A = |alpha| ||q~||, C = |alpha| rq max||x|| + rounding slack
-    float A1, C1;    // first term only (64-query tiles)
-    float pad[3];
-};
 // Bound slots of the two-level scan, per query: kShadowEpochs epochs x 32 slots filled inside the scan launch
 // (after tiles 1, 2, 4, ..., 256) and one more "epoch" filled BEFORE it by prep_queries_kernel from a sample of
 // the shard (below).
@@ -229,6 +245,7 @@ struct ShadowPrep {
     uint32_t* slots;         // [Bpad][kShadowSlotWords]
     uint32_t* ovf;           // [Bpad]
     uint32_t* done;          // [Bpad] arrival counters of the gather's list merge
+    float* kq;               // optional [Bpad]: kscale of every query, contiguous (MFMA-tiled scan over the shadow)
     const uint32_t* xn_max;  // bits of max ||x||^2
     float alpha;
     // sample for the pre-bound (sample_stride == 0: none, the slots of the pre-epoch stay +inf)
@@ -327,11 +344,18 @@ __device__ __forceinline__ void shadow_prep_wave(const ShadowPrep& p, int b, int
             *reinterpret_cast<uint32_t*>(p.q8a + (int64_t)b * d + c) = 0u;
             *reinterpret_cast<uint32_t*>(p.q8b + (int64_t)b * d + c) = 0u;
         }
-        if (lane == 0) p.sq[b] = ShadowQ{0.f, 0.f, 0.f, 0.f, 0.f, {0.f, 0.f, 0.f}};
+        if (lane == 0) {
+            p.sq[b] = ShadowQ{0.f, 0.f, 0.f, 0.f, 0.f, {0.f, 0.f, 0.f}};
+            if (p.kq) p.kq[b] = 0.f;
+        }
         return;
     }
     const ShadowTerms t = shadow_terms_wave(d, v, lane, p.q8a + (int64_t)b * d, p.q8b + (int64_t)b * d);
-    if (lane == 0) p.sq[b] = shadow_consts(t, p.alpha, p.xn_max);
+    if (lane == 0) {
+        const ShadowQ c = shadow_consts(t, p.alpha, p.xn_max);
+        p.sq[b] = c;
+        if (p.kq) p.kq[b] = c.kscale;
+    }
 }
 // Pre-bound: slice `slice` of the sample - kShadowSampleTiles 32-row tiles of the shadow, spread over the shard -
 // scored against the FIRST int8 term of query b by this wave (v_dot4_i32_i8: exact integers, the scan's own
@@ -477,6 +501,7 @@ int shadow_build(const ShadowStore& s, int64_t row0, int64_t row1, hipStream_t s
 int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof);
 
 bool mm_supported(int d, int store_dtype, int kc);
+bool mm8_supported(int d, int kc);
 // Enqueue the segmented scan on `st`; returns PRAG_OK or a negative status.  `prof` brackets
 // the launch over the largest segment.
 int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof);

@@ -56,13 +56,21 @@ struct MmArgs {
     int* widx;
     int cap_wg;
     unsigned long long* dbg;  // diagnostic builds: {core-clock ticks, 100 MHz ticks} of block 0; else null
+    // 8-bit selection (I8 kernels): shadow rows, their scales, first int8 query term, per-query key scale
+    const signed char* rows8;
+    const float* sscale;
+    const signed char* q8;
+    const float* kq;
 };
 
 // LDS map (bytes): A even/odd K tile at 0 / 32 KiB, B even/odd at 64 / 96 KiB ([256 rows][128 B],
 // 16-B pieces XOR-swizzled with (row>>1)&7), then 1 KiB of row norms and 1 KiB of bounds.
+// (8-bit selection: two more KiB - the row scales of the tile and the key scales of the query block)
 constexpr int kMmLdsXn = 131072;
 constexpr int kMmLdsTau = 131072 + 1024;
-constexpr int kMmLdsCnt = 131072 + 2048;   // [Bpad] survivor counters of this workgroup
+constexpr int kMmLdsSs = 131072 + 2048;
+constexpr int kMmLdsKq = 131072 + 3072;
+constexpr int kMmLdsCnt = 131072 + 4096;   // [Bpad] survivor counters of this workgroup
 
 // ABL != 0: timing-only ablations (wrong results) for tools/mm_ablate.py, built with -DPRAG_MM_DIAG;
 // bit 0 no MFMAs, bit 1 no LDS-DMA, bit 2 no fragment reads, bit 3 no filter, bit 4 vmcnt(14)
@@ -70,11 +78,18 @@ constexpr int kMmLdsCnt = 131072 + 2048;   // [Bpad] survivor counters of this w
 // int8 MFMA on the same bytes (with NKT = d/128: what an 8-bit shadow of the rows would cost)
 // MODE 0: the launch over the first segment (no bound yet; every row becomes a candidate);
 // MODE 1: inner product / cosine (key = -score); MODE 2: squared L2 (key = ||x||^2 - 2 score).
-template <int NKT /* d / 64, even */, int MODE = 1, int ABL = 0>
+// I8: the same pipeline over the 8-bit shadow of the rows (chunk-major inside 32-row tiles: a 128-byte K tile of
+// 32 consecutive rows is one contiguous 4-KiB block) and the first int8 term of the queries, K tiles of 128
+// elements on v_mfma_i32_32x32x32_i8 - twice the fp16 rate, exact integer dot products.  The selection key
+//   key = ||x_i||^2 (L2) + kq_b * (s_i * dot)        (two float roundings, the same expression wherever it is formed)
+// is within A1 e_i + C1 of the exact key (flat_internal.h, ShadowQ): the caller keeps a deeper candidate list and
+// the certificate uses that bound.
+template <int NKT /* d / 64 (I8: d / 128), even */, int MODE = 1, int ABL = 0, bool I8 = false>
 __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     constexpr bool FIRST = MODE == 0;
     static_assert(NKT % 2 == 0 && NKT >= 4, "K tiles are consumed in even/odd pairs");
-    constexpr int64_t RB = (int64_t)NKT * 128;  // bytes per fp16 row
+    constexpr int64_t RB = (int64_t)NKT * 128;  // bytes per row (fp16, or int8 with 128-element K tiles)
+    constexpr int KA = I8 ? 4096 : 128;         // bytes from one K tile of a row to the next in global memory
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef const __attribute__((address_space(1))) char* gcptr;
     typedef __attribute__((address_space(3))) char* lptr;
@@ -111,8 +126,8 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     //      (the per-lane parts are rebuilt inside tile_ptr, once per tile, from an opaque copy of
     //      the lane id: kept live across the main loop they get spilled, and a reload waits
     //      behind s_waitcnt vmcnt(0))
-    const gcptr rows_g = (gcptr) reinterpret_cast<const char*>(a.rows);
-    const gcptr q_g = (gcptr) reinterpret_cast<const char*>(a.q16);
+    const gcptr rows_g = (gcptr)(I8 ? reinterpret_cast<const char*>(a.rows8) : reinterpret_cast<const char*>(a.rows));
+    const gcptr q_g = (gcptr)(I8 ? reinterpret_cast<const char*>(a.q8) : reinterpret_cast<const char*>(a.q16));
     const lptr lds0 = (lptr)smem;
     const lptr dA = lds0 + w * 1024;
     const lptr dB = lds0 + 65536 + (64 * (w >> 2) + 8 * (w & 3)) * 128;
@@ -134,7 +149,10 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
         TilePtr p;
         p.row0 = a.row0 + (int64_t)rt * 256;
         p.q0 = qb * 256;
-        p.pa = rows_g + (p.row0 + a_thr) * RB + colb;
+        if constexpr (I8)   // (row0 is a multiple of 256: the row's place inside its 32-row tile is a_thr & 31)
+            p.pa = rows_g + ((p.row0 + a_thr) >> 5) * (32 * RB) + (a_thr & 31) * 128 + colb;
+        else
+            p.pa = rows_g + (p.row0 + a_thr) * RB + colb;
         p.pb = q_g + (int64_t)(p.q0 + b_thr) * RB + colb;
         return p;
     };
@@ -144,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     // the four 16-KiB staging steps of one K tile (kt_) into buffer buf_ (0 even, 1 odd)
 #define MM_SA0(tp_, kt_, buf_)                                    \
     {                                                             \
-        const gcptr g0_ = (tp_).pa + (kt_) * 128;                 \
+        const gcptr g0_ = (tp_).pa + (kt_) * KA;                  \
         const gcptr g1_ = g0_ + 128 * RB;                         \
         const lptr l0_ = dA + (buf_) * 32768;                     \
         const lptr l1_ = l0_ + 16384;                             \
@@ -153,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     }
 #define MM_SA1(tp_, kt_, buf_)                                    \
     {                                                             \
-        const gcptr g0_ = (tp_).pa + 64 * RB + (kt_) * 128;       \
+        const gcptr g0_ = (tp_).pa + 64 * RB + (kt_) * KA;        \
         const gcptr g1_ = g0_ + 128 * RB;                         \
         const lptr l0_ = dA + (buf_) * 32768 + 8192;              \
         const lptr l1_ = l0_ + 16384;                             \
@@ -193,14 +211,14 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                            \
             if constexpr (ABL & 1) {                                                                  \
                 asm volatile("" ::"v"(AF_[0][ks]), "v"(AF_[1][ks]), "v"(BF_[ks]));                    \
-            } else if constexpr (ABL & 64) {  /* timing probe: the same bytes through the int8 MFMA */ \
+            } else if constexpr (I8 || (ABL & 64)) {  /* (ABL 64: timing probe, fp16 bytes through the int8 MFMA) */ \
                 typedef int i32x16_ __attribute__((ext_vector_type(16)));                              \
                 c0_ = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(                \
                     __builtin_bit_cast(i32x4, AF_[0][ks]), __builtin_bit_cast(i32x4, BF_[ks]),         \
-                    __builtin_bit_cast(i32x16_, c0_), 0, 0, 0));                                       \
+                    __builtin_bit_cast(i32x16_, ((first_) && ks == 0) ? zero16 : c0_), 0, 0, 0));      \
                 c1_ = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(                \
                     __builtin_bit_cast(i32x4, AF_[1][ks]), __builtin_bit_cast(i32x4, BF_[ks]),         \
-                    __builtin_bit_cast(i32x16_, c1_), 0, 0, 0));                                       \
+                    __builtin_bit_cast(i32x16_, ((first_) && ks == 0) ? zero16 : c1_), 0, 0, 0));      \
             } else {                                                                                  \
                 c0_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF_[0][ks], BF_[ks], ((first_) && ks == 0) ? zero16 : c0_, 0, 0, 0); \
                 c1_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF_[1][ks], BF_[ks], ((first_) && ks == 0) ? zero16 : c1_, 0, 0, 0); \
@@ -269,15 +287,17 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
                 // row norms and bounds of this tile, well ahead of the filter.  Not in phase 1: at
                 // d = 256 this is the tile's first K-tile pair and the lagging wave group may still
                 // be reading the previous tile's copy until it passes the barrier that ends phase 1.
-                if (w < 2) {
+                if (w < (I8 ? 4 : 2)) {
                     // (the lane offset is rebuilt here on purpose: hoisted out of the tile loop it costs
                     // a VGPR pair the loop does not have, and a spilled pointer reloads behind vmcnt(0))
                     int l16;
                     asm volatile("v_lshlrev_b32 %0, 4, %1" : "=v"(l16) : "v"(lane));
-                    const gcptr src = w == 0 ? (gcptr) reinterpret_cast<const char*>(a.xnorm + cur.row0)
-                                             : (gcptr) reinterpret_cast<const char*>(a.tau + cur.q0);
+                    const gcptr src = w == 0   ? (gcptr) reinterpret_cast<const char*>(a.xnorm + cur.row0)
+                                      : w == 1 ? (gcptr) reinterpret_cast<const char*>(a.tau + cur.q0)
+                                      : w == 2 ? (gcptr) reinterpret_cast<const char*>(a.sscale + cur.row0)
+                                               : (gcptr) reinterpret_cast<const char*>(a.kq + cur.q0);
                     const gcptr gx = src + l16;
-                    const lptr lx = lds0 + (w == 0 ? kMmLdsXn : kMmLdsTau);
+                    const lptr lx = lds0 + (w == 0 ? kMmLdsXn : w == 1 ? kMmLdsTau : w == 2 ? kMmLdsSs : kMmLdsKq);
                     MM_GLDS(gx, lx);
                 }
             }
@@ -338,11 +358,13 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
             const int r = le & 31, h = le >> 5;
             const int64_t rbase = cur.row0 + 128 * wr + 4 * h;
             const int qbase = cur.q0 + 64 * wc + r;
-            float tauf[2], thr[2];
+            float tauf[2], thr[2], al[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 tauf[nt] = unsortable_f32(*reinterpret_cast<const uint32_t*>(smem + kMmLdsTau + (64 * wc + 32 * nt + r) * 4));
                 thr[nt] = tauf[nt] * a.inv_alpha;  // key <= tau  <=>  score >= tau / alpha  (alpha < 0)
+                // I8: key = xn + kq_b * (s_i * dot); the query's kq = alpha * (its int8 scale) stands where alpha does
+                al[nt] = I8 ? *reinterpret_cast<const float*>(smem + kMmLdsKq + (64 * wc + 32 * nt + r) * 4) : a.alpha;
             }
             // The other wave group waits at the next barrier while this one filters, so every
             // instruction here is exposed twice per tile: the common case is kept to ~12 (inner
@@ -354,17 +376,25 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
 #define MM_MIN3(d_, x_, y_, z_) asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d_) : "v"(x_), "v"(y_), "v"(z_))
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                f32x4 xn[4];
+                f32x4 xn[4], ss[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     if ((FIRST && a.use_norm) || MODE == 2)
                         xn[g] = *reinterpret_cast<const f32x4*>(smem + kMmLdsXn + (128 * wr + 32 * mt + 8 * g + 4 * h) * 4);
                     else
                         xn[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (I8)
+                        ss[g] = *reinterpret_cast<const f32x4*>(smem + kMmLdsSs + (128 * wr + 32 * mt + 8 * g + 4 * h) * 4);
                 }
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const f32x16& c = acc[mt][nt];
+                    f32x16 c = acc[mt][nt];
+                    if constexpr (I8) {   // t = s_i * dot (the integer converts exactly: |dot| <= 128 * 127^2 * NKT < 2^24)
+                        typedef int i32x16_ __attribute__((ext_vector_type(16)));
+                        const i32x16_ ci = __builtin_bit_cast(i32x16_, acc[mt][nt]);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) c[e] = ss[e >> 2][e & 3] * (float)ci[e];
+                    }
                     const int q = qbase + 32 * nt;
                     const int64_t rb = rbase + 32 * mt;
                     if constexpr (FIRST) {
@@ -378,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
                             i32x4 iv;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                kv[e] = fmaf(a.alpha, c[4 * g + e], xn[g][e]);
+                                kv[e] = fmaf(al[nt], c[4 * g + e], xn[g][e]);
                                 iv[e] = (int)row + e;
                             }
                             if (row + 3 < a.row1) {
@@ -401,11 +431,13 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
                             MM_MAX3(m, c[0], c[1], c[2]);
 #pragma unroll
                             for (int e = 3; e < 15; e += 2) MM_MAX3(m, m, c[e], c[e + 1]);
-                            any = fmaxf(m, c[15]) >= thr[nt];
+                            // (I8: the key itself is formed - one multiply - so that this test and the
+                            //  survivor's key below are the same arithmetic; kq < 0: the largest t has the smallest key)
+                            any = I8 ? al[nt] * fmaxf(m, c[15]) <= tauf[nt] : fmaxf(m, c[15]) >= thr[nt];
                         } else {
                             float kk[16];
 #pragma unroll
-                            for (int e = 0; e < 16; ++e) kk[e] = fmaf(a.alpha, c[e], xn[e >> 2][e & 3]);
+                            for (int e = 0; e < 16; ++e) kk[e] = fmaf(al[nt], c[e], xn[e >> 2][e & 3]);
                             float m;
                             MM_MIN3(m, kk[0], kk[1], kk[2]);
 #pragma unroll
@@ -422,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
                                 bool hit = false;
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
-                                    key[e] = fmaf(a.alpha, c[4 * g + e], xn[g][e]);
+                                    key[e] = fmaf(al[nt], c[4 * g + e], xn[g][e]);
                                     hit |= key[e] <= tauf[nt];
                                 }
                                 if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
@@ -655,9 +687,13 @@ bool mm_supported(int d, int store_dtype, int kc) {
     return store_dtype == PRAG_F16 && (d == 256 || d == 512 || d == 768 || d == 1024) && kc >= 8 && kc <= kMmMaxKc;
 }
 
-template <int NKT, int MODE, int ABL = 0>
+bool mm8_supported(int d, int kc) {
+    return (d == 512 || d == 768 || d == 1024) && kc >= 8 && kc <= kMmMaxKc;   // d / 128 K tiles, an even number >= 4
+}
+
+template <int NKT, int MODE, int ABL = 0, bool I8 = false>
 static int launch_mm_impl(const MmArgs& a, int grid, hipStream_t st) {
-    auto kern = scan_mm_kernel<NKT, MODE, ABL>;
+    auto kern = scan_mm_kernel<NKT, MODE, ABL, I8>;
     static LdsOptIn lds_opt_in;
     {
         const int rc_ = lds_opt_in.ensure(reinterpret_cast<const void*>(kern), 160 * 1024);
@@ -675,8 +711,16 @@ static int launch_mm(const MmArgs& a, bool first, int grid, hipStream_t st) {
     return launch_mm_impl<NKT, 1, ABL>(a, grid, st);
 }
 
+template <int NKT8>
+static int launch_mm8(const MmArgs& a, bool first, int grid, hipStream_t st) {
+    if (first) return launch_mm_impl<NKT8, 0, 0, true>(a, grid, st);
+    if (a.use_norm) return launch_mm_impl<NKT8, 2, 0, true>(a, grid, st);
+    return launch_mm_impl<NKT8, 1, 0, true>(a, grid, st);
+}
+
 int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
-    PRAG_REQUIRE(mm_supported(s.d, PRAG_F16, s.kc) && s.Bpad % 256 == 0 && s.Bpad <= kMmMaxQueries &&
+    PRAG_REQUIRE((s.i8 ? mm8_supported(s.d, s.kc) && s.rows8 && s.sscale && s.q8 && s.kq
+                       : mm_supported(s.d, PRAG_F16, s.kc)) && s.Bpad % 256 == 0 && s.Bpad <= kMmMaxQueries &&
                      s.cap_q >= kMmFirstSeg && s.max_wg >= 1 && s.max_wg <= s.wg_slots,
                  PRAG_EUNSUPPORTED, "internal: MFMA-tiled scan called outside its envelope");
     const int64_t first_rows = std::min<int64_t>(s.N, kMmFirstSeg);
@@ -700,6 +744,10 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
     a.widx = s.widx;
     a.cap_wg = s.cap_wg;
     a.dbg = nullptr;
+    a.rows8 = s.rows8;
+    a.sscale = s.sscale;
+    a.q8 = s.q8;
+    a.kq = s.kq;
 #ifdef PRAG_MM_DIAG
     static unsigned long long* dbg_dev = nullptr;
     if (getenv("PRAG_MM_CLOCK")) {
@@ -719,6 +767,13 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
         const bool biggest = hi == s.N;  // segments grow x16: the last one dominates
         if (biggest) prof.begin(st);
         int rc;
+        if (s.i8) {
+            switch (s.d) {
+                case 512: rc = launch_mm8<4>(a, first, grid, st); break;
+                case 768: rc = launch_mm8<6>(a, first, grid, st); break;
+                default: rc = launch_mm8<8>(a, first, grid, st); break;
+            }
+        } else
         switch (s.d) {
             case 256: rc = launch_mm<4>(a, first, grid, st); break;
             case 512: rc = launch_mm<8>(a, first, grid, st); break;

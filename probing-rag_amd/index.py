@@ -284,6 +284,15 @@ def _ix_last_exact_fallbacks(self) -> int:
     return n.value
 
 
+def _ix_last_tiled8(self) -> int:
+    """Batches of > 128 queries on an index that keeps the 8-bit shadow: queries of the most recent search that
+    failed the certificate of the int8-tile selection and sent the batch to the fp16 tiles (0: the first tier
+    answered; -1: that search did not take the int8 tiles)."""
+    n = ctypes.c_int(0)
+    _lib.check(_lib.lib().prag_index_last_tiled8(self._h, ctypes.byref(n)))
+    return n.value
+
+
 def _ix_set_shadow(self, mode=1):
     """Two-level exact search through an 8-bit shadow of the rows (prag_index_set_shadow): 0/False off,
     1/True (the default) for shards of >= 2^20 rows when the device has room, 2 at any size.  Same
@@ -305,6 +314,7 @@ HipFlatIndex.set_shadow = _ix_set_shadow
 HipFlatIndex.prepare = _ix_prepare
 HipFlatIndex.set_candidate_depth = _ix_set_candidate_depth
 HipFlatIndex.last_exact_fallbacks = _ix_last_exact_fallbacks
+HipFlatIndex.last_tiled8 = _ix_last_tiled8
 
 
 def _ix_set_scan_workgroups(self, n: int):

@@ -1,0 +1,147 @@
+"""GPU: batches of > 128 queries on an index that keeps the 8-bit shadow (flat_mm.hip, I8 kernels).
+First tier: candidate selection on int8 matrix tiles over the shadow (256 candidates per query, the
+shadow's Cauchy-Schwarz bound in the certificate); a batch in which any query fails that certificate is
+repeated on the fp16 tiles.  Either way the results must be the float64 definition's, bit for bit
+(reference call: utils.py:378-380 batch_topk_sim -> IndexFlat.search)."""
+import numpy as np
+import pytest
+
+from oracle import oracle_c, oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+
+METRICS = [onp.METRIC_L2, onp.METRIC_IP, onp.METRIC_COS]
+
+
+def _stored(X, metric, store):
+    xs = onp.normalize_rows(X) if metric == onp.METRIC_COS else X
+    return onp.store_round(xs, store)
+
+
+def _check(D, I, D0, I0, metric):
+    assert np.array_equal(I, I0), np.argwhere(I != I0)[:4]
+    if metric == onp.METRIC_L2:
+        np.testing.assert_allclose(D, D0, rtol=1e-4, atol=1e-6)
+    else:
+        np.testing.assert_allclose(D, D0, atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("store", ["f16", "f32"])
+@pytest.mark.parametrize("metric", METRICS)
+@pytest.mark.parametrize("N,B,k,d", [(30_000, 300, 10, 768), (2049, 129, 5, 768), (70_000, 257, 10, 512),
+                                     (9_000, 513, 26, 1024), (300, 200, 10, 768), (1, 130, 5, 768)])
+def test_int8_tiles_match_definition(metric, store, N, B, k, d):
+    import probing_rag_amd as pra
+    X = onp.synth_rows(42, 0, N, d)
+    if N > 40:
+        X[N // 2] = X[3]
+        X[N - 1] = X[3]              # exact duplicates: ties resolved by id
+    Q = onp.synth_rows(7, 0, B, d)
+    if N > 40:
+        Q[0] = X[3]
+    ix = pra.HipFlatIndex(d, metric, store)
+    ix.set_shadow(2)
+    ix.add(X[: N // 2])
+    ix.add(X[N // 2:])
+    D, I = ix.search(Q, k)
+    assert ix.last_tiled8() >= 0                     # the int8 tiles ran
+    D0, I0 = oracle_c.flat_search(_stored(X, metric, store), Q, k, metric)
+    _check(D, I, D0, I0, metric)
+    # the same through device tensors (the tier decision is then a 4-byte read-back)
+    import torch
+    Dt, It = ix.search(torch.from_numpy(Q).cuda(), k)
+    assert ix.last_tiled8() >= 0
+    _check(Dt.cpu().numpy(), It.cpu().numpy(), D0, I0, metric)
+    # shadow off: the fp16 tiles alone answer, same results
+    ix.set_shadow(0)
+    D1, I1 = ix.search(Q, k)
+    assert ix.last_tiled8() == -1
+    _check(D1, I1, D0, I0, metric)
+    ix.close()
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_first_tier_answers_a_random_corpus(metric):
+    """Exchangeable rows: every query clears the 8-bit certificate with 256 candidates (no second tier,
+    no exact fallback) and the ids are those of the fp16 tiles."""
+    import probing_rag_amd as pra
+    import torch
+    N, d, B, k = 1_200_000, 768, 1000, 10
+    ix = pra.HipFlatIndex(d, metric, "f16", capacity=N)
+    ix.add_synthetic(42, 0, N)
+    q = torch.from_numpy(onp.synth_rows(7, 0, B, d)).cuda()
+    ix.set_shadow(0)
+    D0, I0 = ix.search(q, k)
+    assert ix.last_tiled8() == -1
+    ix.set_shadow(2)           # (mode 1 takes the int8 tiles from 4 M rows on: below that the fp16 tiles are faster)
+    ix.prepare()
+    D1, I1 = ix.search(q, k)
+    assert ix.last_tiled8() == 0, ix.last_tiled8()
+    assert ix.last_exact_fallbacks() == 0
+    assert torch.equal(I0, I1)
+    assert torch.equal(D0, D1)
+    # a sample of the queries against the float64 oracle over the first 150 k rows (searched separately)
+    sub = pra.HipFlatIndex(d, metric, "f16", capacity=150_000)
+    sub.set_shadow(2)
+    sub.add_synthetic(42, 0, 150_000)
+    Ds, Is = sub.search(q[:140], k)
+    assert sub.last_tiled8() >= 0
+    _, Iref = oracle_c.flat_search(sub.reconstruct_n(0, 150_000), q[:140].cpu().numpy(), k, metric)
+    assert np.array_equal(Is.cpu().numpy(), Iref)
+    sub.close()
+    ix.close()
+
+
+@pytest.mark.parametrize("store", ["f16", "f32"])
+@pytest.mark.parametrize("metric", METRICS)
+def test_second_tier_on_a_corpus_of_look_alikes(metric, store):
+    """Thousands of rows inside the 8-bit error band of every query's k-th score: 256 candidates cannot clear
+    the certificate, the batch is repeated on the fp16 tiles (and their exact fallback) - results still the
+    definition's, through host arrays and through device tensors."""
+    import probing_rag_amd as pra
+    import torch
+    N, d, B, k = 20_000, 768, 150, 10
+    rng = np.random.default_rng(5)
+    base = onp.synth_rows(5, 0, 1, d)[0]
+    X = (base[None, :] + 2e-3 * rng.standard_normal((N, d))).astype(np.float32)
+    Q = (base[None, :] + 2e-3 * rng.standard_normal((B, d))).astype(np.float32)
+    ix = pra.HipFlatIndex(d, metric, store)
+    ix.set_shadow(2)
+    ix.add(X)
+    D0, I0 = oracle_c.flat_search(_stored(X, metric, store), Q, k, metric)
+    D, I = ix.search(Q, k)
+    assert ix.last_tiled8() > 0
+    _check(D, I, D0, I0, metric)
+    Dt, It = ix.search(torch.from_numpy(Q).cuda(), k)
+    assert ix.last_tiled8() > 0
+    _check(Dt.cpu().numpy(), It.cpu().numpy(), D0, I0, metric)
+    ix.close()
+
+
+def test_sharded_large_batch_equals_unsharded():
+    """Row shards searched with tagged ids through the int8 tiles, merged: identical to one index."""
+    import probing_rag_amd as pra
+    import torch
+    N, d, B, k = 90_000, 768, 260, 10
+    X = onp.synth_rows(42, 0, N, d)
+    Q = torch.from_numpy(onp.synth_rows(7, 0, B, d)).cuda()
+    one = pra.HipFlatIndex(d, "cos", "f16")
+    one.set_shadow(2)
+    one.add(X)
+    D0, I0 = one.search(Q, k)
+    assert one.last_tiled8() >= 0
+    from probing_rag_amd.sharded import search_shards_on_one_gpu
+    shards = []
+    bounds = [0, 20_001, 55_555, N]
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        sh = pra.HipFlatIndex(d, "cos", "f16")
+        sh.set_shadow(2)
+        sh.add(X[lo:hi])
+        shards.append(sh)
+    D1, I1 = search_shards_on_one_gpu(shards, Q, k, "cos")
+    assert all(sh.last_tiled8() >= 0 for sh in shards)
+    assert torch.equal(I0, I1)
+    assert torch.allclose(D0, D1, atol=1e-6)
+    for sh in shards:
+        sh.close()
+    one.close()

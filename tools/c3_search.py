@@ -11,13 +11,25 @@ N, d, B, k = int(os.environ.get("C3_N", 1_000_000)), 768, int(os.environ.get("C3
 ix = pra.HipFlatIndex(d, "cos", "f16", capacity=N)
 ix.add_synthetic(42, 0, N)
 Q = torch.from_numpy(onp.synth_rows(7, 0, B, d)).cuda()
-for _ in range(3):
-    ix.search(Q, k)
-torch.cuda.synchronize()
 n = int(os.environ.get("C3_REPS", 10))
-t0 = time.perf_counter()
-for _ in range(n):
-    ix.search(Q, k)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / n
-print(f"{B} x {N} x {d}: {dt*1e3:.3f} ms/search -> {B*N/dt:.3e} scores/s, {2*B*N*d/dt/1e12:.0f} TFLOP/s", flush=True)
+for shadow in (0, 2):       # 0: fp16 tiles; 2: int8 tiles over the 8-bit shadow first (PRAG_MM8=0 switches them off)
+    ix.set_shadow(shadow)
+    ix.prepare()
+    for _ in range(3):
+        ix.search(Q, k)
+    torch.cuda.synchronize()
+    ix.profile(256)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        D, I = ix.search(Q, k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    seg = np.asarray(ix.profile_read())
+    ix.profile(0)
+    print(f"shadow={shadow} {B} x {N} x {d}: {dt*1e3:.3f} ms/search -> {B*N/dt:.3e} scores/s, {2*B*N*d/dt/1e12:.0f} Top/s; "
+          f"largest segment {seg.mean():.3f} ms; int8 tier failed {ix.last_tiled8()}, exact fallbacks {ix.last_exact_fallbacks()}",
+          flush=True)
+    if shadow == 0:
+        I_ref = I.clone()
+    else:
+        print("ids identical to the fp16 tiles:", bool(torch.equal(I, I_ref)), flush=True)
