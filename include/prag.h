@@ -234,7 +234,8 @@ int prag_index_d(const prag_index_t* ix);
  * selection vs the gap to the last candidate); a query that cannot be certified - dense
  * near-duplicates, squared-L2 cancellation, a deep-list overflow - is recomputed by an exact
  * float64 scan of every row inside the same call (one more pass over the shard for that query).
- * No host synchronisation on the device-io path.
+ * No host synchronisation on the device-io path - with one exception: a batch of > 128 queries that
+ * takes the int8 tiles (prag_index_last_tiled8 below) waits for `stream` once, to read 4 bytes.
  * With io_is_device == 0 the call copies in/out and synchronises `stream`. */
 int prag_index_search(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset,
                       float* D, int64_t* I, int io_is_device, void* stream);
@@ -291,8 +292,8 @@ int prag_index_last_tiled8(prag_index_t* ix, int* n_failed_out);
 
 /* Two-level exact search: keep an 8-bit shadow of the stored rows (+d+8 bytes per row, built on the
  * device as rows are added - `prag_index_add*` extend it before they return, so no search pays for
- * the build) and scan IT for batches of <= 64 queries (d a multiple of 128, <= 1024,
- * k <= 26): half the bytes of fp16 storage, a quarter of float32.  Results do not change: a
+ * the build) and scan IT for batches of <= 128 queries (d a multiple of 128, <= 1024,
+ * k <= 26; larger batches: prag_index_last_tiled8 above): half the bytes of fp16 storage, a quarter of float32.  Results do not change: a
  * proof-carrying filter (Cauchy-Schwarz bound on the quantisation error of every row) keeps each row
  * that can still belong to the top k, the survivors are scored in float64 from the stored rows, and a
  * query whose candidate store overflows is recomputed by the exact scan.
