@@ -29,7 +29,8 @@ def _check(D, I, D0, I0, metric):
 @pytest.mark.parametrize("store", ["f16", "f32"])
 @pytest.mark.parametrize("metric", METRICS)
 @pytest.mark.parametrize("N,B,k,d", [(30_000, 300, 10, 768), (2049, 129, 5, 768), (70_000, 257, 10, 512),
-                                     (9_000, 513, 26, 1024), (300, 200, 10, 768), (1, 130, 5, 768)])
+                                     (9_000, 513, 26, 1024), (300, 200, 10, 768), (1, 130, 5, 768),
+                                     (12_000, 1100, 10, 768)])      # two 1024-query chunks
 def test_int8_tiles_match_definition(metric, store, N, B, k, d):
     import probing_rag_amd as pra
     X = onp.synth_rows(42, 0, N, d)
