@@ -770,7 +770,19 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
         if (s.i8) {
             switch (s.d) {
                 case 512: rc = launch_mm8<4>(a, first, grid, st); break;
-                case 768: rc = launch_mm8<6>(a, first, grid, st); break;
+                case 768:
+#ifdef PRAG_MM_DIAG
+                {   // timing-only ablations of the int8 tiles (wrong results): 8 no filter, 1 no MFMAs, 9 neither
+                    const char* e = getenv("PRAG_MM_ABLATE");
+                    const int abl = e ? atoi(e) : 0;
+                    if (!first && !a.use_norm && abl == 8) { rc = launch_mm_impl<6, 1, 8, true>(a, grid, st); break; }
+                    if (!first && !a.use_norm && abl == 1) { rc = launch_mm_impl<6, 1, 1, true>(a, grid, st); break; }
+                    if (!first && !a.use_norm && abl == 9) { rc = launch_mm_impl<6, 1, 9, true>(a, grid, st); break; }
+                    if (!first && !a.use_norm && abl == 2) { rc = launch_mm_impl<6, 1, 2, true>(a, grid, st); break; }
+                    if (!first && !a.use_norm && abl == 4) { rc = launch_mm_impl<6, 1, 4, true>(a, grid, st); break; }
+                }
+#endif
+                    rc = launch_mm8<6>(a, first, grid, st); break;
                 default: rc = launch_mm8<8>(a, first, grid, st); break;
             }
         } else
