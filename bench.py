@@ -50,7 +50,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA
 MFMA_I8_PEAK_TOP = 5000.0  # int8 MFMA: 2x the bf16 rate per clock (MI355X_MICROARCH.md, MFMA table)
-MM8_MIN_ROWS = 4 << 20     # prag_index_search takes the int8 tiles (> 128 queries, shadow kept) from this shard size on
+MM8_MIN_ROWS = 5 << 19     # prag_index_search takes the int8 tiles (> 128 queries, shadow kept) from this shard size on
 D_MODEL, D_EMB, N_LAYERS = 2048, 768, 6
 
 

@@ -1278,11 +1278,12 @@ struct prag_index {
     // query fails that certificate is repeated on the fp16 tiles (PRAG_MM8=0: fp16 tiles only)
     int mm8_mode = 1;
     // ... on shards of at least this many rows (shadow mode 2 = "any size": no minimum).  Measured, 1000 queries x
-    // 768: 1 M rows 2.10 ms against 1.71 on the fp16 tiles - the 256-deep lists cost 0.49 ms of compaction sorts
-    // and 0.14 ms of rerank, and with the bound of a segment coming from <= 166 k rows one score in 650 survives
-    // the filter, so the int8 scan itself gains only 7 % -; 21 M rows 19.4 ms against 28.7 (0.76 ns per row and
-    // 1000 queries in the last segment against 1.34)
-    int64_t mm8_min_rows = 4ll << 20;
+    // 768, int8 tiles against fp16 tiles: 1 M rows 2.04 ms / 1.73 - the 256-deep lists cost sort compactions and
+    // 0.14 ms of rerank, and with the bound of a segment coming from <= 166 k rows one score in 650 survives the
+    // filter, so the int8 scan itself gains only 7 % -; 2.625 M rows (an 8-GPU shard of 21 M) 3.59 / 3.82;
+    // 4 Mi rows 5.27 / 5.92 (before the balanced gather of the compaction); 8 M 8.60 / 11.09; 21 M 19.4 / 28.7
+    // (0.76 ns per row and 1000 queries in the last segment against 1.34)
+    int64_t mm8_min_rows = 5ll << 19;   // 2.5 Mi
     float* mm_kq = nullptr;            // [mm_q_cap] key scale of every query
     uint32_t* tier_word_host = nullptr;   // pinned: flag count read back between the two tiers (device-io searches)
     int mm8_last_failed = -1;             // queries of the last 8-bit tiled search that failed its certificate (-1: none ran)

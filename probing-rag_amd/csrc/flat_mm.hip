@@ -523,24 +523,17 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
 // ---------------------------------------------------------------------------
 constexpr int kMmCompactCap = 4096;  // entries staged in LDS; a query with more is flagged as overflowed
 
-__global__ __launch_bounds__(256) void mm_compact_kernel(uint32_t* __restrict__ cnt, float* __restrict__ ckey,
-                                                        int* __restrict__ cidx, int cap_q, int KC,
-                                                        uint32_t* __restrict__ tau, int* __restrict__ cand,
-                                                        uint32_t* __restrict__ ovf, uint32_t* __restrict__ ovf_any,
-                                                        const uint32_t* __restrict__ wcnt,
-                                                        const float* __restrict__ wkey, const int* __restrict__ widx,
-                                                        int cap_wg, int n_wg, int wg_stride, int Bpad) {
-    __shared__ unsigned long long s_v[kMmCompactCap];
-    __shared__ unsigned long long s_m[2][4];
-    __shared__ int s_tot[4];
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t c = cnt[q];
-    int n = c < (uint32_t)cap_q ? (int)c : cap_q;
-    bool over = c > (uint32_t)cap_q || n > kMmCompactCap;
-    n = n < kMmCompactCap ? n : kMmCompactCap;
-    const int64_t o = (int64_t)q * cap_q;
-    for (int i = tid; i < n; i += 256) s_v[i] = pack_key(ckey[o + i], cidx[o + i]);
-    // this segment's survivors: 256 workgroups per step, offsets by a block prefix sum
+// This segment's survivors of query q -> s_v[n ...): 256 workgroups per step.  The entries of a step are numbered
+// by a block prefix sum over the workgroups' counts and dealt round-robin to the threads (8-step binary search in
+// the prefix array for the owning workgroup): every thread issues the same number of independent loads.  (One
+// thread per workgroup copying its own region serially - the first version - left 64 threads with ~32 dependent
+// round trips each when the candidate lists are deep: 122 us per compaction of 1000 queries at 256 candidates.)
+// Returns true when a region or the staging buffer overflowed; n is advanced.  All 256 threads call it.
+__device__ __forceinline__ bool mm_gather_survivors(unsigned long long* s_v, int& n, int q, const uint32_t* __restrict__ wcnt,
+                                                    const float* __restrict__ wkey, const int* __restrict__ widx,
+                                                    int cap_wg, int n_wg, int wg_stride, int Bpad, int* s_tot, int* s_incl) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    bool over = false;
     for (int w0 = 0; w0 < n_wg; w0 += 256) {
         const int wg = w0 + tid;
         const uint32_t cw = wg < n_wg ? wcnt[(int64_t)q * wg_stride + wg] : 0u;
@@ -560,15 +553,48 @@ __global__ __launch_bounds__(256) void mm_compact_kernel(uint32_t* __restrict__ 
             before += j < w ? s_tot[j] : 0;
             total += s_tot[j];
         }
-        const int at = n + before + incl - mine;
-        const int64_t wo = ((int64_t)wg * Bpad + q) * cap_wg;
-        for (int j = 0; j < mine; ++j) {
-            if (at + j < kMmCompactCap) s_v[at + j] = pack_key(wkey[wo + j], widx[wo + j]);
+        s_incl[tid] = before + incl;            // inclusive prefix over the 256 workgroups of this step
+        __syncthreads();
+        for (int e = tid; e < total; e += 256) {
+            int lo = 0, hi = 255;               // first t with s_incl[t] > e
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int mid = (lo + hi) >> 1;
+                if (s_incl[mid] > e) hi = mid; else lo = mid + 1;
+            }
+            const int t = lo;
+            const int j = e - (t > 0 ? s_incl[t - 1] : 0);
+            const int64_t wo = ((int64_t)(w0 + t) * Bpad + q) * cap_wg;
+            if (n + e < kMmCompactCap) s_v[n + e] = pack_key(wkey[wo + j], widx[wo + j]);
             else over = true;
         }
         n = n + total < kMmCompactCap ? n + total : kMmCompactCap;
         __syncthreads();
     }
+    return over;
+}
+
+
+__global__ __launch_bounds__(256) void mm_compact_kernel(uint32_t* __restrict__ cnt, float* __restrict__ ckey,
+                                                        int* __restrict__ cidx, int cap_q, int KC,
+                                                        uint32_t* __restrict__ tau, int* __restrict__ cand,
+                                                        uint32_t* __restrict__ ovf, uint32_t* __restrict__ ovf_any,
+                                                        const uint32_t* __restrict__ wcnt,
+                                                        const float* __restrict__ wkey, const int* __restrict__ widx,
+                                                        int cap_wg, int n_wg, int wg_stride, int Bpad) {
+    __shared__ unsigned long long s_v[kMmCompactCap];
+    __shared__ unsigned long long s_m[2][4];
+    __shared__ int s_tot[4];
+    __shared__ int s_incl[256];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t c = cnt[q];
+    int n = c < (uint32_t)cap_q ? (int)c : cap_q;
+    bool over = c > (uint32_t)cap_q || n > kMmCompactCap;
+    n = n < kMmCompactCap ? n : kMmCompactCap;
+    const int64_t o = (int64_t)q * cap_q;
+    for (int i = tid; i < n; i += 256) s_v[i] = pack_key(ckey[o + i], cidx[o + i]);
+    // this segment's survivors: 256 workgroups per step, offsets by a block prefix sum
+    over |= mm_gather_survivors(s_v, n, q, wcnt, wkey, widx, cap_wg, n_wg, wg_stride, Bpad, s_tot, s_incl);
     __syncthreads();
     unsigned long long prev = 0;
     for (int round = 0; round < KC; ++round) {
@@ -624,41 +650,15 @@ __global__ __launch_bounds__(256) void mm_compact_sort_kernel(uint32_t* __restri
                                                              int wg_stride, int Bpad) {
     __shared__ unsigned long long s_v[kMmCompactCap];
     __shared__ int s_tot[4];
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    __shared__ int s_incl[256];
+    const int q = blockIdx.x, tid = threadIdx.x;
     const uint32_t c = cnt[q];
     int n = c < (uint32_t)cap_q ? (int)c : cap_q;
     bool over = c > (uint32_t)cap_q || n > kMmCompactCap;
     n = n < kMmCompactCap ? n : kMmCompactCap;
     const int64_t o = (int64_t)q * cap_q;
     for (int i = tid; i < n; i += 256) s_v[i] = pack_key(ckey[o + i], cidx[o + i]);
-    for (int w0 = 0; w0 < n_wg; w0 += 256) {
-        const int wg = w0 + tid;
-        const uint32_t cw = wg < n_wg ? wcnt[(int64_t)q * wg_stride + wg] : 0u;
-        over |= cw > (uint32_t)cap_wg;
-        const int mine = cw < (uint32_t)cap_wg ? (int)cw : cap_wg;
-        int incl = mine;
-#pragma unroll
-        for (int sft = 1; sft < 64; sft <<= 1) {
-            const int up = __shfl_up(incl, sft, 64);
-            if (lane >= sft) incl += up;
-        }
-        if (lane == 63) s_tot[w] = incl;
-        __syncthreads();
-        int before = 0, total = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            before += j < w ? s_tot[j] : 0;
-            total += s_tot[j];
-        }
-        const int at = n + before + incl - mine;
-        const int64_t wo = ((int64_t)wg * Bpad + q) * cap_wg;
-        for (int j = 0; j < mine; ++j) {
-            if (at + j < kMmCompactCap) s_v[at + j] = pack_key(wkey[wo + j], widx[wo + j]);
-            else over = true;
-        }
-        n = n + total < kMmCompactCap ? n + total : kMmCompactCap;
-        __syncthreads();
-    }
+    over |= mm_gather_survivors(s_v, n, q, wcnt, wkey, widx, cap_wg, n_wg, wg_stride, Bpad, s_tot, s_incl);
     int n_pad = 2;
     while (n_pad < n) n_pad <<= 1;
     for (int i = n + tid; i < n_pad; i += 256) s_v[i] = ~0ull;
