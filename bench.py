@@ -50,7 +50,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F16_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA
 MFMA_I8_PEAK_TOP = 5000.0  # int8 MFMA: 2x the bf16 rate per clock (MI355X_MICROARCH.md, MFMA table)
-MM8_MIN_ROWS = 5 << 19     # prag_index_search takes the int8 tiles (> 128 queries, shadow kept) from this shard size on
+MM8_MIN_ROWS = 2 << 20     # prag_index_search takes the int8 tiles (> 128 queries, shadow kept) from this shard size on
 D_MODEL, D_EMB, N_LAYERS = 2048, 768, 6
 
 
@@ -494,12 +494,12 @@ def main(argv=None):
     mm_tf = mm_flops = rows_last = None
     if tiled:
         # the profiled launch is the last corpus segment (segments: 2048 rows, then x16 on the fp16 tiles;
-        # the int8 tiles keep 256 candidates per query and grow by 1 + 32 CUs / (256 x query blocks), at most 16)
+        # the int8 tiles keep 256 candidates per query and grow x3)
         i8_tiles = local.last_tiled8() >= 0
         growth = 16
         if i8_tiles:
             n_qb = min((args.queries + 255) // 256 * 256, 1024) // 256
-            growth = max(2, min(16, 1 + 32 * n_cu // (256 * n_qb), 1 + 3000 // 256))
+            growth = 3
         seg0 = 2048
         while seg0 * growth < n_local:
             seg0 *= growth

@@ -1283,7 +1283,8 @@ struct prag_index {
     // filter, so the int8 scan itself gains only 7 % -; 2.625 M rows (an 8-GPU shard of 21 M) 3.59 / 3.82;
     // 4 Mi rows 5.27 / 5.92 (before the balanced gather of the compaction); 8 M 8.60 / 11.09; 21 M 19.4 / 28.7
     // (0.76 ns per row and 1000 queries in the last segment against 1.34)
-    int64_t mm8_min_rows = 5ll << 19;   // 2.5 Mi
+    // (those with segment growth 9; with growth 3: 1 M rows 1.90 / 1.73, 2.625 M 3.36 / 3.90, 21 M 17.8)
+    int64_t mm8_min_rows = 2ll << 20;
     float* mm_kq = nullptr;            // [mm_q_cap] key scale of every query
     uint32_t* tier_word_host = nullptr;   // pinned: flag count read back between the two tiers (device-io searches)
     int mm8_last_failed = -1;             // queries of the last 8-bit tiled search that failed its certificate (-1: none ran)
@@ -1799,6 +1800,11 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
         const int g_wg = 1 + (cap_wg / 4) * cu_budget / std::max(1, kc * n_qb);
         const int g_lds = 1 + 3000 / kc;
         m.growth = std::max(2, std::min(16, std::min(g_wg, g_lds)));
+        // int8 tiles: a segment yields ~(growth - 1) * 256 survivors per query, each an LDS atomic and two stores in
+        // the filter while the other wave group waits; short segments keep the bound fresh.  Measured, 1000 queries,
+        // growth 9 / 6 / 4 / 3 / 2: 2.625 M rows 3.81 / 3.66 / 3.57 / 3.39 / 3.96 ms, 21 M rows 19.1 / 18.5 / 18.2 /
+        // 17.9 / 17.9, 1 M rows 2.13 / 1.95 / 1.97 / 1.90 / 1.94 (same box)
+        if (i8) m.growth = std::min(m.growth, kMm8Growth);
     }
     int rc = PRAG_OK;
     for (int c0 = 0; c0 < B; c0 += chunk) {  // chunks of <= 4096 queries (LDS counters)
@@ -1871,6 +1877,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
 constexpr int kMm8Kc = 256;
 constexpr int kMm8CapWg = 128;    // survivors one workgroup can hold per query and segment
 constexpr int kMm8Chunk = 1024;   // queries per mm_run call
+constexpr int kMm8Growth = 3;     // segment i+1 ends at 3 x the end of segment i (search_tiled)
 
 extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D,
                                  int64_t* I, int io_is_device, void* stream) {

@@ -74,7 +74,7 @@ def test_first_tier_answers_a_random_corpus(metric):
     ix.set_shadow(0)
     D0, I0 = ix.search(q, k)
     assert ix.last_tiled8() == -1
-    ix.set_shadow(2)           # (mode 1 takes the int8 tiles from 2.5 Mi rows on: below that the fp16 tiles are faster)
+    ix.set_shadow(2)           # (mode 1 takes the int8 tiles from 2 Mi rows on: below that the fp16 tiles are faster)
     ix.prepare()
     D1, I1 = ix.search(q, k)
     assert ix.last_tiled8() == 0, ix.last_tiled8()
