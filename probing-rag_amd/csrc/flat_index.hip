@@ -1753,6 +1753,14 @@ static int launch_merge_rerank(int kc, bool f32, const float* pk, const int* pi,
     return PRAG_OK;
 }
 
+// candidates per query of the 8-bit tiled selection: the certificate needs the KC-th selection key to clear the
+// k-th exact key by the shadow's error bound (~0.55 sigma of the score distribution on 768 Gaussian elements with
+// the worst row's residual): rank ~110 at 1 M and at 21 M rows for k = 10; 256 leaves 0.2 sigma of margin
+constexpr int kMm8Kc = 256;
+constexpr int kMm8CapWg = 128;    // survivors one workgroup can hold per query and segment
+constexpr int kMm8Chunk = 1024;   // queries per mm_run call
+constexpr int kMm8Growth = 3;     // segment i+1 ends at 3 x the end of segment i (search_tiled)
+
 // > 128 queries on fp16 rows: MFMA-tiled scan (flat_mm.hip) in chunks of kMmMaxQueries, then the
 // device-flagged fallback through the per-lane-list kernel for queries whose candidate store
 // overflowed.  Leaves the candidate ids in ix->cand.
@@ -1871,13 +1879,6 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
 static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D, int64_t* I,
                              int io_is_device, void* stream, int tag_ids, bool allow_mm8 = true);
 
-// candidates per query of the 8-bit tiled selection: the certificate needs the KC-th selection key to clear the
-// k-th exact key by the shadow's error bound (~0.55 sigma of the score distribution on 768 Gaussian elements with
-// the worst row's residual): rank ~110 at 1 M and at 21 M rows for k = 10; 256 leaves 0.2 sigma of margin
-constexpr int kMm8Kc = 256;
-constexpr int kMm8CapWg = 128;    // survivors one workgroup can hold per query and segment
-constexpr int kMm8Chunk = 1024;   // queries per mm_run call
-constexpr int kMm8Growth = 3;     // segment i+1 ends at 3 x the end of segment i (search_tiled)
 
 extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D,
                                  int64_t* I, int io_is_device, void* stream) {
