@@ -1240,6 +1240,31 @@ __global__ __launch_bounds__(256) void rows_to_f16_kernel(const float* __restric
 
 }  // namespace prag
 
+// ---------------------------------------------------------------------------
+// second tier of the 8-bit tiled selection when only a few queries failed its certificate: those queries are
+// gathered into a compact batch, searched on their own (<= 128 queries: the two-level / list kernels), and their
+// results scattered back over the rows of the batch
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_queries_kernel(const float* __restrict__ q, const int* __restrict__ list, int n,
+                                                            int d, float* __restrict__ out) {
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const float* src = q + (int64_t)list[i] * d;
+    for (int c = threadIdx.x * 4; c < d; c += 1024)
+        *reinterpret_cast<prag::f32x4*>(out + (int64_t)i * d + c) = *reinterpret_cast<const prag::f32x4*>(src + c);
+}
+__global__ __launch_bounds__(64) void scatter_results_kernel(const float* __restrict__ Ds, const int64_t* __restrict__ Is,
+                                                            const int* __restrict__ list, int n, int k,
+                                                            float* __restrict__ D, int64_t* __restrict__ I) {
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const int64_t b = list[i];
+    for (int j = threadIdx.x; j < k; j += 64) {
+        D[b * k + j] = Ds[(int64_t)i * k + j];
+        I[b * k + j] = Is[(int64_t)i * k + j];
+    }
+}
+
 // ===========================================================================
 // host side
 // ===========================================================================
@@ -1291,6 +1316,12 @@ struct prag_index {
     float* mm_kq = nullptr;            // [mm_q_cap] key scale of every query
     uint32_t* tier_word_host = nullptr;   // pinned: flag count read back between the two tiers (device-io searches)
     int mm8_last_failed = -1;             // queries of the last 8-bit tiled search that failed its certificate (-1: none ran)
+    // few failed queries: searched again as a compact batch (mm8_second_tier)
+    int* t2_list = nullptr;
+    float* t2_q = nullptr;
+    float* t2_D = nullptr;
+    int64_t* t2_I = nullptr;
+    int t2_cap = 0, t2_k = 0;
     // fp32 indexes: fp16 copy of the rows for the tiled scan's candidate selection (built on the
     // first search with > 128 queries, dropped by add; the rerank always reads the fp32 rows)
     _Float16* rows16 = nullptr;
@@ -1896,6 +1927,40 @@ extern "C" int prag_index_search_tagged(prag_index_t* ix, const float* q, int B,
     return index_search_impl(ix, q, B, k, id_offset, D, I, io_is_device, stream, 1);
 }
 
+// Second tier of the 8-bit tiled selection (n_failed > 0 queries of the batch failed its certificate; their batch
+// rows are in ix->flag_list).  Few of them - at most kMm8SubsetMax and a quarter of the batch: a corpus with the
+// odd query sitting in a cluster of look-alikes - are searched again as a compact batch of their own (<= 128 queries
+// take the two-level search or the list kernels: one pass over the shard instead of the fp16 tiles for everybody);
+// otherwise the whole batch goes through the fp16 tiles.  Results land in D_dev / I_dev either way.
+constexpr int kMm8SubsetMax = 128;
+static int mm8_second_tier(prag_index* ix, const float* q_dev, int B, int k, int64_t id_offset, float* D_dev, int64_t* I_dev,
+                           void* stream, int tag_ids, int n_failed) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (n_failed > kMm8SubsetMax || (int64_t)n_failed * 4 > B)
+        return index_search_impl(ix, q_dev, B, k, id_offset, D_dev, I_dev, 1, stream, tag_ids, false);
+    if (ix->t2_cap < kMm8SubsetMax || ix->t2_k < k) {
+        ix->t2_cap = 0; ix->t2_k = 0;
+        const int nk = std::max(k, ix->t2_k);
+        const int rc_ws = ws_regrow({{vpp(&ix->t2_list), (size_t)kMm8SubsetMax * sizeof(int)},
+                                     {vpp(&ix->t2_q), (size_t)kMm8SubsetMax * ix->d * sizeof(float)},
+                                     {vpp(&ix->t2_D), (size_t)kMm8SubsetMax * nk * sizeof(float)},
+                                     {vpp(&ix->t2_I), (size_t)kMm8SubsetMax * nk * sizeof(int64_t)}});
+        if (rc_ws != PRAG_OK) return rc_ws;
+        ix->t2_cap = kMm8SubsetMax;
+        ix->t2_k = nk;
+    }
+    // (the inner search reuses flag_list: keep a copy of the failed rows)
+    PRAG_HIP(hipMemcpyAsync(ix->t2_list, ix->flag_list, (size_t)n_failed * sizeof(int), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(gather_queries_kernel, dim3(n_failed), dim3(256), 0, st, q_dev, ix->t2_list, n_failed, ix->d, ix->t2_q);
+    PRAG_LAUNCH_CHECK();
+    const int rc = index_search_impl(ix, ix->t2_q, n_failed, k, id_offset, ix->t2_D, ix->t2_I, 1, stream, tag_ids, false);
+    if (rc != PRAG_OK) return rc;
+    hipLaunchKernelGGL(scatter_results_kernel, dim3(n_failed), dim3(64), 0, st, ix->t2_D, ix->t2_I, ix->t2_list, n_failed, k,
+                       D_dev, I_dev);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
 static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D, int64_t* I,
                              int io_is_device, void* stream, int tag_ids, bool allow_mm8) {
     PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
@@ -2325,14 +2390,14 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     if (use_mm8 && io_is_device) {
         // tier decision: the flag count of the 8-bit selection comes back in one 4-byte transfer (the one place a
         // device-io search waits for the stream: a > 128-query search is >= 0.1 ms of GPU time, the wait ~10 us);
-        // no flag -> done, otherwise the whole batch goes through the fp16 tiles (and their exact fallback)
+        // no flag -> done, otherwise the second tier (mm8_second_tier)
         if (!ix->tier_word_host) PRAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->tier_word_host), sizeof(uint32_t)));
         PRAG_HIP(hipMemcpyAsync(ix->tier_word_host, flag_word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PRAG_HIP(hipStreamSynchronize(st));
         ix->last_flagged = -1;
         ix->mm8_last_failed = (int)*ix->tier_word_host;
         if (*ix->tier_word_host == 0) return PRAG_OK;
-        return index_search_impl(ix, q_dev, B, k, id_offset, D_dev, I_dev, 1, stream, tag_ids, false);
+        return mm8_second_tier(ix, q_dev, B, k, id_offset, D_dev, I_dev, stream, tag_ids, (int)*ix->tier_word_host);
     }
     if (io_is_device) {
         ix->last_flagged = -1;
@@ -2355,8 +2420,8 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     ix->last_flagged = (int)n_flag;
     if (use_mm8) ix->mm8_last_failed = (int)n_flag;
     if (use_mm8 && n_flag > 0) {
-        // second tier: the staged queries through the fp16 tiles, results into the same staging block
-        const int rc = index_search_impl(ix, q_dev, B, k, id_offset, D_dev, I_dev, 1, stream, tag_ids, false);
+        // second tier on the staged queries, results into the same staging block
+        const int rc = mm8_second_tier(ix, q_dev, B, k, id_offset, D_dev, I_dev, stream, tag_ids, (int)n_flag);
         if (rc != PRAG_OK) return rc;
         rc_io = fetch();
         if (rc_io != PRAG_OK) return rc_io;
@@ -2501,7 +2566,8 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
     if (!ix) return;
     ix->prof.disable();
     void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->q16lo, ix->g_tau, ix->part_key, ix->part_idx, ix->cand,
-                    ix->io_q, ix->io_res, ix->mm_cnt, ix->mm_ovf, ix->mm_kq, ix->mm_ckey, ix->mm_cidx,
+                    ix->io_q, ix->io_res, ix->mm_cnt, ix->mm_ovf, ix->mm_kq, ix->mm_ckey, ix->mm_cidx, ix->t2_list, ix->t2_q,
+                    ix->t2_D, ix->t2_I,
                     ix->mm_wcnt, ix->mm_wkey, ix->mm_widx, ix->rows16, ix->qinfo, ix->qn2, ix->flag_list, ix->g_slot,
                     ix->cert_words, ix->ex_key, ix->ex_id, ix->rows8, ix->sscale, ix->serr, ix->shadow_err_max, ix->sh_q8,
                     ix->sh_sq, ix->sh_slots, ix->sh_ovf, ix->sh_cand, ix->sh_ccnt, ix->sh_pkey, ix->sh_pid, ix->ex_done};

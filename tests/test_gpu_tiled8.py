@@ -119,6 +119,38 @@ def test_second_tier_on_a_corpus_of_look_alikes(metric, store):
     ix.close()
 
 
+@pytest.mark.parametrize("store", ["f16", "f32"])
+@pytest.mark.parametrize("metric", METRICS)
+def test_a_few_failed_queries_are_searched_again_on_their_own(metric, store):
+    """A random corpus with ONE cluster of look-alikes and three queries inside it: only those fail the 8-bit
+    certificate; they are gathered into a compact batch, searched by the <= 128-query kernels and scattered back
+    (the other queries keep the first tier's results) - the definition's results for everybody."""
+    import probing_rag_amd as pra
+    import torch
+    N, d, B, k = 40_000, 768, 203, 10
+    rng = np.random.default_rng(9)
+    X = onp.synth_rows(42, 0, N, d)
+    base = onp.synth_rows(5, 0, 1, d)[0] * np.float32(1.7)
+    where = rng.choice(N, 700, replace=False)
+    X[where] = (base[None, :] + 2e-3 * rng.standard_normal((700, d))).astype(np.float32)
+    Q = onp.synth_rows(7, 0, B, d)
+    inside = [5, 100, 202]
+    for i in inside:
+        Q[i] = (base + 2e-3 * rng.standard_normal(d)).astype(np.float32)
+    ix = pra.HipFlatIndex(d, metric, store)
+    ix.set_shadow(2)
+    ix.add(X)
+    D0, I0 = oracle_c.flat_search(_stored(X, metric, store), Q, k, metric)
+    D, I = ix.search(Q, k)
+    n_failed = ix.last_tiled8()
+    assert 1 <= n_failed <= 50, n_failed         # (the three in the cluster; a random query may sit near it too)
+    _check(D, I, D0, I0, metric)
+    Dt, It = ix.search(torch.from_numpy(Q).cuda(), k)
+    assert 1 <= ix.last_tiled8() <= 50
+    _check(Dt.cpu().numpy(), It.cpu().numpy(), D0, I0, metric)
+    ix.close()
+
+
 def test_sharded_large_batch_equals_unsharded():
     """Row shards searched with tagged ids through the int8 tiles, merged: identical to one index."""
     import probing_rag_amd as pra
