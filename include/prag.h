@@ -283,7 +283,8 @@ int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out);
 
 /* Measurement hook: batches of > 128 queries on an index that keeps the 8-bit shadow (below) select their
  * candidates on int8 matrix tiles over the shadow first (256 candidates per query, the shadow's error bound
- * in the certificate) and repeat the whole batch on the fp16 tiles when any query fails that certificate
+ * in the certificate); queries that fail that certificate are searched again - a few of them as a compact
+ * batch of their own, more than 128 or a quarter of the batch by repeating the whole batch on the fp16 tiles
  * (the one place a device-io search waits for its stream: a 4-byte read-back between the tiers).
  * *n_failed_out = queries of the most recent search that failed the 8-bit certificate (0: the first tier
  * answered), -1 if that search did not take the 8-bit tiles.  Reference call: utils.py:378-380
