@@ -1302,8 +1302,8 @@ struct prag_index {
     size_t mm_c_entries = 0;      // entries of mm_ckey / mm_cidx, mm_wcnt words
     int mm_mode = 1;   // 0 = never take the MFMA-tiled path (PRAG_SCAN_MM=0)
     // 8-bit selection for the MFMA-tiled scan (> 128 queries on an index that keeps a shadow): int8 MFMA over the
-    // shadow, kMm8Kc candidates per query, the shadow's error bound in the certificate; a search in which any
-    // query fails that certificate is repeated on the fp16 tiles (PRAG_MM8=0: fp16 tiles only)
+    // shadow, kMm8Kc candidates per query, the shadow's error bound in the certificate; the queries that fail that
+    // certificate go through a second tier (mm8_second_tier; PRAG_MM8=0: fp16 tiles only)
     int mm8_mode = 1;
     // ... on shards of at least this many rows (shadow mode 2 = "any size": no minimum).  Measured, 1000 queries x
     // 768, int8 tiles against fp16 tiles: 1 M rows 2.04 ms / 1.73 - the 256-deep lists cost sort compactions and
@@ -1939,8 +1939,8 @@ static int mm8_second_tier(prag_index* ix, const float* q_dev, int B, int k, int
     if (n_failed > kMm8SubsetMax || (int64_t)n_failed * 4 > B)
         return index_search_impl(ix, q_dev, B, k, id_offset, D_dev, I_dev, 1, stream, tag_ids, false);
     if (ix->t2_cap < kMm8SubsetMax || ix->t2_k < k) {
-        ix->t2_cap = 0; ix->t2_k = 0;
         const int nk = std::max(k, ix->t2_k);
+        ix->t2_cap = 0; ix->t2_k = 0;
         const int rc_ws = ws_regrow({{vpp(&ix->t2_list), (size_t)kMm8SubsetMax * sizeof(int)},
                                      {vpp(&ix->t2_q), (size_t)kMm8SubsetMax * ix->d * sizeof(float)},
                                      {vpp(&ix->t2_D), (size_t)kMm8SubsetMax * nk * sizeof(float)},
@@ -1978,7 +1978,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     if (exact_only) kc = 32;  // (sizes the unused candidate workspace)
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // > 128 queries on an index that keeps an up-to-date shadow: first tier = int8 tiles over the shadow with a
-    // deep candidate list; any query that fails the (much wider) certificate sends the search to the fp16 tiles
+    // deep candidate list; the queries that fail the (much wider) certificate are searched again (mm8_second_tier)
     const bool use_mm8 = allow_mm8 && ix->mm8_mode && ix->mm_mode && !exact_only && kc <= 32 && B > 128 && ix->ntotal > 0 &&
                          (ix->shadow_mode >= 2 || ix->ntotal >= ix->mm8_min_rows) &&
                          ix->cert_mode != 0 && ix->rows8 != nullptr && ix->shadow_rows == ix->ntotal && shadow_wanted(ix) &&

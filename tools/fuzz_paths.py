@@ -74,4 +74,4 @@ for key in sorted(by, key=lambda k_: -by[k_][2] / max(1, by[k_][1]))[:22]:
     c_ = by[key]
     print(key, f"cases {c_[0]} queries {c_[1]} fallbacks {c_[2]} = {c_[2] / max(1, c_[1]):.3f} per query")
 print(f"fuzz ok: {n_case} cases in {time.time() - t0:.0f} s, {n_fb} exact fallbacks on the tiled path; "
-      f"{n_t8} cases took the int8 tiles, {n_t8_second} of them went on to the fp16 tiles", flush=True)
+      f"{n_t8} cases took the int8 tiles, {n_t8_second} of them needed the second tier", flush=True)
