@@ -528,7 +528,10 @@ def main(argv=None):
         "rank_devices": rank_devices, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": ("i8 shadow scan (MFMA i8, i32 accumulate) over f16 rows; f64 exact rerank of the filter's survivors"
-                  if scan_kernel == "scan8_kernel" else "f16 (MFMA, f32 accumulate; f64 rerank + exactness certificate)"),
+                  if scan_kernel == "scan8_kernel" else
+                  "i8 tiles over the 8-bit shadow (MFMA i8, i32 accumulate; 256 candidates per query) over f16 rows; f64 rerank + "
+                  "exactness certificate" if (tiled and i8_tiles) else
+                  "f16 (MFMA, f32 accumulate; f64 rerank + exactness certificate)"),
         "data": "synthetic",
         "config": {"workload": f"gate B={args.gate_batch} x 6 layers x d_model=2048 fp16 + flat {args.metric} "
                                f"top-{args.k} of {args.queries} queries over {args.docs} x 768 {args.store} docs",
