@@ -77,6 +77,12 @@ def parse(argv=None):
                          "size with the 8-GPU gate share (2.6 M rows, 512 gate rows): 0.537 ms per pass on one "
                          "stream, 0.542 overlapped (the scan loses to the gate what the gate's latency saves)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
+    ap.add_argument("--measure-traffic", type=int, default=1,
+                    help="1 (default, 1 GPU): measure roofline.traffic in THIS run - two child `rocprofv3 --pmc` passes "
+                         "(FETCH_SIZE, WRITE_SIZE; counters cannot be read inside the timed process) over "
+                         "tools/prof_kernels.py at the run's shard size, after the timed region, ~10 s each at 21 M rows; "
+                         "skipped when this process is itself being profiled or rocprofv3 is missing.  0: quote the "
+                         "committed summary under profiles/ instead")
     # BASELINE config 5 as a timed run (not part of the default line): see bench_e2e.py
     ap.add_argument("--e2e", action="store_true",
                     help="time the retrieve-decide loop around a Gemma-2B-shaped random-weight decoder: HIP path vs the "
@@ -266,6 +272,45 @@ def variant_record(torch, ix, q, k, store, metric, n_local, shadow=0):
                     "algorithmic_bytes_per_launch": alg_bytes, "stored_row_bytes": stored,
                     "whole_search_frac": alg_bytes * passes / (ms_search * 1e-3) / 1e9 / HBM_PEAK_GBS})
     return rec
+
+
+def measure_traffic(n_local, store, metric, queries, shadow, kernel):
+    """HBM bytes per launch of `kernel` from two separate child `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE) over
+    tools/prof_kernels.py, corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE in KiB reports half of
+    a wide streaming read; WRITE_SIZE in KiB is exact).  Returns (bytes or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    # a profiler's environment is inherited by children: never start a counter pass from inside a profiled run
+    if any(k.startswith(("ROCP", "ROCPROF", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is being profiled: no nested rocprofv3 pass"
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix="prag_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--",
+               sys.executable, os.path.join(ROOT, "tools", "prof_kernels.py"), "--skip-gate", "--docs", str(n_local),
+               "--queries", str(queries), "--store", store, "--metric", metric, "--shadow", str(1 if shadow else 0),
+               "--iters", "3"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=300, check=False)
+        except Exception as e:
+            return None, f"rocprofv3 --pmc {counter} failed: {type(e).__name__}"
+        rows = []
+        for f in glob.glob(os.path.join(out_dir, "**", "*_counter_collection.csv"), recursive=True):
+            rows += [r for r in csv.DictReader(open(f)) if kernel.split("_kernel")[0] in r["Kernel_Name"] and r["Counter_Name"] == counter]
+        shutil.rmtree(out_dir, ignore_errors=True)
+        if not rows:
+            return None, f"no {kernel} launch in the --pmc {counter} pass"
+        full = max(int(r["Grid_Size"]) for r in rows)          # (the list scan's pre-pass runs on a few workgroups)
+        vals = [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == full]
+        got[counter] = sum(vals) / len(vals)
+    return 2.0 * got["FETCH_SIZE"] * 1024 + got["WRITE_SIZE"] * 1024, \
+        "measured by this run: child `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over tools/prof_kernels.py " \
+        "(reads doubled per the gfx950 correction of MI355X_MICROARCH.md)"
 
 
 def launch_command(n_gpus, argv, port=None):
@@ -519,6 +564,12 @@ def main(argv=None):
                     traffic_source = f"profiles/{name} (separate --pmc pass, not measured in this run)"
             except Exception:
                 traffic = None
+    if args.measure_traffic and world == 1 and not tiled:
+        t_meas, note = measure_traffic(n_local, args.store, args.metric, args.queries, args.shadow, scan_kernel)
+        if t_meas is not None:
+            traffic, traffic_source = t_meas, note
+        else:
+            traffic_source = (traffic_source + "; " if traffic_source else "") + "not measured in this run: " + note
     gate_avg_ms = float(np.mean(gate_ms)) if gate_ms else float("nan")
     gate_flops = 2.0 * L * (d_model * 512 + 512 * 512 + 512 * 2) * Bg
     out = {

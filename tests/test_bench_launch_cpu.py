@@ -80,3 +80,19 @@ def test_nccl_with_too_few_gpus_exits_nonzero():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
     assert "RCCL ranks need" in out.stderr
+
+
+def test_traffic_is_never_measured_from_inside_a_profiled_run(monkeypatch):
+    """roofline.traffic comes from child `rocprofv3 --pmc` passes; a run that is itself under a profiler (the
+    profiler's environment is inherited) or a box without rocprofv3 must fall back to the committed summary
+    without starting anything."""
+    import bench
+    started = []
+    monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: started.append(a))
+    monkeypatch.setenv("ROCPROF_KERNEL_TRACE", "1")
+    val, note = bench.measure_traffic(1000, "f16", "cos", 64, 1, "scan8_kernel")
+    assert val is None and isinstance(note, str) and not started
+    monkeypatch.delenv("ROCPROF_KERNEL_TRACE")
+    monkeypatch.setenv("PATH", "/nonexistent")
+    val, note = bench.measure_traffic(1000, "f16", "cos", 64, 1, "scan8_kernel")
+    assert val is None and "rocprofv3" in note and not started
