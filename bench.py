@@ -21,7 +21,9 @@ gate rows are split across ranks.
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects
   roofline      dominant kernel of the headline step (scan8 - or scan_topk with --shadow 0 -, HBM-bound),
                 measured live with HIP events on the launch stream inside libprag; algorithmic bytes =
-                the rows in the form that is scanned
+                the rows in the form that is scanned; `traffic` = HBM bytes per launch from two child
+                `rocprofv3 --pmc` passes started by this run after the timed region (--measure-traffic 0, a run
+                under a profiler, or a box without rocprofv3: the committed summary under profiles/ is quoted)
   variants      (1 GPU) the other call shapes SURVEY.md section 8d names, same corpus size:
                 the reference's literal call (float32 rows, squared L2, k=5, one query) and fp16
                 rows with 1 / 32 / 1000 queries - each with its own roofline fraction
