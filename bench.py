@@ -276,10 +276,9 @@ def variant_record(torch, ix, q, k, store, metric, n_local, shadow=0):
     return rec
 
 
-def measure_traffic(n_local, store, metric, queries, shadow, kernel):
-    """HBM bytes per launch of `kernel` from two separate child `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE) over
-    tools/prof_kernels.py, corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE in KiB reports half of
-    a wide streaming read; WRITE_SIZE in KiB is exact).  Returns (bytes or None, note)."""
+def _pmc_passes(counters, kernel_substr, prof_args):
+    """One child `rocprofv3 --pmc <counter>` pass per counter (never combined with trace domains) over
+    tools/prof_kernels.py; returns ({counter: mean value over the full-grid launches of the kernel} or None, note)."""
     import csv
     import glob
     import shutil
@@ -290,12 +289,10 @@ def measure_traffic(n_local, store, metric, queries, shadow, kernel):
     if any(k.startswith(("ROCP", "ROCPROF", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, "this process is being profiled: no nested rocprofv3 pass"
     got = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counter in counters:
         out_dir = tempfile.mkdtemp(prefix="prag_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--",
-               sys.executable, os.path.join(ROOT, "tools", "prof_kernels.py"), "--skip-gate", "--docs", str(n_local),
-               "--queries", str(queries), "--store", store, "--metric", metric, "--shadow", str(1 if shadow else 0),
-               "--iters", "3"]
+               sys.executable, os.path.join(ROOT, "tools", "prof_kernels.py")] + list(prof_args)
         try:
             subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, timeout=300, check=False)
@@ -303,16 +300,38 @@ def measure_traffic(n_local, store, metric, queries, shadow, kernel):
             return None, f"rocprofv3 --pmc {counter} failed: {type(e).__name__}"
         rows = []
         for f in glob.glob(os.path.join(out_dir, "**", "*_counter_collection.csv"), recursive=True):
-            rows += [r for r in csv.DictReader(open(f)) if kernel.split("_kernel")[0] in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            rows += [r for r in csv.DictReader(open(f)) if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter]
         shutil.rmtree(out_dir, ignore_errors=True)
         if not rows:
-            return None, f"no {kernel} launch in the --pmc {counter} pass"
+            return None, f"no {kernel_substr} launch in the --pmc {counter} pass"
         full = max(int(r["Grid_Size"]) for r in rows)          # (the list scan's pre-pass runs on a few workgroups)
         vals = [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == full]
         got[counter] = sum(vals) / len(vals)
+    return got, "measured by this run: child `rocprofv3 --pmc` passes over tools/prof_kernels.py, one counter per pass"
+
+
+def measure_traffic(n_local, store, metric, queries, shadow, kernel):
+    """HBM bytes per launch of `kernel` from two separate child `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE),
+    corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE in KiB reports half of a wide streaming
+    read; WRITE_SIZE in KiB is exact).  Returns (bytes or None, note)."""
+    got, note = _pmc_passes(("FETCH_SIZE", "WRITE_SIZE"), kernel.split("_kernel")[0],
+                            ["--skip-gate", "--docs", str(n_local), "--queries", str(queries), "--store", store,
+                             "--metric", metric, "--shadow", str(1 if shadow else 0), "--iters", "3"])
+    if got is None:
+        return None, note
     return 2.0 * got["FETCH_SIZE"] * 1024 + got["WRITE_SIZE"] * 1024, \
         "measured by this run: child `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over tools/prof_kernels.py " \
         "(reads doubled per the gfx950 correction of MI355X_MICROARCH.md)"
+
+
+def measure_gate_mfma(gate_batch):
+    """Matrix-pipe utilisation of prober_fused_kernel: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), each
+    counter in its own child pass.  Returns (fraction or None, note)."""
+    got, note = _pmc_passes(("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES"), "prober_fused",
+                            ["--skip-scan", "--gate-batch", str(gate_batch), "--iters", "5"])
+    if got is None or not got["SQ_BUSY_CU_CYCLES"]:
+        return None, note
+    return got["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * got["SQ_BUSY_CU_CYCLES"]), note
 
 
 def launch_command(n_gpus, argv, port=None):
@@ -572,6 +591,9 @@ def main(argv=None):
             traffic, traffic_source = t_meas, note
         else:
             traffic_source = (traffic_source + "; " if traffic_source else "") + "not measured in this run: " + note
+    gate_mfma_busy, gate_mfma_note = None, "not measured (--measure-traffic 0 or more than one rank)"
+    if args.measure_traffic and world == 1:
+        gate_mfma_busy, gate_mfma_note = measure_gate_mfma(Bg)
     gate_avg_ms = float(np.mean(gate_ms)) if gate_ms else float("nan")
     gate_flops = 2.0 * L * (d_model * 512 + 512 * 512 + 512 * 2) * Bg
     out = {
@@ -622,6 +644,7 @@ def main(argv=None):
                           "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                           "frac": gate_flops / (gate_avg_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF,
                           "avg_launch_ms": gate_avg_ms,
+                          "matrix_pipe_busy_frac_of_cu_busy": gate_mfma_busy, "matrix_pipe_busy_source": gate_mfma_note,
                           "hbm_GBs": (L * Bg * d_model * 2 + L * 1318914 * 2) / (gate_avg_ms * 1e-3) / 1e9},
     }
 
