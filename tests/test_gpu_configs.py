@@ -99,6 +99,14 @@ def test_c4_full_corpus_equals_its_eight_shards():
     assert torch.equal(out[64][1], out[1000][1][:64]) and torch.allclose(out[64][0], out[1000][0][:64], rtol=1e-6, atol=0)
     D2, I2 = whole.search(qd, k)                                   # idempotent
     assert torch.equal(I2, out[1000][1]) and torch.allclose(D2, out[1000][0], rtol=1e-6, atol=0)
+    # the 1000-query batch went through the int8 tiles over the shadow (>= 2 Mi rows) and every query cleared their
+    # certificate; the fp16 tiles alone give the same lists
+    assert whole.last_tiled8() == 0
+    whole.set_shadow(0)
+    D3, I3 = whole.search(qd, k)
+    assert whole.last_tiled8() == -1
+    assert torch.equal(I3, out[1000][1]) and torch.allclose(D3, out[1000][0], rtol=1e-6, atol=0)
+    whole.set_shadow(1)
     # planted rows: the score the search reports is the exact cosine to the stored row
     for i in (0, 7, 15):
         row = whole.reconstruct_n(int(planted[i]), 1)[0].astype(np.float64)
