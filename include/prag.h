@@ -287,7 +287,9 @@ int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out);
  * batch of their own, more than 128 or a quarter of the batch by repeating the whole batch on the fp16 tiles
  * (the one place a device-io search waits for its stream: a 4-byte read-back between the tiers).
  * *n_failed_out = queries of the most recent search that failed the 8-bit certificate (0: the first tier
- * answered), -1 if that search did not take the 8-bit tiles.  Reference call: utils.py:378-380
+ * answered), -1 if that search did not take the 8-bit tiles (fewer than 2 Mi rows in shadow mode 1, no
+ * shadow, or two whole-batch repeats in a row: the index then skips the 8-bit tiles until rows are added or
+ * prag_index_set_shadow is called).  Reference call: utils.py:378-380
  * (batch_topk_sim -> IndexFlat.search); results are the definition's either way. */
 int prag_index_last_tiled8(prag_index_t* ix, int* n_failed_out);
 

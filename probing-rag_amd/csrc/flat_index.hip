@@ -1322,6 +1322,11 @@ struct prag_index {
     float* t2_D = nullptr;
     int64_t* t2_I = nullptr;
     int t2_cap = 0, t2_k = 0;
+    // two searches in a row whose whole batch had to be repeated on the fp16 tiles (a corpus the 8-bit bound cannot
+    // separate: a few rows of huge norm, look-alikes everywhere): the int8 tiles are skipped from then on, until rows
+    // are added or prag_index_set_shadow is called
+    int mm8_whole_batch_streak = 0;
+    bool mm8_auto_off = false;
     // fp32 indexes: fp16 copy of the rows for the tiled scan's candidate selection (built on the
     // first search with > 128 queries, dropped by add; the rerank always reads the fp32 rows)
     _Float16* rows16 = nullptr;
@@ -1504,6 +1509,8 @@ static int shadow_ensure(prag_index* ix, hipStream_t st) {
         const int rc = shadow_build(ss, ix->shadow_rows, ix->ntotal, st);
         if (rc != PRAG_OK) return rc;
         ix->shadow_rows = ix->ntotal;
+        ix->mm8_whole_batch_streak = 0;     // new rows: the 8-bit tiles get another chance
+        ix->mm8_auto_off = false;
     }
     return PRAG_OK;
 }
@@ -1936,8 +1943,11 @@ constexpr int kMm8SubsetMax = 128;
 static int mm8_second_tier(prag_index* ix, const float* q_dev, int B, int k, int64_t id_offset, float* D_dev, int64_t* I_dev,
                            void* stream, int tag_ids, int n_failed) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (n_failed > kMm8SubsetMax || (int64_t)n_failed * 4 > B)
+    if (n_failed > kMm8SubsetMax || (int64_t)n_failed * 4 > B) {
+        if (++ix->mm8_whole_batch_streak >= 2) ix->mm8_auto_off = true;
         return index_search_impl(ix, q_dev, B, k, id_offset, D_dev, I_dev, 1, stream, tag_ids, false);
+    }
+    ix->mm8_whole_batch_streak = 0;
     if (ix->t2_cap < kMm8SubsetMax || ix->t2_k < k) {
         const int nk = std::max(k, ix->t2_k);
         ix->t2_cap = 0; ix->t2_k = 0;
@@ -1979,7 +1989,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // > 128 queries on an index that keeps an up-to-date shadow: first tier = int8 tiles over the shadow with a
     // deep candidate list; the queries that fail the (much wider) certificate are searched again (mm8_second_tier)
-    const bool use_mm8 = allow_mm8 && ix->mm8_mode && ix->mm_mode && !exact_only && kc <= 32 && B > 128 && ix->ntotal > 0 &&
+    const bool use_mm8 = allow_mm8 && ix->mm8_mode && !ix->mm8_auto_off && ix->mm_mode && !exact_only && kc <= 32 && B > 128 && ix->ntotal > 0 &&
                          (ix->shadow_mode >= 2 || ix->ntotal >= ix->mm8_min_rows) &&
                          ix->cert_mode != 0 && ix->rows8 != nullptr && ix->shadow_rows == ix->ntotal && shadow_wanted(ix) &&
                          mm8_supported(ix->d, kMm8Kc) && mm_supported(ix->d, PRAG_F16, kMm8Kc) && k <= kMm8Kc / 8;
@@ -2396,7 +2406,10 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         PRAG_HIP(hipStreamSynchronize(st));
         ix->last_flagged = -1;
         ix->mm8_last_failed = (int)*ix->tier_word_host;
-        if (*ix->tier_word_host == 0) return PRAG_OK;
+        if (*ix->tier_word_host == 0) {
+            ix->mm8_whole_batch_streak = 0;
+            return PRAG_OK;
+        }
         return mm8_second_tier(ix, q_dev, B, k, id_offset, D_dev, I_dev, stream, tag_ids, (int)*ix->tier_word_host);
     }
     if (io_is_device) {
@@ -2418,7 +2431,10 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     uint32_t n_flag = 0;
     memcpy(&n_flag, ix->io_res_host + (size_t)B * k * 12, sizeof(n_flag));
     ix->last_flagged = (int)n_flag;
-    if (use_mm8) ix->mm8_last_failed = (int)n_flag;
+    if (use_mm8) {
+        ix->mm8_last_failed = (int)n_flag;
+        if (n_flag == 0) ix->mm8_whole_batch_streak = 0;
+    }
     if (use_mm8 && n_flag > 0) {
         // second tier on the staged queries, results into the same staging block
         const int rc = mm8_second_tier(ix, q_dev, B, k, id_offset, D_dev, I_dev, stream, tag_ids, (int)n_flag);
@@ -2539,6 +2555,8 @@ extern "C" int prag_index_set_shadow(prag_index_t* ix, int mode) {
     PRAG_REQUIRE(ix != nullptr && mode >= 0 && mode <= 2, PRAG_EINVAL, "prag_index_set_shadow: mode %d (0, 1 or 2)", mode);
     ix->shadow_mode = mode;
     ix->shadow_no_room = false;
+    ix->mm8_whole_batch_streak = 0;
+    ix->mm8_auto_off = false;
     return PRAG_OK;
 }
 

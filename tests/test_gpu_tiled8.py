@@ -116,6 +116,15 @@ def test_second_tier_on_a_corpus_of_look_alikes(metric, store):
     Dt, It = ix.search(torch.from_numpy(Q).cuda(), k)
     assert ix.last_tiled8() > 0
     _check(Dt.cpu().numpy(), It.cpu().numpy(), D0, I0, metric)
+    # two whole-batch repeats in a row: the index stops trying the int8 tiles (every search would pay for both
+    # tiers) until rows are added or set_shadow is called
+    D3, I3 = ix.search(Q, k)
+    assert ix.last_tiled8() == -1
+    _check(D3, I3, D0, I0, metric)
+    ix.set_shadow(2)
+    D4, I4 = ix.search(Q, k)
+    assert ix.last_tiled8() > 0
+    _check(D4, I4, D0, I0, metric)
     ix.close()
 
 
