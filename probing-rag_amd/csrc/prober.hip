@@ -84,18 +84,23 @@ struct ProberArgs {
 
 #ifdef PRAG_MM_DIAG
 // timing-only build (make diag): s_memtime stamps of three workgroups, read by tools/prober_stamps.py
-__device__ unsigned long long g_pstamp[3 * 8 * 32];
-#define PSTAMP_T(var)                                                                         \
+// second half of the buffer: s_memrealtime (100 MHz) at the same points - the clock the chip holds inside the
+// kernel is d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md "DVFS give-back" item 6)
+__device__ unsigned long long g_pstamp[2 * 3 * 8 * 32];
+#define PSTAMP_T(var, var2)                                                                   \
     {                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                    \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(var), "=s"(var2)::"memory"); \
         __builtin_amdgcn_sched_barrier(0);                                                    \
     }
 #define PSTAMP(i)                                                                             \
     if (ps_sel >= 0) {                                                                        \
-        unsigned long long t_;                                                                \
-        PSTAMP_T(t_)                                                                          \
-        if (lane == 0) g_pstamp[(ps_sel * 8 + w) * 32 + (i)] = t_;                            \
+        unsigned long long t_, r_;                                                            \
+        PSTAMP_T(t_, r_)                                                                      \
+        if (lane == 0) {                                                                      \
+            g_pstamp[(ps_sel * 8 + w) * 32 + (i)] = t_;                                       \
+            g_pstamp[3 * 8 * 32 + (ps_sel * 8 + w) * 32 + (i)] = r_;                          \
+        }                                                                                     \
     }
 #else
 #define PSTAMP(i)
@@ -904,7 +909,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void prober_fused_kernel(ProberA
 
 #ifdef PRAG_MM_DIAG
 extern "C" int prag_diag_prober_stamps(unsigned long long* out, int n) {
-    if (n > 3 * 8 * 32) n = 3 * 8 * 32;
+    if (n > 2 * 3 * 8 * 32) n = 2 * 3 * 8 * 32;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pstamp), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -2;
 }
 #endif

@@ -27,11 +27,12 @@ for _ in range(20):
     ens.gate(x, 0, 0.0)
 torch.cuda.synchronize()
 lib = _lib.lib()
-buf = (ctypes.c_ulonglong * (3 * 8 * 32))()
+buf = (ctypes.c_ulonglong * (2 * 3 * 8 * 32))()
 fn = lib.prag_diag_prober_stamps
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert fn(buf, len(buf)) == 0
-s = np.frombuffer(buf, dtype=np.uint64).astype(np.int64).reshape(3, 8, 32)
+both = np.frombuffer(buf, dtype=np.uint64).astype(np.int64).reshape(2, 3, 8, 32)
+s, rt = both[0], both[1]   # s_memtime (core cycles) and s_memrealtime (100 MHz) at the same points
 names = ["prologue", "fc1 loop", "stats+sync", "epilogue 1 (cols 0,1)", "publish 0", "sync + LN1 stats",
          "pass 0: k loop | epilogue 1 (cols 2,3)", "sync, publish 1, sync, stats, sync",
          "pass 1: k loop | epilogue 2 (pass 0)", "epilogue 2 (pass 1)", "sync + logits"]
@@ -39,7 +40,10 @@ LAST = len(names)
 tick = 0.01   # s_memtime ticks once per shader cycle: phases are printed in units of 100 cycles
 for sel in range(3):
     t0 = s[sel, :, 0].min()
-    print(f"workgroup {sel}: total {(s[sel, :, LAST].max() - t0) * tick:7.2f} x100 cycles")
+    dc, dr = s[sel, :, LAST] - s[sel, :, 0], rt[sel, :, LAST] - rt[sel, :, 0]
+    print(f"workgroup {sel}: total {(s[sel, :, LAST].max() - t0) * tick:7.2f} x100 cycles; in-kernel clock "
+          f"{np.median(dc / np.maximum(dr, 1)) * 100:.0f} MHz over the workgroup's lifetime "
+          f"(fc1 loop alone: {np.median((s[sel, :, 2] - s[sel, :, 1]) / np.maximum(rt[sel, :, 2] - rt[sel, :, 1], 1)) * 100:.0f} MHz)")
     for i, nm in enumerate(names):
         d = (s[sel, :, i + 1] - s[sel, :, i]) * tick
         print(f"   {nm:40s} {d.mean():7.2f} c  (waves {d.min():6.2f} .. {d.max():6.2f})   ends at {((s[sel, :, i + 1].max()) - t0) * tick:7.2f}")
