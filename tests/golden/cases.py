@@ -81,3 +81,54 @@ def synth_train_batch(case: dict, step: int):
     """(acts [B,T,d] f32, pred_lens int64 [B], labels int64 [B]) of optimiser step `step` (1-based)."""
     sub = dict(case, xseed=case["xseed"] + 1000 * step)
     return synth_pool_inputs(sub)
+
+
+# the retrieval wrappers (utils.py:374-380 find_topk_sim / batch_topk_sim): a stub encoder whose `encode`
+# returns preset float32 embeddings (sentence-transformers is not in the image: embeddings are inputs,
+# SURVEY.md section 8c) and a recording index that notes what `index.search` is handed
+TOPK_CASE = dict(name="topk_N3000_B5", N=3000, d=768, B=5, k=5, xseed=42, qseed=7)
+
+
+class StubEncoder:
+    """`model_retr.encode(query)`: a list of strings -> float32 [len(query), d]; one string -> float32 [d]
+    (what SentenceTransformer.encode returns for a str)."""
+    def __init__(self, emb):
+        self.emb = np.ascontiguousarray(emb, dtype=np.float32)
+        self.calls = []
+
+    def encode(self, query):
+        self.calls.append(type(query).__name__)
+        if isinstance(query, str):
+            return self.emb[0].copy()
+        return self.emb[: len(query)].copy()
+
+
+class RecordingIndex:
+    """Wraps any object with `search(x, k)`; records how the wrapper called it."""
+    def __init__(self, inner):
+        self.inner = inner
+        self.calls = []
+
+    def search(self, *args, **kwargs):
+        x = args[0]
+        self.calls.append("args=%d kwargs=%s type=%s dtype=%s shape=%s c_contiguous=%s" % (
+            len(args), sorted(kwargs), type(x).__name__, getattr(x, "dtype", None), tuple(getattr(x, "shape", ())),
+            bool(getattr(x, "flags", None) is not None and x.flags["C_CONTIGUOUS"])))
+        k = kwargs["k"] if "k" in kwargs else args[1]
+        return self.inner.search(x, k)
+
+
+class OracleIndex:
+    """The oracle's flat search behind the duck-typed `search(x, k)` of faiss.IndexFlatL2."""
+    def __init__(self, xs, metric=onp.METRIC_L2):
+        self.xs, self.metric = xs, metric
+
+    def search(self, x, k):
+        return onp.flat_search(self.xs, np.asarray(x, dtype=np.float32), k, self.metric)
+
+
+def topk_inputs(case=TOPK_CASE):
+    X = onp.synth_rows(case["xseed"], 0, case["N"], case["d"])
+    Q = onp.synth_rows(case["qseed"], 0, case["B"], case["d"])
+    Q[1] = X[17] + np.float32(0.01) * Q[1]      # a planted neighbour
+    return X, Q

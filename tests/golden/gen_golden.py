@@ -12,7 +12,9 @@ SURVEY.md §8c) and evaluates the genuine ``ImprovedProbe`` (utils.py:29-57),
 ``return_prober_logit_gemma_2b`` (utils.py:389-390), ``_method_2_util``
 (utils.py:181-189), ``return_acc`` (utils.py:158-170) and ``method_2_train``
 (utils.py:191-197, with torch.optim.AdamW / ExponentialLR as in train.py:131-135)
-on deterministic inputs.  Weights and inputs come from the counter-based generator
+on deterministic inputs, and the retrieval wrappers ``batch_topk_sim`` / ``find_topk_sim``
+(utils.py:374-380) against a recording index (what they hand to ``index.search``: array type, dtype,
+shape, ``k`` as a keyword) -> ``topk_golden.npz`` (``--only topk`` regenerates just that file).  Weights and inputs come from the counter-based generator
 ``oracle_np.synth_rows`` so that the fixtures only need to store seeds,
 shapes and the reference's OUTPUTS (a few KB), never weights or source.
 
@@ -50,10 +52,33 @@ def import_reference_utils():
     return ref_utils
 
 
+def gen_topk(ru):
+    """utils.py:374-380 run as they are: the reference's own `batch_topk_sim` and `find_topk_sim` call a
+    recording index (over the oracle's flat search - faiss is not in the image) with a stub
+    encoder.  Stored: the call descriptions and the D / I they return."""
+    case = cases.TOPK_CASE
+    X, Q = cases.topk_inputs(case)
+    out = {}
+    enc = cases.StubEncoder(Q)
+    rec = cases.RecordingIndex(cases.OracleIndex(X))
+    D, I = ru.batch_topk_sim(enc, ["q%d" % i for i in range(case["B"])], rec, case["k"])   # exp_rag.py:432 call shape
+    out["batch/D"], out["batch/I"] = np.asarray(D, np.float32), np.asarray(I, np.int64)
+    D1, I1 = ru.find_topk_sim(enc, "one question", rec, case["k"])
+    out["find/D"], out["find/I"] = np.asarray(D1, np.float32), np.asarray(I1, np.int64)
+    out["index_calls"] = np.array(rec.calls)
+    out["encode_calls"] = np.array(enc.calls)
+    path = os.path.join(HERE, "topk_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", rec.calls, enc.calls)
+
+
 def main():
     import torch
     torch.set_num_threads(4)
     ru = import_reference_utils()
+    gen_topk(ru)
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "topk":
+        return
     out = {}
 
     # ---- known-answer: parameter count (exp_parameter_check.py:52) ---------

@@ -580,3 +580,45 @@ def test_float32_tie_across_shards_is_broken_by_the_float64_scores():
         for sh in shards:
             sh.close()
     whole.close()
+
+
+def test_reference_wrappers_replayed_on_the_hip_index():
+    """utils.py:374-380 pinned: the golden file holds what the REFERENCE's own `batch_topk_sim` / `find_topk_sim`
+    handed to `index.search` and got back (tests/golden/gen_golden.py gen_topk).  The build's functions of the same
+    names over `IndexFlatL2` (make_indexer.py:450) make the same calls and return the same ids (scores to 1e-4)."""
+    import probing_rag_amd as pra
+    from tests.golden import cases
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "topk_golden.npz"), allow_pickle=False)
+    case = cases.TOPK_CASE
+    X, Q = cases.topk_inputs(case)
+    ix = pra.IndexFlatL2(case["d"])
+    ix.add(X)
+    enc = cases.StubEncoder(Q)
+    rec = cases.RecordingIndex(ix)
+    D, I = pra.batch_topk_sim(enc, ["q%d" % i for i in range(case["B"])], rec, case["k"])
+    D1, I1 = pra.find_topk_sim(enc, "one question", rec, case["k"])
+    assert rec.calls == list(g["index_calls"]) and enc.calls == list(g["encode_calls"])
+    assert isinstance(D, np.ndarray) and D.dtype == np.float32 and I.dtype == np.int64      # what exp_rag.py:436 indexes
+    assert I[0].tolist() == g["batch/I"][0].tolist()
+    _check(D, I, g["batch/D"], g["batch/I"], onp.METRIC_L2)
+    _check(D1, I1, g["find/D"], g["find/I"], onp.METRIC_L2)
+    ix.close()
+
+
+def test_against_faiss_where_it_is_installed():
+    """faiss-cpu is the reference's index (make_indexer.py:449-450) and is NOT in this image, so the flat-search
+    half of the oracle is 'parity unpinned' (SURVEY.md section 8c).  On any box that has it this test pins a10 at once:
+    same ids as faiss.IndexFlatL2 / IndexFlatIP, scores to 1e-4."""
+    faiss = pytest.importorskip("faiss")
+    import probing_rag_amd as pra
+    X = onp.synth_rows(42, 0, 20_000, 768)
+    Q = onp.synth_rows(7, 0, 40, 768)
+    for metric, make, mine in ((onp.METRIC_L2, faiss.IndexFlatL2, pra.IndexFlatL2), (onp.METRIC_IP, faiss.IndexFlatIP, pra.IndexFlatIP)):
+        ref = make(768)
+        ref.add(X)
+        D0, I0 = ref.search(Q, 5)
+        ix = mine(768)
+        ix.add(X)
+        D, I = ix.search(Q, 5)
+        _check(D, I, D0, I0, metric)
+        ix.close()

@@ -1,5 +1,7 @@
 """CPU: the oracle restatement against golden vectors produced by the
 reference's own classes (tests/golden/gen_golden.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -161,3 +163,25 @@ def test_flat_search_agrees_with_an_independent_brute_force():
     dist, idx = NearestNeighbors(n_neighbors=k, algorithm="brute", metric="cosine").fit(Xn.astype(np.float64)).kneighbors(Q.astype(np.float64))
     assert np.array_equal(I1, idx)
     np.testing.assert_allclose(D1, 1.0 - dist, atol=1e-6)
+
+
+def test_topk_wrappers_hand_the_index_what_the_reference_does():
+    """utils.py:374-380: `batch_topk_sim` / `find_topk_sim` were run AS THEY ARE in the reference against a
+    recording index (tests/golden/gen_golden.py gen_topk -> topk_golden.npz).  The build's functions of the same
+    names must make the same calls (array type, dtype, shape, `k` as a keyword; `encode` gets the list / the str)
+    and, over the same oracle index, return the same D / I."""
+    import importlib
+    pra_index = importlib.import_module("probing-rag_amd.index")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "topk_golden.npz"), allow_pickle=False)
+    case = cases.TOPK_CASE
+    X, Q = cases.topk_inputs(case)
+    enc = cases.StubEncoder(Q)
+    rec = cases.RecordingIndex(cases.OracleIndex(X))
+    D, I = pra_index.batch_topk_sim(enc, ["q%d" % i for i in range(case["B"])], rec, case["k"])
+    D1, I1 = pra_index.find_topk_sim(enc, "one question", rec, case["k"])
+    assert rec.calls == list(g["index_calls"])
+    assert enc.calls == list(g["encode_calls"])
+    assert np.array_equal(I, g["batch/I"]) and np.array_equal(I1, g["find/I"])
+    np.testing.assert_array_equal(D, g["batch/D"])
+    np.testing.assert_array_equal(D1, g["find/D"])
+    assert int(g["batch/I"][1, 0]) == 17                      # the planted neighbour
