@@ -400,19 +400,24 @@ __device__ __forceinline__ void scan_topk_body(const ScanArgs& a, char* smem) {
     // refill is unconditional and branch-free - past the last tile it re-reads the
     // (clamped) last row - so the registers never merge across control flow and
     // the compiler keeps counted vmcnt waits instead of draining the queue.
-    u32x4 ldA[NLD], ldB[NLD];
+    // float32 rows with 32-deep lists and no high-precision query tile (d >= 1024: two query tiles do not fit LDS):
+    // 64 list registers + two sets of 8 staging registers + the prefetched norms do not fit 256 VGPRs (280 B of
+    // scratch in round 3).  That shape keeps ONE chunk in flight and reads the row norms in the epilogue.
+    constexpr bool ONE_SET = F32 && !HP && KC == 32;
+    u32x4 ldA[NLD], ldB[ONE_SET ? 1 : NLD];
     // wave-uniform tile base (scalar registers) + a per-lane 32-bit offset: no 64-bit vector address
     // arithmetic and no per-row clamp in the loop.  The rows are allocated in multiples of 256, so the
     // rows of the last, partial tile past N are readable; their scores are masked in the epilogue.
-    int lane_off[NLD];
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) lane_off[i] = st_doc[i] * (int)row_bytes + col_b;
+    // Load i of a lane sits 32/NLD rows below load 0: ONE lane offset, the rest is wave-uniform (an array of
+    // NLD offsets cost NLD - 1 registers the 32-deep lists and the float32 rows did not have: scratch).
+    const int lane_off0 = st_doc[0] * (int)row_bytes + col_b;
+    const int64_t ld_step = (int64_t)(32 / NLD) * row_bytes;
     const int tile_last = a.n_tiles - 1;
     auto issue = [&](u32x4 (&ld)[NLD], int tile, int c) {
         const int tc = tile < tile_last ? tile : tile_last;     // prefetch past the end: re-read the last tile
         const char* base = rows + (int64_t)tc * (32 * row_bytes) + c * chunk_bytes;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) ld[i] = *reinterpret_cast<const u32x4*>(base + lane_off[i]);
+        for (int i = 0; i < NLD; ++i) ld[i] = *reinterpret_cast<const u32x4*>(base + i * ld_step + lane_off0);
     };
 
     const int a_off = r * 128;
@@ -440,7 +445,7 @@ __device__ __forceinline__ void scan_topk_body(const ScanArgs& a, char* smem) {
     auto body = [&](u32x4 (&ld)[NLD]) {
         // norms of this tile's rows: requested at its first chunk, i.e. OLDER than
         // every prefetch issued below, so waiting for them does not drain the queue
-        if (a.use_norm && c_cur == 0) {
+        if (a.use_norm && (ONE_SET ? c_cur == NCH - 1 : c_cur == 0)) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 xn[g] = *reinterpret_cast<const f32x4*>(a.xnorm + (int64_t)tile_cur * 32 + 8 * g + 4 * hh);
@@ -569,7 +574,13 @@ __device__ __forceinline__ void scan_topk_body(const ScanArgs& a, char* smem) {
     };
 
     const int n_it = n_my * NCH;
-    if (n_it > 0) {
+    if constexpr (ONE_SET) {
+        if (n_it > 0) {
+            issue(ldA, tile_nx, c_nx);
+            advance(tile_nx, c_nx);
+            for (int it = 0; it < n_it; ++it) body(ldA);
+        }
+    } else if (n_it > 0) {
         issue(ldA, tile_nx, c_nx);
         advance(tile_nx, c_nx);
         issue(ldB, tile_nx, c_nx);
@@ -1168,51 +1179,66 @@ __global__ __launch_bounds__(1024) void merge_rerank_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------
-// cross-shard merge: one thread per query, n_parts sorted lists of k
+// cross-shard merge: one wave per query, lane p walks the sorted list of part p
 // ---------------------------------------------------------------------------
+// k rounds of a 64-lane lexicographic minimum over (score, residual tag, id); the winning lane pops its head and
+// prefetches the next entry.  (Round 3 ran one THREAD per query with a head pointer per part in a runtime-indexed
+// array: 272 B of scratch per lane and a serial k x n_parts loop - the exchange step of every sharded search.)
 __global__ __launch_bounds__(64) void merge_shards_kernel(const float* __restrict__ Dp,
                                                          const int64_t* __restrict__ Ip, int64_t d_stride,
                                                          int64_t i_stride, int n_parts, int B,
                                                          int k, int metric_l2, int tagged, float* __restrict__ D,
                                                          int64_t* __restrict__ I) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
     const int64_t id_mask = tagged ? (int64_t)((1ull << kTagShift) - 1) : ~0ll;
-    // every part is already ordered, so a head pointer per part is enough;
-    // heads live in a bitmap-free form: re-scan from the stored head positions
-    int head[64];
-    for (int p = 0; p < n_parts; ++p) head[p] = 0;
+    const bool part = lane < n_parts;
+    const float* dp = Dp + (int64_t)lane * d_stride + (int64_t)b * k;
+    const int64_t* ip = Ip + (int64_t)lane * i_stride + (int64_t)b * k;
+    int head = 0;
+    float dv = 0.f;
+    int64_t raw = -1;
+    if (part) {
+        dv = dp[0];
+        raw = ip[0];
+    }
     for (int j = 0; j < k; ++j) {
-        int best = -1;
-        float bd = 0.f;
-        int64_t bi = 0, br = 0;
-        for (int p = 0; p < n_parts; ++p) {
-            if (head[p] >= k) continue;
-            const int64_t o = (int64_t)b * k + head[p];
-            const int64_t raw = Ip[p * i_stride + o];
-            if (raw < 0) continue;  // padding sorts last
-            const int64_t id = raw & id_mask;
-            const int64_t rk = tagged ? (raw >> kTagShift) : 0;      // float32 residual of the float64 score (tag_id)
-            const float dv = Dp[p * d_stride + o];
-            bool take;
-            if (best < 0) take = true;
-            else if (dv != bd) take = metric_l2 ? (dv < bd) : (dv > bd);
-            else if (rk != br) take = metric_l2 ? (rk < br) : (rk > br);
-            else take = id < bi;
-            if (take) {
-                best = p;
-                bd = dv;
-                bi = id;
-                br = rk;
+        // this lane's candidate as (hi, lo): hi = score key (ascending = better) . residual key, lo = id
+        const bool valid = part && head < k && raw >= 0;              // padding (-1) sorts last
+        const float dz = dv + 0.0f;                                   // -0 and +0 compare equal, as floats do
+        const uint32_t kd = metric_l2 ? sortable_u32(dz) : ~sortable_u32(dz);
+        const uint32_t rk = tagged ? (uint32_t)((unsigned long long)raw >> kTagShift) : 0u;
+        unsigned long long hi = valid ? (((unsigned long long)kd << 32) | (metric_l2 ? rk : 0xFFFFFFu - rk)) : ~0ull;
+        unsigned long long lo = valid ? (unsigned long long)(raw & id_mask) : ~0ull;
+        const unsigned long long my_hi = hi, my_lo = lo;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long ohi = __shfl_xor(hi, off, 64), olo = __shfl_xor(lo, off, 64);
+            if (ohi < hi || (ohi == hi && olo < lo)) {
+                hi = ohi;
+                lo = olo;
             }
         }
-        if (best >= 0) {
-            D[(int64_t)b * k + j] = bd;
-            I[(int64_t)b * k + j] = bi;
-            head[best]++;
-        } else {
-            D[(int64_t)b * k + j] = metric_l2 ? FLT_MAX : -FLT_MAX;
-            I[(int64_t)b * k + j] = -1;
+        const unsigned long long won = __ballot(valid && my_hi == hi && my_lo == lo);
+        if (won == 0ull) {   // every part exhausted: faiss padding
+            if (lane == 0) {
+                D[(int64_t)b * k + j] = metric_l2 ? FLT_MAX : -FLT_MAX;
+                I[(int64_t)b * k + j] = -1;
+            }
+            continue;
+        }
+        const int wl = __ffsll((long long)won) - 1;                   // equal entries in two parts: the lower part first
+        const float out_d = __shfl(dv, wl, 64);
+        if (lane == 0) {
+            D[(int64_t)b * k + j] = out_d;
+            I[(int64_t)b * k + j] = (int64_t)lo;
+        }
+        if (lane == wl) {
+            ++head;
+            if (head < k) {
+                dv = dp[head];
+                raw = ip[head];
+            }
         }
     }
 }
@@ -1683,7 +1709,9 @@ static int dispatch_scan_kc(int kc, const ScanArgs& a, int grid, hipStream_t st,
     switch (kc) {
         case 8: return launch_scan<QT, 8, F32, HP>(a, grid, st, prof);
         case 16: return launch_scan<QT, 16, F32, HP>(a, grid, st, prof);
-        case 32: return launch_scan<QT, 32, F32, HP>(a, grid, st, prof);
+        case 32:
+            if constexpr (QT == 32) return launch_scan<QT, 32, F32, HP>(a, grid, st, prof);
+            break;   // 64-query tiles never carry 32-deep lists (index_search_impl: wide_ok)
     }
     set_error("internal: KC=%d", kc);
     return PRAG_EUNSUPPORTED;
@@ -1712,7 +1740,9 @@ static int dispatch_flagged(int kc, const ScanArgs& a, int grid, const uint32_t*
     switch (kc) {
         case 8: return launch_flagged<QT, 8>(a, grid, q_flag, n_groups, part_stride, st);
         case 16: return launch_flagged<QT, 16>(a, grid, q_flag, n_groups, part_stride, st);
-        case 32: return launch_flagged<QT, 32>(a, grid, q_flag, n_groups, part_stride, st);
+        case 32:
+            if constexpr (QT == 32) return launch_flagged<QT, 32>(a, grid, q_flag, n_groups, part_stride, st);
+            break;
     }
     set_error("internal: KC=%d", kc);
     return PRAG_EUNSUPPORTED;
@@ -1737,7 +1767,9 @@ static int launch_qs(const ScanArgs& a, int grid, hipStream_t st, EventRing& pro
 
 // query-stationary kernel: fp16 rows, d in {256,512,768,1024}, lists up to 16 deep
 static bool qs_supported(int d, int store, int kc) {
-    return store == PRAG_F16 && kc <= 16 && (d == 256 || d == 512 || d == 768 || d == 1024);
+    // (d = 1024 with 16-deep lists: 128 VGPRs of query fragments + the lists spill - those batches take two
+    // passes of the 64-query list kernel, or the 128-query shadow tiles when the index keeps a shadow)
+    return store == PRAG_F16 && kc <= 16 && (d == 256 || d == 512 || d == 768 || (d == 1024 && kc <= 8));
 }
 
 static int dispatch_qs(int d, int kc, const ScanArgs& a, int grid, hipStream_t st, EventRing& prof) {
@@ -1750,8 +1782,9 @@ static int dispatch_qs(int d, int kc, const ScanArgs& a, int grid, hipStream_t s
         if (kc == 8) return launch_qs<D_ / 32, 8, false>(a, grid, st, prof); \
         return launch_qs<D_ / 32, 16, false>(a, grid, st, prof);             \
     }
-    PRAG_QS(256) PRAG_QS(512) PRAG_QS(768) PRAG_QS(1024)
+    PRAG_QS(256) PRAG_QS(512) PRAG_QS(768)
 #undef PRAG_QS
+    if (d == 1024 && kc == 8) return a.use_norm ? launch_qs<32, 8, true>(a, grid, st, prof) : launch_qs<32, 8, false>(a, grid, st, prof);
     set_error("internal: query-stationary scan does not cover d=%d", d);
     return PRAG_EUNSUPPORTED;
 }
@@ -1881,7 +1914,7 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
     // in mm_ovf, the rerank puts it on the certificate's flag list and the exact scan recomputes it
     if (kc > 32) return PRAG_OK;
     if (ix->mm_mode == 2) return PRAG_OK;  // PRAG_SCAN_MM=2 (tests of the tests): overflow goes unrepaired
-    const bool fb64 = 64 * qstride + 8 * 4096 + 64 * 12 + 64 <= 160 * 1024 - 64;
+    const bool fb64 = 64 * qstride + 8 * 4096 + 64 * 12 + 64 <= 160 * 1024 - 64 && kc < 32;
     const int fq = fb64 ? 64 : 32;
     const int fb_grid = std::max(1, std::min(cu_budget, (n_tiles + 7) / 8));
     const int n_groups = Bpad / fq;
@@ -2027,7 +2060,8 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     // ---- workspace --------------------------------------------------------------
     const int qstride = (ix->d * 2 + 255) / 256 * 256;
     // 64-query tiles when they fit LDS; fp32 rows with 32-deep lists stay at 32 (VGPR budget)
-    const bool wide_ok = 64 * qstride + 8 * 4096 + 64 * 12 <= 160 * 1024 && !(ix->store == PRAG_F32 && kc == 32);
+    // (64 queries x 32-deep lists = 128 list registers per lane: scratch on either row type - two 32-query tiles)
+    const bool wide_ok = 64 * qstride + 8 * 4096 + 64 * 12 <= 160 * 1024 && kc < 32;
     // > 128 queries: the contraction bounds the search -> MFMA-tiled scan, 256 queries per tile
     const bool use_mm = !exact_only && ix->ntotal > 0 && mm_supported(ix->d, PRAG_F16, kc) &&
                         ((B > 128 && ix->mm_mode) || kc > 32);
@@ -2461,7 +2495,7 @@ static int merge_topk_impl(const float* Dp, const int64_t* Ip, int64_t d_stride,
     PRAG_REQUIRE(n_parts >= 1 && n_parts <= 64, PRAG_EINVAL, "n_parts=%d outside [1,64]", n_parts);
     PRAG_REQUIRE(B >= 0 && k >= 1, PRAG_EINVAL, "B=%d k=%d", B, k);
     if (B == 0) return PRAG_OK;
-    hipLaunchKernelGGL(merge_shards_kernel, dim3((B + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(merge_shards_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
                        Dp, Ip, d_stride, i_stride, n_parts, B, k, metric == PRAG_METRIC_L2 ? 1 : 0, tagged, D_dev, I_dev);
     PRAG_LAUNCH_CHECK();
     return PRAG_OK;

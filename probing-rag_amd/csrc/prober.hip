@@ -1537,11 +1537,9 @@ static int forward_impl(prag_prober_t* p, const void* x_dev, int x_dtype, int64_
         if (ct == 1) return launch_fused<NA_, NB_, 1, 4>(a, n_run, st, p->prof);     \
         if (ct == 2) return launch_fused<NA_, NB_, 2, 8>(a, n_run, st, p->prof);     \
     }
-    if (p->na == 1 && nb == 1 && ct == 4) {
-        static const int nwv = getenv("PRAG_PROBER_NWV") ? atoi(getenv("PRAG_PROBER_NWV")) : 8;  // tuning knob
-        if (nwv == 4) return launch_fused<1, 1, 4, 4>(a, n_run, st, p->prof);
-        return launch_fused<1, 1, 4, 8>(a, n_run, st, p->prof);
-    }
+    // (a 4-wave form of the 128-row tile - one wave per SIMD, 512 registers - was kept behind an environment knob
+    // through round 3: slower, and 132 B of scratch per lane; removed)
+    if (p->na == 1 && nb == 1 && ct == 4) return launch_fused<1, 1, 4, 8>(a, n_run, st, p->prof);
     PRAG_DISPATCH(1, 1)
     PRAG_DISPATCH(1, 2)
     PRAG_DISPATCH(2, 1)

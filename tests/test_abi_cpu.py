@@ -78,3 +78,26 @@ def test_product_library_has_no_result_corrupting_knobs():
     # a boolean in the product build, so "2" (overflow unrepaired) cannot be selected
     src = open(os.path.join(_lib.CSRC, "flat_index.hip")).read()
     assert 'ix->mm_mode = atoi(e) != 0;' in src
+
+
+def test_no_kernel_of_the_library_uses_scratch():
+    """Every kernel of libprag.so's gfx950 code objects has .private_segment_fixed_size == 0 and no spilled
+    register (tools/code_object_audit.py: llvm-objdump --offloading + llvm-readelf --notes).  The library holds
+    only kernels its dispatch can reach, so the whole list is checked: a spilled value reloads behind
+    `s_waitcnt vmcnt(0)` and drains the loads the scan kernels keep in flight (round 3 shipped five such
+    variants, among them the reference's own fp32 index type at k = 13..26)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import code_object_audit
+    if not os.path.exists(os.path.join(code_object_audit.LLVM, "llvm-readelf")):
+        pytest.skip("no llvm-readelf in this image")
+    _lib.build()
+    ks = code_object_audit.kernels(_lib.LIB_PATH)
+    assert len(ks) >= 100, len(ks)                       # the audit really found the kernels
+    names = " ".join(k["demangled"] for k in ks)
+    for must in ("prober_fused_kernel<1, 1, 4, 8>", "scan8_kernel", "scan_topk_kernel<32, 32, true, false>",
+                 "scan_mm_kernel", "merge_shards_kernel", "exact_scan_kernel"):
+        assert must in names, must
+    bad = [(k["demangled"], k["private_segment_fixed_size"], k["vgpr_spill_count"]) for k in ks
+           if k["private_segment_fixed_size"] or k["vgpr_spill_count"]]      # (SGPR spills go to VGPR lanes, not memory)
+    assert not bad, bad
