@@ -136,6 +136,14 @@ void prag_prober_destroy(prag_prober_t* p);
 int prag_pool_accumulate(float* acc_dev, const void* h_dev, int h_dtype, int64_t n_elems,
                          int assign, void* stream);
 
+/* The same for every probed layer of one decode step in ONE launch (exp_rag.py:317-329 registers one hook per
+ * layer of range(6,17,2): six `activations.detach().cpu()` per generated token in the reference, six launches per
+ * token with the call above): acc_dev float32 [n_layers, n_elems]; h_dev_ptrs is a HOST array of n_layers device
+ * pointers (wherever the model left each layer's activations; n_elems elements of type h_dtype each).
+ * n_layers <= 64, n_elems a multiple of 4. */
+int prag_pool_accumulate_layers(float* acc_dev, const void* const* h_dev_ptrs, int n_layers, int h_dtype,
+                                int64_t n_elems, int assign, void* stream);
+
 /* Replaces input_tensor_method1 + per-sample mean (train.py:153-162, 202-205;
  * utils.py:134-143, 184-186): out[b,:] = mean over the last pred_lens[b]
  * positions of acts[b] ([B,T,d], element type dtype: PRAG_F32 / PRAG_F16 / PRAG_BF16).  out float32 [B,d];

@@ -62,6 +62,7 @@ SIGNATURES = {
     "prag_prober_profile_read": (_I, [_P, _FP, _I, ctypes.POINTER(_I)]),
     "prag_prober_destroy": (None, [_P]),
     "prag_pool_accumulate": (_I, [_P, _P, _I, _L, _I, _P]),
+    "prag_pool_accumulate_layers": (_I, [_P, _P, _I, _I, _L, _I, _P]),
     "prag_pool_ragged": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "prag_pool_masked_mean": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
     "prag_trainer_create": (_I, [ctypes.POINTER(_P), _I, _I, _I] + [ctypes.c_double] * 7 + [ctypes.c_uint32]),

@@ -1055,6 +1055,33 @@ __global__ __launch_bounds__(256) void pool_accumulate_kernel(float* __restrict_
     }
 }
 
+// the same for every probed layer of one decode step in ONE launch: layer l's activations sit wherever the model
+// left them (pointer table passed by value), its accumulator at acc + l * n
+struct PoolLayerPtrs {
+    const void* h[64];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pool_accumulate_layers_kernel(float* __restrict__ acc, PoolLayerPtrs ptrs,
+                                                                    int64_t n, int assign) {
+    const T* __restrict__ h = reinterpret_cast<const T*>(ptrs.h[blockIdx.y]);
+    float* __restrict__ dst_l = acc + (int64_t)blockIdx.y * n;
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        f32x4 v;
+        if constexpr (sizeof(T) == 4) {
+            v = *reinterpret_cast<const f32x4*>(h + i);
+        } else if constexpr (std::is_same<T, _Float16>::value) {
+            const half4 hv = *reinterpret_cast<const half4*>(h + i);
+            v = {(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+        } else {   // bf16 bits
+            v = load4_as_f32(h + i);
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(dst_l + i);
+        *dst = assign ? v : (*dst + v);
+    }
+}
+
 // out[b,:] = sum or mean of the last pred_lens[b] positions of acts[b] ([B,T,d])
 template <typename T>
 __global__ __launch_bounds__(256) void pool_ragged_kernel(const T* __restrict__ acts, int Tlen, int d,
@@ -1105,7 +1132,12 @@ struct prag_prober {
     std::vector<SmallLayer> h_small;
     SmallLayer* d_small = nullptr;
     float* small_ws = nullptr;
-    int small_mode = 1;   // PRAG_PROBER_SMALL=0: always the MFMA-tiled kernel
+    void* small_sync = nullptr;   // arrival counters of the one-launch form (zero between launches)
+    // PRAG_PROBER_SMALL=0: always the MFMA-tiled kernel; 1 (default): three short launches; 3: the same stages in
+    // ONE launch with in-launch hand-offs (round 4: built, bit-identical, and SLOWER - 30.2 against 25.2 us per gate
+    // at one pooled state, profiles/r04c_latency.txt: a hand-off costs a write-through drain, an atomic, a poll and
+    // a load from beyond L2, ~5 us, where a kernel boundary costs ~2 us and leaves the data in L2; kept for A/B)
+    int small_mode = 1;
     _Float16* ws_h = nullptr;  // [L][maxB][d] hi / lo workspace for fp32 activations
     _Float16* ws_l = nullptr;
     int64_t ws_rows = 0;
@@ -1227,9 +1259,12 @@ extern "C" int prag_prober_create(prag_prober_t** out, int n_layers, int d_model
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_small), sizeof(SmallLayer) * n_layers);
     if (e == hipSuccess)
         e = hipMalloc(reinterpret_cast<void**>(&p->small_ws), sizeof(float) * 2 * n_layers * kSmallMaxB * kHidden);
+    if (e == hipSuccess) e = hipMalloc(&p->small_sync, small_sync_bytes());
+    if (e == hipSuccess) e = hipMemset(p->small_sync, 0, small_sync_bytes());
     if (e != hipSuccess) {
         if (p->d_layers) (void)hipFree(p->d_layers);
         if (p->d_small) (void)hipFree(p->d_small);
+        if (p->small_ws) (void)hipFree(p->small_ws);
         set_error("hipMalloc failed: %s", hipGetErrorString(e));
         delete p;
         return PRAG_EHIP;
@@ -1490,6 +1525,8 @@ static int forward_impl(prag_prober_t* p, const void* x_dev, int x_dtype, int64_
         r.theta = fuse ? gate->theta : 0.0;
         r.probsum = fuse ? gate->probsum : nullptr;
         r.decision = fuse ? gate->decision : nullptr;
+        r.sync = p->small_sync;
+        r.fused = p->small_mode == 3;
         p->prof.begin(st);
         const int rc = small_run(r, st);
         p->prof.end(st);
@@ -1603,6 +1640,7 @@ extern "C" void prag_prober_destroy(prag_prober_t* p) {
     if (p->d_layers) (void)hipFree(p->d_layers);
     if (p->d_small) (void)hipFree(p->d_small);
     if (p->small_ws) (void)hipFree(p->small_ws);
+    if (p->small_sync) (void)hipFree(p->small_sync);
     if (p->ws_h) (void)hipFree(p->ws_h);
     if (p->ws_l) (void)hipFree(p->ws_l);
     delete p;
@@ -1627,6 +1665,33 @@ extern "C" int prag_pool_accumulate(float* acc_dev, const void* h_dev, int h_dty
     else
         hipLaunchKernelGGL(pool_accumulate_kernel<unsigned short>, dim3(blocks), dim3(256), 0, st, acc_dev,
                            reinterpret_cast<const unsigned short*>(h_dev), n_elems, assign);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+extern "C" int prag_pool_accumulate_layers(float* acc_dev, const void* const* h_dev_ptrs, int n_layers, int h_dtype,
+                                           int64_t n_elems, int assign, void* stream) {
+    PRAG_REQUIRE(acc_dev && h_dev_ptrs, PRAG_EINVAL, "prag_pool_accumulate_layers: NULL pointer");
+    PRAG_REQUIRE(n_layers >= 1 && n_layers <= 64, PRAG_EINVAL, "n_layers=%d outside [1,64]", n_layers);
+    PRAG_REQUIRE(n_elems >= 0 && n_elems % 4 == 0, PRAG_EINVAL, "n_elems=%lld must be a multiple of 4",
+                 (long long)n_elems);
+    PRAG_REQUIRE(h_dtype == PRAG_F32 || h_dtype == PRAG_F16 || h_dtype == PRAG_BF16, PRAG_EINVAL, "h_dtype=%d",
+                 h_dtype);
+    PoolLayerPtrs ptrs{};
+    for (int l = 0; l < n_layers; ++l) {
+        PRAG_REQUIRE(h_dev_ptrs[l] != nullptr, PRAG_EINVAL, "prag_pool_accumulate_layers: layer %d pointer is NULL", l);
+        ptrs.h[l] = h_dev_ptrs[l];
+    }
+    if (n_elems == 0) return PRAG_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)std::min<int64_t>((n_elems / 4 + 255) / 256, 512), (unsigned)n_layers);
+    if (h_dtype == PRAG_F32)
+        hipLaunchKernelGGL(pool_accumulate_layers_kernel<float>, grid, dim3(256), 0, st, acc_dev, ptrs, n_elems, assign);
+    else if (h_dtype == PRAG_F16)
+        hipLaunchKernelGGL(pool_accumulate_layers_kernel<_Float16>, grid, dim3(256), 0, st, acc_dev, ptrs, n_elems, assign);
+    else
+        hipLaunchKernelGGL(pool_accumulate_layers_kernel<unsigned short>, grid, dim3(256), 0, st, acc_dev, ptrs, n_elems,
+                           assign);
     PRAG_LAUNCH_CHECK();
     return PRAG_OK;
 }

@@ -32,12 +32,15 @@ struct SmallRun {
     double theta;
     float* probsum;             // [B][2] or null
     int32_t* decision;          // [B] or null
+    void* sync = nullptr;       // device block of small_sync_bytes() bytes, zero between launches (one-launch form)
+    int fused = 0;              // 1: one launch (needs `sync`; measured slower, prober.hip); 0: three launches
 };
 
 constexpr int kSmallMaxB = 8;
 constexpr int kSmallMaxElems = 16384;   // B * d staged in LDS as f32 (64 KiB)
 inline bool small_supported(int B, int d) { return B >= 1 && B <= kSmallMaxB && (int64_t)B * d <= kSmallMaxElems; }
-// Enqueue the three launches on `st`.
+// Enqueue the gate on `st`: one launch (r.sync given), or the three launches of rounds 2-3.
 int small_run(const SmallRun& r, hipStream_t st);
+size_t small_sync_bytes();
 
 }  // namespace prag

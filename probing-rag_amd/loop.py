@@ -17,17 +17,56 @@ from . import _lib
 
 
 class HiddenStatePool:
-    """acc[l] = sum over all positions of every forward pass after the first."""
+    """acc[l] = sum over all positions of every forward pass after the first.
 
-    def __init__(self, n_layers: int, d_model: int, batch: int = 1, device=None):
+    A decode step (one position per pass, KV cache on) of ALL hooked layers is added in ONE launch
+    (``prag_pool_accumulate_layers``): each layer's hook only notes where the model left its activations, the
+    last layer's hook - or ``pooled()`` / ``reset()`` - flushes the set.  The noted tensors are kept alive until
+    then and must not be overwritten in place by the model meanwhile (TransformerLens hook points and HF hidden
+    states are not); ``defer=False`` adds every layer at once in its own launch, as round 3 did."""
+
+    def __init__(self, n_layers: int, d_model: int, batch: int = 1, device=None, defer: bool = True):
         _lib.require_gpu()
         import torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.acc = torch.zeros((n_layers, batch, d_model), dtype=torch.float32, device=self.device)
         self.passes = [0] * n_layers
+        self.defer = bool(defer) and n_layers <= 64
+        self._pending = {}      # slot -> (tensor [B,1,d], assign)
 
     def reset(self):            # `cache = {}` exp_rag.py:397, 423
+        self._pending = {}
         self.passes = [0] * len(self.passes)
+
+    def _flush(self):
+        """Add the noted decode-step activations: one launch when every layer noted one of the same kind."""
+        import torch
+        if not self._pending:
+            return
+        pend, self._pending = self._pending, {}
+        L = len(self.passes)
+        items = [pend.get(s) for s in range(L)]
+        dts = {torch.float32: _lib.PRAG_F32, torch.float16: _lib.PRAG_F16, torch.bfloat16: _lib.PRAG_BF16}
+        full = all(it is not None for it in items)
+        if full:
+            a0, as0 = items[0]
+            full = all(a.dtype == a0.dtype and a.shape == a0.shape and a.device == a0.device and asg == as0
+                       for a, asg in items) and tuple(a0.shape[:1]) == tuple(self.acc.shape[1:2])
+        if full:
+            a0, as0 = items[0]
+            n = a0.numel()
+            ptrs = (ctypes.c_void_p * L)(*[a.data_ptr() for a, _ in items])
+            with torch.cuda.device(a0.device):
+                _lib.check(_lib.lib().prag_pool_accumulate_layers(ctypes.c_void_p(self.acc.data_ptr()), ptrs, L, dts[a0.dtype],
+                                                                  n, as0, _lib.current_stream_ptr(a0.device)))
+            return
+        for slot, it in enumerate(items):
+            if it is None:
+                continue
+            a, asg = it
+            with torch.cuda.device(a.device):
+                _lib.check(_lib.lib().prag_pool_accumulate(ctypes.c_void_p(self.acc[slot].data_ptr()), ctypes.c_void_p(a.data_ptr()),
+                                                           dts[a.dtype], a.numel(), asg, _lib.current_stream_ptr(a.device)))
 
     def hook(self, slot: int):
         """Returns a forward hook for layer slot `slot` (``model.add_hook(name, fn)``)."""
@@ -50,6 +89,14 @@ class HiddenStatePool:
         dst = self.acc[slot]
         dt = {torch.float32: _lib.PRAG_F32, torch.float16: _lib.PRAG_F16, torch.bfloat16: _lib.PRAG_BF16}[a.dtype]
         st = _lib.current_stream_ptr(a.device)
+        if T == 1 and self.defer and (Bt * d) % 4 == 0:
+            if slot in self._pending:        # a second pass of this layer before the others caught up
+                self._flush()
+            self._pending[slot] = (a, 1 if n == 1 else 0)
+            if len(self._pending) == len(self.passes):
+                self._flush()
+            return
+        self._flush()                        # keep the order of additions per layer
         with torch.cuda.device(a.device):
             if T == 1:
                 _lib.check(_lib.lib().prag_pool_accumulate(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(a.data_ptr()),
@@ -64,6 +111,7 @@ class HiddenStatePool:
                                                            _lib.PRAG_F32, Bt * d, 1 if n == 1 else 0, st))
 
     def pooled(self):
+        self._flush()
         if min(self.passes) < 2:   # torch.concat([]) raises in the reference
             raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
         return self.acc
