@@ -38,6 +38,7 @@ Other sizes are parity/diagnostic cases, e.g. BASELINE config 3:
 import argparse
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -79,6 +80,11 @@ def parse(argv=None):
                          "size with the 8-GPU gate share (2.6 M rows, 512 gate rows): 0.537 ms per pass on one "
                          "stream, 0.542 overlapped (the scan loses to the gate what the gate's latency saves)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("PRAG_BENCH_LAUNCH_TIMEOUT", "1800")),
+                    help="`--gpus N` without a launcher: seconds after which the torch.distributed.run child (its whole "
+                         "process group) is killed and this process exits 124")
+    ap.add_argument("--no-shard-variant", action="store_true",
+                    help="skip the 8-GPU shard shape (2 625 000 rows, 64 queries, 512 gate rows) in `variants`")
     ap.add_argument("--measure-traffic", type=int, default=1,
                     help="1 (default, 1 GPU): measure roofline.traffic in THIS run - two child `rocprofv3 --pmc` passes "
                          "(FETCH_SIZE, WRITE_SIZE; counters cannot be read inside the timed process) over "
@@ -276,6 +282,32 @@ def variant_record(torch, ix, q, k, store, metric, n_local, shadow=0):
     return rec
 
 
+def _run_group(cmd, cwd=None, env=None, timeout=None):
+    """Run `cmd` as a child in a session of its own and wait; on timeout kill the WHOLE process group (rocprofv3
+    starts the Python program as a grandchild: killing the profiler alone left it holding the GPU and ~48 GB).
+    Returns None on exit (any code) or a short error string."""
+    try:
+        proc = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                start_new_session=True)
+    except Exception as e:
+        return type(e).__name__
+    try:
+        proc.wait(timeout=timeout)
+        return None
+    except subprocess.TimeoutExpired:
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return "timeout"
+
+
 def _pmc_passes(counters, kernel_substr, prof_args):
     """One child `rocprofv3 --pmc <counter>` pass per counter (never combined with trace domains) over
     tools/prof_kernels.py; returns ({counter: mean value over the full-grid launches of the kernel} or None, note)."""
@@ -293,11 +325,10 @@ def _pmc_passes(counters, kernel_substr, prof_args):
         out_dir = tempfile.mkdtemp(prefix="prag_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--",
                sys.executable, os.path.join(ROOT, "tools", "prof_kernels.py")] + list(prof_args)
-        try:
-            subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL,
-                           stderr=subprocess.DEVNULL, timeout=300, check=False)
-        except Exception as e:
-            return None, f"rocprofv3 --pmc {counter} failed: {type(e).__name__}"
+        err = _run_group(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, timeout=300)
+        if err is not None:
+            shutil.rmtree(out_dir, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {counter} failed: {err}"
         rows = []
         for f in glob.glob(os.path.join(out_dir, "**", "*_counter_collection.csv"), recursive=True):
             rows += [r for r in csv.DictReader(open(f)) if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter]
@@ -310,13 +341,13 @@ def _pmc_passes(counters, kernel_substr, prof_args):
     return got, "measured by this run: child `rocprofv3 --pmc` passes over tools/prof_kernels.py, one counter per pass"
 
 
-def measure_traffic(n_local, store, metric, queries, shadow, kernel):
+def measure_traffic(n_local, store, metric, queries, shadow, kernel, k=10):
     """HBM bytes per launch of `kernel` from two separate child `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE),
     corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE in KiB reports half of a wide streaming
     read; WRITE_SIZE in KiB is exact).  Returns (bytes or None, note)."""
     got, note = _pmc_passes(("FETCH_SIZE", "WRITE_SIZE"), kernel.split("_kernel")[0],
                             ["--skip-gate", "--docs", str(n_local), "--queries", str(queries), "--store", store,
-                             "--metric", metric, "--shadow", str(1 if shadow else 0), "--iters", "3"])
+                             "--metric", metric, "--shadow", str(1 if shadow else 0), "--iters", "3", "--k", str(k)])
     if got is None:
         return None, note
     return 2.0 * got["FETCH_SIZE"] * 1024 + got["WRITE_SIZE"] * 1024, \
@@ -357,7 +388,28 @@ def self_launch(args, argv):
     env.setdefault("OMP_NUM_THREADS", "8")
     cmd = launch_command(args.gpus, argv)
     print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
-    return subprocess.run(cmd, env=env).returncode
+    timeout = getattr(args, "launch_timeout", None)
+    if not timeout or timeout <= 0:
+        return subprocess.run(cmd, env=env).returncode
+    # a hung rendezvous or collective must not hang the caller: the child gets a session of its own, and on timeout
+    # its whole process group (the launcher and every rank) is killed - never this process replaced or re-executed
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {args.gpus}-rank child did not finish within {timeout:.0f} s: killing its process group",
+              file=sys.stderr, flush=True)
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=15)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
 
 
 def clustered_variant(torch, pra, d_emb, k, n_rows=4_194_304, n_centres=4096, sigma=0.0175, B=64):
@@ -383,6 +435,78 @@ def clustered_variant(torch, pra, d_emb, k, n_rows=4_194_304, n_centres=4096, si
         rec["two_level" if shadow else "rows_scanned_directly"] = {
             "ms_per_search": ms, "scan_kernel_ms": float(np.mean(kern)) if kern else None, "exact_fallbacks_last_search": fb}
     rec["ids_identical"] = bool(torch.equal(res[0][1], res[2][1]))
+    ix.close()
+    return rec
+
+
+SHARD_ROWS, SHARD_QUERIES, SHARD_GATE_ROWS = 2_625_000, 64, 512     # one rank's share of the headline at 8 GPUs
+
+
+def shard_variant(torch, pra, ens, k, metric, ms_per_pass_full, passes=300):
+    """The 8-GPU shard shape on this one GPU: what ONE rank of the 8-rank job runs per pass - the gate over 512 of
+    the 4096 pooled states, then the top-k of the 64 replicated queries over its 2 625 000 rows (the all-gather of
+    8 x 64 x 10 x 12 bytes and the merge are not in it).  predicted_strong_scaling_eff = ms_per_pass(21 M rows, this
+    run) / 8 / pass_ms: the efficiency an 8-GPU run can reach at best (fixed costs do not shrink with the shard)."""
+    from probing_rag_amd.synth import synth_rows
+    d_emb, d_model, L = D_EMB, D_MODEL, N_LAYERS
+    ix = pra.HipFlatIndex(d_emb, metric, "f16", capacity=SHARD_ROWS)
+    ix.add_synthetic(42, 0, SHARD_ROWS)
+    ix.set_shadow(1)
+    ix.prepare()
+    q = torch.from_numpy(synth_rows(7, 0, SHARD_QUERIES, d_emb)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    x = torch.randn((L, SHARD_GATE_ROWS, d_model), generator=g, device="cuda", dtype=torch.float32).half()
+    gate_out = (torch.empty((L, SHARD_GATE_ROWS, 2), dtype=torch.float32, device="cuda"),
+                torch.empty((SHARD_GATE_ROWS, 2), dtype=torch.float32, device="cuda"),
+                torch.empty((SHARD_GATE_ROWS,), dtype=torch.int32, device="cuda"))
+    out = (torch.empty((SHARD_QUERIES, k), dtype=torch.float32, device="cuda"),
+           torch.empty((SHARD_QUERIES, k), dtype=torch.int64, device="cuda"))
+
+    def timed(fn, n):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def one_pass():
+        ens.gate(x, 0, 0.0, out=gate_out)
+        ix.search(q, k, out=out)
+
+    pass_ms = timed(one_pass, passes)                       # no event rings inside the timed loop
+    search_ms = timed(lambda: ix.search(q, k, out=out), passes)
+    gate_ms = timed(lambda: ens.gate(x, 0, 0.0, out=gate_out), passes)
+    ix.profile(256)
+    ens.profile(256)
+    for _ in range(200):
+        one_pass()
+    torch.cuda.synchronize()
+    scan_ms = ix.profile_read()
+    gk_ms = ens.profile_read()
+    ix.profile(0)
+    ens.profile(0)
+    fb = ix.last_exact_fallbacks()
+    I_two_level = out[1].clone()
+    ix.set_shadow(0)
+    _, I_direct = ix.search(q, k)
+    scan_k = float(np.mean(scan_ms)) if scan_ms else float("nan")
+    gate_k = float(np.mean(gk_ms)) if gk_ms else float("nan")
+    alg = SHARD_ROWS * (d_emb + 8)
+    rec = {"what": "one rank's pass of the 8-GPU job on this GPU: gate over 512 x 6 x 2048 fp16 states, then %s top-%d of "
+                   "64 queries over 2 625 000 x 768 fp16 rows (two-level search); host-timed back to back, "
+                   "no event records in the timed loops" % (metric, k),
+           "rows": SHARD_ROWS, "queries": SHARD_QUERIES, "gate_rows": SHARD_GATE_ROWS, "k": k,
+           "pass_ms": pass_ms, "search_alone_ms": search_ms, "gate_alone_ms": gate_ms,
+           "scan8_kernel_ms_in_pass": scan_k, "gate_kernel_ms_in_pass": gate_k,
+           "rest_of_pass_ms (prep, gather + merge, exact probe, launch gaps)": pass_ms - scan_k - gate_k,
+           "scan8_frac_of_8TBs": alg / (scan_k * 1e-3) / 1e9 / HBM_PEAK_GBS if scan_k == scan_k else None,
+           "exact_fallbacks_last_search": fb,
+           "ids_identical_to_direct_scan_of_the_rows": bool(torch.equal(I_two_level, I_direct)),
+           "ms_per_pass_21M_this_run": ms_per_pass_full,
+           "predicted_strong_scaling_eff": ms_per_pass_full / 8.0 / pass_ms}
     ix.close()
     return rec
 
@@ -564,7 +688,6 @@ def main(argv=None):
         i8_tiles = local.last_tiled8() >= 0
         growth = 16
         if i8_tiles:
-            n_qb = min((args.queries + 255) // 256 * 256, 1024) // 256
             growth = 3
         seg0 = 2048
         while seg0 * growth < n_local:
@@ -586,13 +709,13 @@ def main(argv=None):
             except Exception:
                 traffic = None
     if args.measure_traffic and world == 1 and not tiled:
-        t_meas, note = measure_traffic(n_local, args.store, args.metric, args.queries, args.shadow, scan_kernel)
+        t_meas, note = measure_traffic(n_local, args.store, args.metric, args.queries, args.shadow, scan_kernel, args.k)
         if t_meas is not None:
             traffic, traffic_source = t_meas, note
         else:
             traffic_source = (traffic_source + "; " if traffic_source else "") + "not measured in this run: " + note
     gate_mfma_busy, gate_mfma_note = None, "not measured (--measure-traffic 0 or more than one rank)"
-    if args.measure_traffic and world == 1:
+    if args.measure_traffic and world == 1 and not args.no_variants:     # (shard / diagnostic runs skip the two passes)
         gate_mfma_busy, gate_mfma_note = measure_gate_mfma(Bg)
     gate_avg_ms = float(np.mean(gate_ms)) if gate_ms else float("nan")
     gate_flops = 2.0 * L * (d_model * 512 + 512 * 512 + 512 * 2) * Bg
@@ -652,6 +775,12 @@ def main(argv=None):
     if world == 1 and not args.no_variants:
         variants = {}
         local.set_scan_workgroups(0)          # searches alone on the chip
+        if not args.no_shard_variant and args.docs > SHARD_ROWS:
+            try:
+                variants[f"shard_{SHARD_ROWS}_q{SHARD_QUERIES}_gate{SHARD_GATE_ROWS}"] = \
+                    shard_variant(torch, pra, ens, args.k, args.metric, ms_per_step / args.inner)
+            except Exception as e:
+                variants[f"shard_{SHARD_ROWS}_q{SHARD_QUERIES}_gate{SHARD_GATE_ROWS}"] = {"error": f"{type(e).__name__}: {e}"}
         try:
             qv = torch.from_numpy(synth_rows(7, 0, 1000, d_emb)).cuda()
             if args.store == "f16" and args.metric == "cos":
@@ -721,4 +850,12 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:      # a rank that dies says who it was before the launcher tears the job down
+        print(f"bench.py: rank {os.environ.get('RANK', '0')} of {os.environ.get('WORLD_SIZE', '1')} "
+              f"(local rank {os.environ.get('LOCAL_RANK', '0')}, pid {os.getpid()}, backend "
+              f"{os.environ.get('PRAG_BENCH_BACKEND', 'nccl')}) failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        raise

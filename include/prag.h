@@ -242,8 +242,10 @@ int prag_index_d(const prag_index_t* ix);
  * selection vs the gap to the last candidate); a query that cannot be certified - dense
  * near-duplicates, squared-L2 cancellation, a deep-list overflow - is recomputed by an exact
  * float64 scan of every row inside the same call (one more pass over the shard for that query).
- * No host synchronisation on the device-io path - with one exception: a batch of > 128 queries that
- * takes the int8 tiles (prag_index_last_tiled8 below) waits for `stream` once, to read 4 bytes.
+ * No host synchronisation on the device-io path: every fallback - the exact scan, the second tier of the
+ * 8-bit tiled selection (prag_index_last_tiled8 below) - is enqueued unconditionally and switched by a word
+ * on the device, so a search whose workspaces exist (any earlier search of the same shape made them) can be
+ * captured into a HIP graph and replayed, and every rank of a lockstep retrieval issues the same launches.
  * With io_is_device == 0 the call copies in/out and synchronises `stream`. */
 int prag_index_search(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset,
                       float* D, int64_t* I, int io_is_device, void* stream);
@@ -276,6 +278,23 @@ int prag_index_search_tagged(prag_index_t* ix, const float* q, int B, int k, int
 int prag_merge_topk_packed_tagged(const void* parts_dev, int64_t part_stride_bytes, int n_parts, int B, int k,
                                   int metric, float* D_dev, int64_t* I_dev, void* stream);
 
+/* The exchange in C: a C / ctypes host shards the index without torch.distributed.
+ * prag_index_set_comm hands the index the caller's RCCL communicator (an ncclComm_t, borrowed; NULL with world 1 =
+ * single GPU), this process's rank and the world size.  prag_index_search_sharded is then the whole sharded search
+ * of utils.py:378-380's call in one entry point: local search with tagged ids into this rank's packed block,
+ * ONE ncclAllGather of world x (B*k*12 bytes, padded to 16) on `stream`, the (score, residual, id) merge; q
+ * replicated on every rank, identical D / I on every rank, device pointers, no host synchronisation.  id_offset =
+ * global id of this shard's first row.  RCCL is bound at run time (dlopen): hosts that cannot reach a communicator
+ * of their own (Python: torch.distributed does not expose its ncclComm_t) create one with the three helpers -
+ * prag_rccl_unique_id on one rank, the 128 bytes broadcast by any means, prag_rccl_comm_init_rank on every rank
+ * (collective, on the current device). */
+int prag_rccl_unique_id(void* id_out_128);
+int prag_rccl_comm_init_rank(void** comm_out, int world, int rank, const void* id_128);
+int prag_rccl_comm_destroy(void* comm);
+int prag_index_set_comm(prag_index_t* ix, void* nccl_comm, int rank, int world);
+int prag_index_search_sharded(prag_index_t* ix, const float* q_dev, int B, int k, int64_t id_offset,
+                              float* D_dev, int64_t* I_dev, void* stream);
+
 /* Read back stored rows [row0,row0+n) as float32 (what the scan sees). */
 int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n, float* out_host);
 
@@ -291,14 +310,16 @@ int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out);
 
 /* Measurement hook: batches of > 128 queries on an index that keeps the 8-bit shadow (below) select their
  * candidates on int8 matrix tiles over the shadow first (256 candidates per query, the shadow's error bound
- * in the certificate); queries that fail that certificate are searched again - a few of them as a compact
- * batch of their own, more than 128 or a quarter of the batch by repeating the whole batch on the fp16 tiles
- * (the one place a device-io search waits for its stream: a 4-byte read-back between the tiers).
+ * in the certificate); queries that fail that certificate are searched again - up to 64 of them (and at most
+ * a quarter of the batch) as a compact batch of their own, more than that by repeating the whole batch on the
+ * fp16 tiles.  Both continuations are always enqueued and the failed count, on the device, opens one of them:
+ * the search never reads it back.  It travels to the host asynchronously; this hook waits for it.
  * *n_failed_out = queries of the most recent search that failed the 8-bit certificate (0: the first tier
- * answered), -1 if that search did not take the 8-bit tiles (fewer than 2 Mi rows in shadow mode 1, no
- * shadow, or two whole-batch repeats in a row: the index then skips the 8-bit tiles until rows are added or
- * prag_index_set_shadow is called).  Reference call: utils.py:378-380
- * (batch_topk_sim -> IndexFlat.search); results are the definition's either way. */
+ * answered); -1: that search did not take the 8-bit tiles (fewer than 2 Mi rows in shadow mode 1, no shadow,
+ * <= 128 queries); -2: it skipped them because two searches in a row had to repeat their whole batch (they are
+ * probed again after 64, 128, ... 4096 eligible searches, or at once when rows are added or
+ * prag_index_set_shadow is called); -3: unknown - the search was captured into a graph.  Reference call:
+ * utils.py:378-380 (batch_topk_sim -> IndexFlat.search); results are the definition's either way. */
 int prag_index_last_tiled8(prag_index_t* ix, int* n_failed_out);
 
 /* Two-level exact search: keep an 8-bit shadow of the stored rows (+d+8 bytes per row, built on the

@@ -101,6 +101,7 @@ struct ExactArgs {
     int64_t* I;
     uint32_t* done;   // [f_cap] workgroups that have written their list of flag slot f (zero between searches)
     int tag_ids;
+    Gate gate;
 };
 
 template <int CTRL>
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(kExThreads) void exact_scan_kernel(ExactArgs a) {
     __shared__ ExTopK tk;
     __shared__ __attribute__((aligned(16))) float s_q[1536];
     __shared__ int s_last;
+    if (gate_closed(a.gate)) return;
     const uint32_t nf = *a.n_flag;
     if ((uint32_t)a.f0 >= nf) return;
     const int f1 = (int)std::min<uint32_t>(nf, (uint32_t)(a.f0 + a.f_cap));
@@ -276,6 +278,7 @@ int exact_run(const ExactRun& r, hipStream_t st) {
     a.I = r.I;
     a.done = r.done;
     a.tag_ids = r.tag_ids;
+    a.gate = r.gate;
     for (int f0 = 0; f0 < r.B; f0 += r.f_cap) {
         a.f0 = f0;
         if (r.store_f32)

@@ -27,6 +27,7 @@
 #include <new>
 #include <vector>
 
+#include "exchange.h"
 #include "flat_internal.h"
 
 namespace prag {
@@ -114,10 +115,10 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
                                                           uint32_t mm_first_rows, float* __restrict__ qinfo,
                                                           double* __restrict__ qn2, uint32_t* __restrict__ n_flag,
                                                           int* __restrict__ flag_list, int flag_all,
-                                                          uint32_t* __restrict__ g_slot, ShadowPrep sp) {
+                                                          uint32_t* __restrict__ g_slot, ShadowPrep sp, Gate gate) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= Bpad) return;
+    if (b >= Bpad || gate_closed(gate)) return;
     // blockIdx.y > 0 (two-level search only): this wave scores slice blockIdx.y - 1 of the shadow's sample
     // against its query and writes one bound slot; everything else is the work of the y == 0 wave
     const bool sampler = blockIdx.y > 0;
@@ -249,6 +250,7 @@ struct ScanArgs {
     int* out_idx;
     uint32_t* g_tau;         // [QT] chip-wide pruning bound per query (sortable-uint keys, +inf at start)
     uint32_t* g_slot;        // [QT][2 epochs][32] bound slots (below), or null: bound from g_tau only
+    Gate gate;               // flat_internal.h: the kernels return at once when it is closed
 };
 
 // Chip-wide pruning bound without a pre-pass.  Twice per launch ("epochs": after a wave's 1st and 4th
@@ -629,6 +631,7 @@ __device__ __forceinline__ void scan_topk_body(const ScanArgs& a, char* smem) {
 template <int QT, int KC, bool F32, bool HP>
 __global__ __launch_bounds__(512, 1) void scan_topk_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (gate_closed(a.gate)) return;
     scan_topk_body<QT, KC, F32, HP>(a, smem);
 }
 
@@ -641,6 +644,7 @@ __global__ __launch_bounds__(512, 1) void scan_topk_flagged_kernel(ScanArgs a, c
                                                                    int n_groups, int64_t part_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_any;
+    if (gate_closed(a.gate)) return;
     if (q_flag[(int64_t)n_groups * QT] == 0) return;  // the "any query flagged" word: the common case
     for (int g = 0; g < n_groups; ++g) {
         if (threadIdx.x == 0) s_any = 0;
@@ -683,6 +687,7 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
     constexpr int DG = 128;       // rows per workgroup step
     constexpr int STAGE = DG * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (gate_closed(a.gate)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -940,11 +945,12 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
                                                          int QT, int* __restrict__ cand_idx /*[q][KC]*/,
                                                          uint32_t* __restrict__ tau_out /*[q] or null*/,
                                                          const uint32_t* __restrict__ q_flag /*or null*/,
-                                                         int64_t part_stride, int any_idx) {
+                                                         int64_t part_stride, int any_idx, Gate gate) {
     __shared__ unsigned long long s_head[kMergeMaxLists];
     __shared__ unsigned long long s_surv[KC * KC];
     __shared__ unsigned long long s_misc[4];
     __shared__ unsigned long long s_out[KC];
+    if (gate_closed(gate)) return;
     // flagged mode (fallback of the MFMA-tiled scan): block = global query, lists of its group of QT
     // queries start at part_stride * group; groups without a flagged query keep their candidates
     int q = blockIdx.x;
@@ -1061,6 +1067,7 @@ __global__ __launch_bounds__(1024) void rerank_kernel(const void* __restrict__ r
                                                      const uint32_t* __restrict__ kth_sel /*[B] sortable, or null*/) {
     __shared__ double s_score[64];
     __shared__ int s_idx[64];
+    if (gate_closed(cert.gate)) return;
     const int b = blockIdx.x;
     rerank_block<F32>(rows, d, metric_l2, q32 + (int64_t)b * d, [&](int c) { return cand_idx[(int64_t)b * KC + c]; }, KC,
                       k, id_offset, D + (int64_t)b * k, I + (int64_t)b * k, s_score, s_idx, cert, b,
@@ -1078,6 +1085,7 @@ __global__ __launch_bounds__(1024) void rerank_sort_kernel(const void* __restric
                                                           const uint32_t* __restrict__ kth_sel /*[B] sortable*/) {
     __shared__ unsigned long long s_key[kMmMaxKc];
     __shared__ int s_id[kMmMaxKc];
+    if (gate_closed(cert.gate)) return;
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float* q = q32 + (int64_t)b * d;
@@ -1170,6 +1178,7 @@ __global__ __launch_bounds__(1024) void merge_rerank_kernel(const float* __restr
     __shared__ unsigned long long s_out[KC];
     __shared__ double s_score[64];
     __shared__ int s_idx[64];
+    if (gate_closed(cert.gate)) return;
     const int b = q0 + blockIdx.x;  // global query; blockIdx.x = its slot in this pass's query tile
     merge_lists_block<KC, 1024>(part_key, part_idx, n_lists, QT, (int)blockIdx.x, s_head, s_surv, s_misc, s_out);
     rerank_block<F32>(rows, d, metric_l2, q32 + (int64_t)b * d,
@@ -1272,23 +1281,36 @@ __global__ __launch_bounds__(256) void rows_to_f16_kernel(const float* __restric
 // results scattered back over the rows of the batch
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_queries_kernel(const float* __restrict__ q, const int* __restrict__ list, int n,
-                                                            int d, float* __restrict__ out) {
+                                                            int d, float* __restrict__ out, prag::Gate gate) {
     const int i = blockIdx.x;
-    if (i >= n) return;
+    if (i >= n || prag::gate_closed(gate)) return;
     const float* src = q + (int64_t)list[i] * d;
     for (int c = threadIdx.x * 4; c < d; c += 1024)
         *reinterpret_cast<prag::f32x4*>(out + (int64_t)i * d + c) = *reinterpret_cast<const prag::f32x4*>(src + c);
 }
+// rows [0, *n_dev) of the compact batch go back to their rows of the result (the rest were padding)
 __global__ __launch_bounds__(64) void scatter_results_kernel(const float* __restrict__ Ds, const int64_t* __restrict__ Is,
-                                                            const int* __restrict__ list, int n, int k,
-                                                            float* __restrict__ D, int64_t* __restrict__ I) {
+                                                            const int* __restrict__ list, const uint32_t* __restrict__ n_dev, int k,
+                                                            float* __restrict__ D, int64_t* __restrict__ I, prag::Gate gate) {
     const int i = blockIdx.x;
-    if (i >= n) return;
+    if (prag::gate_closed(gate) || (uint32_t)i >= *n_dev) return;
     const int64_t b = list[i];
     for (int j = threadIdx.x; j < k; j += 64) {
         D[b * k + j] = Ds[(int64_t)i * k + j];
         I[b * k + j] = Is[(int64_t)i * k + j];
     }
+}
+// The tier decision, on the device: t2_word[0] = queries that failed the 8-bit certificate (the gates of the second
+// tier compare it with ranges chosen by the host); the failed rows are copied out of the flag list (the inner
+// searches reuse it) and the compact batch is padded to `cap` entries with its first row (duplicate queries, whose
+// results are not scattered back).
+__global__ __launch_bounds__(64) void mm8_tier_plan_kernel(const uint32_t* __restrict__ n_flag, const int* __restrict__ flag_list,
+                                                          uint32_t* __restrict__ t2_word, int* __restrict__ t2_list, int cap) {
+    const uint32_t n = *n_flag;
+    if (threadIdx.x == 0) t2_word[0] = n;
+    if (n == 0) return;
+    const int first = flag_list[0];
+    for (int i = threadIdx.x; i < cap; i += 64) t2_list[i] = (uint32_t)i < n ? flag_list[i] : first;
 }
 
 // ===========================================================================
@@ -1340,8 +1362,17 @@ struct prag_index {
     // (those with segment growth 9; with growth 3: 1 M rows 1.90 / 1.73, 2.625 M 3.36 / 3.90, 21 M 17.8)
     int64_t mm8_min_rows = 2ll << 20;
     float* mm_kq = nullptr;            // [mm_q_cap] key scale of every query
-    uint32_t* tier_word_host = nullptr;   // pinned: flag count read back between the two tiers (device-io searches)
-    int mm8_last_failed = -1;             // queries of the last 8-bit tiled search that failed its certificate (-1: none ran)
+    // The tier decision is taken on the device (mm8_second_tier): every kernel of the second tier is enqueued with a
+    // Gate on t2_word[0] = queries that failed the 8-bit certificate.  The count travels to the host asynchronously
+    // (pinned word + event) for prag_index_last_tiled8 and the auto-off heuristic: no search waits for it.
+    Gate gate;                            // gate of the search being enqueued (second-tier inner searches), else open
+    uint32_t* t2_word = nullptr;          // device: [0] failed count of the last 8-bit tiled search
+    uint32_t* tier_word_host = nullptr;   // pinned copy
+    hipEvent_t tier_event = nullptr;
+    bool tier_pending = false;            // a copy is in flight (tier_event)
+    int tier_hi_sub = 0;                  // largest failed count the compact-batch tier takes in that search
+    int mm8_last_failed = -1;             // queries of the last 8-bit tiled search that failed its certificate
+                                          // (-1: it did not take the 8-bit tiles; -2: skipped, see mm8_auto_off; -3: unknown - captured)
     // few failed queries: searched again as a compact batch (mm8_second_tier)
     int* t2_list = nullptr;
     float* t2_q = nullptr;
@@ -1353,6 +1384,9 @@ struct prag_index {
     // are added or prag_index_set_shadow is called
     int mm8_whole_batch_streak = 0;
     bool mm8_auto_off = false;
+    // ... but not for good: after mm8_off_period eligible searches the tiles get ONE probe (a single whole-batch
+    // repeat switches them off again and doubles the period, up to 4096 searches)
+    int mm8_off_count = 0, mm8_off_period = 64;
     // fp32 indexes: fp16 copy of the rows for the tiled scan's candidate selection (built on the
     // first search with > 128 queries, dropped by add; the rerank always reads the fp32 rows)
     _Float16* rows16 = nullptr;
@@ -1400,6 +1434,13 @@ struct prag_index {
     int* sh_pid = nullptr;
     size_t sh_part_entries = 0;
     int cert_mode = 1;   // 0 = certificate off (PRAG_CERT=0: timing experiments only)
+    // row-sharded search in C (prag_index_set_comm / prag_index_search_sharded): the caller's RCCL communicator
+    // (borrowed), this rank and the world size; packed exchange buffers [D float32 [B,k] | I int64 [B,k]]
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    char* xch_send = nullptr;
+    char* xch_recv = nullptr;
+    size_t xch_send_cap = 0, xch_recv_cap = 0;
     int last_flagged = -1;   // flag count of the last host-io search (-1: last search was device-io)
     EventRing prof;
 };
@@ -1537,6 +1578,8 @@ static int shadow_ensure(prag_index* ix, hipStream_t st) {
         ix->shadow_rows = ix->ntotal;
         ix->mm8_whole_batch_streak = 0;     // new rows: the 8-bit tiles get another chance
         ix->mm8_auto_off = false;
+        ix->mm8_off_count = 0;
+        ix->mm8_off_period = 64;
     }
     return PRAG_OK;
 }
@@ -1791,11 +1834,11 @@ static int dispatch_qs(int d, int kc, const ScanArgs& a, int grid, hipStream_t s
 
 static int launch_merge(int kc, const float* pk, const int* pi, int n_lists, int QT, int nq, int* cand,
                         uint32_t* tau_out, hipStream_t st, const uint32_t* q_flag = nullptr,
-                        int64_t part_stride = 0, int any_idx = 0) {
+                        int64_t part_stride = 0, int any_idx = 0, Gate gate = Gate{}) {
     switch (kc) {
-        case 8: hipLaunchKernelGGL(merge_lists_kernel<8>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out, q_flag, part_stride, any_idx); break;
-        case 16: hipLaunchKernelGGL(merge_lists_kernel<16>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out, q_flag, part_stride, any_idx); break;
-        case 32: hipLaunchKernelGGL(merge_lists_kernel<32>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out, q_flag, part_stride, any_idx); break;
+        case 8: hipLaunchKernelGGL(merge_lists_kernel<8>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out, q_flag, part_stride, any_idx, gate); break;
+        case 16: hipLaunchKernelGGL(merge_lists_kernel<16>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out, q_flag, part_stride, any_idx, gate); break;
+        case 32: hipLaunchKernelGGL(merge_lists_kernel<32>, dim3(nq), dim3(256), 0, st, pk, pi, n_lists, QT, cand, tau_out, q_flag, part_stride, any_idx, gate); break;
         default: set_error("internal: KC=%d", kc); return PRAG_EUNSUPPORTED;
     }
     PRAG_LAUNCH_CHECK();
@@ -1875,6 +1918,7 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
     m.cap_wg = cap_wg;
     m.wg_slots = ix->n_cu;
     m.max_wg = cu_budget;
+    m.gate = ix->gate;
     // segment growth: keep the expected survivors of a segment (~(growth-1) * KC per query) inside the
     // per-workgroup regions (64 per query) and the compaction's staging buffer (4096)
     {
@@ -1905,7 +1949,8 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
         m.cnt = ix->mm_cnt + c0;
         m.ovf = ix->mm_ovf + c0;
         m.ovf_any = ix->mm_ovf + Bpad;
-        rc = mm_run(m, st, ix->prof);
+        static EventRing no_prof_mm;     // a gated second-tier search is not part of the profiled launches
+        rc = mm_run(m, st, ix->gate.word ? no_prof_mm : ix->prof);
         if (rc != PRAG_OK) return rc;
     }
     // Queries whose candidate buffer overflowed (flag set on the device): their groups go
@@ -1941,11 +1986,12 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
     a.out_idx = ix->part_idx;
     a.g_tau = ix->g_tau;
     a.g_slot = nullptr;
+    a.gate = ix->gate;
     rc = fb64 ? dispatch_flagged<64>(kc, a, fb_grid, ix->mm_ovf, n_groups, part_stride, st)
               : dispatch_flagged<32>(kc, a, fb_grid, ix->mm_ovf, n_groups, part_stride, st);
     if (rc != PRAG_OK) return rc;
     rc = launch_merge(kc, ix->part_key, ix->part_idx, fb_grid, fq, B, ix->cand, ix->g_tau, st, ix->mm_ovf,
-                      part_stride, Bpad);
+                      part_stride, Bpad, ix->gate);
     if (rc != PRAG_OK) return rc;
     return PRAG_OK;
 }
@@ -1967,41 +2013,147 @@ extern "C" int prag_index_search_tagged(prag_index_t* ix, const float* q, int B,
     return index_search_impl(ix, q, B, k, id_offset, D, I, io_is_device, stream, 1);
 }
 
-// Second tier of the 8-bit tiled selection (n_failed > 0 queries of the batch failed its certificate; their batch
-// rows are in ix->flag_list).  Few of them - at most kMm8SubsetMax and a quarter of the batch: a corpus with the
-// odd query sitting in a cluster of look-alikes - are searched again as a compact batch of their own (<= 128 queries
-// take the two-level search or the list kernels: one pass over the shard instead of the fp16 tiles for everybody);
-// otherwise the whole batch goes through the fp16 tiles.  Results land in D_dev / I_dev either way.
-constexpr int kMm8SubsetMax = 128;
-static int mm8_second_tier(prag_index* ix, const float* q_dev, int B, int k, int64_t id_offset, float* D_dev, int64_t* I_dev,
-                           void* stream, int tag_ids, int n_failed) {
+extern "C" int prag_index_set_comm(prag_index_t* ix, void* nccl_comm, int rank, int world) {
+    PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
+    PRAG_REQUIRE(world >= 1 && rank >= 0 && rank < world, PRAG_EINVAL, "rank %d of %d", rank, world);
+    PRAG_REQUIRE(nccl_comm != nullptr || world == 1, PRAG_EINVAL, "world=%d needs a communicator", world);
+    ix->comm = nccl_comm;
+    ix->comm_rank = rank;
+    ix->comm_world = world;
+    return PRAG_OK;
+}
+
+// The sharded search as ONE call: local search with tagged ids straight into this rank's slot of the packed exchange
+// format, ONE all-gather on the caller's stream, the (score, residual, id) merge - what ShardedFlatIndex.search did
+// with torch.distributed in between (sharded.py, rounds 1-3).  Device pointers; nothing waits for the stream.
+extern "C" int prag_index_search_sharded(prag_index_t* ix, const float* q_dev, int B, int k, int64_t id_offset,
+                                         float* D_dev, int64_t* I_dev, void* stream) {
+    PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
+    PRAG_REQUIRE(B >= 0 && k >= 1, PRAG_EINVAL, "B=%d k=%d", B, k);
+    if (B == 0) return PRAG_OK;
+    PRAG_REQUIRE(q_dev && D_dev && I_dev, PRAG_EINVAL, "prag_index_search_sharded: NULL pointer");
+    PRAG_REQUIRE(id_offset >= 0 && id_offset + ix->ntotal < (1ll << kTagShift), PRAG_EUNSUPPORTED,
+                 "tagged ids hold %d-bit global row ids", kTagShift);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (n_failed > kMm8SubsetMax || (int64_t)n_failed * 4 > B) {
-        if (++ix->mm8_whole_batch_streak >= 2) ix->mm8_auto_off = true;
-        return index_search_impl(ix, q_dev, B, k, id_offset, D_dev, I_dev, 1, stream, tag_ids, false);
+    const int world = ix->comm ? ix->comm_world : 1;
+    const size_t i_off = ((size_t)B * k * 4 + 7) / 8 * 8;           // the I block starts 8-byte aligned behind the D block
+    const size_t stride = (i_off + (size_t)B * k * 8 + 15) / 16 * 16;
+    if (stride > ix->xch_send_cap) {
+        ix->xch_send_cap = 0;
+        const int rc_ws = ws_regrow({{vpp(&ix->xch_send), stride}});
+        if (rc_ws != PRAG_OK) return rc_ws;
+        ix->xch_send_cap = stride;
     }
-    ix->mm8_whole_batch_streak = 0;
-    if (ix->t2_cap < kMm8SubsetMax || ix->t2_k < k) {
+    if (ix->comm && stride * world > ix->xch_recv_cap) {
+        ix->xch_recv_cap = 0;
+        const int rc_ws = ws_regrow({{vpp(&ix->xch_recv), stride * world}});
+        if (rc_ws != PRAG_OK) return rc_ws;
+        ix->xch_recv_cap = stride * world;
+    }
+    int rc = index_search_impl(ix, q_dev, B, k, id_offset, reinterpret_cast<float*>(ix->xch_send),
+                               reinterpret_cast<int64_t*>(ix->xch_send + i_off), 1, stream, 1);
+    if (rc != PRAG_OK) return rc;
+    const char* parts = ix->xch_send;
+    if (ix->comm) {      // also with one rank: the collective the multi-rank path issues, in its dtype and shape
+        rc = rccl_all_gather_bytes(ix->comm, ix->xch_send, ix->xch_recv, stride, st);
+        if (rc != PRAG_OK) return rc;
+        parts = ix->xch_recv;
+    }
+    return prag_merge_topk_packed_tagged(parts, (int64_t)stride, world, B, k, ix->metric, D_dev, I_dev, stream);
+}
+
+// Second tier of the 8-bit tiled selection.  The queries that failed its certificate are on the device (flag count
+// in *flag_word, batch rows in ix->flag_list) and so is the decision what to do about them: BOTH continuations are
+// enqueued, each behind a Gate on the failed count, and the one that does not apply returns at the top of every kernel
+// (~2 us per launch; a > 128-query search is >= 0.1 ms of GPU time):
+//   1 .. hi_sub failed  (hi_sub = min(kMm8SubsetMax, B / 4): the odd query sitting in a cluster of look-alikes) - they
+//                       are gathered into a compact batch of kMm8SubsetMax queries (padded with duplicates), searched by
+//                       the <= 64-query kernels - the two-level search over the shadow, with its own certificate and
+//                       exact fallback - and scattered back over their rows of the result;
+//   more than that      the WHOLE batch is repeated on the fp16 tiles.
+// Round 3 read the count back (hipMemcpyAsync + hipStreamSynchronize) and branched on the host: the one place a
+// device-io search waited for its stream - not capturable into a graph, a stall for a pipelined caller, and in the
+// lockstep multi-rank path every rank took its tier decision alone.  Now the count only travels to the host
+// asynchronously, for prag_index_last_tiled8 and the auto-off heuristic (consume_tier_stats).
+constexpr int kMm8SubsetMax = 64;
+static void consume_tier_stats(prag_index* ix, bool wait) {
+    if (!ix->tier_pending) return;
+    if (wait) {
+        if (hipEventSynchronize(ix->tier_event) != hipSuccess) return;
+    } else if (hipEventQuery(ix->tier_event) != hipSuccess) {
+        (void)hipGetLastError();          // hipErrorNotReady: look again at the next search
+        return;
+    }
+    ix->tier_pending = false;
+    const int n = (int)*ix->tier_word_host;
+    ix->mm8_last_failed = n;
+    if (n > ix->tier_hi_sub) {            // the whole batch went through both tiers
+        if (++ix->mm8_whole_batch_streak >= 2) {
+            ix->mm8_auto_off = true;
+            ix->mm8_off_count = 0;
+        }
+    } else {
+        ix->mm8_whole_batch_streak = 0;
+        if (n == 0) ix->mm8_off_period = 64;
+    }
+}
+
+struct GateScope {          // ix->gate is reset on every path out of the second tier
+    prag_index* ix;
+    ~GateScope() { ix->gate = Gate{}; }
+};
+
+static int mm8_second_tier(prag_index* ix, const float* q_dev, int B, int k, int64_t id_offset, float* D_dev, int64_t* I_dev,
+                           void* stream, int tag_ids, const uint32_t* flag_word) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (ix->t2_cap < kMm8SubsetMax || ix->t2_k < k || !ix->t2_word) {
         const int nk = std::max(k, ix->t2_k);
         ix->t2_cap = 0; ix->t2_k = 0;
         const int rc_ws = ws_regrow({{vpp(&ix->t2_list), (size_t)kMm8SubsetMax * sizeof(int)},
                                      {vpp(&ix->t2_q), (size_t)kMm8SubsetMax * ix->d * sizeof(float)},
                                      {vpp(&ix->t2_D), (size_t)kMm8SubsetMax * nk * sizeof(float)},
-                                     {vpp(&ix->t2_I), (size_t)kMm8SubsetMax * nk * sizeof(int64_t)}});
+                                     {vpp(&ix->t2_I), (size_t)kMm8SubsetMax * nk * sizeof(int64_t)},
+                                     {vpp(&ix->t2_word), 4 * sizeof(uint32_t)}});
         if (rc_ws != PRAG_OK) return rc_ws;
         ix->t2_cap = kMm8SubsetMax;
         ix->t2_k = nk;
     }
-    // (the inner search reuses flag_list: keep a copy of the failed rows)
-    PRAG_HIP(hipMemcpyAsync(ix->t2_list, ix->flag_list, (size_t)n_failed * sizeof(int), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(gather_queries_kernel, dim3(n_failed), dim3(256), 0, st, q_dev, ix->t2_list, n_failed, ix->d, ix->t2_q);
+    if (!ix->tier_word_host) {
+        PRAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->tier_word_host), 4 * sizeof(uint32_t)));
+        PRAG_HIP(hipEventCreateWithFlags(&ix->tier_event, hipEventDisableTiming));
+    }
+    hipLaunchKernelGGL(mm8_tier_plan_kernel, dim3(1), dim3(64), 0, st, flag_word, ix->flag_list, ix->t2_word, ix->t2_list,
+                       kMm8SubsetMax);
     PRAG_LAUNCH_CHECK();
-    const int rc = index_search_impl(ix, ix->t2_q, n_failed, k, id_offset, ix->t2_D, ix->t2_I, 1, stream, tag_ids, false);
+    const uint32_t hi_sub = (uint32_t)std::min(kMm8SubsetMax, B / 4);
+    {   // statistics, never waited for by a search; a capturing stream records nothing (the count stays unknown)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        ix->tier_pending = false;
+        if (!capturing) {
+            PRAG_HIP(hipMemcpyAsync(ix->tier_word_host, ix->t2_word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            PRAG_HIP(hipEventRecord(ix->tier_event, st));
+            ix->tier_pending = true;
+            ix->tier_hi_sub = (int)hi_sub;
+        } else {
+            ix->mm8_last_failed = -3;
+        }
+    }
+    GateScope scope{ix};
+    // ---- a few failed queries: compact batch through the <= 64-query kernels -----------------------------------------
+    ix->gate = Gate{ix->t2_word, 1u, hi_sub};
+    hipLaunchKernelGGL(gather_queries_kernel, dim3(kMm8SubsetMax), dim3(256), 0, st, q_dev, ix->t2_list, kMm8SubsetMax, ix->d,
+                       ix->t2_q, ix->gate);
+    PRAG_LAUNCH_CHECK();
+    int rc = index_search_impl(ix, ix->t2_q, kMm8SubsetMax, k, id_offset, ix->t2_D, ix->t2_I, 1, stream, tag_ids, false);
     if (rc != PRAG_OK) return rc;
-    hipLaunchKernelGGL(scatter_results_kernel, dim3(n_failed), dim3(64), 0, st, ix->t2_D, ix->t2_I, ix->t2_list, n_failed, k,
-                       D_dev, I_dev);
+    hipLaunchKernelGGL(scatter_results_kernel, dim3(kMm8SubsetMax), dim3(64), 0, st, ix->t2_D, ix->t2_I, ix->t2_list, ix->t2_word,
+                       k, D_dev, I_dev, ix->gate);
     PRAG_LAUNCH_CHECK();
-    return PRAG_OK;
+    // ---- more than that: the whole batch on the fp16 tiles ------------------------------------------------------------
+    ix->gate = Gate{ix->t2_word, hi_sub + 1u, 0xFFFFFFFFu};
+    rc = index_search_impl(ix, q_dev, B, k, id_offset, D_dev, I_dev, 1, stream, tag_ids, false);
+    return rc;
 }
 
 static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D, int64_t* I,
@@ -2022,12 +2174,24 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // > 128 queries on an index that keeps an up-to-date shadow: first tier = int8 tiles over the shadow with a
     // deep candidate list; the queries that fail the (much wider) certificate are searched again (mm8_second_tier)
-    const bool use_mm8 = allow_mm8 && ix->mm8_mode && !ix->mm8_auto_off && ix->mm_mode && !exact_only && kc <= 32 && B > 128 && ix->ntotal > 0 &&
-                         (ix->shadow_mode >= 2 || ix->ntotal >= ix->mm8_min_rows) &&
-                         ix->cert_mode != 0 && ix->rows8 != nullptr && ix->shadow_rows == ix->ntotal && shadow_wanted(ix) &&
-                         mm8_supported(ix->d, kMm8Kc) && mm_supported(ix->d, PRAG_F16, kMm8Kc) && k <= kMm8Kc / 8;
+    if (allow_mm8) consume_tier_stats(ix, false);     // the previous search's failed count, if it has arrived
+    const bool mm8_eligible = allow_mm8 && ix->mm8_mode && ix->mm_mode && !exact_only && kc <= 32 && B > 128 && ix->ntotal > 0 &&
+                              (ix->shadow_mode >= 2 || ix->ntotal >= ix->mm8_min_rows) &&
+                              ix->cert_mode != 0 && ix->rows8 != nullptr && ix->shadow_rows == ix->ntotal && shadow_wanted(ix) &&
+                              mm8_supported(ix->d, kMm8Kc) && mm_supported(ix->d, PRAG_F16, kMm8Kc) && k <= kMm8Kc / 8;
+    if (mm8_eligible && ix->mm8_auto_off && ++ix->mm8_off_count >= ix->mm8_off_period) {
+        // one probe after a while: a serving index must not lose the 8-bit tiles for good over two bad batches
+        ix->mm8_auto_off = false;
+        ix->mm8_whole_batch_streak = 1;      // a single whole-batch repeat switches them off again ...
+        ix->mm8_off_period = std::min(4096, ix->mm8_off_period * 2);   // ... for twice as long
+        ix->mm8_off_count = 0;
+    }
+    const bool use_mm8 = mm8_eligible && !ix->mm8_auto_off;
     if (use_mm8) kc = kMm8Kc;
-    else if (allow_mm8) ix->mm8_last_failed = -1;
+    else if (allow_mm8) {
+        ix->tier_pending = false;
+        ix->mm8_last_failed = mm8_eligible ? -2 : -1;
+    }
 
     // ---- host i/o staging -----------------------------------------------------
     const float* q_dev = q;
@@ -2178,6 +2342,9 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     cert.tag_ids = tag_ids;
     cert.sq8 = nullptr;        // (set below, once the query workspace of the 8-bit selection exists)
     cert.e_max = ix->shadow_err_max;
+    cert.gate = ix->gate;
+    static EventRing no_prof_gated;   // a gated second-tier search is not part of the profiled launches
+    EventRing& prof = ix->gate.word ? no_prof_gated : ix->prof;
     {
         // which operands the selection kernel rounds (flat_internal.h "Exactness certificate")
         const bool hp = !use_mm && !use_qs && use_hp;
@@ -2268,7 +2435,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
                        ix->metric == PRAG_METRIC_COS ? 1 : 0, ix->q32, ix->q16, ix->q16lo, ix->g_tau,
                        use_mm ? ix->mm_cnt : nullptr, ix->mm_ovf,
                        (uint32_t)std::min<int64_t>(ix->ntotal, kMmFirstSeg), ix->qinfo, ix->qn2, flag_word,
-                       ix->flag_list, exact_only && ix->ntotal > 0 ? 1 : 0, ix->g_slot, sprep);
+                       ix->flag_list, exact_only && ix->ntotal > 0 ? 1 : 0, ix->g_slot, sprep, ix->gate);
     PRAG_LAUNCH_CHECK();
 
     bool reranked = false;
@@ -2312,7 +2479,8 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         ss.ovf = ix->sh_ovf;
         ss.done = ix->sh_ovf + ix->sh_q_cap;
         ss.cert = cert;
-        rc = shadow_search(ss, st, ix->prof);
+        ss.gate = ix->gate;
+        rc = shadow_search(ss, st, prof);
         if (rc != PRAG_OK) return rc;
         reranked = true;
     } else if (ix->ntotal == 0 || exact_only) {
@@ -2332,6 +2500,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         a.use_norm = metric_l2;
         a.out_key = ix->part_key;
         a.out_idx = ix->part_idx;
+        a.gate = ix->gate;
         auto run_scan = [&](const ScanArgs& sa, int g, EventRing& ring) -> int {
             if (use_qs) return dispatch_qs(ix->d, kc, sa, g, st, ring);
             if (QT == 32 && use_hp)
@@ -2372,10 +2541,10 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
                 rc = run_scan(pre, pre_grid, no_prof);
                 if (rc != PRAG_OK) return rc;
                 rc = launch_merge(kc, ix->part_key, ix->part_idx, pre_grid, QT, nq, ix->cand + (size_t)p0 * kc,
-                                  ix->g_tau + p0, st);
+                                  ix->g_tau + p0, st, nullptr, 0, 0, ix->gate);
                 if (rc != PRAG_OK) return rc;
             }
-            rc = run_scan(a, grid, ix->prof);
+            rc = run_scan(a, grid, prof);
             if (rc != PRAG_OK) return rc;
             // the end of the search for this query tile: list merge + exact rerank + certificate in one launch
             rc = launch_merge_rerank(kc, ix->store == PRAG_F32, ix->part_key, ix->part_idx, n_lists, QT, nq, p0,
@@ -2430,21 +2599,21 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     er.grid = ex_grid;
     er.done = ix->ex_done;
     er.tag_ids = tag_ids;
+    er.gate = ix->gate;
     const bool may_flag = certify && ix->ntotal > 0;
-    if (use_mm8 && io_is_device) {
-        // tier decision: the flag count of the 8-bit selection comes back in one 4-byte transfer (the one place a
-        // device-io search waits for the stream: a > 128-query search is >= 0.1 ms of GPU time, the wait ~10 us);
-        // no flag -> done, otherwise the second tier (mm8_second_tier)
-        if (!ix->tier_word_host) PRAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->tier_word_host), sizeof(uint32_t)));
-        PRAG_HIP(hipMemcpyAsync(ix->tier_word_host, flag_word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        PRAG_HIP(hipStreamSynchronize(st));
+    if (use_mm8) {
+        // second tier, decided on the device (mm8_second_tier): no read-back, no host branch
+        const int rc = mm8_second_tier(ix, q_dev, B, k, id_offset, D_dev, I_dev, stream, tag_ids, flag_word);
+        if (rc != PRAG_OK) return rc;
         ix->last_flagged = -1;
-        ix->mm8_last_failed = (int)*ix->tier_word_host;
-        if (*ix->tier_word_host == 0) {
-            ix->mm8_whole_batch_streak = 0;
-            return PRAG_OK;
-        }
-        return mm8_second_tier(ix, q_dev, B, k, id_offset, D_dev, I_dev, stream, tag_ids, (int)*ix->tier_word_host);
+        if (io_is_device) return PRAG_OK;
+        // host i/o: one transfer back, then the statistics are there too
+        PRAG_HIP(hipMemcpyAsync(ix->io_res_host, ix->io_res, (size_t)B * k * 12, hipMemcpyDeviceToHost, st));
+        PRAG_HIP(hipStreamSynchronize(st));
+        consume_tier_stats(ix, true);
+        memcpy(I, ix->io_res_host, (size_t)B * k * sizeof(int64_t));
+        memcpy(D, ix->io_res_host + (size_t)B * k * 8, (size_t)B * k * sizeof(float));
+        return PRAG_OK;
     }
     if (io_is_device) {
         ix->last_flagged = -1;
@@ -2465,20 +2634,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     uint32_t n_flag = 0;
     memcpy(&n_flag, ix->io_res_host + (size_t)B * k * 12, sizeof(n_flag));
     ix->last_flagged = (int)n_flag;
-    if (use_mm8) {
-        ix->mm8_last_failed = (int)n_flag;
-        if (n_flag == 0) ix->mm8_whole_batch_streak = 0;
-    }
-    if (use_mm8 && n_flag > 0) {
-        // second tier on the staged queries, results into the same staging block
-        const int rc = mm8_second_tier(ix, q_dev, B, k, id_offset, D_dev, I_dev, stream, tag_ids, (int)n_flag);
-        if (rc != PRAG_OK) return rc;
-        rc_io = fetch();
-        if (rc_io != PRAG_OK) return rc_io;
-        uint32_t nf2 = 0;
-        PRAG_HIP(hipMemcpy(&nf2, ix->cert_words, sizeof(nf2), hipMemcpyDeviceToHost));
-        ix->last_flagged = (int)nf2;
-    } else if (may_flag && n_flag > 0) {
+    if (may_flag && n_flag > 0) {
         const int rc = exact_run(er, st);
         if (rc != PRAG_OK) return rc;
         rc_io = fetch();
@@ -2573,6 +2729,7 @@ extern "C" int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_
 
 extern "C" int prag_index_last_tiled8(prag_index_t* ix, int* n_failed_out) {
     PRAG_REQUIRE(ix != nullptr && n_failed_out != nullptr, PRAG_EINVAL, "prag_index_last_tiled8: NULL pointer");
+    consume_tier_stats(ix, true);     // the count travels asynchronously: a measurement hook may wait for it
     *n_failed_out = ix->mm8_last_failed;
     return PRAG_OK;
 }
@@ -2591,6 +2748,8 @@ extern "C" int prag_index_set_shadow(prag_index_t* ix, int mode) {
     ix->shadow_no_room = false;
     ix->mm8_whole_batch_streak = 0;
     ix->mm8_auto_off = false;
+    ix->mm8_off_count = 0;
+    ix->mm8_off_period = 64;
     return PRAG_OK;
 }
 
@@ -2619,7 +2778,7 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
     ix->prof.disable();
     void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->q16lo, ix->g_tau, ix->part_key, ix->part_idx, ix->cand,
                     ix->io_q, ix->io_res, ix->mm_cnt, ix->mm_ovf, ix->mm_kq, ix->mm_ckey, ix->mm_cidx, ix->t2_list, ix->t2_q,
-                    ix->t2_D, ix->t2_I,
+                    ix->t2_D, ix->t2_I, ix->t2_word, ix->xch_send, ix->xch_recv,
                     ix->mm_wcnt, ix->mm_wkey, ix->mm_widx, ix->rows16, ix->qinfo, ix->qn2, ix->flag_list, ix->g_slot,
                     ix->cert_words, ix->ex_key, ix->ex_id, ix->rows8, ix->sscale, ix->serr, ix->shadow_err_max, ix->sh_q8,
                     ix->sh_sq, ix->sh_slots, ix->sh_ovf, ix->sh_cand, ix->sh_ccnt, ix->sh_pkey, ix->sh_pid, ix->ex_done};
@@ -2628,5 +2787,6 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
     if (ix->io_q_host) (void)hipHostFree(ix->io_q_host);
     if (ix->io_res_host) (void)hipHostFree(ix->io_res_host);
     if (ix->tier_word_host) (void)hipHostFree(ix->tier_word_host);
+    if (ix->tier_event) (void)hipEventDestroy(ix->tier_event);
     delete ix;
 }

@@ -48,6 +48,22 @@ __device__ __forceinline__ unsigned long long group_min16_u64(unsigned long long
 constexpr uint32_t kSortablePosInf = 0xFF800000u;  // sortable_u32(+inf)
 constexpr uint32_t kSortableNegInf = 0x007FFFFFu;  // sortable_u32(-inf)
 
+// A launch that is enqueued unconditionally and switched on the device: every kernel of the second tier of the
+// 8-bit tiled selection carries one and returns at once when it is closed, so the tier decision needs no host
+// round trip (a device-io search never waits for its stream, and every rank of a lockstep retrieval issues the
+// same launches).  word == nullptr: always open.
+struct Gate {
+    const uint32_t* word = nullptr;
+    uint32_t lo = 0, hi = 0;          // open iff lo <= *word <= hi
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ bool gate_closed(const Gate& g) {
+    if (!g.word) return false;
+    const uint32_t v = *g.word;       // written by an earlier kernel of the same stream
+    return v < g.lo || v > g.hi;
+}
+#endif
+
 // ---------------------------------------------------------------------------
 // MFMA-tiled scan for large query batches (flat_mm.hip): 256 queries x 256 rows per
 // workgroup tile, candidates collected by threshold filtering.
@@ -86,6 +102,7 @@ struct MmSearch {
     const float* sscale = nullptr;        // [cap]
     const signed char* q8 = nullptr;      // [Bpad][d], zero rows past B
     const float* kq = nullptr;            // [Bpad], 0 past B
+    Gate gate;
 };
 
 constexpr int kMmFirstSeg = 2048;    // rows of the first segment (all of them become candidates); segments grow x16
@@ -171,6 +188,7 @@ struct CertArgs {
     // within A1 e_i + C1 of its exact key (ShadowQ, same bound as the two-level search), so eps = A1 max_i e_i + C1
     const ShadowQ* sq8;       // [B] or null (fp16 selection: the model above)
     const uint32_t* e_max;    // float bits of max_i e_i
+    Gate gate;                // the rerank / merge-rerank / gather kernels return at once when it is closed
 };
 
 __device__ __forceinline__ double cert_eps(const CertArgs& c, int b, int metric_l2) {
@@ -220,6 +238,7 @@ struct ExactRun {
     int grid;               // workgroups of the scan
     uint32_t* done;         // [f_cap] zero-initialised arrival counters (the kernel leaves them zero)
     int tag_ids;
+    Gate gate;
 };
 size_t exact_part_entries(int f_cap, int grid, int k);
 // Enqueue ceil(B / f_cap) launches of the exact scan (list merge folded in); each exits at once when no query is flagged.
@@ -490,6 +509,7 @@ struct ShadowSearch {
     uint32_t* ovf;           // [Bpad]
     uint32_t* done;          // [Bpad]
     CertArgs cert;           // flag list: queries whose candidate regions overflowed go to the exact scan
+    Gate gate;
 };
 bool shadow_store_supported(int d);
 bool shadow_tile128_ok(int d, int kc);

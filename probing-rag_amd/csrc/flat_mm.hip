@@ -61,6 +61,7 @@ struct MmArgs {
     const float* sscale;
     const signed char* q8;
     const float* kq;
+    Gate gate;
 };
 
 // LDS map (bytes): A even/odd K tile at 0 / 32 KiB, B even/odd at 64 / 96 KiB ([256 rows][128 B],
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     constexpr int64_t RB = (int64_t)NKT * 128;  // bytes per row (fp16, or int8 with 128-element K tiles)
     constexpr int KA = I8 ? 4096 : 128;         // bytes from one K tile of a row to the next in global memory
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (gate_closed(a.gate)) return;
     typedef const __attribute__((address_space(1))) char* gcptr;
     typedef __attribute__((address_space(3))) char* lptr;
     const int tid = threadIdx.x;
@@ -581,9 +583,10 @@ __global__ __launch_bounds__(256) void mm_compact_kernel(uint32_t* __restrict__ 
                                                         uint32_t* __restrict__ ovf, uint32_t* __restrict__ ovf_any,
                                                         const uint32_t* __restrict__ wcnt,
                                                         const float* __restrict__ wkey, const int* __restrict__ widx,
-                                                        int cap_wg, int n_wg, int wg_stride, int Bpad) {
+                                                        int cap_wg, int n_wg, int wg_stride, int Bpad, Gate gate) {
     __shared__ unsigned long long s_v[kMmCompactCap];
     __shared__ unsigned long long s_m[2][4];
+    if (gate_closed(gate)) return;
     __shared__ int s_tot[4];
     __shared__ int s_incl[256];
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -647,9 +650,10 @@ __global__ __launch_bounds__(256) void mm_compact_sort_kernel(uint32_t* __restri
                                                              const uint32_t* __restrict__ wcnt,
                                                              const float* __restrict__ wkey,
                                                              const int* __restrict__ widx, int cap_wg, int n_wg,
-                                                             int wg_stride, int Bpad) {
+                                                             int wg_stride, int Bpad, Gate gate) {
     __shared__ unsigned long long s_v[kMmCompactCap];
     __shared__ int s_tot[4];
+    if (gate_closed(gate)) return;
     __shared__ int s_incl[256];
     const int q = blockIdx.x, tid = threadIdx.x;
     const uint32_t c = cnt[q];
@@ -748,6 +752,7 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
     a.sscale = s.sscale;
     a.q8 = s.q8;
     a.kq = s.kq;
+    a.gate = s.gate;
 #ifdef PRAG_MM_DIAG
     static unsigned long long* dbg_dev = nullptr;
     if (getenv("PRAG_MM_CLOCK")) {
@@ -827,11 +832,11 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
         if (s.kc <= 32)
             hipLaunchKernelGGL(mm_compact_kernel, dim3(s.B), dim3(256), 0, st, s.cnt, s.ckey, s.cidx, s.cap_q, s.kc, s.tau,
                                s.cand, s.ovf, s.ovf_any, s.wcnt, s.wkey, s.widx, s.cap_wg, first ? 0 : grid, s.wg_slots,
-                               s.Bpad);
+                               s.Bpad, s.gate);
         else
             hipLaunchKernelGGL(mm_compact_sort_kernel, dim3(s.B), dim3(256), 0, st, s.cnt, s.ckey, s.cidx, s.cap_q, s.kc,
                                s.tau, s.cand, s.ovf, s.ovf_any, s.wcnt, s.wkey, s.widx, s.cap_wg, first ? 0 : grid,
-                               s.wg_slots, s.Bpad);
+                               s.wg_slots, s.Bpad, s.gate);
         PRAG_LAUNCH_CHECK();
         lo = hi;
         hi = std::min<int64_t>(s.N, hi * (int64_t)std::max(2, std::min(16, s.growth)));

@@ -171,6 +171,7 @@ struct Scan8Args {
 
     int dbg;                    // timing experiments only (PRAG_SHADOW_DBG; results are WRONG): bit 0 no warm-up
                                 // (no second visits), bit 1 nothing is collected
+    Gate gate;
 };
 
 // (kShadowEpochs = 9 in flat_internal.h: bound slots refreshed after tiles 1, 2, 4, ..., 256; per query
@@ -217,6 +218,7 @@ struct KeyList {   // sorted KC smallest keys (no ids: the lists only feed the b
 template <int QT, int KC, bool LISTS = true, int NCHS = 0>
 __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (gate_closed(a.gate)) return;
     constexpr int NQ = QT / 32;
     // 32-query tiles carry the query as two int8 terms (the HBM-bound loop has matrix-pipe slack for the
     // second MFMA); 64-query tiles use the first term only and pay with a wider eps (more candidates)
@@ -739,6 +741,7 @@ struct GatherArgs {
 template <bool F32>
 __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a) {
     __shared__ ShTopK tk;
+    if (gate_closed(a.cert.gate)) return;
     __shared__ int s_ids[kShIds];
     __shared__ __attribute__((aligned(16))) float s_q[1024];
     __shared__ int s_n, s_over;
@@ -1000,6 +1003,7 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         a.cand = reinterpret_cast<int2*>(s.cand);
         a.ccnt = s.ccnt;
         a.cap = cap;
+        a.gate = s.gate;
 #ifdef PRAG_MM_DIAG
         static const int dbg_env = getenv("PRAG_SHADOW_DBG") ? atoi(getenv("PRAG_SHADOW_DBG")) : 0;
         a.dbg = dbg_env;
@@ -1041,6 +1045,7 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         g.I = s.I;
         g.ovf = s.ovf;
         g.cert = s.cert;
+        g.cert.gate = s.gate;
         g.dbg = a.dbg;
         if (s.store.store_f32)
             hipLaunchKernelGGL(shadow_gather_kernel<true>, dim3(nsplit, nq), dim3(kShThreads), 0, st, g);

@@ -104,6 +104,30 @@ class HipFlatIndex:
         del keep
         return D, I
 
+    # ---- row-sharded search through the C-level exchange (prag_index_set_comm / prag_index_search_sharded) ----
+    def set_comm(self, comm_ptr, rank: int, world: int):
+        """Hand the index an RCCL communicator (an ncclComm_t as an integer / c_void_p; None with world 1)."""
+        _lib.check(_lib.lib().prag_index_set_comm(self._h, ctypes.c_void_p(comm_ptr) if comm_ptr else None,
+                                                  int(rank), int(world)))
+
+    def search_sharded(self, x, k: int, id_offset: int = 0, out=None):
+        """Local search + ONE RCCL all-gather + merge in one C call; device tensors in, device tensors out."""
+        import torch
+        k = int(k)
+        if not (isinstance(x, torch.Tensor) and x.is_cuda):
+            x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).to(self.device)
+        ptr, B, _, keep = self._rows_arg(x)
+        if out is None:
+            D = torch.empty((B, k), dtype=torch.float32, device=x.device)
+            I = torch.empty((B, k), dtype=torch.int64, device=x.device)
+        else:
+            D, I = out
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().prag_index_search_sharded(self._h, ptr, B, k, int(id_offset), ctypes.c_void_p(D.data_ptr()),
+                                                            ctypes.c_void_p(I.data_ptr()), _lib.current_stream_ptr(x.device)))
+        del keep
+        return D, I
+
     def reconstruct_n(self, row0: int = 0, n: int = None) -> np.ndarray:
         n = self.ntotal - row0 if n is None else n
         out = np.empty((n, self.d), np.float32)

@@ -1,7 +1,14 @@
 """Row-sharded flat index: one process per GPU, corpus rows partitioned
 contiguously across ranks, local fused top-k, then ONE exchange step — an
-all-gather of the per-rank (D, I) [B,k] blocks over torch.distributed (backend
-"nccl" = RCCL over xGMI on ROCm) — and a (score, id) merge on every rank.
+all-gather of the per-rank (D, I) [B,k] blocks over RCCL (xGMI) — and a
+(score, id) merge on every rank.
+
+Under the "nccl" backend (= RCCL on ROCm) the whole search is ONE C call,
+``prag_index_search_sharded``: local search, ``ncclAllGather`` on the caller's
+stream, merge (include/prag.h; a communicator of the library's own is created
+with ``prag_rccl_*`` because torch.distributed does not expose its ncclComm_t).
+This class is then a thin caller.  Under gloo (CPU tests, ranks sharing a GPU)
+the exchange goes through ``torch.distributed.all_gather_into_tensor``.
 
 The reference has no distributed code (single process, faiss-cpu on one host:
 exp_rag.py:248, 432-436); this is the MI355X-native scaling of that call.
@@ -11,6 +18,11 @@ latency-bound, the scan time falls as 1/world.
 import torch
 
 from . import _lib
+
+
+def ctypes_void(v):
+    import ctypes
+    return ctypes.c_void_p(v)
 
 
 def partition_rows(n_total: int, world: int, rank: int):
@@ -95,6 +107,55 @@ class ShardedFlatIndex:
         self.id_offset = 0
         self.ntotal = 0
         self._synced = True
+        self._comm = None           # ncclComm_t of the C-level exchange (enable_c_exchange)
+        import os
+        want = os.environ.get("PRAG_C_EXCHANGE", "auto")
+        if engine is None and self.distributed and want != "0" and \
+                (want == "1" or (self.world > 1 and dist.get_backend(group) == "nccl")):
+            self.enable_c_exchange()
+
+    # ---- exchange in C ---------------------------------------------------------
+    def enable_c_exchange(self):
+        """Collective.  Creates an RCCL communicator of the library's own over the ranks of this group (rank 0's
+        ncclGetUniqueId travels through torch.distributed) and hands it to the local index; `search` is then one
+        C call.  Every rank falls back to the torch.distributed exchange together if any rank fails."""
+        import ctypes
+        lib = _lib.lib()
+        ok, comm = 1, ctypes.c_void_p()
+        ident = [None]
+        try:
+            if self.rank == 0:
+                buf = ctypes.create_string_buffer(128)
+                _lib.check(lib.prag_rccl_unique_id(buf))
+                ident = [bytes(buf.raw)]
+        except Exception as e:      # noqa: BLE001 - reported, then every rank falls back together
+            ok, ident = 0, [b""]
+            print(f"ShardedFlatIndex: C-level exchange unavailable on rank 0 ({e})", flush=True)
+        self.dist.broadcast_object_list(ident, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                        group=self.group)
+        if len(ident[0]) != 128:
+            ok = 0
+        if ok:
+            try:
+                with torch.cuda.device(self.engine.device):
+                    _lib.check(lib.prag_rccl_comm_init_rank(ctypes.byref(comm), self.world, self.rank, ident[0]))
+            except Exception as e:  # noqa: BLE001
+                ok = 0
+                print(f"ShardedFlatIndex: ncclCommInitRank failed on rank {self.rank} ({e})", flush=True)
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.engine.device)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 1:
+            self._comm = comm.value
+            self.engine.index.set_comm(self._comm, self.rank, self.world)
+        elif comm.value:
+            lib.prag_rccl_comm_destroy(comm)
+        return self._comm is not None
+
+    def close(self):
+        if self._comm:
+            self.engine.index.set_comm(None, 0, 1)
+            _lib.lib().prag_rccl_comm_destroy(ctypes_void(self._comm))
+            self._comm = None
 
     # ---- build -------------------------------------------------------------
     def add_local(self, x):
@@ -133,6 +194,8 @@ class ShardedFlatIndex:
         """q replicated on every rank -> identical (D [B,k], I [B,k]) on every rank."""
         if not self._synced:
             raise RuntimeError("ShardedFlatIndex.sync() must run (on every rank) after adding rows")
+        if self._comm is not None:      # local search + ncclAllGather + merge: one C call
+            return self.engine.index.search_sharded(q, k, self.id_offset)
         if hasattr(self.engine, "search_packed"):
             if self.world == 1:     # nothing to exchange: plain local search, results owned by the caller
                 return self.engine.search(q, k, self.id_offset)

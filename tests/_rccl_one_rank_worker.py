@@ -32,6 +32,35 @@ def main():
     dist.all_gather_into_tensor(gathered, buf)
     D1, I1 = ix.engine.merge_packed(gathered, B, k, ix.metric)
     assert torch.equal(I1, I0) and torch.equal(D1, D0)
+    # the exchange in C (include/prag.h: prag_rccl_* + prag_index_set_comm + prag_index_search_sharded): a
+    # communicator of the library's own over the one rank, then the whole sharded search as ONE call - local search
+    # with tagged ids, ncclAllGather on the current stream, merge
+    assert ix._comm is None                                    # one rank: not enabled by itself
+    assert ix.enable_c_exchange(), "RCCL communicator of the library's own could not be created"
+    D2, I2 = ix.search(q, k)
+    assert torch.equal(I2, I0) and torch.equal(D2, D0)
+    for B2 in (1, 300):                                        # the reference's call shape, and the tiled scans
+        q2 = torch.from_numpy(onp.synth_rows(8, 0, B2, d)).cuda()
+        Da, Ia = ix.engine.index.search(q2, k)
+        Db, Ib = ix.search(q2, k)
+        assert torch.equal(Ia, Ib) and torch.equal(Da, Db)
+    # ... captured into a graph and replayed: nothing in the call waits for the stream
+    out = (torch.empty_like(D0), torch.empty_like(I0))
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ix.engine.index.search_sharded(q, k, ix.id_offset, out=out)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            ix.engine.index.search_sharded(q, k, ix.id_offset, out=out)
+    out[1].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[1], I0) and torch.equal(out[0], D0)
+    del g
+    ix.close()
+    assert ix._comm is None
     # shard sizes (ShardedFlatIndex.sync), timing reduction and device list (bench.py)
     counts = torch.zeros(1, dtype=torch.int64, device="cuda")
     dist.all_gather_into_tensor(counts, torch.tensor([N], dtype=torch.int64, device="cuda"))

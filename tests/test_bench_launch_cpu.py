@@ -15,11 +15,15 @@ import bench
 calls = []
 class _Done:
     returncode = 7
+    pid = 0
+    def wait(self, timeout=None):
+        return 7
 def fake_run(cmd, env=None, **kw):
     calls.append({{"cmd": cmd, "torch_loaded": "torch" in sys.modules,
-                   "ipc": (env or {{}}).get("HSA_ENABLE_IPC_MODE_LEGACY")}})
+                   "ipc": (env or {{}}).get("HSA_ENABLE_IPC_MODE_LEGACY"), "new_session": kw.get("start_new_session")}})
     return _Done()
 bench.subprocess.run = fake_run
+bench.subprocess.Popen = fake_run
 for name in ("execv", "execve", "execvp", "execvpe", "execl", "execle", "execlp"):
     setattr(os, name, lambda *a, **k: (_ for _ in ()).throw(AssertionError("exec used")))
 try:
@@ -54,7 +58,38 @@ def test_gpus_n_spawns_torchrun_child_before_torch_is_imported():
     assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]     # the flags travel unchanged
     assert call["torch_loaded"] is False and rec["torch_loaded_after"] is False   # no GPU initialised
     assert call["ipc"] == "0"
+    assert call["new_session"] is True                                        # killable as a group on timeout
     assert rec["code"] == 7                                                   # the child's exit code
+
+
+def test_a_hung_launch_is_killed_as_a_group_and_exits_nonzero(monkeypatch, tmp_path):
+    """A rendezvous or collective that never completes must not hang the caller: after --launch-timeout the child
+    AND its descendants (the ranks) are killed and the exit code is 124; the parent is never replaced."""
+    import signal
+    import time
+    import bench
+    pidfile = tmp_path / "grandchild.pid"
+    child = ("import os, subprocess, sys, time\n"
+             "p = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(600)'])\n"
+             f"open({str(pidfile)!r}, 'w').write(str(p.pid))\n"
+             "time.sleep(600)\n")
+    monkeypatch.setattr(bench, "launch_command", lambda n, argv, port=None: [sys.executable, "-c", child])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delitem(sys.modules, "torch", raising=False)
+    args = bench.parse(["--gpus", "2", "--launch-timeout", "3"])
+    t0 = time.time()
+    rc = bench.self_launch(args, ["--gpus", "2"])
+    assert rc == 124 and time.time() - t0 < 60
+    gpid = int(pidfile.read_text())
+    for _ in range(50):                       # the grandchild went down with the group
+        try:
+            os.kill(gpid, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        os.kill(gpid, signal.SIGKILL)
+        raise AssertionError("the rank processes survived the launcher's timeout")
 
 
 def test_a_rank_does_not_launch_again():

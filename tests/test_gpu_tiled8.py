@@ -48,7 +48,7 @@ def test_int8_tiles_match_definition(metric, store, N, B, k, d):
     assert ix.last_tiled8() >= 0                     # the int8 tiles ran
     D0, I0 = oracle_c.flat_search(_stored(X, metric, store), Q, k, metric)
     _check(D, I, D0, I0, metric)
-    # the same through device tensors (the tier decision is then a 4-byte read-back)
+    # the same through device tensors (the tier decision is taken on the device either way)
     import torch
     Dt, It = ix.search(torch.from_numpy(Q).cuda(), k)
     assert ix.last_tiled8() >= 0
@@ -117,14 +117,25 @@ def test_second_tier_on_a_corpus_of_look_alikes(metric, store):
     assert ix.last_tiled8() > 0
     _check(Dt.cpu().numpy(), It.cpu().numpy(), D0, I0, metric)
     # two whole-batch repeats in a row: the index stops trying the int8 tiles (every search would pay for both
-    # tiers) until rows are added or set_shadow is called
+    # tiers) until rows are added, set_shadow is called, or 64 eligible searches have gone by (one probe, then
+    # 128, ... 4096)
     D3, I3 = ix.search(Q, k)
-    assert ix.last_tiled8() == -1
+    assert ix.last_tiled8() == -2
     _check(D3, I3, D0, I0, metric)
     ix.set_shadow(2)
     D4, I4 = ix.search(Q, k)
     assert ix.last_tiled8() > 0
     _check(D4, I4, D0, I0, metric)
+    ix.search(Q, k)
+    assert ix.last_tiled8() > 0                      # second repeat in a row: off again
+    qd = torch.from_numpy(Q).cuda()
+    seen = []
+    for _ in range(64):
+        ix.search(qd, k)
+        seen.append(ix.last_tiled8())
+    assert seen[:63] == [-2] * 63 and seen[63] > 0   # the probe
+    ix.search(qd, k)
+    assert ix.last_tiled8() == -2                    # one failed probe switches them off again, for longer
     ix.close()
 
 
@@ -187,3 +198,56 @@ def test_sharded_large_batch_equals_unsharded():
     for sh in shards:
         sh.close()
     one.close()
+
+
+def test_large_batch_search_is_graph_capturable_and_never_waits():
+    """The device-io search of > 128 queries on the int8 tiles issues a fixed list of launches whatever the data:
+    both second-tier continuations are always enqueued and switched by the failed count on the device.  So it can be
+    captured into a HIP graph and replayed - on a corpus where the first tier answers, where a few queries fail
+    (compact batch) and where everything fails (whole batch on the fp16 tiles) - with the definition's results."""
+    import probing_rag_amd as pra
+    import torch
+    d, k = 768, 10
+    rng = np.random.default_rng(9)
+    base = onp.synth_rows(5, 0, 1, d)[0] * np.float32(1.7)
+
+    def corpus(kind, N, B):
+        X = onp.synth_rows(42, 0, N, d)
+        Q = onp.synth_rows(7, 0, B, d)
+        if kind == "few":
+            where = rng.choice(N, 700, replace=False)
+            X[where] = (base[None, :] + 2e-3 * rng.standard_normal((700, d))).astype(np.float32)
+            for i in (5, 100, B - 1):
+                Q[i] = (base + 2e-3 * rng.standard_normal(d)).astype(np.float32)
+        elif kind == "all":
+            X = (base[None, :] + 2e-3 * rng.standard_normal((N, d))).astype(np.float32)
+            Q = (base[None, :] + 2e-3 * rng.standard_normal((B, d))).astype(np.float32)
+        return X, Q
+
+    for kind, N, B in (("none", 30_000, 300), ("few", 40_000, 203), ("all", 20_000, 150)):
+        X, Q = corpus(kind, N, B)
+        ix = pra.HipFlatIndex(d, "ip", "f16")
+        ix.set_shadow(2)
+        ix.add(X)
+        D0, I0 = oracle_c.flat_search(_stored(X, onp.METRIC_IP, "f16"), Q, k, onp.METRIC_IP)
+        qd = torch.from_numpy(Q).cuda()
+        out = (torch.empty((B, k), dtype=torch.float32, device="cuda"), torch.empty((B, k), dtype=torch.int64, device="cuda"))
+        ix.search(qd, k, out=out)                       # sizes every workspace (allocation is not capturable)
+        n_failed = ix.last_tiled8()
+        assert (n_failed == 0) if kind == "none" else (1 <= n_failed <= 50) if kind == "few" else n_failed > B // 4, (kind, n_failed)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                ix.search(qd, k, out=out)
+        assert ix.last_tiled8() == -3                   # a captured search reports nothing back
+        for _ in range(2):
+            out[0].zero_()
+            out[1].zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            _check(out[0].cpu().numpy(), out[1].cpu().numpy(), D0, I0, onp.METRIC_IP)
+        ix.set_shadow(2)                                # (the 'all' corpus: re-arm the tiles for the next handle state)
+        del g
+        ix.close()

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--skip-gate", action="store_true")
     ap.add_argument("--shadow", type=int, default=1)
     ap.add_argument("--skip-scan", action="store_true")
+    ap.add_argument("--k", type=int, default=10)
     args = ap.parse_args()
     import torch
     import probing_rag_amd as pra
@@ -35,7 +36,7 @@ def main():
         ix.set_shadow(args.shadow)
         q = torch.from_numpy(synth_rows(7, 0, args.queries, 768)).cuda()
         for _ in range(args.iters):
-            ix.search(q, 10)
+            ix.search(q, args.k)
     if not args.skip_gate:
         ens = pra.HipProberEnsemble(6, 2048, 2, weights="f16")
         for l in range(6):
