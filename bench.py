@@ -219,20 +219,14 @@ def _timed_searches(torch, ix, q, k, min_s=0.6, max_reps=200):
     return dt / reps * 1e3, ms, ix.last_exact_fallbacks()
 
 
-def scan_model(B, k, store, metric, n_local, shadow):
-    """(kernel name, algorithmic bytes per launch, launches per search) - mirrors prag_index_search's choice.
-    Algorithmic bytes = what one pass over the shard has to read: the rows in the form that is scanned
-    (+4 B of ||x||^2 per row for L2; the 8-bit shadow carries 8 B of scale and error bound per row)."""
-    if B > 128:
-        return "scan_mm_kernel", None, 1
-    if B > 64 and shadow and k <= 12 and n_local >= (1 << 20):     # one pass with 128-query tiles
-        return "scan8_kernel", n_local * (D_EMB + 8) + (n_local * 4 if metric == "l2" else 0), 1
-    if B > 64 and store == "f16":
-        return "scan_qs_kernel", n_local * D_EMB * 2 + (n_local * 4 if metric == "l2" else 0), 1 + (B - 1) // 128
-    if shadow and k <= 26 and n_local >= (1 << 20):
-        return "scan8_kernel", n_local * (D_EMB + 8) + (n_local * 4 if metric == "l2" else 0), 1 + (B - 1) // 64
-    elt = 2 if store == "f16" else 4
-    return "scan_topk_kernel", n_local * D_EMB * elt + (n_local * 4 if metric == "l2" else 0), 1 + (B - 1) // 64
+def scan_model(ix):
+    """(kernel name, algorithmic bytes per launch, launches per search, tiled?) of the most recent search on `ix`,
+    read from the plan the library executed (prag_index_last_plan: the dispatch is decided in ONE place,
+    plan_search in flat_index.hip; round 3 re-derived it here).  Algorithmic bytes = what one pass over the shard
+    has to read: the rows in the form that is scanned (+4 B of ||x||^2 per row for L2; the 8-bit shadow carries
+    8 B of scale and error bound per row)."""
+    plan = ix.last_plan()
+    return plan["family"], plan["bytes_per_launch"], plan["launches"], bool(plan["tiled"])
 
 
 def stored_row_bytes(store, metric, n_local):
@@ -252,16 +246,14 @@ def variant_record(torch, ix, q, k, store, metric, n_local, shadow=0):
     B = q.shape[0]
     ix.set_shadow(1 if shadow else 0)
     ms_search, kern_ms, fb = _timed_searches(torch, ix, q, k)
-    kernel, alg_bytes, passes = scan_model(B, k, store, metric, n_local, shadow)
-    tiled = B > 128
+    kernel, alg_bytes, passes, tiled = scan_model(ix)
     rec = {"store": store, "metric": metric, "k": k, "queries": B, "rows": n_local, "shadow": bool(shadow),
            "ms_per_search": ms_search, "scores_per_s": B * n_local / (ms_search * 1e-3),
            "exact_fallbacks_last_search": fb}
     if tiled:   # MFMA-bound: price the whole search (all segments, compactions, rerank) against the matrix peak
         tf = 2.0 * B * n_local * D_EMB / (ms_search * 1e-3) / 1e12
         i8 = bool(shadow) and ix.last_tiled8() >= 0
-        rec.update({"kernel": ("scan_mm_kernel<int8 tiles over the 8-bit shadow> (whole search)" if i8
-                               else "scan_mm_kernel (whole search)"), "bound": "mfma", "achieved": tf,
+        rec.update({"kernel": kernel + " (whole search)", "bound": "mfma", "achieved": tf,
                     "peak": MFMA_I8_PEAK_TOP if i8 else MFMA_F16_PEAK_TF, "unit": "Top/s" if i8 else "TFLOP/s",
                     "frac": tf / (MFMA_I8_PEAK_TOP if i8 else MFMA_F16_PEAK_TF),
                     "frac_of_f16_peak": tf / MFMA_F16_PEAK_TF,
@@ -675,10 +667,7 @@ def main(argv=None):
     scores = args.queries * args.docs
     value = scores * passes_total / dt
     # which scan kernel served the pass
-    scan_kernel, alg_bytes, launches = scan_model(args.queries, args.k, args.store, args.metric, n_local, args.shadow)
-    tiled = args.queries > 128                                        # MFMA-tiled scan, 256-query tiles
-    if tiled:
-        alg_bytes = n_local * d_emb * 2
+    scan_kernel, alg_bytes, launches, tiled = scan_model(local)     # the plan the timed searches executed
     scan_avg_ms = float(np.mean(scan_ms)) if scan_ms else float("nan")
     achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
     mm_tf = mm_flops = rows_last = None

@@ -308,6 +308,16 @@ int prag_index_set_candidate_depth(prag_index_t* ix, int depth);
  * certified and went through the exact float64 scan.  Synchronises `stream`. */
 int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out);
 
+/* The search plan - which kernel family makes the corpus pass, query-tile height, candidate depth, grid, corpus
+ * passes per search, algorithmic bytes per pass, workspace bytes - is a pure function of the request shape and the
+ * index state.  prag_plan_search describes the plan of a hypothetical index (no GPU needed: d, metric, store_dtype,
+ * rows, queries, k, whether it keeps an up-to-date 8-bit shadow (2 = shadow kept at any size), compute units);
+ * prag_index_last_plan returns the plan the most recent search on this handle executed.  Both write a
+ * NUL-terminated line of `key=value` fields; bench.py prices its roofline with it. */
+int prag_plan_search(int d, int metric, int store_dtype, int64_t ntotal, int B, int k, int shadow_ready, int n_cu,
+                     char* out, int cap);
+int prag_index_last_plan(prag_index_t* ix, char* out, int cap);
+
 /* Measurement hook: batches of > 128 queries on an index that keeps the 8-bit shadow (below) select their
  * candidates on int8 matrix tiles over the shadow first (256 candidates per query, the shadow's error bound
  * in the certificate); queries that fail that certificate are searched again - up to 64 of them (and at most

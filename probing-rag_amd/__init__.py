@@ -10,7 +10,7 @@ from .prober import (Config_Maker, HipProber, HipProberEnsemble, gate_from_logit
                      load_prober, load_prober_cfg_gemma_2b, load_prober_models, prober_checkpoint_path,
                      return_prober_logit_gemma_2b)
 from .index import (HipFlatIndex, IndexFlatIP, IndexFlatL2, batch_topk_sim, encode_query,  # noqa: F401
-                    find_topk_sim, merge_topk, read_index, read_index_header, write_index)
+                    find_topk_sim, merge_topk, plan_search, read_index, read_index_header, write_index)
 from .docstore import Docstore, lookup_passages, read_docstore, write_docstore  # noqa: F401
 from .sharded import ShardedFlatIndex, partition_rows, search_shards_on_one_gpu  # noqa: F401
 from .trainer import HipProberTrainer, method_2_train  # noqa: F401

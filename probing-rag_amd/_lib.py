@@ -90,6 +90,8 @@ SIGNATURES = {
     "prag_rccl_comm_destroy": (_I, [_P]),
     "prag_index_set_comm": (_I, [_P, _P, _I, _I]),
     "prag_index_search_sharded": (_I, [_P, _P, _I, _I, _L, _P, _P, _P]),
+    "prag_plan_search": (_I, [_I, _I, _I, _L, _I, _I, _I, _I, ctypes.c_char_p, _I]),
+    "prag_index_last_plan": (_I, [_P, ctypes.c_char_p, _I]),
     "prag_index_last_fallbacks": (_I, [_P, _P, ctypes.POINTER(_I)]),
     "prag_index_last_tiled8": (_I, [_P, ctypes.POINTER(_I)]),
     "prag_index_set_shadow": (_I, [_P, _I]),

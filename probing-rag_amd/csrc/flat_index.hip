@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "exchange.h"
@@ -1349,6 +1350,7 @@ struct prag_index {
     size_t mm_w_entries = 0;      // entries of mm_wkey / mm_widx
     size_t mm_c_entries = 0;      // entries of mm_ckey / mm_cidx, mm_wcnt words
     int mm_mode = 1;   // 0 = never take the MFMA-tiled path (PRAG_SCAN_MM=0)
+    int mm_shape16 = 1;   // tiled scans on 16 x 16 MFMA tiles (PRAG_MM_SHAPE=32: the 32 x 32 form, A/B timing)
     // 8-bit selection for the MFMA-tiled scan (> 128 queries on an index that keeps a shadow): int8 MFMA over the
     // shadow, kMm8Kc candidates per query, the shadow's error bound in the certificate; the queries that fail that
     // certificate go through a second tier (mm8_second_tier; PRAG_MM8=0: fp16 tiles only)
@@ -1442,6 +1444,7 @@ struct prag_index {
     char* xch_recv = nullptr;
     size_t xch_send_cap = 0, xch_recv_cap = 0;
     int last_flagged = -1;   // flag count of the last host-io search (-1: last search was device-io)
+    std::string last_plan;   // plan_describe of the most recent search (prag_index_last_plan)
     EventRing prof;
 };
 
@@ -1616,6 +1619,7 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
     if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e);
     if (const char* e = getenv("PRAG_CERT")) ix->cert_mode = atoi(e);
 #endif
+    if (const char* e = getenv("PRAG_MM_SHAPE")) ix->mm_shape16 = atoi(e) != 32;
     if (const char* e = getenv("PRAG_MM8")) ix->mm8_mode = atoi(e) != 0;
     if (const char* e = getenv("PRAG_MM8_MIN_ROWS")) ix->mm8_min_rows = atoll(e);
     if (const char* e = getenv("PRAG_PREPASS")) ix->prepass_mode = atoi(e);
@@ -1873,10 +1877,173 @@ static int launch_merge_rerank(int kc, bool f32, const float* pk, const int* pi,
 // candidates per query of the 8-bit tiled selection: the certificate needs the KC-th selection key to clear the
 // k-th exact key by the shadow's error bound (~0.55 sigma of the score distribution on 768 Gaussian elements with
 // the worst row's residual): rank ~110 at 1 M and at 21 M rows for k = 10; 256 leaves 0.2 sigma of margin
-constexpr int kMm8Kc = 256;
+// (kMm8Kc = 256, kMm8CapWg, kMm8Chunk, kMm8Growth: with the search plan below)
+
+// ---------------------------------------------------------------------------------------------------------------
+// Search plan: every dispatch decision of a search as a PURE function of the request shape and the index state
+// (no pointers, no HIP calls): which kernel family makes the corpus pass, the tile height, the candidate depth,
+// the grid, the bound strategy, the workspace it needs.  index_search_impl executes a plan; prag_plan_search
+// describes one on a host without a GPU (tests/test_host_logic_cpu.py walks the shape grid); prag_index_last_plan
+// is what bench.py prices its roofline with (round 3 re-derived the dispatch in Python).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kMm8Kc = 256;       // candidates per query of the 8-bit tiled selection (see search_tiled)
 constexpr int kMm8CapWg = 128;    // survivors one workgroup can hold per query and segment
 constexpr int kMm8Chunk = 1024;   // queries per mm_run call
 constexpr int kMm8Growth = 3;     // segment i+1 ends at 3 x the end of segment i (search_tiled)
+
+struct PlanEnv {
+    int d = 0, metric = PRAG_METRIC_L2, store = PRAG_F16;
+    int64_t ntotal = 0;
+    int B = 0, k = 0;
+    int kc_min = 0, hp_mode = 1, mm_mode = 1, mm8_mode = 1, cert_mode = 1, prepass_mode = -1, wg_cap = 0, n_cu = 256;
+    int shadow_mode = 1;
+    int64_t mm8_min_rows = 2ll << 20;
+    bool shadow_ready = false;    // the index keeps an up-to-date shadow and wants one at this size
+    bool mm8_auto_off = false;
+    bool allow_mm8 = true;
+};
+
+struct SearchPlan {
+    int kc = 0;                   // 0: k is beyond the deepest list (PRAG_EUNSUPPORTED)
+    bool exact_only = false, mm8_eligible = false, use_mm8 = false, use_mm = false, shadow128 = false, use_qs = false,
+         use_shadow = false, use_hp = false, certify = true, use_slots = false, prepass = false;
+    int qstride = 0, QT = 32, Bpad = 0, n_tiles = 0, cu_budget = 0, grid = 1, mm_chunk = 0, mm_cap_wg = 0, ex_grid = 1,
+        ex_fcap = 1;
+    size_t part_need = 0, cand_need = 0;
+    const char* family = "";      // kernel of the corpus pass
+    int launches = 0;             // corpus passes per search (tiled scans: segments)
+    int64_t bytes_per_launch = 0; // algorithmic bytes one pass over the shard reads, in the form that is scanned
+    size_t ws_bytes = 0;          // device workspace of the groups this plan touches
+};
+
+static SearchPlan plan_search(const PlanEnv& e) {
+    SearchPlan P;
+    const int B = e.B, k = e.k, d = e.d;
+    int kc = std::max(pick_kc(k), pick_kc(k) ? e.kc_min : 0);
+    if (kc == 0) return P;
+    // float32 rows with 33..64 queries are rounded to fp16 inside the scan (no high-precision terms at
+    // that tile height): the certificate's error bound is ~5e-4 ||q|| ||x||, which an 8-deep list clears
+    // only ~99 % of the time at 21 M rows - and a miss costs a 64 GB exact pass.  A 16-deep list does.
+    if (e.store == PRAG_F32 && kc == 8 && B > 32) kc = 16;
+    // k > 26 on a dimension the MFMA-tiled scan does not cover: straight to the exact float64 scan
+    P.exact_only = kc > 32 && !mm_supported(d, PRAG_F16, kc);
+    if (P.exact_only) kc = 32;  // (sizes the unused candidate workspace)
+    // > 128 queries on an index that keeps an up-to-date shadow: first tier = int8 tiles over the shadow with a
+    // deep candidate list; the queries that fail the (much wider) certificate are searched again (mm8_second_tier)
+    P.mm8_eligible = e.allow_mm8 && e.mm8_mode && e.mm_mode && !P.exact_only && kc <= 32 && B > 128 && e.ntotal > 0 &&
+                     (e.shadow_mode >= 2 || e.ntotal >= e.mm8_min_rows) && e.cert_mode != 0 && e.shadow_ready &&
+                     mm8_supported(d, kMm8Kc) && mm_supported(d, PRAG_F16, kMm8Kc) && k <= kMm8Kc / 8;
+    P.use_mm8 = P.mm8_eligible && !e.mm8_auto_off;
+    if (P.use_mm8) kc = kMm8Kc;
+    P.kc = kc;
+    P.qstride = (d * 2 + 255) / 256 * 256;
+    // 64-query tiles when they fit LDS
+    // (64 queries x 32-deep lists = 128 list registers per lane: scratch on either row type - two 32-query tiles)
+    const bool wide_ok = 64 * P.qstride + 8 * 4096 + 64 * 12 <= 160 * 1024 && kc < 32;
+    // > 128 queries: the contraction bounds the search -> MFMA-tiled scan, 256 queries per tile
+    P.use_mm = !P.exact_only && e.ntotal > 0 && mm_supported(d, PRAG_F16, kc) && ((B > 128 && e.mm_mode) || kc > 32);
+    // 65..128 queries: one pass over the 8-bit shadow with 128-query tiles when the index keeps one ...
+    P.shadow128 = !P.exact_only && !P.use_mm && B > 64 && B <= 128 && e.cert_mode != 0 && e.ntotal > 0 && e.shadow_ready &&
+                  shadow_supported(d, kc, k, B) && shadow_tile128_ok(d, kc);
+    // ... else the query-stationary kernel over the fp16 rows (128 queries per corpus pass)
+    P.use_qs = !P.exact_only && !P.use_mm && !P.shadow128 && B > 64 && qs_supported(d, e.store, kc);
+    P.QT = P.use_mm ? 256 : (P.use_qs || P.shadow128) ? 128 : ((B > 32 && wide_ok) ? 64 : 32);
+    // <= 32 queries (the reference's call shape): high-precision selection, if two query tiles fit LDS
+    P.use_hp = e.hp_mode && P.QT == 32 && 2 * 32 * P.qstride + 8 * 4096 + 32 * 12 <= 160 * 1024;
+    P.Bpad = (B + P.QT - 1) / P.QT * P.QT;
+    P.n_tiles = (int)((e.ntotal + 31) / 32);
+    P.cu_budget = e.wg_cap > 0 ? std::min(e.wg_cap, e.n_cu) : e.n_cu;
+    P.grid = P.use_qs ? std::max(1, std::min(P.cu_budget, (P.n_tiles + 3) / 4))
+                      : std::max(1, std::min(P.cu_budget, (P.n_tiles + 7) / 8));
+    // (the pre-pass may use up to 64 workgroups; the tiled scan sizes its own fallback lists)
+    P.part_need = P.use_mm ? 0 : (size_t)std::max(P.grid, 64) * P.QT * kc;
+    P.cand_need = (size_t)P.Bpad * kc;
+    // queries per mm_run call and survivors one workgroup can hold per query and segment.  Deep lists
+    // (k > 26) yield up to KC/8 survivors per 256-row tile right after the first segment: they get
+    // 512 slots and 256-query chunks.
+    P.mm_chunk = P.use_mm8 ? std::min(P.Bpad, kMm8Chunk) : kc > 32 ? 256 : std::min(P.Bpad, kMmMaxQueries);
+    P.mm_cap_wg = P.use_mm8 ? kMm8CapWg : kc > 32 ? 512 : kMmCapWg;
+    P.certify = e.cert_mode != 0 || P.exact_only;
+    P.ex_grid = (int)std::max<int64_t>(1, std::min<int64_t>(2 * (int64_t)P.cu_budget, (e.ntotal + 31) / 32));
+    // flagged queries one round of the exact scan can hold: <= 64 MB of per-workgroup lists
+    P.ex_fcap = (int)std::max<int64_t>(1, std::min<int64_t>(B, (64ll << 20) / ((int64_t)P.ex_grid * k * 12)));
+    // (the shadow's eps constants read max ||x||^2 and its overflow path needs the exact scan: both exist
+    // only with the certificate on - a diag build with PRAG_CERT=0 scans the rows directly)
+    P.use_shadow = P.certify && !P.exact_only && !P.use_mm && !P.use_qs && e.ntotal > 0 && e.shadow_ready &&
+                   shadow_supported(d, kc, k, B);
+    // Bound for the list scan: slots filled inside the launch (no extra launches: best on shards
+    // of a few million rows, where two launches are ~6 % of the search) or the pre-pass (its bound
+    // is there from the first tile: measured 1.5 % faster at 21 M rows).  Crossover ~8 M rows.
+    constexpr int64_t kSample = 8192;
+    const bool want_slots = e.prepass_mode < 0 ? e.ntotal <= (8ll << 20) : e.prepass_mode == 0;
+    P.use_slots = !P.use_qs && want_slots && !(P.QT == 64 && kc == 32);
+    P.prepass = e.ntotal >= 16 * kSample && !P.use_slots;
+    // ---- what the corpus pass is and what it has to read ----------------------------------------------------------
+    const int64_t N = e.ntotal, l2 = e.metric == PRAG_METRIC_L2 ? 4 * N : 0;
+    const int64_t elt_b = e.store == PRAG_F32 ? 4 : 2;
+    if (N == 0) { P.family = "none (empty index)"; P.launches = 0; }
+    else if (P.exact_only) { P.family = "exact_scan_kernel"; P.launches = B; P.bytes_per_launch = N * d * elt_b; }
+    else if (P.use_mm) {
+        P.family = P.use_mm8 ? "scan_mm_kernel<int8 tiles over the 8-bit shadow>" : "scan_mm_kernel";
+        const int growth = P.use_mm8 ? kMm8Growth : 16;      // (search_tiled lowers it for deep lists)
+        int segs = 1;
+        for (int64_t hi = std::min<int64_t>(N, kMmFirstSeg); hi < N; hi = std::min<int64_t>(N, hi * growth)) ++segs;
+        P.launches = segs * ((P.Bpad + P.mm_chunk - 1) / P.mm_chunk);
+        P.bytes_per_launch = P.use_mm8 ? N * (d + 4) + l2 : N * d * 2 + l2;
+    } else if (P.use_shadow) {
+        P.family = "scan8_kernel";
+        P.launches = P.Bpad / P.QT;
+        P.bytes_per_launch = N * (d + 8) + l2;
+    } else if (P.use_qs) {
+        P.family = "scan_qs_kernel";
+        P.launches = P.Bpad / 128;
+        P.bytes_per_launch = N * d * 2 + l2;
+    } else {
+        P.family = "scan_topk_kernel";
+        P.launches = P.Bpad / P.QT;
+        P.bytes_per_launch = N * d * elt_b + l2;
+    }
+    // ---- workspace (the groups index_search_impl grows; bytes) ------------------------------------------------------
+    size_t ws = (size_t)P.Bpad * (4 * 4 + 8 + 4 + (size_t)d * 4 + (size_t)d * 2 * 2 + 4 + kSlotWords * 4);   // per-query block
+    ws += P.part_need * 8 + P.cand_need * 4;
+    if (P.use_mm) {
+        ws += (size_t)P.Bpad * 12 + 4;
+        ws += (size_t)std::max(P.mm_chunk, e.n_cu) * std::max<size_t>(kMmCapQ, e.n_cu) * 12;
+        ws += (size_t)e.n_cu * P.mm_chunk * P.mm_cap_wg * 8;
+    }
+    if (P.certify && N > 0) ws += exact_part_entries(P.ex_fcap, P.ex_grid, k) * 12 + (size_t)P.ex_fcap * 4;
+    if (P.use_shadow || P.use_mm8) {
+        const size_t BpadS = P.use_mm8 ? P.Bpad : (size_t)(B + 63) / 64 * 64;
+        ws += BpadS * (2 * (size_t)d + shadow_q_bytes() + shadow_slot_words() * 4 + 8);
+        if (P.use_shadow) ws += (size_t)e.n_cu * (P.QT == 128 ? 128 : 64) * 512 * 8 + (size_t)e.n_cu * 128 * 4 + BpadS * shadow_split() * k * 12;
+    }
+    P.ws_bytes = ws;
+    return P;
+}
+
+static int plan_describe(const PlanEnv& e, const SearchPlan& P, char* out, int cap) {
+    return snprintf(out, cap,
+                    "family=%s QT=%d kc=%d Bpad=%d grid=%d launches=%d bytes_per_launch=%lld ws_bytes=%zu hp=%d slots=%d "
+                    "prepass=%d shadow=%d tiled=%d int8_tiles=%d exact_only=%d store=%s metric=%d d=%d rows=%lld queries=%d k=%d",
+                    P.family, P.QT, P.kc, P.Bpad, P.grid, P.launches, (long long)P.bytes_per_launch, P.ws_bytes, (int)P.use_hp,
+                    (int)P.use_slots, (int)P.prepass, (int)P.use_shadow, (int)P.use_mm, (int)P.use_mm8, (int)P.exact_only,
+                    e.store == PRAG_F32 ? "f32" : "f16", e.metric, e.d, (long long)e.ntotal, e.B, e.k);
+}
+
+extern "C" int prag_plan_search(int d, int metric, int store_dtype, int64_t ntotal, int B, int k, int shadow_ready, int n_cu,
+                                char* out, int cap) {
+    PRAG_REQUIRE(out != nullptr && cap > 0, PRAG_EINVAL, "prag_plan_search: NULL buffer");
+    PRAG_REQUIRE(d >= 16 && d % 16 == 0 && B >= 1 && k >= 1 && ntotal >= 0 && n_cu >= 1, PRAG_EINVAL,
+                 "prag_plan_search: d=%d B=%d k=%d ntotal=%lld n_cu=%d", d, B, k, (long long)ntotal, n_cu);
+    PlanEnv e;
+    e.d = d; e.metric = metric; e.store = store_dtype; e.ntotal = ntotal; e.B = B; e.k = k; e.n_cu = n_cu;
+    e.shadow_ready = shadow_ready != 0 && shadow_store_supported(d);
+    e.shadow_mode = shadow_ready >= 2 ? 2 : 1;
+    const SearchPlan P = plan_search(e);
+    PRAG_REQUIRE(P.kc != 0, PRAG_EUNSUPPORTED, "k=%d: at most 911 results per query", k);
+    plan_describe(e, P, out, cap);
+    return PRAG_OK;
+}
 
 // > 128 queries on fp16 rows: MFMA-tiled scan (flat_mm.hip) in chunks of kMmMaxQueries, then the
 // device-flagged fallback through the per-lane-list kernel for queries whose candidate store
@@ -1919,6 +2086,7 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
     m.wg_slots = ix->n_cu;
     m.max_wg = cu_budget;
     m.gate = ix->gate;
+    m.shape16 = ix->mm_shape16 != 0;
     // segment growth: keep the expected survivors of a segment (~(growth-1) * KC per query) inside the
     // per-workgroup regions (64 per query) and the compaction's staging buffer (4096)
     {
@@ -2162,36 +2330,38 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     PRAG_REQUIRE(B >= 0 && k >= 1, PRAG_EINVAL, "B=%d k=%d", B, k);
     if (B == 0) return PRAG_OK;
     PRAG_REQUIRE(q && D && I, PRAG_EINVAL, "prag_index_search: NULL pointer");
-    int kc = std::max(pick_kc(k), pick_kc(k) ? ix->kc_min : 0);
-    PRAG_REQUIRE(kc != 0, PRAG_EUNSUPPORTED, "k=%d: at most 911 results per query", k);
-    // float32 rows with 33..64 queries are rounded to fp16 inside the scan (no high-precision terms at
-    // that tile height): the certificate's error bound is ~5e-4 ||q|| ||x||, which an 8-deep list clears
-    // only ~99 % of the time at 21 M rows - and a miss costs a 64 GB exact pass.  A 16-deep list does.
-    if (ix->store == PRAG_F32 && kc == 8 && B > 32) kc = 16;
-    // k > 26 on a dimension the MFMA-tiled scan does not cover: straight to the exact float64 scan
-    const bool exact_only = kc > 32 && !mm_supported(ix->d, PRAG_F16, kc);
-    if (exact_only) kc = 32;  // (sizes the unused candidate workspace)
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    // > 128 queries on an index that keeps an up-to-date shadow: first tier = int8 tiles over the shadow with a
-    // deep candidate list; the queries that fail the (much wider) certificate are searched again (mm8_second_tier)
+    // ---- plan: every dispatch decision, as a pure function of the shape and the index state (plan_search) --------
+    PlanEnv env;
+    env.d = ix->d; env.metric = ix->metric; env.store = ix->store; env.ntotal = ix->ntotal; env.B = B; env.k = k;
+    env.kc_min = ix->kc_min; env.hp_mode = ix->hp_mode; env.mm_mode = ix->mm_mode; env.mm8_mode = ix->mm8_mode;
+    env.cert_mode = ix->cert_mode; env.prepass_mode = ix->prepass_mode; env.wg_cap = ix->wg_cap; env.n_cu = ix->n_cu;
+    env.shadow_mode = ix->shadow_mode; env.mm8_min_rows = ix->mm8_min_rows; env.allow_mm8 = allow_mm8;
+    env.shadow_ready = ix->ntotal > 0 && ix->rows8 != nullptr && ix->shadow_rows == ix->ntotal && shadow_wanted(ix);
     if (allow_mm8) consume_tier_stats(ix, false);     // the previous search's failed count, if it has arrived
-    const bool mm8_eligible = allow_mm8 && ix->mm8_mode && ix->mm_mode && !exact_only && kc <= 32 && B > 128 && ix->ntotal > 0 &&
-                              (ix->shadow_mode >= 2 || ix->ntotal >= ix->mm8_min_rows) &&
-                              ix->cert_mode != 0 && ix->rows8 != nullptr && ix->shadow_rows == ix->ntotal && shadow_wanted(ix) &&
-                              mm8_supported(ix->d, kMm8Kc) && mm_supported(ix->d, PRAG_F16, kMm8Kc) && k <= kMm8Kc / 8;
-    if (mm8_eligible && ix->mm8_auto_off && ++ix->mm8_off_count >= ix->mm8_off_period) {
+    env.mm8_auto_off = ix->mm8_auto_off;
+    SearchPlan P = plan_search(env);
+    PRAG_REQUIRE(P.kc != 0, PRAG_EUNSUPPORTED, "k=%d: at most 911 results per query", k);
+    if (P.mm8_eligible && ix->mm8_auto_off && ++ix->mm8_off_count >= ix->mm8_off_period) {
         // one probe after a while: a serving index must not lose the 8-bit tiles for good over two bad batches
         ix->mm8_auto_off = false;
         ix->mm8_whole_batch_streak = 1;      // a single whole-batch repeat switches them off again ...
         ix->mm8_off_period = std::min(4096, ix->mm8_off_period * 2);   // ... for twice as long
         ix->mm8_off_count = 0;
+        env.mm8_auto_off = false;
+        P = plan_search(env);
     }
-    const bool use_mm8 = mm8_eligible && !ix->mm8_auto_off;
-    if (use_mm8) kc = kMm8Kc;
-    else if (allow_mm8) {
-        ix->tier_pending = false;
-        ix->mm8_last_failed = mm8_eligible ? -2 : -1;
+    if (allow_mm8) {                         // (second-tier inner searches keep the outer search's plan on record)
+        char buf[640];
+        plan_describe(env, P, buf, (int)sizeof(buf));
+        ix->last_plan = buf;
+        if (!P.use_mm8) {
+            ix->tier_pending = false;
+            ix->mm8_last_failed = P.mm8_eligible ? -2 : -1;
+        }
     }
+    const int kc = P.kc;
+    const bool exact_only = P.exact_only, use_mm8 = P.use_mm8;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
     // ---- host i/o staging -----------------------------------------------------
     const float* q_dev = q;
@@ -2222,23 +2392,9 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     }
 
     // ---- workspace --------------------------------------------------------------
-    const int qstride = (ix->d * 2 + 255) / 256 * 256;
-    // 64-query tiles when they fit LDS; fp32 rows with 32-deep lists stay at 32 (VGPR budget)
-    // (64 queries x 32-deep lists = 128 list registers per lane: scratch on either row type - two 32-query tiles)
-    const bool wide_ok = 64 * qstride + 8 * 4096 + 64 * 12 <= 160 * 1024 && kc < 32;
-    // > 128 queries: the contraction bounds the search -> MFMA-tiled scan, 256 queries per tile
-    const bool use_mm = !exact_only && ix->ntotal > 0 && mm_supported(ix->d, PRAG_F16, kc) &&
-                        ((B > 128 && ix->mm_mode) || kc > 32);
-    // 65..128 queries: one pass over the 8-bit shadow with 128-query tiles when the index keeps one ...
-    const bool shadow128 = !exact_only && !use_mm && B > 64 && B <= 128 && ix->cert_mode != 0 && ix->ntotal > 0 &&
-                           ix->rows8 != nullptr && ix->shadow_rows == ix->ntotal && shadow_wanted(ix) &&
-                           shadow_supported(ix->d, kc, k, B) && shadow_tile128_ok(ix->d, kc);
-    // ... else the query-stationary kernel over the fp16 rows (128 queries per corpus pass)
-    const bool use_qs = !exact_only && !use_mm && !shadow128 && B > 64 && qs_supported(ix->d, ix->store, kc);
-    const int QT = use_mm ? 256 : (use_qs || shadow128) ? 128 : ((B > 32 && wide_ok) ? 64 : 32);
-    // <= 32 queries (the reference's call shape): high-precision selection, if two query tiles fit LDS
-    const bool use_hp = ix->hp_mode && QT == 32 && 2 * 32 * qstride + 8 * 4096 + 32 * 12 <= 160 * 1024;
-    const int Bpad = (B + QT - 1) / QT * QT;
+    const int qstride = P.qstride, QT = P.QT, Bpad = P.Bpad;
+    const bool use_mm = P.use_mm, shadow128 = P.shadow128, use_qs = P.use_qs, use_hp = P.use_hp;
+    (void)shadow128;
     if (Bpad > ix->q_cap) {
         ix->q_cap = 0;
         const int rc_ws = ws_regrow({{vpp(&ix->qinfo), (size_t)Bpad * 4 * sizeof(float)},
@@ -2252,20 +2408,16 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         if (rc_ws != PRAG_OK) return rc_ws;
         ix->q_cap = Bpad;
     }
-    const int n_tiles = (int)((ix->ntotal + 31) / 32);
-    const int cu_budget = ix->wg_cap > 0 ? std::min(ix->wg_cap, ix->n_cu) : ix->n_cu;
-    const int grid = use_qs ? std::max(1, std::min(cu_budget, (n_tiles + 3) / 4))
-                            : std::max(1, std::min(cu_budget, (n_tiles + 7) / 8));
+    const int n_tiles = P.n_tiles, cu_budget = P.cu_budget, grid = P.grid;
     const int n_lists = grid;  // one merged list per workgroup and query
-    // (the pre-pass may use up to 64 workgroups; the tiled scan sizes its own fallback lists)
-    const size_t part_need = use_mm ? 0 : (size_t)std::max(grid, 64) * QT * kc;
+    const size_t part_need = P.part_need;
     if (part_need > ix->part_cap) {
         ix->part_cap = 0;
         const int rc_ws = ws_regrow({{vpp(&ix->part_key), part_need * sizeof(float)}, {vpp(&ix->part_idx), part_need * sizeof(int)}});
         if (rc_ws != PRAG_OK) return rc_ws;
         ix->part_cap = part_need;
     }
-    const size_t cand_need = (size_t)Bpad * kc;
+    const size_t cand_need = P.cand_need;
     if (cand_need > ix->cand_cap) {
         ix->cand_cap = 0;
         const int rc_ws = ws_regrow({{vpp(&ix->cand), cand_need * sizeof(int)}});
@@ -2276,8 +2428,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     // queries per mm_run call and survivors one workgroup can hold per query and segment.  Deep lists
     // (k > 26) yield up to KC/8 survivors per 256-row tile right after the first segment: they get
     // 512 slots and 256-query chunks.
-    const int mm_chunk = use_mm8 ? std::min(Bpad, kMm8Chunk) : kc > 32 ? 256 : std::min(Bpad, kMmMaxQueries);
-    const int mm_cap_wg = use_mm8 ? kMm8CapWg : kc > 32 ? 512 : kMmCapWg;
+    const int mm_chunk = P.mm_chunk, mm_cap_wg = P.mm_cap_wg;
     if (use_mm) {
         if (Bpad > ix->mm_q_cap) {
             ix->mm_q_cap = 0;
@@ -2306,10 +2457,8 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
 
     const int metric_l2 = ix->metric == PRAG_METRIC_L2;
     // ---- exactness certificate: error model of the scan that will run, exact-scan workspace -------
-    const bool certify = ix->cert_mode != 0 || exact_only;
-    const int ex_grid = (int)std::max<int64_t>(1, std::min<int64_t>(2 * (int64_t)cu_budget, (ix->ntotal + 31) / 32));
-    // flagged queries one round of the exact scan can hold: <= 64 MB of per-workgroup lists
-    const int ex_fcap = (int)std::max<int64_t>(1, std::min<int64_t>(B, (64ll << 20) / ((int64_t)ex_grid * k * 12)));
+    const bool certify = P.certify;
+    const int ex_grid = P.ex_grid, ex_fcap = P.ex_fcap;
     if (certify && ix->ntotal > 0) {
         const size_t need = exact_part_entries(ex_fcap, ex_grid, k);
         if (need > ix->ex_entries) {
@@ -2368,8 +2517,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     constexpr int kShadowCap = 512;
     // (the shadow's eps constants read max ||x||^2 and its overflow path needs the exact scan: both exist
     // only with the certificate on - a diag build with PRAG_CERT=0 scans the rows directly)
-    const bool use_shadow = certify && !exact_only && !use_mm && !use_qs && ix->ntotal > 0 && ix->rows8 != nullptr &&
-                            ix->shadow_rows == ix->ntotal && shadow_wanted(ix) && shadow_supported(ix->d, kc, k, B);
+    const bool use_shadow = P.use_shadow;
     ShadowPrep sprep{};
     if (use_shadow || use_mm8) {   // workspace of the two-level search; its query terms come out of prep_queries_kernel
         const int BpadS = use_mm8 ? Bpad : (B + 63) / 64 * 64;
@@ -2522,9 +2670,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         // Bound for the list scan: slots filled inside the launch (no extra launches: best on shards
         // of a few million rows, where two launches are ~6 % of the search) or the pre-pass (its bound
         // is there from the first tile: measured 1.5 % faster at 21 M rows).  Crossover ~8 M rows.
-        const bool want_slots = ix->prepass_mode < 0 ? ix->ntotal <= (8ll << 20) : ix->prepass_mode == 0;
-        const bool use_slots = !use_qs && want_slots && !(QT == 64 && kc == 32);
-        const bool prepass = ix->ntotal >= 16 * kSample && !use_slots;
+        const bool use_slots = P.use_slots, prepass = P.prepass;
         static EventRing no_prof;  // the pre-pass is not part of the profiled scan launches
         for (int p0 = 0; p0 < Bpad; p0 += QT) {
             a.q16 = ix->q16 + (size_t)p0 * ix->d;
@@ -2724,6 +2870,12 @@ extern "C" int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_
     PRAG_HIP(hipMemcpyAsync(&n, ix->cert_words, sizeof(n), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream)));
     PRAG_HIP(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
     *n_out = (int)n;
+    return PRAG_OK;
+}
+
+extern "C" int prag_index_last_plan(prag_index_t* ix, char* out, int cap) {
+    PRAG_REQUIRE(ix != nullptr && out != nullptr && cap > 0, PRAG_EINVAL, "prag_index_last_plan: bad argument");
+    snprintf(out, cap, "%s", ix->last_plan.c_str());
     return PRAG_OK;
 }
 

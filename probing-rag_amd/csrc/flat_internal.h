@@ -103,6 +103,7 @@ struct MmSearch {
     const signed char* q8 = nullptr;      // [Bpad][d], zero rows past B
     const float* kq = nullptr;            // [Bpad], 0 past B
     Gate gate;
+    bool shape16 = false;                 // 16 x 16 MFMA tiles instead of 32 x 32 (same results; see scan_mm_kernel)
 };
 
 constexpr int kMmFirstSeg = 2048;    // rows of the first segment (all of them become candidates); segments grow x16

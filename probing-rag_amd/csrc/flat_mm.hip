@@ -85,7 +85,14 @@ constexpr int kMmLdsCnt = 131072 + 4096;   // [Bpad] survivor counters of this w
 //   key = ||x_i||^2 (L2) + kq_b * (s_i * dot)        (two float roundings, the same expression wherever it is formed)
 // is within A1 e_i + C1 of the exact key (flat_internal.h, ShadowQ): the caller keeps a deeper candidate list and
 // the certificate uses that bound.
-template <int NKT /* d / 64 (I8: d / 128), even */, int MODE = 1, int ABL = 0, bool I8 = false>
+// S16: the same tiles on v_mfma_f32_16x16x32_f16 / v_mfma_i32_16x16x64_i8 (a wave's 128 rows x 64 queries = 8 x 4
+// tiles of 16 x 16 instead of 4 x 2 of 32 x 32).  Same LDS image, same 16-B fragment reads (a K-32 step of a 16-row
+// tile is one ds_read_b128 per lane: piece 4 s + lane / 16 of row lane % 16), same MFMA cycles per flop; the chip
+// holds a higher clock on this shape under matrix load (tools/micro/mfma_shape.hip: bare loops 2.06 against 1.70 GHz
+// with all 256 CUs issuing; cdna_hip_programming.md section 5.4 rule 28).  The selection keys differ from the 32 x 32
+// form in the last bits (another accumulation order); the results do not - the rerank scores in float64 and
+// certifies (flat_internal.h).
+template <int NKT /* d / 64 (I8: d / 128), even */, int MODE = 1, int ABL = 0, bool I8 = false, bool S16 = false>
 __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     constexpr bool FIRST = MODE == 0;
     static_assert(NKT % 2 == 0 && NKT >= 4, "K tiles are consumed in even/odd pairs");
@@ -116,11 +123,23 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     //      swizzle term (row>>1)&7 only depends on r, k-step ks flips byte bits 5..6 ---------
     const int swz = (r >> 1) & 7;
     int a_off[4], b_off[4];
+    if constexpr (!S16) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const int piece = ((2 * ks + h) ^ swz) << 4;
-        a_off[ks] = (128 * wr + r) * 128 + piece;
-        b_off[ks] = 65536 + (64 * wc + r) * 128 + piece;
+        for (int ks = 0; ks < 4; ++ks) {
+            const int piece = ((2 * ks + h) ^ swz) << 4;
+            a_off[ks] = (128 * wr + r) * 128 + piece;
+            b_off[ks] = 65536 + (64 * wc + r) * 128 + piece;
+        }
+    } else {
+        // 16 x 16 tiles: lane (c16, q4) reads row c16 of its tile, piece 4 s + q4 of K-32 step s; the swizzle term
+        // ((row >> 1) & 7) = (c16 >> 1) & 7 for every tile (tiles start at multiples of 16 rows)
+        const int c16 = lane & 15, q4 = lane >> 4, swz16 = (c16 >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int piece = (((4 * (ks & 1) + q4) ^ swz16) << 4);
+            a_off[ks] = (128 * wr + c16) * 128 + piece;          // (only [0] and [1] are used)
+            b_off[ks] = 65536 + (64 * wc + c16) * 128 + piece;
+        }
     }
 
     // ---- LDS-DMA geometry: one wave instruction fills 8 rows x 128 B linearly, so lane l
@@ -199,6 +218,19 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
         MM_GLDS(g1_, l1_);                                        \
     }
 #define MM_LDSR(off_) ((ABL & 4) ? hz : *reinterpret_cast<const half8*>(smem + (off_)))
+    // the 8 A fragments of a 64-row quadrant (base_ = byte offset of its first row in the buffer) and the 4 B
+    // fragments of a 32-query half: 32 x 32 shape = [row tile of 32][k-step of 16]; 16 x 16 shape = fragment
+    // f = 2 * (tile of 16) + (k-step of 32), kept in the same registers
+#define MM_READ_A(base_)                                                                              \
+    _Pragma("unroll") for (int f = 0; f < 8; ++f) {                                                   \
+        if constexpr (S16) A[f >> 2][f & 3] = MM_LDSR(a_off[f & 1] + (f >> 1) * 2048 + (base_));      \
+        else A[f >> 2][f & 3] = MM_LDSR(a_off[f & 3] + (f >> 2) * 4096 + (base_));                    \
+    }
+#define MM_READ_B(BF_, base_)                                                                         \
+    _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                   \
+        if constexpr (S16) BF_[f] = MM_LDSR(b_off[f & 1] + (f >> 1) * 2048 + (base_));                \
+        else BF_[f] = MM_LDSR(b_off[f] + (base_));                                                    \
+    }
     // everything staged four or more phases ago has landed; the barrier publishes it
 #define MM_WAIT_BAR()                                     \
     {                                                     \
@@ -207,8 +239,33 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
         __builtin_amdgcn_s_barrier();                     \
         __builtin_amdgcn_sched_barrier(0);                \
     }
-#define MM_MFMA8(c0_, c1_, AF_, BF_, first_)                                                          \
-    {                                                                                                 \
+#define MM_MFMA8(MQ_, NQ_, AF_, BF_, first_)                                                          \
+    if constexpr (S16) {                                                                              \
+        /* quadrant = 4 row tiles x 2 query tiles of 16 x 16, two K-32 steps: 16 MFMAs of 16 cycles */ \
+        __builtin_amdgcn_s_setprio(1);                                                                \
+        _Pragma("unroll") for (int sk = 0; sk < 2; ++sk)                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+            f32x4& t_ = acc16[4 * (MQ_) + i][2 * (NQ_) + j];                                          \
+            const int fa_ = 2 * i + sk, fb_ = 2 * j + sk;                                             \
+            if constexpr (ABL & 1) {                                                                  \
+                asm volatile("" ::"v"(AF_[fa_ >> 2][fa_ & 3]), "v"(BF_[fb_]));                        \
+            } else if constexpr (I8) {                                                                \
+                t_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(                 \
+                    __builtin_bit_cast(i32x4, AF_[fa_ >> 2][fa_ & 3]), __builtin_bit_cast(i32x4, BF_[fb_]), \
+                    __builtin_bit_cast(i32x4, ((first_) && sk == 0) ? zero4 : t_), 0, 0, 0));          \
+            } else {                                                                                  \
+                t_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF_[fa_ >> 2][fa_ & 3], BF_[fb_],         \
+                                                            ((first_) && sk == 0) ? zero4 : t_, 0, 0, 0); \
+            }                                                                                         \
+        }                                                                                             \
+        __builtin_amdgcn_s_setprio(0);                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } else {                                                                                          \
+        f32x16& c0_ = acc[2 * (MQ_)][NQ_];                                                            \
+        f32x16& c1_ = acc[2 * (MQ_) + 1][NQ_];                                                        \
         __builtin_amdgcn_s_setprio(1);                                                                \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                            \
             if constexpr (ABL & 1) {                                                                  \
@@ -233,7 +290,9 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     }
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 acc[4][2];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x16 acc[4][2];     // 32 x 32 tiles: [row tile][query tile]
+    f32x4 acc16[8][4];    // 16 x 16 tiles (S16): [row tile][query tile]; only one of the two sets is ever used
     half8 A[2][4], Bx[4], By[4];
     half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};  // ablation 3 only: an opaque constant in place of the fragment reads
     if constexpr (ABL & 4) asm volatile("" : "+v"(hz));
@@ -241,6 +300,7 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i >> 1][i & 1] = zero16;
     }
+    static_assert(!S16 || ABL == 0, "the timing-only ablations exist for the 32 x 32 form");
 
     uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem + kMmLdsCnt);
     for (int i = tid; i < a.Bpad; i += 512) s_cnt[i] = 0;  // published by the prologue's barrier
@@ -256,8 +316,7 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     MM_SA0(cur, 1, 1)
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) Bx[ks] = MM_LDSR(b_off[ks]);
+    MM_READ_B(Bx, 0)
     if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs one barrier behind
 
     for (int ti = 0; ti < n_my; ++ti) {
@@ -274,16 +333,12 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
             // Bx/By swap roles every K tile.
             // ===== even K tile: queries 0-31 in Bx (read one phase ago), 32-63 in By =====
             // phase 1: quadrant (rows 0-63, queries 0-31)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) A[m][ks] = MM_LDSR(a_off[ks] + m * 4096);
+            MM_READ_A(0)
             MM_SB1(cur, ko, 1)
             MM_WAIT_BAR()
-            MM_MFMA8(acc[0][0], acc[1][0], A, Bx, it == 0)
+            MM_MFMA8(0, 0, A, Bx, it == 0)
             // phase 2: (rows 0-63, queries 32-63)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) By[ks] = MM_LDSR(b_off[ks] + 4096);
+            MM_READ_B(By, 4096)
             MM_SA1(cur, ko, 1)
             if (it == NKT / 2 - 2) {
                 // row norms and bounds of this tile, well ahead of the filter.  Not in phase 1: at
@@ -304,47 +359,35 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
                 }
             }
             MM_WAIT_BAR()
-            MM_MFMA8(acc[0][1], acc[1][1], A, By, it == 0)
+            MM_MFMA8(0, 1, A, By, it == 0)
             // phase 3: (rows 64-127, queries 32-63)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) A[m][ks] = MM_LDSR(a_off[ks] + (2 + m) * 4096);
+            MM_READ_A(8192)
             MM_SB0(tn, ke2, 0)
             MM_WAIT_BAR()
-            MM_MFMA8(acc[2][1], acc[3][1], A, By, it == 0)
+            MM_MFMA8(1, 1, A, By, it == 0)
             // phase 4: (rows 64-127, queries 0-31); By <- queries 0-31 of the odd K tile
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) By[ks] = MM_LDSR(b_off[ks] + 32768);
+            MM_READ_B(By, 32768)
             MM_SA0(tn, ke2, 0)
             MM_WAIT_BAR()
-            MM_MFMA8(acc[2][0], acc[3][0], A, Bx, it == 0)
+            MM_MFMA8(1, 0, A, Bx, it == 0)
             // ===== odd K tile: queries 0-31 in By, 32-63 in Bx =====
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) A[m][ks] = MM_LDSR(a_off[ks] + 32768 + m * 4096);
+            MM_READ_A(32768)
             MM_SB1(tn, ke2, 0)
             MM_WAIT_BAR()
-            MM_MFMA8(acc[0][0], acc[1][0], A, By, false)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) Bx[ks] = MM_LDSR(b_off[ks] + 32768 + 4096);
+            MM_MFMA8(0, 0, A, By, false)
+            MM_READ_B(Bx, 32768 + 4096)
             MM_SA1(tn, ke2, 0)
             MM_WAIT_BAR()
-            MM_MFMA8(acc[0][1], acc[1][1], A, Bx, false)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) A[m][ks] = MM_LDSR(a_off[ks] + 32768 + (2 + m) * 4096);
+            MM_MFMA8(0, 1, A, Bx, false)
+            MM_READ_A(32768 + 8192)
             MM_SB0(tn, ko2, 1)
             MM_WAIT_BAR()
-            MM_MFMA8(acc[2][1], acc[3][1], A, Bx, false)
+            MM_MFMA8(1, 1, A, Bx, false)
             // phase 8: Bx <- queries 0-31 of the next even K tile (next tile's first one at the end)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) Bx[ks] = MM_LDSR(b_off[ks]);
+            MM_READ_B(Bx, 0)
             MM_SA0(tn, ko2, 1)
             MM_WAIT_BAR()
-            MM_MFMA8(acc[2][0], acc[3][0], A, By, false)
+            MM_MFMA8(1, 0, A, By, false)
         }
 
         // ---- filter: 128 scores per lane against the bound of their query ----------------
@@ -357,16 +400,27 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
             // value reloads behind s_waitcnt vmcnt(0), i.e. drains the DMA pipeline once per tile)
             int le = lane;
             asm volatile("" : "+v"(le));
-            const int r = le & 31, h = le >> 5;
+            // A lane's 128 scores as groups of 16 for ONE query: 32 x 32 tiles are such groups (row tile mt, query
+            // tile nt: rows 32 mt + 8 g + 4 h + e, query 32 nt + r).  With 16 x 16 tiles a group is gathered from
+            // four of them: NMT = 2 row blocks of 64, NNT = 4 query tiles of 16; rows 64 mt + 16 g + 4 q4 + e.
+            constexpr int NMT = S16 ? 2 : 4, NNT = S16 ? 4 : 2, RT_ROWS = S16 ? 64 : 32, G_ROWS = S16 ? 16 : 8,
+                          QT_COLS = S16 ? 16 : 32;
+            const int r = S16 ? (le & 15) : (le & 31), h = S16 ? (le >> 4) : (le >> 5);
             const int64_t rbase = cur.row0 + 128 * wr + 4 * h;
             const int qbase = cur.q0 + 64 * wc + r;
-            float tauf[2], thr[2], al[2];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                tauf[nt] = unsortable_f32(*reinterpret_cast<const uint32_t*>(smem + kMmLdsTau + (64 * wc + 32 * nt + r) * 4));
+            // per-query constants: the 32 x 32 form keeps its two queries' values across the row tiles; the 16 x 16
+            // form (four queries per lane) reads them from LDS where they are used - twelve more live registers
+            // spilled the int8 squared-L2 variant
+            float tauf[NNT], thr[NNT], al[NNT];
+            auto q_consts = [&](int nt) {
+                tauf[nt] = unsortable_f32(*reinterpret_cast<const uint32_t*>(smem + kMmLdsTau + (64 * wc + QT_COLS * nt + r) * 4));
                 thr[nt] = tauf[nt] * a.inv_alpha;  // key <= tau  <=>  score >= tau / alpha  (alpha < 0)
                 // I8: key = xn + kq_b * (s_i * dot); the query's kq = alpha * (its int8 scale) stands where alpha does
-                al[nt] = I8 ? *reinterpret_cast<const float*>(smem + kMmLdsKq + (64 * wc + 32 * nt + r) * 4) : a.alpha;
+                al[nt] = I8 ? *reinterpret_cast<const float*>(smem + kMmLdsKq + (64 * wc + QT_COLS * nt + r) * 4) : a.alpha;
+            };
+            if constexpr (!S16) {
+#pragma unroll
+                for (int nt = 0; nt < NNT; ++nt) q_consts(nt);
             }
             // The other wave group waits at the next barrier while this one filters, so every
             // instruction here is exposed twice per tile: the common case is kept to ~12 (inner
@@ -377,34 +431,40 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
 #define MM_MAX3(d_, x_, y_, z_) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d_) : "v"(x_), "v"(y_), "v"(z_))
 #define MM_MIN3(d_, x_, y_, z_) asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d_) : "v"(x_), "v"(y_), "v"(z_))
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < NMT; ++mt) {
                 f32x4 xn[4], ss[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     if ((FIRST && a.use_norm) || MODE == 2)
-                        xn[g] = *reinterpret_cast<const f32x4*>(smem + kMmLdsXn + (128 * wr + 32 * mt + 8 * g + 4 * h) * 4);
+                        xn[g] = *reinterpret_cast<const f32x4*>(smem + kMmLdsXn + (128 * wr + RT_ROWS * mt + G_ROWS * g + 4 * h) * 4);
                     else
                         xn[g] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if constexpr (I8)
-                        ss[g] = *reinterpret_cast<const f32x4*>(smem + kMmLdsSs + (128 * wr + 32 * mt + 8 * g + 4 * h) * 4);
+                        ss[g] = *reinterpret_cast<const f32x4*>(smem + kMmLdsSs + (128 * wr + RT_ROWS * mt + G_ROWS * g + 4 * h) * 4);
                 }
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    f32x16 c = acc[mt][nt];
-                    if constexpr (I8) {   // t = s_i * dot (the integer converts exactly: |dot| <= 128 * 127^2 * NKT < 2^24)
-                        typedef int i32x16_ __attribute__((ext_vector_type(16)));
-                        const i32x16_ ci = __builtin_bit_cast(i32x16_, acc[mt][nt]);
+                for (int nt = 0; nt < NNT; ++nt) {
+                    if constexpr (S16) q_consts(nt);
+                    // 16 x 16 tiles: row tile g of the 64-row block mt, query tile nt -> c[4 g ..]
+                    // I8: t = s_i * dot (the integer converts exactly: |dot| <= 128 * 127^2 * NKT < 2^24)
+                    f32x16 c;
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) c[e] = ss[e >> 2][e & 3] * (float)ci[e];
-                    }
-                    const int q = qbase + 32 * nt;
-                    const int64_t rb = rbase + 32 * mt;
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float raw;
+                            if constexpr (S16) raw = acc16[4 * mt + g][nt][e];
+                            else raw = acc[mt][nt][4 * g + e];
+                            c[4 * g + e] = I8 ? ss[g][e] * (float)__builtin_bit_cast(int, raw) : raw;
+                        }
+                    const int q = qbase + QT_COLS * nt;
+                    const int64_t rb = rbase + RT_ROWS * mt;
                     if constexpr (FIRST) {
                         // no bound yet: every row is a candidate, slot = row - row0 (no counters);
                         // the four rows of a register quad are consecutive slots -> 16-B stores
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const int64_t row = rb + 8 * g;
+                            const int64_t row = rb + G_ROWS * g;
                             const int64_t o = (int64_t)q * a.cap_q + (row - a.row0);
                             f32x4 kv;
                             i32x4 iv;
@@ -460,7 +520,7 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
                                     hit |= key[e] <= tauf[nt];
                                 }
                                 if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
-                                const int64_t row0q = rb + 8 * g;
+                                const int64_t row0q = rb + G_ROWS * g;
                                 int np = 0;
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) np += (key[e] <= tauf[nt] && row0q + e < a.row1) ? 1 : 0;
@@ -514,6 +574,8 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
 #undef MM_SB0
 #undef MM_SB1
 #undef MM_LDSR
+#undef MM_READ_A
+#undef MM_READ_B
 #undef MM_WAIT_BAR
 #undef MM_MFMA8
 }
@@ -695,9 +757,9 @@ bool mm8_supported(int d, int kc) {
     return (d == 512 || d == 768 || d == 1024) && kc >= 8 && kc <= kMmMaxKc;   // d / 128 K tiles, an even number >= 4
 }
 
-template <int NKT, int MODE, int ABL = 0, bool I8 = false>
+template <int NKT, int MODE, int ABL = 0, bool I8 = false, bool S16 = false>
 static int launch_mm_impl(const MmArgs& a, int grid, hipStream_t st) {
-    auto kern = scan_mm_kernel<NKT, MODE, ABL, I8>;
+    auto kern = scan_mm_kernel<NKT, MODE, ABL, I8, S16>;
     static LdsOptIn lds_opt_in;
     {
         const int rc_ = lds_opt_in.ensure(reinterpret_cast<const void*>(kern), 160 * 1024);
@@ -709,14 +771,27 @@ static int launch_mm_impl(const MmArgs& a, int grid, hipStream_t st) {
 }
 
 template <int NKT, int ABL = 0>
-static int launch_mm(const MmArgs& a, bool first, int grid, hipStream_t st) {
+static int launch_mm(const MmArgs& a, bool first, int grid, hipStream_t st, bool s16 = false) {
+    if constexpr (ABL == 0) {
+        if (s16) {
+            if (first) return launch_mm_impl<NKT, 0, 0, false, true>(a, grid, st);
+            if (a.use_norm) return launch_mm_impl<NKT, 2, 0, false, true>(a, grid, st);
+            return launch_mm_impl<NKT, 1, 0, false, true>(a, grid, st);
+        }
+    }
     if (first) return launch_mm_impl<NKT, 0, 0>(a, grid, st);
     if (a.use_norm) return launch_mm_impl<NKT, 2, 0>(a, grid, st);
     return launch_mm_impl<NKT, 1, ABL>(a, grid, st);
 }
 
 template <int NKT8>
-static int launch_mm8(const MmArgs& a, bool first, int grid, hipStream_t st) {
+static int launch_mm8(const MmArgs& a, bool first, int grid, hipStream_t st, bool s16 = false) {
+    // (squared L2 on the int8 tiles stays on the 32 x 32 form: its filter needs row norms AND row scales, and the
+    // 16 x 16 variant of it spilled five registers)
+    if (s16 && !a.use_norm) {
+        if (first) return launch_mm_impl<NKT8, 0, 0, true, true>(a, grid, st);
+        return launch_mm_impl<NKT8, 1, 0, true, true>(a, grid, st);
+    }
     if (first) return launch_mm_impl<NKT8, 0, 0, true>(a, grid, st);
     if (a.use_norm) return launch_mm_impl<NKT8, 2, 0, true>(a, grid, st);
     return launch_mm_impl<NKT8, 1, 0, true>(a, grid, st);
@@ -774,7 +849,7 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
         int rc;
         if (s.i8) {
             switch (s.d) {
-                case 512: rc = launch_mm8<4>(a, first, grid, st); break;
+                case 512: rc = launch_mm8<4>(a, first, grid, st, s.shape16); break;
                 case 768:
 #ifdef PRAG_MM_DIAG
                 {   // timing-only ablations of the int8 tiles (wrong results): 8 no filter, 1 no MFMAs, 9 neither
@@ -787,13 +862,13 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
                     if (!first && !a.use_norm && abl == 4) { rc = launch_mm_impl<6, 1, 4, true>(a, grid, st); break; }
                 }
 #endif
-                    rc = launch_mm8<6>(a, first, grid, st); break;
-                default: rc = launch_mm8<8>(a, first, grid, st); break;
+                    rc = launch_mm8<6>(a, first, grid, st, s.shape16); break;
+                default: rc = launch_mm8<8>(a, first, grid, st, s.shape16); break;
             }
         } else
         switch (s.d) {
-            case 256: rc = launch_mm<4>(a, first, grid, st); break;
-            case 512: rc = launch_mm<8>(a, first, grid, st); break;
+            case 256: rc = launch_mm<4>(a, first, grid, st, s.shape16); break;
+            case 512: rc = launch_mm<8>(a, first, grid, st, s.shape16); break;
             case 768:
 #ifdef PRAG_MM_DIAG
             {
@@ -809,15 +884,15 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
                     case 40: rc = launch_mm<12, 40>(a, first, grid, st); break;
                     case 56: rc = launch_mm<12, 56>(a, first, grid, st); break;
                     case 72: rc = launch_mm<6, 72>(a, first, grid, st); break;   // 768 int8 per row
-                    default: rc = launch_mm<12>(a, first, grid, st); break;
+                    default: rc = launch_mm<12>(a, first, grid, st, s.shape16); break;
                 }
                 break;
             }
 #else
-                rc = launch_mm<12>(a, first, grid, st);
+                rc = launch_mm<12>(a, first, grid, st, s.shape16);
                 break;
 #endif
-            default: rc = launch_mm<16>(a, first, grid, st); break;
+            default: rc = launch_mm<16>(a, first, grid, st, s.shape16); break;
         }
         if (biggest) prof.end(st);
         if (rc != PRAG_OK) return rc;

@@ -308,6 +308,34 @@ def _ix_last_exact_fallbacks(self) -> int:
     return n.value
 
 
+def parse_plan(line: str) -> dict:
+    """`key=value` fields of a plan line -> dict (ints where they parse)."""
+    out = {}
+    import re
+    for m in re.finditer(r"(\w+)=((?:[^= ]| (?!\w+=))*)", line):
+        v = m.group(2).strip()
+        try:
+            out[m.group(1)] = int(v)
+        except ValueError:
+            out[m.group(1)] = v
+    return out
+
+
+def plan_search(d: int, metric, store: str, ntotal: int, B: int, k: int, shadow: int = 0, n_cu: int = 256) -> dict:
+    """The plan `prag_index_search` would execute for this shape (pure host logic: works without a GPU)."""
+    buf = ctypes.create_string_buffer(768)
+    _lib.check(_lib.lib().prag_plan_search(int(d), _lib.metric_id(metric), _lib.PRAG_F32 if store == "f32" else _lib.PRAG_F16,
+                                           int(ntotal), int(B), int(k), int(shadow), int(n_cu), buf, len(buf)))
+    return parse_plan(buf.value.decode())
+
+
+def _ix_last_plan(self) -> dict:
+    """The plan the most recent search on this index executed (kernel family, tile, passes, bytes per pass, ...)."""
+    buf = ctypes.create_string_buffer(768)
+    _lib.check(_lib.lib().prag_index_last_plan(self._h, buf, len(buf)))
+    return parse_plan(buf.value.decode())
+
+
 def _ix_last_tiled8(self) -> int:
     """Batches of > 128 queries on an index that keeps the 8-bit shadow: queries of the most recent search that
     failed the certificate of the int8-tile selection and sent the batch to the fp16 tiles (0: the first tier
@@ -339,6 +367,7 @@ HipFlatIndex.prepare = _ix_prepare
 HipFlatIndex.set_candidate_depth = _ix_set_candidate_depth
 HipFlatIndex.last_exact_fallbacks = _ix_last_exact_fallbacks
 HipFlatIndex.last_tiled8 = _ix_last_tiled8
+HipFlatIndex.last_plan = _ix_last_plan
 
 
 def _ix_set_scan_workgroups(self, n: int):

@@ -232,3 +232,58 @@ def test_read_index_header_against_hand_assembled_faiss_files(tmp_path):
             assert msg in str(e)
         else:
             raise AssertionError(f"accepted a bad header ({msg})")
+
+
+def test_search_plan_over_the_shape_grid():
+    """The dispatch of prag_index_search is ONE pure function (plan_search, flat_index.hip) that runs without a
+    GPU: walk the whole shape grid and check the invariants the kernels rely on - tile heights, candidate depth,
+    padding, the routes round 4 closed because their kernels spilled, and that bytes / passes are what the
+    chosen kernel family reads (bench.py prices its roofline with them)."""
+    fams = {"scan8_kernel", "scan_topk_kernel", "scan_qs_kernel", "scan_mm_kernel",
+            "scan_mm_kernel<int8 tiles over the 8-bit shadow>", "exact_scan_kernel"}
+    n_plans = 0
+    for d in (64, 256, 320, 512, 768, 1024, 1536):
+        for store in ("f16", "f32"):
+            for metric in ("l2", "ip", "cos"):
+                for N in (1, 5000, 1 << 20, 2_625_000, 21_000_000):
+                    for shadow in (0, 1, 2):
+                        prev_ws = 0
+                        for B in (1, 32, 33, 64, 65, 128, 129, 1000, 4097):
+                            for k in (1, 5, 10, 12, 13, 26, 27, 100, 911):
+                                p = pra.plan_search(d, metric, store, N, B, k, shadow)
+                                n_plans += 1
+                                assert p["family"] in fams, p
+                                assert p["QT"] in (32, 64, 128, 256) and p["Bpad"] % p["QT"] == 0 and p["Bpad"] >= B
+                                assert p["kc"] >= min(k, 32) and (p["kc"] >= k or p["exact_only"])
+                                assert p["grid"] >= 1 and p["launches"] >= 1 and p["bytes_per_launch"] > 0 and p["ws_bytes"] > 0
+                                assert not (p["QT"] == 64 and p["kc"] == 32)             # 128 list registers per lane
+                                if p["family"] == "scan_qs_kernel":
+                                    assert store == "f16" and not (d == 1024 and p["kc"] == 16) and 64 < B <= 128
+                                if p["tiled"]:
+                                    assert p["QT"] == 256 and d in (256, 512, 768, 1024)
+                                if p["int8_tiles"]:
+                                    assert shadow and B > 128 and p["kc"] == 256 and k <= 32 and (N >= 2 << 20 or shadow == 2)
+                                if p["shadow"]:
+                                    assert shadow and d % 128 == 0 and d <= 1024 and B <= 128 and p["family"] == "scan8_kernel"
+                                if p["hp"]:
+                                    assert p["QT"] == 32
+                                elt = 4 if store == "f32" else 2
+                                norms = 4 * N if metric == "l2" else 0
+                                want = {"scan8_kernel": N * (d + 8) + norms, "scan_topk_kernel": N * d * elt + norms,
+                                        "scan_qs_kernel": N * d * 2 + norms, "scan_mm_kernel": N * d * 2 + norms,
+                                        "exact_scan_kernel": N * d * elt}.get(p["family"])
+                                if want is not None:
+                                    assert p["bytes_per_launch"] == want, p
+                                if p["family"] in ("scan8_kernel", "scan_topk_kernel"):
+                                    assert p["launches"] == p["Bpad"] // p["QT"]
+    assert n_plans > 20_000
+    # the headline, the reference's call, config 3 and the 8-GPU shard
+    assert pra.plan_search(768, "cos", "f16", 21_000_000, 64, 10, 1)["family"] == "scan8_kernel"
+    ref = pra.plan_search(768, "l2", "f32", 21_000_000, 1, 5, 0)
+    assert (ref["family"], ref["QT"], ref["kc"], ref["hp"], ref["bytes_per_launch"]) == ("scan_topk_kernel", 32, 8, 1, 21_000_000 * 3076)
+    c3 = pra.plan_search(768, "cos", "f16", 1_000_000, 1000, 10, 0)
+    assert (c3["family"], c3["Bpad"], c3["launches"]) == ("scan_mm_kernel", 1024, 4)
+    assert pra.plan_search(768, "cos", "f16", 2_625_000, 1000, 10, 1)["int8_tiles"] == 1
+    assert pra.plan_search(768, "cos", "f16", 1_000_000, 1000, 10, 1)["int8_tiles"] == 0       # below 2 Mi rows
+    with __import__("pytest").raises(pra.PragError, match="911"):
+        pra.plan_search(768, "cos", "f16", 1000, 1, 912)
