@@ -368,7 +368,15 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     auto issue = [&](u32x4 (&ldr)[4], int tile, int c) {
         const char* base = rows + (int64_t)tile * (32 * row_bytes) + c * 4096;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ldr[i] = *reinterpret_cast<const u32x4*>(base + lane16 + 1024 * i);
+        for (int i = 0; i < 4; ++i) {
+#ifdef PRAG_SCAN8_NT
+            // read-once stream: non-temporal loads leave L2 / the Infinity Cache to what IS reused between launches
+            // (in a retrieve-decide pass: the gate's 22 MB of weights and states) - A/B in profiles/r04h_*
+            ldr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + lane16 + 1024 * i));
+#else
+            ldr[i] = *reinterpret_cast<const u32x4*>(base + lane16 + 1024 * i);
+#endif
+        }
     };
     const int a_off = r * 128;
     const int a_sw = (r >> 1) & 7;
