@@ -178,10 +178,11 @@ __global__ __launch_bounds__(kExThreads) void exact_scan_kernel(ExactArgs a) {
                     if (e < d) {
                         if constexpr (F32) {
                             const float* p = reinterpret_cast<const float*>(a.rows) + row * d + e;
-                            v0[it] = *reinterpret_cast<const u32x4*>(p);
-                            v1[it] = *reinterpret_cast<const u32x4*>(p + 4);
+                            v0[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+                            v1[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 4));
                         } else {
-                            v0[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const _Float16*>(a.rows) + row * d + e);
+                            v0[it] = __builtin_nontemporal_load(
+                                reinterpret_cast<const u32x4*>(reinterpret_cast<const _Float16*>(a.rows) + row * d + e));
                         }
                     }
                 }

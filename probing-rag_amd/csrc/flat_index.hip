@@ -420,7 +420,14 @@ __device__ __forceinline__ void scan_topk_body(const ScanArgs& a, char* smem) {
         const int tc = tile < tile_last ? tile : tile_last;     // prefetch past the end: re-read the last tile
         const char* base = rows + (int64_t)tc * (32 * row_bytes) + c * chunk_bytes;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) ld[i] = *reinterpret_cast<const u32x4*>(base + i * ld_step + lane_off0);
+        for (int i = 0; i < NLD; ++i) {
+            // (read-once stream: non-temporal, like the 8-bit scan - flat_shadow.hip)
+#ifdef PRAG_SCAN_PLAIN_LOADS
+            ld[i] = *reinterpret_cast<const u32x4*>(base + i * ld_step + lane_off0);
+#else
+            ld[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + i * ld_step + lane_off0));
+#endif
+        }
     };
 
     const int a_off = r * 128;
@@ -679,6 +686,12 @@ __global__ __launch_bounds__(512, 1) void scan_topk_flagged_kernel(ScanArgs a, c
 // waited for with s_waitcnt vmcnt(0)-like counts that drain the DMA ring (loads return in order).
 // The per-group side data - row norms (L2) and the chip-wide bounds - therefore travel by LDS-DMA
 // too (two 512-B transfers per group, issued by waves 0 and 1 a whole group ahead of their use).
+// (the corpus chunks are read once: non-temporal LDS-DMA, aux = 2, like the other scans' streams)
+#ifdef PRAG_SCAN_PLAIN_LOADS
+constexpr int kQsAux = 0;
+#else
+constexpr int kQsAux = 2;
+#endif
 template <int NKS /* d/32 */, int KC, bool L2>
 __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
     constexpr int kSideXn = 4 * 128 * 128;          // LDS: [128] f32 row norms of the running group
@@ -736,8 +749,8 @@ __global__ __launch_bounds__(512, 2) void scan_qs_kernel(ScanArgs a) {
     // chunk c of the group behind `ptr` -> ring stage `stg` (c, stg compile-time)
 #define PRAG_DMA(ptr, c_, stg_)                                                                          \
     {                                                                                                   \
-        __builtin_amdgcn_global_load_lds(ptr[0] + (c_) * 128, lds0 + (stg_) * STAGE + (2 * w) * 1024, 16, 0, 0);     \
-        __builtin_amdgcn_global_load_lds(ptr[1] + (c_) * 128, lds0 + (stg_) * STAGE + (2 * w + 1) * 1024, 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds(ptr[0] + (c_) * 128, lds0 + (stg_) * STAGE + (2 * w) * 1024, 16, 0, kQsAux);     \
+        __builtin_amdgcn_global_load_lds(ptr[1] + (c_) * 128, lds0 + (stg_) * STAGE + (2 * w + 1) * 1024, 16, 0, kQsAux); \
     }
 
     TopList<KC> top;

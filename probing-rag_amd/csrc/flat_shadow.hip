@@ -369,12 +369,14 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
         const char* base = rows + (int64_t)tile * (32 * row_bytes) + c * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-#ifdef PRAG_SCAN8_NT
             // read-once stream: non-temporal loads leave L2 / the Infinity Cache to what IS reused between launches
-            // (in a retrieve-decide pass: the gate's 22 MB of weights and states) - A/B in profiles/r04h_*
-            ldr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + lane16 + 1024 * i));
-#else
+            // (in a retrieve-decide pass: the gate's 22 MB of weights and states).  Same box, plain / nt loads
+            // (profiles/r04h_scan8_nt_loads_ab.txt): 2.625 M-row shard 0.400-0.426 -> 0.362-0.390 ms and the gate that
+            // follows it 55.8 -> 40.1 us; 21 M rows 2.78 -> 2.69 ms (0.733 -> 0.757 of 8 TB/s).
+#ifdef PRAG_SCAN_PLAIN_LOADS
             ldr[i] = *reinterpret_cast<const u32x4*>(base + lane16 + 1024 * i);
+#else
+            ldr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + lane16 + 1024 * i));
 #endif
         }
     };

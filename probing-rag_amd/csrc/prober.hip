@@ -44,43 +44,10 @@
 #include <vector>
 
 #include "prag_common.h"
+#include "prober_internal.h"
 #include "prober_small.h"
 
 namespace prag {
-
-constexpr int kHidden = 512;
-constexpr int kClasses = 2;
-constexpr float kLnEps = 1e-5f;
-
-struct LayerDev {
-    const u32x4* W1f;    // [NA][d/16][16 row tiles][64 lanes] x 16 B
-    const u32x4* W2f;    // [NA][32 k steps][16 row tiles][64 lanes] x 16 B
-    const u32x4* W2q;    // fp16-weight mode: fp8 (e4m3) copy for the lo term, [8 k blocks][16 row tiles][2][64 lanes] x 16 B
-    const float* wsum1;  // [512] row sums of the packed (scaled) W1
-    const float* b1;     // [512] b1 + W1 . ln0_b
-    const float* b2;     // [512] b2 + W2 . ln1_b
-    const float* w2sum;  // [512] row sums of the packed (scaled) W2
-    const float* W3;     // [2][512] W3 * ln2_w
-    float b3[2];         // b3 + W3 . ln2_b
-    float w3sum[2];      // row sums of W3 * ln2_w
-    float sc1, sc2;      // 2^-e of the packed fc1 / fc2 weights
-};
-
-struct ProberArgs {
-    const LayerDev* layers;
-    const _Float16* xh;  // raw fp16 activations, or hi part of the normalised ones
-    const _Float16* xl;  // lo part (NB == 2) or nullptr
-    int64_t x_layer_stride;
-    int layer0;
-    int B;
-    int d;
-    int n_tiles;    // row tiles per layer (set by the launcher)
-    int n_run;      // layers in this launch
-    float* logits;  // [n_run][B][2]
-#ifdef PRAG_MM_DIAG
-    int stamps;     // 1: phase stamps of three workgroups
-#endif
-};
 
 #ifdef PRAG_MM_DIAG
 // timing-only build (make diag): s_memtime stamps of three workgroups, read by tools/prober_stamps.py
@@ -106,53 +73,6 @@ __device__ unsigned long long g_pstamp[2 * 3 * 8 * 32];
 #define PSTAMP(i)
 #endif
 
-__device__ __forceinline__ float silu_f(float h) {
-    // h * sigmoid(h) as v_mul + v_exp_f32 + v_add + v_rcp_f32 + v_mul; the two transcendentals
-    // are ~1 ulp, far inside the 1e-4 budget.  (__frcp_rn / "1.0f / x" expand to the full IEEE
-    // division sequence - v_div_scale, v_div_fmas, v_div_fixup: ~10 extra VALU per element.)
-    return h * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * h));
-}
-
-// Pointers fetched from a struct in memory have no provable address space and
-// compile to flat_load (which counts on lgkmcnt too and forces full drains at
-// every barrier); these helpers pin them to global memory.
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-typedef const __attribute__((address_space(1))) u32x4* gptr_u32x4;
-typedef const __attribute__((address_space(1))) float* gptr_f32;
-__device__ __forceinline__ gptr_u32x4 as_global(const u32x4* p) { return (gptr_u32x4)p; }
-__device__ __forceinline__ gptr_f32 as_global(const float* p) { return (gptr_f32)p; }
-
-__device__ __forceinline__ float xor32(float v) { return v + __shfl_xor(v, 32, 64); }
-
-// 1/sqrt(v) for the LayerNorm scales inside the fused kernel: v_rsq_f32 (1 ulp) instead of the IEEE
-// sqrt + division sequence (~35 dependent VALU each, on the critical path between the fc2 phases)
-__device__ __forceinline__ float rsqrt_fast(float v) { return __builtin_amdgcn_rsqf(v); }
-
-// Streams with a uniform base go through buffer loads: resource in SGPRs, one loop-invariant 32-bit lane
-// offset in a VGPR, the moving part of the address in an SGPR.  (global_load with 64-bit lane pointers
-// needs a v_lshl_add_u64 per load and moves 512 B of addresses per instruction: in the fc1 loop that alone
-// cost ~800 of ~3200 cycles per K step - tools/micro/fc1_loop.hip.)  Out-of-range reads return 0.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0,
-                                             bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes, 0x00020000);
-}
-// Values that are the same for the whole workgroup but reach it through a vector load (anything read from
-// the layer table after the first store or barrier): pin them to SGPRs.  A buffer resource the compiler
-// cannot prove uniform is otherwise "waterfalled" - a readfirstlane loop around every load.
-__device__ __forceinline__ float uniform_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
-}
-template <typename T>
-__device__ __forceinline__ const T* uniform_p(const T* p) {
-    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
-    return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uni_off) {
-    return __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, uni_off, 0);
-}
-
 // column tiles per fc2 pass: two wherever the tile has two (every W2 fragment then feeds 4 MFMAs and the
 // 512 KiB of W2 stream through the CU half as often); the 4-wave 128-row variant keeps one (its fc2 phase
 // would hold 128 + 64 accumulator VGPRs)
@@ -171,10 +91,6 @@ template <int NA, int NWV>
 constexpr bool fc2_lo8() {
     return NA == 1;
 }
-// fc1's activation ring: tile t sits in stage t % kRing and is written kAhead K steps before it is read, so
-// one barrier per kAhead K steps orders everything (see the prologue of the kernel)
-constexpr int kRing = 4, kAhead = kRing / 2;
-constexpr int kLoShift = 13;   // lo is scaled by 2^13 before the fp8 conversion (and W2's copy by 2^-13)
 template <int NA, int NWV, int G>
 constexpr int exch_bytes() {
     return fc2_lo8<NA, NWV>() ? (16 * 2 * G + 8 * G * 2) * 1024     // hi fragments + fp8 lo operands
@@ -1142,6 +1058,7 @@ struct prag_prober {
     _Float16* ws_l = nullptr;
     int64_t ws_rows = 0;
     int n_cu = 256;            // compute units of the device the handle lives on (tile-height choice)
+    int shape16 = 1;           // fp16 x fp16 mode on 16 x 16 MFMA tiles (PRAG_PROBER_SHAPE=32: the 32 x 32 kernel)
     EventRing prof;
 };
 
@@ -1176,6 +1093,20 @@ static void pack_fragments(const std::vector<double>& Ws, int K, int n_steps, in
                     }
                     deq[(size_t)row * K + col] = q;
                 }
+            }
+}
+
+// the same for 16 x 16 tiles (prober16.hip): fragment (step, hidden tile g of 16 rows), lane (c16 = lane & 15,
+// q4 = lane >> 4) holds row 16 g + c16, element j -> column kmap(step, q4, j); fp16 only
+template <typename KMap>
+static void pack_fragments16(const std::vector<double>& Ws, int K, int n_steps, KMap kmap, std::vector<_Float16>& out) {
+    out.assign((size_t)n_steps * 32 * 64 * 8, (_Float16)0);
+    for (int step = 0; step < n_steps; ++step)
+        for (int g = 0; g < 32; ++g)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = 16 * g + (lane & 15), q4 = lane >> 4;
+                for (int j = 0; j < 8; ++j)
+                    out[((((size_t)step) * 32 + g) * 64 + lane) * 8 + j] = (_Float16)Ws[(size_t)row * K + kmap(step, q4, j)];
             }
 }
 
@@ -1215,6 +1146,22 @@ static void pack_w2q(const std::vector<double>& Ws, std::vector<unsigned char>& 
                     }
 }
 
+// fp8 copy of the (scaled) fc2 matrix for the 16 x 16 kernel: [4 k blocks][32 hidden tiles][2 halves][64 lanes][16 B];
+// byte b of half hf of lane (c16, q4): hidden unit 128 kb + 64 hf + 16 (b >> 2) + 4 q4 + (b & 3)
+static void pack_w2q16(const std::vector<double>& Ws, std::vector<unsigned char>& out) {
+    out.assign((size_t)4 * 32 * 2 * 64 * 16, 0);
+    for (int kb = 0; kb < 4; ++kb)
+        for (int g = 0; g < 32; ++g)
+            for (int hf = 0; hf < 2; ++hf)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int b = 0; b < 16; ++b) {
+                        const int row = 16 * g + (lane & 15), q4 = lane >> 4;
+                        const int col = 128 * kb + 64 * hf + 16 * (b >> 2) + 4 * q4 + (b & 3);
+                        out[((((size_t)kb * 32 + g) * 2 + hf) * 64 + lane) * 16 + b] =
+                            to_e4m3(std::ldexp(Ws[(size_t)row * kHidden + col], -kLoShift));
+                    }
+}
+
 template <typename T>
 static int upload(prag_prober* p, const std::vector<T>& v, const T** out) {
     void* dptr = nullptr;
@@ -1248,6 +1195,7 @@ extern "C" int prag_prober_create(prag_prober_t** out, int n_layers, int d_model
     p->allocs.resize(n_layers);
     p->h_small.resize(n_layers);
     if (const char* ev = getenv("PRAG_PROBER_SMALL")) p->small_mode = atoi(ev);
+    if (const char* ev = getenv("PRAG_PROBER_SHAPE")) p->shape16 = atoi(ev) != 32;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -1328,6 +1276,14 @@ extern "C" int prag_prober_load_layer(prag_prober_t* p, int li, const float* ln0
     const _Float16* dW1 = nullptr;
     if ((rc = upload(p, packed, &dW1)) != PRAG_OK) return rc;
     L.W1f = reinterpret_cast<const u32x4*>(dW1);
+    L.W1g = L.W2g = L.W2qg = nullptr;
+    if (p->na == 1) {   // the same rounded weights in 16 x 16 fragment order (prober16.hip)
+        std::vector<_Float16> p16;
+        pack_fragments16(Wg, d, d / 32, [](int step, int q4, int j) { return 32 * step + 8 * q4 + j; }, p16);
+        const _Float16* dW1g = nullptr;
+        if ((rc = upload(p, p16, &dW1g)) != PRAG_OK) return rc;
+        L.W1g = reinterpret_cast<const u32x4*>(dW1g);
+    }
     if ((rc = upload(p, wsum, &L.wsum1)) != PRAG_OK) return rc;
     if ((rc = upload(p, b1e, &L.b1)) != PRAG_OK) return rc;
     L.sc1 = (float)std::ldexp(1.0, -e1);
@@ -1377,6 +1333,20 @@ extern "C" int prag_prober_load_layer(prag_prober_t* p, int li, const float* ln0
         const unsigned char* dq = nullptr;
         if ((rc = upload(p, q8, &dq)) != PRAG_OK) return rc;
         L.W2q = reinterpret_cast<const u32x4*>(dq);
+        // 16 x 16 tiles: K-32 step ks = 2 w + p, element j of lane quarter q4 -> hidden unit
+        // 64 w + 16 (2 p + (j >> 2)) + 4 q4 + (j & 3)
+        std::vector<_Float16> p16;
+        pack_fragments16(W2g, H, 16,
+                         [](int step, int q4, int j) { return 64 * (step >> 1) + 16 * (2 * (step & 1) + (j >> 2)) + 4 * q4 + (j & 3); },
+                         p16);
+        const _Float16* dW2g = nullptr;
+        if ((rc = upload(p, p16, &dW2g)) != PRAG_OK) return rc;
+        L.W2g = reinterpret_cast<const u32x4*>(dW2g);
+        std::vector<unsigned char> q16;
+        pack_w2q16(W2g, q16);
+        const unsigned char* dq16 = nullptr;
+        if ((rc = upload(p, q16, &dq16)) != PRAG_OK) return rc;
+        L.W2qg = reinterpret_cast<const u32x4*>(dq16);
     }
 
     // ---- fc3: fp32 VALU, fold ln2 affine --------------------------------------
@@ -1576,6 +1546,9 @@ static int forward_impl(prag_prober_t* p, const void* x_dev, int x_dtype, int64_
     }
     // (a 4-wave form of the 128-row tile - one wave per SIMD, 512 registers - was kept behind an environment knob
     // through round 3: slower, and 132 B of scratch per lane; removed)
+    // fp16 weights x fp16 activations (the throughput mode): 16 x 16 MFMA tiles (prober16.hip) at every tile height;
+    // PRAG_PROBER_SHAPE=32 keeps the 32 x 32 kernel for A/B timing
+    if (p->na == 1 && nb == 1 && p->shape16) return prober16_launch(a, n_run, 32 * ct, st, p->prof);
     if (p->na == 1 && nb == 1 && ct == 4) return launch_fused<1, 1, 4, 8>(a, n_run, st, p->prof);
     PRAG_DISPATCH(1, 1)
     PRAG_DISPATCH(1, 2)

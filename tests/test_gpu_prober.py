@@ -445,3 +445,36 @@ def test_decode_step_of_all_layers_pools_in_one_launch(torch_cuda, dtype):
     want = sum(st.float().sum(dim=2) for st in steps[1:]) + steps[3][0].float().sum(dim=1)[None] * \
         torch.tensor([1.0] + [0.0] * (L - 1), device="cuda")[:, None, None]
     np.testing.assert_allclose(a.pooled().cpu().numpy(), want.cpu().numpy(), atol=1e-4)
+
+
+@pytest.mark.parametrize("d", [2048, 320])
+def test_fp16_mode_on_both_mfma_shapes(torch_cuda, monkeypatch, d):
+    """The fp16 x fp16 mode runs on 16 x 16 MFMA tiles (prober16.hip); PRAG_PROBER_SHAPE=32 keeps the 32 x 32 kernel.
+    Same weights, same folding, same fp8 lo term: the two agree to accumulation-order noise at every tile height
+    (32-, 64- and 128-row tiles, ragged last tiles), and both meet the oracle on the weights the kernel holds."""
+    torch = torch_cuda
+    import probing_rag_amd as pra
+    L = 3
+    states = [cases.synth_state(700 + l, d) for l in range(L)]
+    ens16 = pra.HipProberEnsemble(L, d, 2, weights="f16")
+    monkeypatch.setenv("PRAG_PROBER_SHAPE", "32")
+    ens32 = pra.HipProberEnsemble(L, d, 2, weights="f16")
+    monkeypatch.delenv("PRAG_PROBER_SHAPE")
+    for l, st in enumerate(states):
+        ens16.load_layer(l, st)
+        ens32.load_layer(l, st)
+    rng = np.random.default_rng(d)
+    for B in (3, 33, 64, 100, 130, 1000, 2100):
+        x = torch.from_numpy((rng.standard_normal((L, B, d)) * 2.0 + 0.3).astype(np.float32)).cuda().half()
+        a = ens16.forward(x).cpu().numpy()
+        b = ens32.forward(x).cpu().numpy()
+        np.testing.assert_allclose(a, b, atol=3e-5, rtol=0, err_msg=f"B={B}")
+        if B <= 130:
+            want = _oracle_effective(ens16, x.float().cpu().numpy())
+            np.testing.assert_allclose(a, want, atol=TOL, rtol=0, err_msg=f"B={B}")
+    # a row's logits do not depend on the tile it sits in (tile heights 32 / 64 / 128 share the kernel template)
+    x = torch.from_numpy(rng.standard_normal((L, 3000, d)).astype(np.float32)).cuda().half()
+    big = ens16.forward(x).cpu().numpy()
+    sub = np.array([0, 1, 31, 32, 63, 64, 100, 127, 128, 1500, 2999])
+    small = ens16.forward(x[:, sub].contiguous()).cpu().numpy()
+    np.testing.assert_allclose(small, big[:, sub], atol=2e-6, rtol=0)
