@@ -20,10 +20,30 @@
 //         (tools/micro/mfma16_probe.hip checks that operand bytes pair up by (lane quarter, byte))
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "prag_common.h"
 #include "prober_internal.h"
 
 namespace prag {
+
+#ifdef PRAG_MM_DIAG
+// timing-only build (make diag): s_memtime / s_memrealtime stamps of three workgroups, read by tools/prober_stamps.py
+__device__ unsigned long long g_pstamp16[2 * 3 * 8 * 32];
+#define PSTAMP(i)                                                                                                  \
+    if (ps_sel >= 0) {                                                                                             \
+        unsigned long long t_, r_;                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        if (lane == 0) {                                                                                           \
+            g_pstamp16[(ps_sel * 8 + w) * 32 + (i)] = t_;                                                          \
+            g_pstamp16[3 * 8 * 32 + (ps_sel * 8 + w) * 32 + (i)] = r_;                                             \
+        }                                                                                                          \
+    }
+#else
+#define PSTAMP(i)
+#endif
 
 template <int CT16>
 constexpr int p16_lds_bytes() {
@@ -72,6 +92,10 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
     const float L_w3sum[2] = {uniform_f(L.w3sum[0]), uniform_f(L.w3sum[1])};
     const int d = a.d;
     const int T = d >> 6;
+#ifdef PRAG_MM_DIAG
+    const int ps_sel = !a.stamps ? -1 : vidx == 0 ? 0 : vidx == 17 ? 1 : vidx == a.n_tiles * a.n_run - 1 ? 2 : -1;
+#endif
+    PSTAMP(0)
 
     // epilogue constants -> LDS once (loads issued behind the first activation tile's, stored after the weight prologue)
     constexpr int NCST = (6 * kHidden / 4 + NT - 1) / NT;
@@ -192,6 +216,7 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    PSTAMP(1)
     // ---- fc1 main loop: one barrier per kAhead 64-wide K steps ------------------------------------------------------
     for (int t = 0; t < T; ++t) {
         if ((t & (kAhead - 1)) == 0) {
@@ -245,6 +270,7 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
         }
     }
 
+    PSTAMP(2)
     // ---- LayerNorm-0 statistics -> LDS -------------------------------------------------------------------------------
 #pragma unroll
     for (int c = 0; c < NPASS; ++c) {
@@ -263,6 +289,7 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
         }
     }
     __syncthreads();  // stats visible; every wave is done with the staging ring
+    PSTAMP(3)
 
     float* bufS1 = s_red;               // [NWV][ROWS] partial sums of s
     float* bufS2 = s_red + NWV * ROWS;  // [NWV][ROWS] partial sums of s*s
@@ -286,19 +313,20 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
     (void)c16;                                    \
     (void)q4;
 
-    // epilogue 1 on column tiles [c0, c0 + nc): LN0 fold, bias, SiLU in place, partial LN1 sums -> bufS; two column
-    // tiles at a time (eight independent SiLU chains per hidden tile)
+    // epilogue 1 on column tiles [c0, c0 + nc): LN0 fold, bias, SiLU in place, partial LN1 sums -> bufS; up to four
+    // column tiles at a time (sixteen independent SiLU chains per hidden tile)
     auto ep1_cols = [&](const int c0, const int nc) {
+        constexpr int E1 = CT16 < 4 ? CT16 : 4;
 #pragma unroll
-        for (int cb = 0; cb < CT16; cb += 2) {
+        for (int cb = 0; cb < CT16; cb += E1) {
             if (cb < c0 || cb >= c0 + nc) continue;
             P16_LOCAL_LANE()
             // (memory clobber: without it the per-hidden-tile constants below - the same LDS words for every column
             // group - are merged across the groups and 32 registers of them stay live through the whole epilogue)
             asm volatile("" ::: "memory");
-            float mu[2], rs[2], S1[2], S2[2];
+            float mu[E1], rs[E1], S1[E1], S2[E1];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < E1; ++u) {
                 mu[u] = s_mu0[16 * (cb + u) + c16];
                 rs[u] = s_rs0[16 * (cb + u) + c16] * L_sc1;
                 S1[u] = S2[u] = 0.f;
@@ -308,9 +336,9 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
                 const int nb = 64 * w + 16 * ht + 4 * q4;
                 const f32x4 ws = *reinterpret_cast<const f32x4*>(s_cst + nb);
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(s_cst + kHidden + nb);
-                float sv[2][4];
+                float sv[E1][4];
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < E1; ++u)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float v = fmaf(-mu[u], ws[e], acc[ht][cb + u][e]);
@@ -318,11 +346,11 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
                     }
                 // independent SiLU chains, pinned where they are written (see prober.hip)
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < E1; ++u)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(sv[u][e]));
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < E1; ++u)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         acc[ht][cb + u][e] = sv[u][e];
@@ -332,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < E1; ++u) {
                 const float t1 = rsum4(S1[u]), t2 = rsum4(S2[u]);
                 if (q4 == 0) {
                     bufS1[w * ROWS + 16 * (cb + u) + c16] = t1;
@@ -352,12 +380,11 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
         for (int c = 0; c < CT16; ++c)
             if (c >= c0 && c < c0 + nc) {
                 const int m = 16 * c + c16;
-                float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                for (int ww = 0; ww < NWV; ++ww) {
-                    t1 += bufS1[ww * ROWS + m];
-                    t2 += bufS2[ww * ROWS + m];
-                }
+                // (lane quarter q4 adds waves 2 q4, 2 q4 + 1; the four quarters hold the same batch row)
+                float t1 = bufS1[(2 * q4) * ROWS + m] + bufS1[(2 * q4 + 1) * ROWS + m];
+                float t2 = bufS2[(2 * q4) * ROWS + m] + bufS2[(2 * q4 + 1) * ROWS + m];
+                t1 = rsum4(t1);
+                t2 = rsum4(t2);
                 const float mean1 = t1 * (1.0f / kHidden);
                 const float var = fmaxf(t2 * (1.0f / kHidden) - mean1 * mean1, 0.f);
                 s_mu0[m] = mean1;
@@ -491,14 +518,21 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
                 bq[c2] = i32x8{(int)v0[0], (int)v0[1], (int)v0[2], (int)v0[3], (int)v1[0], (int)v1[1], (int)v1[2], (int)v1[3]};
             }
         };
+        bq_read(0);
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
-            const int ht = n & 3;
-            if (ht == 0) bq_read(n >> 2);
+            const int ht = n & 3, kb = n >> 2;
 #pragma unroll
-            for (int c2 = 0; c2 < GC; ++c2)
+            for (int c2 = 0; c2 < GC; ++c2) {
                 acc2[ht][c2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(q2[n & 3], bq[c2], acc2[ht][c2], 0, 0, 0,
                                                                                 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                if (ht == 3 && kb + 1 < 4) {   // the next k block's operand of this column tile, behind its last use
+                    const char* pz = s_lo + (size_t)((((kb + 1) * GC + c2) * 2) * 64 + lane_f) * 16;
+                    const u32x4 v0 = *reinterpret_cast<const u32x4*>(pz);
+                    const u32x4 v1 = *reinterpret_cast<const u32x4*>(pz + 1024);
+                    bq[c2] = i32x8{(int)v0[0], (int)v0[1], (int)v0[2], (int)v0[3], (int)v1[0], (int)v1[1], (int)v1[2], (int)v1[3]};
+                }
+            }
             if (n + 4 < 16) q2_load(n & 3, n + 4);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -509,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
     // epilogue 2 of pass g: LN1 fold, bias, SiLU, one-pass LN2 sums, fc3 partial dot products -> set.  Column tiles in
     // groups of EG (per-row running sums are registers: two groups of two instead of one of four)
     auto ep2 = [&](const int g, f32x4 (&acc2)[HT][GC], float* set) {
-        constexpr int EG = GC < 2 ? GC : 2;
+        constexpr int EG = GC;      // (two groups of two re-read the per-hidden constants: +1.3 k cycles per call)
 #pragma unroll
         for (int cg = 0; cg < GC; cg += EG) {
             asm volatile("" ::: "memory");   // (keeps the constants' LDS loads of each group apart: see epilogue 1)
@@ -593,6 +627,7 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
         f32x4 acc2a[HT][GC], acc2b[HT][GC];
         const bool loop_first = w >= NWV / 2;
         ep1_cols(0, GC);
+        PSTAMP(4)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             a2_load(u, u);
@@ -600,8 +635,10 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
         }
         publish(0);
         zero2(acc2a);
+        PSTAMP(5)
         __syncthreads();   // fragments and the LN1 partial sums of pass 0 are in LDS
         mean_cols(0, GC);
+        PSTAMP(6)
         if (loop_first) {
             __builtin_amdgcn_s_setprio(2);   // finish the k loop first: the other wave then has the pipe alone
             fc2_loop(acc2a);
@@ -609,12 +646,14 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
         }
         ep1_cols(GC, GC);
         if (!loop_first) fc2_loop(acc2a);
+        PSTAMP(7)
         __syncthreads();   // every wave is done with the exchange area; LN1 partial sums of pass 1 are in LDS
         publish(1);
         zero2(acc2b);
         __syncthreads();
         mean_cols(GC, GC);
         __syncthreads();   // bufS is dead from here on: its bytes become the second set of cross-wave sums
+        PSTAMP(8)
         if (!loop_first) {
             __builtin_amdgcn_s_setprio(2);
             fc2_loop(acc2b);
@@ -622,10 +661,13 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
         }
         ep2(0, acc2a, setT0);
         if (loop_first) fc2_loop(acc2b);
+        PSTAMP(9)
         ep2(1, acc2b, setT1);
+        PSTAMP(10)
         __syncthreads();
         if (tid < 64) logits_row(0, tid, setT0);
         else if (tid < 128) logits_row(1, tid - 64, setT1);
+        PSTAMP(11)
     } else {
         f32x4 acc2[HT][GC];
         ep1_cols(0, CT16);
@@ -646,6 +688,13 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
 
 #undef P16_LOCAL_LANE
 
+#ifdef PRAG_MM_DIAG
+extern "C" int prag_diag_prober16_stamps(unsigned long long* out, int n) {
+    if (n > 2 * 3 * 8 * 32) n = 2 * 3 * 8 * 32;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pstamp16), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -2;
+}
+#endif
+
 template <int CT16>
 static int launch_p16(const ProberArgs& a, int n_run, hipStream_t st, EventRing& prof) {
     constexpr int LDS = p16_lds_bytes<CT16>();
@@ -657,6 +706,9 @@ static int launch_p16(const ProberArgs& a, int n_run, hipStream_t st, EventRing&
         if (rc_ != PRAG_OK) return rc_;
     }
     ProberArgs b = a;
+#ifdef PRAG_MM_DIAG
+    b.stamps = getenv("PRAG_PROBER_STAMPS") ? atoi(getenv("PRAG_PROBER_STAMPS")) : 0;
+#endif
     b.n_tiles = (a.B + 16 * CT16 - 1) / (16 * CT16);
     b.n_run = n_run;
     const int per_xcd = (b.n_tiles * n_run + 7) / 8;

@@ -28,7 +28,8 @@ for _ in range(20):
 torch.cuda.synchronize()
 lib = _lib.lib()
 buf = (ctypes.c_ulonglong * (2 * 3 * 8 * 32))()
-fn = lib.prag_diag_prober_stamps
+# the fp16 x fp16 mode runs prober16.hip (16 x 16 MFMA tiles) unless PRAG_PROBER_SHAPE=32
+fn = lib.prag_diag_prober_stamps if os.environ.get("PRAG_PROBER_SHAPE") == "32" else lib.prag_diag_prober16_stamps
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert fn(buf, len(buf)) == 0
 both = np.frombuffer(buf, dtype=np.uint64).astype(np.int64).reshape(2, 3, 8, 32)
