@@ -2000,7 +2000,9 @@ static SearchPlan plan_search(const PlanEnv& e) {
         P.family = P.use_mm8 ? "scan_mm_kernel<int8 tiles over the 8-bit shadow>" : "scan_mm_kernel";
         const int growth = P.use_mm8 ? kMm8Growth : 16;      // (search_tiled lowers it for deep lists)
         int segs = 1;
-        for (int64_t hi = std::min<int64_t>(N, kMmFirstSeg); hi < N; hi = std::min<int64_t>(N, hi * growth)) ++segs;
+        for (int64_t hi = std::min<int64_t>(N, kMmFirstSeg); hi < N;
+             hi = std::min<int64_t>(N, hi * mm_growth_step(growth, segs - 2, P.use_mm8)))
+            ++segs;
         P.launches = segs * ((P.Bpad + P.mm_chunk - 1) / P.mm_chunk);
         P.bytes_per_launch = P.use_mm8 ? N * (d + 4) + l2 : N * d * 2 + l2;
     } else if (P.use_shadow) {

@@ -107,6 +107,15 @@ struct MmSearch {
 };
 
 constexpr int kMmFirstSeg = 2048;    // rows of the first segment (all of them become candidates); segments grow x16
+// Segment boundaries: the first one grows by `growth` (x16 unless the candidate regions are smaller), the later ones
+// by at most 4 - a filter group of 1024 scores holds a survivor with probability ~ 1 - exp(-1024 kc / rows seen at the
+// last bound update), so a long segment behind a young bound takes the slow path in ~40 % of its groups.  Measured,
+// 1000 x 1 M x 768 (profiles/r04n_c3_growth_schedule.txt): x16 everywhere 1.462 ms, x16 then x4 1.431 ms.  int8 tiles
+// keep their own (already short) growth.
+constexpr int kMmLaterGrowth = 4;
+inline int mm_growth_step(int growth, int step, bool i8) {
+    return (i8 || step == 0) ? growth : (growth < kMmLaterGrowth ? growth : kMmLaterGrowth);
+}
 constexpr int kMmCapQ = kMmFirstSeg; // candidate slots per query in ckey/cidx
 constexpr int kMmCapWg = 64;         // survivors one workgroup can hold per query and segment
 constexpr int kMmMaxQueries = 4096;  // queries per mm_run call (LDS counters); larger batches go in chunks

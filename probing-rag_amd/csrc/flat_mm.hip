@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "flat_internal.h"
 
@@ -837,6 +838,13 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
 #endif
     int64_t lo = 0;
     int64_t hi = first_rows;  // first segment: every row is a candidate
+    static const std::vector<int> sched_env = [] {   // experiment switch: "g1,g2,..." growth per boundary
+        std::vector<int> v;
+        if (const char* e = getenv("PRAG_MM_GROWTH_SCHED"))
+            for (const char* p = e; *p;) { v.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
+        return v;
+    }();
+    int seg_i = 0;
     while (lo < s.N) {
         a.row0 = lo;
         a.row1 = hi;
@@ -914,7 +922,10 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
                                s.wg_slots, s.Bpad, s.gate);
         PRAG_LAUNCH_CHECK();
         lo = hi;
-        hi = std::min<int64_t>(s.N, hi * (int64_t)std::max(2, std::min(16, s.growth)));
+        int g_step = mm_growth_step(s.growth, seg_i, s.i8 != 0);
+        if (!sched_env.empty() && !s.i8) g_step = sched_env[std::min<size_t>(seg_i, sched_env.size() - 1)];
+        ++seg_i;
+        hi = std::min<int64_t>(s.N, hi * (int64_t)std::max(2, std::min(16, g_step)));
     }
     return PRAG_OK;
 }

@@ -12,7 +12,7 @@ ix = pra.HipFlatIndex(d, "cos", "f16", capacity=N)
 ix.add_synthetic(42, 0, N)
 Q = torch.from_numpy(onp.synth_rows(7, 0, B, d)).cuda()
 n = int(os.environ.get("C3_REPS", 10))
-for shadow in (0, 2):       # 0: fp16 tiles; 2: int8 tiles over the 8-bit shadow first (PRAG_MM8=0 switches them off)
+for shadow in ((0,) if os.environ.get("C3_ONLY16") else (0, 2)):       # 0: fp16 tiles; 2: int8 tiles over the 8-bit shadow first (PRAG_MM8=0 switches them off)
     ix.set_shadow(shadow)
     ix.prepare()
     for _ in range(3):
