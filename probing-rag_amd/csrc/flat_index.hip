@@ -1363,6 +1363,7 @@ struct prag_index {
     size_t mm_w_entries = 0;      // entries of mm_wkey / mm_widx
     size_t mm_c_entries = 0;      // entries of mm_ckey / mm_cidx, mm_wcnt words
     int mm_mode = 1;   // 0 = never take the MFMA-tiled path (PRAG_SCAN_MM=0)
+    int shadow_bound_mode = -1;   // -1 auto, 0 off, 1 on (PRAG_SHADOW_BOUND)
     int mm_shape16 = 1;   // tiled scans on 16 x 16 MFMA tiles (PRAG_MM_SHAPE=32: the 32 x 32 form, A/B timing)
     // 8-bit selection for the MFMA-tiled scan (> 128 queries on an index that keeps a shadow): int8 MFMA over the
     // shadow, kMm8Kc candidates per query, the shadow's error bound in the certificate; the queries that fail that
@@ -1633,6 +1634,7 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
     if (const char* e = getenv("PRAG_CERT")) ix->cert_mode = atoi(e);
 #endif
     if (const char* e = getenv("PRAG_MM_SHAPE")) ix->mm_shape16 = atoi(e) != 32;
+    if (const char* e = getenv("PRAG_SHADOW_BOUND")) ix->shadow_bound_mode = atoi(e);
     if (const char* e = getenv("PRAG_MM8")) ix->mm8_mode = atoi(e) != 0;
     if (const char* e = getenv("PRAG_MM8_MIN_ROWS")) ix->mm8_min_rows = atoll(e);
     if (const char* e = getenv("PRAG_PREPASS")) ix->prepass_mode = atoi(e);
@@ -2643,6 +2645,8 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         ss.done = ix->sh_ovf + ix->sh_q_cap;
         ss.cert = cert;
         ss.gate = ix->gate;
+        // one more small launch; pays once the candidate lists are long (measured: profiles/r04p_exact_bound_ab.txt)
+        ss.exact_bound = k <= 32 && (ix->shadow_bound_mode < 0 ? ix->ntotal >= (1ll << 19) : ix->shadow_bound_mode != 0);
         rc = shadow_search(ss, st, prof);
         if (rc != PRAG_OK) return rc;
         reranked = true;

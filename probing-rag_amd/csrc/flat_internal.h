@@ -520,6 +520,7 @@ struct ShadowSearch {
     uint32_t* done;          // [Bpad]
     CertArgs cert;           // flag list: queries whose candidate regions overflowed go to the exact scan
     Gate gate;
+    bool exact_bound = false;   // lower g_tau to an exact k-th best before the gather (shadow_bound_kernel)
 };
 bool shadow_store_supported(int d);
 bool shadow_tile128_ok(int d, int kc);

@@ -748,6 +748,257 @@ struct GatherArgs {
     int dbg;                // timing experiments only (PRAG_SHADOW_DBG bits 32 / 64 / 128; results are WRONG)
 };
 
+// Exact float64 score of one stored row against the staged query: 16 lanes per row (sub = lane & 15), every lane of
+// the group returns the sum.  ONE definition for the bound kernel and the gather: both must form the same bits.
+template <bool F32>
+__device__ __forceinline__ double sh_exact_row(const GatherArgs& a, const float* s_q, int64_t row, bool have, int sub) {
+    const int d = a.d;
+    double s = 0.0;
+    if (have) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {       // d <= 1024
+            const int e = sub * 8 + it * 128;
+            if (e < d) {
+                float xv[8];
+                if constexpr (F32) {
+                    const float* p = reinterpret_cast<const float*>(a.rows) + row * d + e;
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(p);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { xv[j] = x0[j]; xv[4 + j] = x1[j]; }
+                } else {
+                    const half8 h = *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(a.rows) + row * d + e);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[j] = (float)h[j];
+                }
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(s_q + e);
+                const f32x4 q1 = *reinterpret_cast<const f32x4*>(s_q + e + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double qv = (double)(j < 4 ? q0[j] : q1[j - 4]);
+                    const double x = (double)xv[j];
+                    if (a.metric_l2) {
+                        const double df = qv - x;
+                        s = fma(df, df, s);
+                    } else {
+                        s = fma(qv, x, s);
+                    }
+                }
+            }
+        }
+    }
+    s += sh_dpp_f64<0xB1>(s);
+    s += sh_dpp_f64<0x4E>(s);
+    s += sh_dpp_f64<0x141>(s);
+    s += sh_dpp_f64<0x140>(s);
+    return s;
+}
+
+// ---------------------------------------------------------------------------
+// An EXACT bound for the gather - and, when few rows are left under it, the end of the search in the same launch.
+// The scan's own final bound is the maximum over 16 groups of workgroups of the group's best pessimistic key
+// (key + a eps): about the 50th best row of the rows seen by the last epoch, two error terms above the k-th best exact
+// key.  At the 8-GPU shard size ~2 200 candidates per query pass it (measured, 64 queries x 2.6 M rows: 220 MB of
+// stored rows fetched by the gather, 39 of its 58 us; six dependent memory round trips in its publish-and-merge chain).
+// Here ONE workgroup per query reads every candidate entry of the query once, keeps the most promising one per thread
+// (smallest key - a eps), every 16 lanes score their best one exactly in float64 (the gather's arithmetic) and g_tau
+// drops to the k-th best exact key of those 32 rows, moved into the scan's key space and rounded up: the k-th best of
+// ANY k rows bounds the k-th best of all.  Nothing is removed that the round-3 argument kept: a row among the k best has
+// key - a eps <= its exact key <= the k-th best exact key <= this bound.  The rows within ONE error term of that bound
+// are tens, not thousands: up to kShFinish of them are scored right here and D / I written; the sliced gather that
+// follows sees the query's `done` word taken and returns after its first load.  More survivors, a region that
+// overflowed, or fewer than k rows scored: the sliced gather does the work, under the lower bound.
+// ---------------------------------------------------------------------------
+constexpr int kShFinish = 256;                 // survivors this kernel scores itself (steps of 32 rows)
+constexpr uint32_t kShDoneTaken = 0x80000000u; // done[b]: the query was finished by shadow_bound_kernel
+template <bool F32>
+__global__ __launch_bounds__(kShThreads) void shadow_bound_kernel(GatherArgs a, uint32_t* __restrict__ g_tau_w) {
+    if (gate_closed(a.cert.gate)) return;
+#ifdef PRAG_MM_DIAG
+    unsigned long long stamp[10];
+    int n_stamp = 0;
+#define SH_STAMP() do { if (a.dbg & 512) stamp[n_stamp++] = wall_clock64(); } while (0)
+#else
+#define SH_STAMP() do {} while (0)
+#endif
+    SH_STAMP();
+    __shared__ __attribute__((aligned(16))) float s_q[1024];
+    __shared__ unsigned long long s_key[kShFinish];
+    __shared__ int s_fid[kShFinish];
+    __shared__ double s_qn2;
+    __shared__ int s_n, s_over;
+    __shared__ float s_taux;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int sub = lane & 15, slot = lane >> 4;
+    const int qi = blockIdx.x, b = a.q0 + qi, d = a.d;
+    const uint32_t tau_bits = a.g_tau[qi];
+    const float tau_final = unsortable_f32(tau_bits);
+    if (tid == 0) {
+        s_n = 0;
+        s_over = 0;
+        s_taux = tau_final;
+    }
+    // ---- the most promising entry of every thread: two threads per candidate region ------------------------------------
+    // The first 32 slots of the thread's region are fetched WITH its count (one round trip, not two; slots past the count
+    // hold entries of earlier searches and are masked) and stay in registers for the second pass.
+    constexpr int kKeep = 16;
+    const int2 none = int2{0, 0x7fc00000};       // key = NaN: never <= a bound
+    int2 ev0[kKeep];
+    const int rg0 = tid >> 1, par = tid & 1;
+    const bool spec = a.cap >= 2 * kKeep && rg0 < a.n_wg;
+    uint32_t c_raw0 = 0;
+    if (rg0 < a.n_wg) c_raw0 = a.ccnt[(int64_t)rg0 * a.QT + qi];
+    {
+        const int2* src = a.cand + ((int64_t)rg0 * a.QT + qi) * a.cap + par;
+#pragma unroll
+        for (int u = 0; u < kKeep; ++u) ev0[u] = spec ? src[2 * u] : none;
+    }
+    for (int c = tid; c < 1024; c += kShThreads) s_q[c] = c < d ? a.q32[(int64_t)b * d + c] : 0.f;
+    bool over_l = c_raw0 > (uint32_t)a.cap;
+    const int c0 = (int)min(c_raw0, (uint32_t)a.cap);
+    float best = INFINITY;
+    int best_id = 0x7fffffff;
+    auto consider = [&](int2 e) {
+        const float lo = __uint_as_float((uint32_t)e.y);
+        if (lo <= tau_final && (lo < best || (lo == best && e.x < best_id))) {
+            best = lo;
+            best_id = e.x;
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < kKeep; ++u) {
+        if (par + 2 * u >= c0) ev0[u] = none;
+        consider(ev0[u]);
+    }
+    const bool simple = spec && c0 <= 2 * kKeep && a.n_wg <= kShThreads / 2;
+    // every entry the registers do not hold (long regions, more than 256 regions), eight loads in flight
+    auto rest = [&](auto&& fn) {
+        for (int rg = rg0; rg < a.n_wg; rg += kShThreads / 2) {
+            const uint32_t c_raw = rg == rg0 ? c_raw0 : a.ccnt[(int64_t)rg * a.QT + qi];
+            over_l |= c_raw > (uint32_t)a.cap;
+            const int c = (int)min(c_raw, (uint32_t)a.cap);
+            const int2* src = a.cand + ((int64_t)rg * a.QT + qi) * a.cap;
+            for (int j0 = par + (rg == rg0 && spec ? 2 * kKeep : 0); j0 < c; j0 += 16) {
+                int2 ev[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ev[u] = j0 + 2 * u < c ? src[j0 + 2 * u] : none;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) fn(ev[u]);
+            }
+        }
+    };
+    if (!simple) rest(consider);
+    // ---- the best of every 16 lanes (DPP, no LDS): the group that found a row scores it --------------------------------
+    // (32 rows from 32 disjoint parts of the candidate set: two of the k best in one part cost a place in the bound -
+    // the 12th best instead of the 10th, a few more survivors below)
+    const unsigned long long pick = group_min16_u64(best < INFINITY ? pack_key(best, best_id) : ~0ull);
+    if (over_l) s_over = 1;
+    __syncthreads();
+    SH_STAMP();
+    if (w == 1 && a.metric_l2) {   // ||q||^2 in float64 (L2 keys leave it out)
+        double q2 = 0.0;
+        for (int c = lane; c < d; c += 64) q2 = fma((double)s_q[c], (double)s_q[c], q2);
+        for (int o = 32; o > 0; o >>= 1) q2 += __shfl_xor(q2, o, 64);
+        if (lane == 0) s_qn2 = q2;
+    }
+    {
+        const int ci = w * 4 + slot;
+        const bool have = pick != ~0ull;
+        const int64_t row = have ? (int64_t)(uint32_t)pick : 0;
+        const double s = sh_exact_row<F32>(a, s_q, row, have, sub);
+        if (sub == 0) {
+            s_key[ci] = have ? (a.metric_l2 ? sortable_u64(s) : ~sortable_u64(s)) : ~0ull;
+            s_fid[ci] = have ? (int)row : 0x7fffffff;      // the first 32 entries of the final ranking
+        }
+    }
+    __syncthreads();
+    SH_STAMP();
+    if (tid < 32) {
+        const unsigned long long kv = s_key[tid];
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const unsigned long long kj = s_key[j];
+            rank += (kj < kv) || (kj == kv && j < tid);
+        }
+        if (rank == a.k - 1 && kv != ~0ull) {
+            const double sc = unsortable_f64(a.metric_l2 ? kv : ~kv);
+            // the scan's key space: -score (inner product, cosine), ||x||^2 - 2 q.x = ||q - x||^2 - ||q||^2 (L2)
+            const double t = a.metric_l2 ? sc - s_qn2 : -sc;
+            float tf = __double2float_ru(t);
+            tf = fmaf(2.4e-7f, fabsf(tf) + (a.metric_l2 ? (float)s_qn2 : 0.f), tf) + 1e-37f;   // upward only: never excludes
+            const uint32_t v = sortable_u32(tf);
+            if (v < tau_bits) {
+                g_tau_w[qi] = v;
+                s_taux = tf;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- second pass: what the exact bound still admits ----------------------------------------------------------------
+    const float tau_x = s_taux;
+    // (the row this thread's group has scored already is not admitted again: its exact key sits in s_key[0..31])
+    const int picked = pick != ~0ull ? (int)(uint32_t)pick : -1;
+    auto admit = [&](int2 e) {
+        if (__uint_as_float((uint32_t)e.y) <= tau_x && e.x != picked) {
+            const int at = 32 + atomicAdd(&s_n, 1);
+            if (at < kShFinish) s_fid[at] = e.x;
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < kKeep; ++u) admit(ev0[u]);
+    if (!simple) rest(admit);
+    for (int i = 32 + tid; i < kShFinish; i += kShThreads) s_key[i] = ~0ull;
+    __syncthreads();
+    SH_STAMP();
+    const int n_fin = 32 + s_n;
+    // finish here only when it is certain and small: no overflowed region, at most kShFinish survivors (fewer than k
+    // is fine: the scan excluded every other row for good - the padding below is what the gather's merge writes)
+    if (s_over || n_fin > kShFinish) return;
+    for (int i0 = 32; i0 < n_fin; i0 += 32) {
+        const int ci = i0 + w * 4 + slot;
+        const bool have = ci < n_fin;
+        const int64_t row = have ? s_fid[ci] : 0;
+        const double s = sh_exact_row<F32>(a, s_q, row, have, sub);
+        if (sub == 0 && have) s_key[ci] = a.metric_l2 ? sortable_u64(s) : ~sortable_u64(s);
+    }
+    __syncthreads();
+    SH_STAMP();
+    // rank by counting, 16 lanes per entry (a serial loop over ~50 entries was 6 of the kernel's 20 us: two dependent LDS
+    // reads per step); groups without a pick hold (worst key, no id) - what pads the gather's merge when fewer than k
+    // rows exist (n_fin >= 32 >= k)
+    for (int i0 = 0; i0 < n_fin; i0 += 32) {
+        const int ci = i0 + w * 4 + slot;
+        const bool have = ci < n_fin;
+        const unsigned long long kv = have ? s_key[ci] : 0ull;
+        const int iv = have ? s_fid[ci] : 0;
+        int rank = 0;
+        for (int j = sub; j < n_fin; j += 16) {
+            const unsigned long long kj = s_key[j];
+            const int ij = s_fid[j];
+            rank += ((kj < kv) || (kj == kv && (ij < iv || (ij == iv && j < ci)))) ? 1 : 0;
+        }
+        rank += __builtin_amdgcn_update_dpp(0, rank, 0xB1, 0xF, 0xF, false);
+        rank += __builtin_amdgcn_update_dpp(0, rank, 0x4E, 0xF, 0xF, false);
+        rank += __builtin_amdgcn_update_dpp(0, rank, 0x141, 0xF, 0xF, false);
+        rank += __builtin_amdgcn_update_dpp(0, rank, 0x140, 0xF, 0xF, false);
+        if (have && sub == 0 && rank < a.k) {
+            const bool ok = iv != 0x7fffffff;
+            const double sc = ok ? unsortable_f64(a.metric_l2 ? kv : ~kv) : 0.0;
+            a.D[(int64_t)b * a.k + rank] = ok ? (float)sc : (a.metric_l2 ? FLT_MAX : -FLT_MAX);
+            a.I[(int64_t)b * a.k + rank] = ok ? tag_id((int64_t)iv + a.id_offset, sc, a.cert.tag_ids) : -1;
+        }
+    }
+    if (tid == 0) a.done[b] = kShDoneTaken;
+    SH_STAMP();
+#ifdef PRAG_MM_DIAG
+    if ((a.dbg & 512) && tid == 0)
+        printf("[bound] query %d: %d ranked; x10 ns: entries+select %llu, 32 rows %llu, bound+filter %llu, survivors' rows %llu, rank+write %llu\n",
+               qi, n_fin, stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4]);
+#endif
+#undef SH_STAMP
+}
+
 template <bool F32>
 __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a) {
     __shared__ ShTopK tk;
@@ -773,6 +1024,7 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
     // One memory round trip brings the query, the final bound and the region counts of the slice, a second one
     // every filled slot of every region (instead of a count -> entries chain per region).
     const float tau_final = unsortable_f32(a.g_tau[qi]);
+    const uint32_t taken = a.done[b];              // (uniform; read with the loads below in flight)
     const int nsplit = (int)gridDim.x;             // slices per query (<= kShSplit)
     const int per = (a.n_wg + nsplit - 1) / nsplit;
     const int wg0 = blockIdx.x * per, wg1 = min(a.n_wg, wg0 + per);
@@ -784,6 +1036,7 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
         s_rc[i] = (int)min(c, (uint32_t)a.cap);
     }
     for (int c = tid; c < d; c += kShThreads) s_q[c] = a.q32[(int64_t)b * d + c];
+    if (taken == kShDoneTaken) return;             // shadow_bound_kernel wrote this query's D / I already
     __syncthreads();
     if (over_l) s_over = 1;
     for (int base = 0; base < ((PRAG_SH_DBG(a.dbg) & 128) ? 0 : nreg * a.cap); base += 8 * kShThreads) {
@@ -806,6 +1059,13 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
     }
     __syncthreads();
     const int n_ids = (PRAG_SH_DBG(a.dbg) & 32) ? 0 : min(s_n, kShIds);
+#ifdef PRAG_MM_DIAG
+    if ((a.dbg & 256) && tid == 0 && (qi < 2 || (a.dbg & 512))) {
+        int tot = 0;
+        for (int i = 0; i < nreg; ++i) tot += s_rc[i];
+        printf("[gather] query %d slice %d: %d regions hold %d entries (cap %d), %d pass the final bound\n", qi, (int)blockIdx.x, nreg, tot, a.cap, s_n);
+    }
+#endif
     if (s_over && tid == 0 && atomicExch(a.ovf + b, 1u) == 0u) cert_flag(a.cert, b);   // exact scan recomputes b
     // (Round 3: a second-level filter here - both int8 query terms over the candidate's 8-bit row before its stored
     // row is fetched, for the tiles whose scan used one term - was built and measured: search time unchanged at
@@ -819,44 +1079,7 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
         const int ci = i0 + w * 4 + slot;
         const bool have = ci < n_ids;
         const int64_t row = have ? s_ids[ci] : 0;
-        double s = 0.0;
-        if (have) {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {       // d <= 1024
-                const int e = sub * 8 + it * 128;
-                if (e < d) {
-                    float xv[8];
-                    if constexpr (F32) {
-                        const float* p = reinterpret_cast<const float*>(a.rows) + row * d + e;
-                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(p);
-                        const f32x4 x1 = *reinterpret_cast<const f32x4*>(p + 4);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { xv[j] = x0[j]; xv[4 + j] = x1[j]; }
-                    } else {
-                        const half8 h = *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(a.rows) + row * d + e);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) xv[j] = (float)h[j];
-                    }
-                    const f32x4 q0 = *reinterpret_cast<const f32x4*>(s_q + e);
-                    const f32x4 q1 = *reinterpret_cast<const f32x4*>(s_q + e + 4);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const double qv = (double)(j < 4 ? q0[j] : q1[j - 4]);
-                        const double x = (double)xv[j];
-                        if (a.metric_l2) {
-                            const double df = qv - x;
-                            s = fma(df, df, s);
-                        } else {
-                            s = fma(qv, x, s);
-                        }
-                    }
-                }
-            }
-        }
-        s += sh_dpp_f64<0xB1>(s);
-        s += sh_dpp_f64<0x4E>(s);
-        s += sh_dpp_f64<0x141>(s);
-        s += sh_dpp_f64<0x140>(s);
+        const double s = sh_exact_row<F32>(a, s_q, row, have, sub);
         if (sub == 0 && have) {
             const unsigned long long key = a.metric_l2 ? sortable_u64(s) : ~sortable_u64(s);
             if (key <= tk.bound) {
@@ -1057,6 +1280,13 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         g.cert = s.cert;
         g.cert.gate = s.gate;
         g.dbg = a.dbg;
+        if (s.exact_bound) {     // (k <= 32: the kernel scores 32 rows)
+            if (s.store.store_f32)
+                hipLaunchKernelGGL(shadow_bound_kernel<true>, dim3(nq), dim3(kShThreads), 0, st, g, s.g_tau + p0);
+            else
+                hipLaunchKernelGGL(shadow_bound_kernel<false>, dim3(nq), dim3(kShThreads), 0, st, g, s.g_tau + p0);
+            PRAG_LAUNCH_CHECK();
+        }
         if (s.store.store_f32)
             hipLaunchKernelGGL(shadow_gather_kernel<true>, dim3(nsplit, nq), dim3(kShThreads), 0, st, g);
         else

@@ -11,6 +11,15 @@ pytestmark = pytest.mark.gpu
 METRICS = [onp.METRIC_L2, onp.METRIC_IP, onp.METRIC_COS]
 
 
+@pytest.fixture(params=[None, "1"], ids=["bound-auto", "bound-on"])
+def shadow_bound(request, monkeypatch):
+    """Second run with the exact-bound / finish kernel in front of the gather forced on (shadow_bound_kernel,
+    flat_shadow.hip; by itself it starts at 2^19 rows - the big-corpus tests and the bench riders cover that side)."""
+    if request.param:
+        monkeypatch.setenv("PRAG_SHADOW_BOUND", request.param)     # read when the index is created
+    return request.param
+
+
 def _stored(X, metric, store):
     xs = onp.normalize_rows(X) if metric == onp.METRIC_COS else X
     return onp.store_round(xs, store)
@@ -30,7 +39,7 @@ def _check(D, I, D0, I0, metric):
                                      (4097, 40, 12, 512), (777, 1, 1, 1024), (30_000, 7, 10, 768),
                                      (20_000, 3, 26, 256), (9000, 50, 20, 768),      # 32-deep bound lists
                                      (5000, 70, 5, 384)])
-def test_shadow_search_matches_definition(metric, store, N, B, k, d):
+def test_shadow_search_matches_definition(metric, store, N, B, k, d, shadow_bound):
     import probing_rag_amd as pra
     X = onp.synth_rows(42, 0, N, d)
     if N > 40:
@@ -54,7 +63,7 @@ def test_shadow_search_matches_definition(metric, store, N, B, k, d):
 
 
 @pytest.mark.parametrize("metric", METRICS)
-def test_shadow_on_rows_the_quantiser_handles_badly(metric):
+def test_shadow_on_rows_the_quantiser_handles_badly(metric, shadow_bound):
     """Near-parallel rows with one huge element each: the per-row 8-bit grid is coarse relative to the
     differences that decide the ranking, the filter cannot exclude much, candidate regions overflow -
     flagged queries must come out of the exact scan; results still exact."""
@@ -104,7 +113,7 @@ def test_shadow_filter_statistics_on_a_random_corpus():
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
-def test_shadow_equals_the_direct_scan_on_clustered_rows(seed):
+def test_shadow_equals_the_direct_scan_on_clustered_rows(seed, shadow_bound):
     """Mid-size shards (a few tiles per wave: the warm-up / second-visit logic and the early bound slots
     carry the whole search) with clustered, unevenly scaled rows: the two-level search and the direct
     scan of the stored rows are independent routes to the same answer and must agree bit for bit; a few
@@ -172,7 +181,7 @@ def test_contiguous_clusters_stay_on_the_two_level_path():
 @pytest.mark.parametrize("metric", METRICS)
 @pytest.mark.parametrize("N,B,k,d", [(40_000, 128, 10, 768), (9_001, 65, 5, 768), (20_000, 100, 12, 512),
                                      (300, 77, 10, 768)])
-def test_128_query_tiles_match_definition(metric, store, N, B, k, d):
+def test_128_query_tiles_match_definition(metric, store, N, B, k, d, shadow_bound):
     """65..128 queries take ONE pass over the shadow with 128-query tiles (list-less scan8, bound from the
     slot epochs alone): results are the float64 definition's bit for bit, duplicates and planted rows included."""
     import probing_rag_amd as pra
