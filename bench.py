@@ -300,6 +300,9 @@ def _run_group(cmd, cwd=None, env=None, timeout=None):
         return "timeout"
 
 
+GATE_KERNELS = ("prober16_kernel", "prober_fused_kernel")
+
+
 def _pmc_passes(counters, kernel_substr, prof_args):
     """One child `rocprofv3 --pmc <counter>` pass per counter (never combined with trace domains) over
     tools/prof_kernels.py; returns ({counter: mean value over the full-grid launches of the kernel} or None, note)."""
@@ -323,7 +326,9 @@ def _pmc_passes(counters, kernel_substr, prof_args):
             return None, f"rocprofv3 --pmc {counter} failed: {err}"
         rows = []
         for f in glob.glob(os.path.join(out_dir, "**", "*_counter_collection.csv"), recursive=True):
-            rows += [r for r in csv.DictReader(open(f)) if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            subs = (kernel_substr,) if isinstance(kernel_substr, str) else tuple(kernel_substr)
+            rows += [r for r in csv.DictReader(open(f))
+                     if any(s_ in r["Kernel_Name"] for s_ in subs) and r["Counter_Name"] == counter]
         shutil.rmtree(out_dir, ignore_errors=True)
         if not rows:
             return None, f"no {kernel_substr} launch in the --pmc {counter} pass"
@@ -348,9 +353,10 @@ def measure_traffic(n_local, store, metric, queries, shadow, kernel, k=10):
 
 
 def measure_gate_mfma(gate_batch):
-    """Matrix-pipe utilisation of prober_fused_kernel: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), each
-    counter in its own child pass.  Returns (fraction or None, note)."""
-    got, note = _pmc_passes(("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES"), "prober_fused",
+    """Matrix-pipe utilisation of the fused prober kernel (prober16_kernel: 16x16x32 MFMA tiles, the default;
+    prober_fused_kernel: the 32x32x16 form behind PRAG_PROBER_SHAPE=32): SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x
+    SQ_BUSY_CU_CYCLES), each counter in its own child pass.  Returns (fraction or None, note)."""
+    got, note = _pmc_passes(("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES"), GATE_KERNELS,
                             ["--skip-scan", "--gate-batch", str(gate_batch), "--iters", "5"])
     if got is None or not got["SQ_BUSY_CU_CYCLES"]:
         return None, note
@@ -752,7 +758,7 @@ def main(argv=None):
                       "stored_row_bytes": stored_row_bytes(args.store, args.metric, n_local),
                       "avg_launch_ms": scan_avg_ms,
                       "launches_per_pass": launches, "launches_timed": len(scan_ms)}),
-        "roofline_gate": {"bound": "mfma", "kernel": "prober_fused_kernel", "achieved": gate_flops / (gate_avg_ms * 1e-3) / 1e12,
+        "roofline_gate": {"bound": "mfma", "kernel": GATE_KERNELS[1 if os.environ.get("PRAG_PROBER_SHAPE") == "32" else 0], "achieved": gate_flops / (gate_avg_ms * 1e-3) / 1e12,
                           "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                           "frac": gate_flops / (gate_avg_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF,
                           "avg_launch_ms": gate_avg_ms,

@@ -1432,6 +1432,9 @@ struct prag_index {
     // 8-bit shadow (flat_shadow.hip): 0 off, 1 (default) on for shards >= kShadowMinRows when the device has
     // room for it, 2 on at any size
     int shadow_mode = 1;
+    bool shadow_failed = false;    // the shadow could not be extended at the end of an add (rows are committed; they are
+                                   // scanned directly until prag_index_set_shadow is called again); the message stays
+                                   // in prag_last_error
     bool shadow_no_room = false;   // mode 1: the allocation did not fit next to the rows; rows are scanned directly
     signed char* rows8 = nullptr;
     float* sscale = nullptr;
@@ -1530,7 +1533,7 @@ constexpr int64_t kShadowMinRows = 1 << 20;
 // Does this index keep a shadow at its current size / mode?  (mode 1: shards of >= 2^20 rows when the
 // device has room for d + 8 more bytes per row with 2 GB to spare; mode 2: any size)
 static bool shadow_wanted(prag_index* ix) {
-    if (!ix->shadow_mode || ix->ntotal == 0 || !shadow_store_supported(ix->d)) return false;
+    if (!ix->shadow_mode || ix->ntotal == 0 || !shadow_store_supported(ix->d) || ix->shadow_failed) return false;
     if (ix->shadow_mode >= 2) return true;
     if (ix->ntotal < kShadowMinRows || ix->shadow_no_room) return false;
     if (ix->shadow_cap < ix->cap) {
@@ -1557,7 +1560,15 @@ static int shadow_ensure(prag_index* ix, hipStream_t st) {
         PRAG_LAUNCH_CHECK();
         ix->xn_max_rows = ix->ntotal;
     }
-    if (!shadow_wanted(ix)) return PRAG_OK;
+    if (!shadow_wanted(ix)) {
+        if ((ix->shadow_no_room || ix->shadow_failed) && ix->rows8) {   // an undersized shadow nobody will read again
+            PRAG_HIP(hipStreamSynchronize(st));                          // (a search may still be reading it)
+            for (void* p : {(void*)ix->rows8, (void*)ix->sscale, (void*)ix->serr})
+                if (p) (void)hipFree(p);
+            ix->rows8 = nullptr; ix->sscale = nullptr; ix->serr = nullptr; ix->shadow_cap = 0; ix->shadow_rows = 0;
+        }
+        return PRAG_OK;
+    }
     if (ix->shadow_cap < ix->cap) {    // (re)allocate with the rows; rebuilt from row 0
         PRAG_HIP(hipStreamSynchronize(st));   // a search may still be reading the old shadow on this stream
         for (void* p : {(void*)ix->rows8, (void*)ix->sscale, (void*)ix->serr})
@@ -1597,6 +1608,19 @@ static int shadow_ensure(prag_index* ix, hipStream_t st) {
         ix->mm8_auto_off = false;
         ix->mm8_off_count = 0;
         ix->mm8_off_period = 64;
+    }
+    return PRAG_OK;
+}
+
+// At the end of an add the rows are already committed: a shadow that cannot follow them (allocation, build) must not
+// make the add fail - a caller that retried would add the rows twice.  The index scans its rows directly from then on
+// (shadow_failed; prag_index_set_shadow clears it), the reason stays readable through prag_last_error.
+static int shadow_after_add(prag_index* ix, hipStream_t st) {
+    const int rc = shadow_ensure(ix, st);
+    if (rc != PRAG_OK) {
+        (void)hipGetLastError();
+        ix->shadow_failed = true;
+        (void)shadow_ensure(ix, st);      // frees what is left of the shadow
     }
     return PRAG_OK;
 }
@@ -1692,7 +1716,7 @@ extern "C" int prag_index_add(prag_index_t* ix, const float* x, int64_t n, int s
         rc = launch_add(ix, x, false, 0, 0, n, st);
         if (rc != PRAG_OK) return rc;
         ix->ntotal += n;
-        rc = shadow_ensure(ix, st);
+        rc = shadow_after_add(ix, st);
         PRAG_HIP(hipStreamSynchronize(st));
         return rc;
     }
@@ -1715,7 +1739,7 @@ extern "C" int prag_index_add(prag_index_t* ix, const float* x, int64_t n, int s
         ix->ntotal += m;
     }
     (void)hipFree(stage);
-    rc = shadow_ensure(ix, st);
+    rc = shadow_after_add(ix, st);
     PRAG_HIP(hipStreamSynchronize(st));
     return rc;
 }
@@ -1730,7 +1754,7 @@ extern "C" int prag_index_add_synthetic(prag_index_t* ix, uint32_t seed, int64_t
     rc = launch_add(ix, nullptr, true, seed, row0, n, nullptr);
     if (rc != PRAG_OK) return rc;
     ix->ntotal += n;
-    rc = shadow_ensure(ix, nullptr);
+    rc = shadow_after_add(ix, nullptr);
     PRAG_HIP(hipDeviceSynchronize());
     return rc;
 }
@@ -2917,6 +2941,7 @@ extern "C" int prag_index_set_shadow(prag_index_t* ix, int mode) {
     PRAG_REQUIRE(ix != nullptr && mode >= 0 && mode <= 2, PRAG_EINVAL, "prag_index_set_shadow: mode %d (0, 1 or 2)", mode);
     ix->shadow_mode = mode;
     ix->shadow_no_room = false;
+    ix->shadow_failed = false;
     ix->mm8_whole_batch_streak = 0;
     ix->mm8_auto_off = false;
     ix->mm8_off_count = 0;

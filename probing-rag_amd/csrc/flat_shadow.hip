@@ -673,6 +673,14 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
 // ---------------------------------------------------------------------------
 // exact float64 scores of the candidates -> top k per query
 // ---------------------------------------------------------------------------
+// s_waitcnt immediate of the publish step below, gfx9 encoding (gfx90a / gfx942 / gfx950): vmcnt[3:0] | expcnt[6:4] |
+// lgkmcnt[11:8] | vmcnt_hi[15:14] - vmcnt = 0, the other counters at their maxima (not waited for).  gfx10+ moved the
+// fields: this file is gfx950 code (Makefile: --offload-arch=gfx950) and refuses to build for anything else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "flat_shadow.hip hand-encodes gfx9 s_waitcnt immediates and relies on gfx950 sc1 write-through: build for gfx950 only"
+#endif
+constexpr int kWaitVmcnt0 = (0 << 14) | (0xF << 8) | (0x7 << 4) | 0x0;
+static_assert(kWaitVmcnt0 == 0x0F70, "vmcnt(0) expcnt(7) lgkmcnt(15), gfx9 field layout");
 constexpr int kShCap = 1024;
 constexpr int kShThreads = 512;
 constexpr int kShSplit = 16;     // workgroups per query (small LDS footprint: several per CU); measured in round 3,
@@ -1107,7 +1115,7 @@ __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a)
         __hip_atomic_store(a.part_key + o + j, ok ? tk.key[j] : ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(a.part_id + o + j, ok ? tk.id[j] : 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the stores above have reached the coherence point
+    __builtin_amdgcn_s_waitcnt(kWaitVmcnt0);   // vmcnt(0): the stores above have reached the coherence point
     __syncthreads();
     if (tid == 0)
         s_n = __hip_atomic_fetch_add(a.done + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)nsplit - 1 ? 1 : 0;

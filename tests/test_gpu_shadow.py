@@ -206,3 +206,32 @@ def test_128_query_tiles_match_definition(metric, store, N, B, k, d, shadow_boun
     Db, Ib = ix.search(qd, k)
     assert np.array_equal(Ib.cpu().numpy(), I)
     ix.close()
+
+
+def test_sliced_gather_merge_never_reads_a_stale_list(monkeypatch):
+    """The 16 slices of a query publish their lists across XCDs with relaxed device-scope stores and the last one to
+    arrive merges them (flat_shadow.hip, end of shadow_gather_kernel).  Two different query batches alternate on the
+    same index 150 times, so every merge finds the OTHER batch's lists in part_key / part_id from the search before:
+    one stale read gives a wrong id.  The bound kernel is off here (it would finish these queries itself)."""
+    import torch
+    import probing_rag_amd as pra
+    monkeypatch.setenv("PRAG_SHADOW_BOUND", "0")
+    N, d, k = 60_000, 768, 10
+    ix = pra.HipFlatIndex(d, onp.METRIC_COS, "f16")
+    ix.set_shadow(2)
+    ix.add_synthetic(42, 0, N)
+    QA = torch.from_numpy(onp.synth_rows(7, 0, 64, d)).cuda()
+    QB = torch.from_numpy(onp.synth_rows(8, 0, 64, d)).cuda()
+    DA, IA = (t.clone() for t in ix.search(QA, k))
+    DB, IB = (t.clone() for t in ix.search(QB, k))
+    X = ix.reconstruct_n(0, N)
+    for Q, I0 in ((QA, IA), (QB, IB)):
+        _, I_ref = oracle_c.flat_search(X, Q.cpu().numpy(), k, onp.METRIC_COS)
+        assert np.array_equal(I0.cpu().numpy(), I_ref)
+    bad = 0
+    for it in range(150):
+        for Q, D0, I0 in ((QA, DA, IA), (QB, DB, IB)):
+            D, I = ix.search(Q, k)
+            bad += int(not (torch.equal(I, I0) and torch.equal(D, D0)))
+    torch.cuda.synchronize()
+    assert bad == 0

@@ -29,7 +29,7 @@ def main(tag, src, rows_per_launch, store):
     for r in rows:
         k = r["Kernel_Name"]
         name = ("scan_topk_kernel" if "scan_topk" in k else "scan8_kernel" if "scan8" in k else
-                "prober_fused_kernel" if "prober_fused" in k else None)
+                "prober16_kernel" if "prober16" in k else "prober_fused_kernel" if "prober_fused" in k else None)
         if name == "scan_topk_kernel" and int(r["Grid_Size"]) != full_grid:
             continue
         if name:
