@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void shadow_build_kernel(const void* __restric
 // the scan
 // ---------------------------------------------------------------------------
 struct Scan8Args {
+    int kslots;                 // bound slots in use per epoch = k (<= KC): see the slot comment in scan8_kernel
     const signed char* rows8;   // [N/32][d/128][32][128]: chunk-major inside 32-row tiles
     const float* sscale;        // [roundup(N,32)]
     const float* serr;
@@ -215,7 +216,7 @@ struct KeyList {   // sorted KC smallest keys (no ids: the lists only feed the b
 // NCHS > 0 (128-query tiles, d = 128 NCHS): the chunks of a tile are unrolled with ONE copy of the epilogue behind
 // them instead of one per staging buffer - the only form in which four query columns per lane fit the register
 // file.  (For 64-query tiles this loop form measured 2-3 % slower than the run-time one, see above.)
-template <int QT, int KC, bool LISTS = true, int NCHS = 0>
+template <int QT, int KC, bool LISTS = true, int NCHS = 0, int ALN = 0, bool QUAD = false>
 __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (gate_closed(a.gate)) return;
@@ -244,8 +245,8 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     uint32_t* s_pre = s_arrive + kShadowEpochs + 1;   // [QT] the sampled pre-bound of every query
     float* s_sqc = reinterpret_cast<float*>(s_pre + QT + 5);   // [QT][3] kscale, A, C (128-query tiles only)
     if (tid <= kShadowEpochs) s_slot_ok[tid] = 0u;   // the flag and the arrival counters behind it
-    // ---- the bound the search starts with: the KC-th smallest of the 32 sample slots prep_queries_kernel filled.
-    // The slices are disjoint row sets, so KC (>= k) rows have exact keys at or below it.  (The MAX over the slots
+    // ---- the bound the search starts with: the k-th smallest of the 32 sample slots prep_queries_kernel filled.
+    // The slices are disjoint row sets, so k rows have exact keys at or below it.  (The MAX over the slots
     // is valid too but has a bad tail - one slice without a good row loosens the bound of that query - and a loose
     // start floods the candidate regions of the first tiles: one query in a few searches overflowed a region.)
     {
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                     const uint32_t x = s_ps[q * 32 + j];
                     rank += (x < v || (x == v && j < i)) ? 1 : 0;
                 }
-                if (rank == KC - 1) s_pre[q] = v;
+                if (rank == a.kslots - 1) s_pre[q] = v;
             }
         }
         __syncthreads();
@@ -356,8 +357,15 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     // wave, 160 KiB per CU) - with the chunk-major row layout the fifth is worth 2-3 % at 64 queries (2.875 ->
     // 2.827 ms at 21 M rows, same box, alternating runs) and nothing at 32 or 1; with two the loop starved.
     // 64 queries x 32-deep lists have no registers beyond three.
-    constexpr int NLD = NCHS > 0 ? 2 :   // (128-query tiles: three spill 13 registers and measured no faster: 3.85 vs 3.79 ms)
-                         QT == 64 ? (KC == 32 ? 3 : 5) : 4;   // (six at 64 queries fit - 253 VGPRs - and are slower: 2.92 vs 2.89 ms)
+#ifndef PRAG_SCAN8_NLD64
+#define PRAG_SCAN8_NLD64 5
+#endif
+#ifndef PRAG_SCAN8_QUAD
+#define PRAG_SCAN8_QUAD 1
+#endif
+    constexpr int NLD = ALN > 0 ? ALN :
+                        NCHS > 0 ? 2 :   // (128-query tiles: three spill 13 registers and measured no faster: 3.85 vs 3.79 ms)
+                         QT == 64 ? (KC == 32 ? 3 : PRAG_SCAN8_NLD64) : 4;   // (six at 64 queries fit - 253 VGPRs - and are slower: 2.92 vs 2.89 ms)
     u32x4 ld[NLD][4];
     // wave-uniform tile base (scalar registers) + a per-lane 32-bit offset: no 64-bit vector address
     // arithmetic and no per-row clamp in the loop - the shadow is allocated in multiples of 256 rows, so
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     // (lane -> byte (8 i + lane / 8) * 128 + (lane % 8) * 16 = 1024 i + 16 lane of the chunk: one unsigned 32-bit lane
     // offset on a scalar base, the four pieces at immediate offsets)
     const uint32_t lane16 = (uint32_t)lane * 16u;
-    auto issue = [&](u32x4 (&ldr)[4], int tile, int c) {
+    auto issue = [&](u32x4 (&ldr)[4], int tile, int c) __attribute__((always_inline)) {
         const char* base = rows + (int64_t)tile * (32 * row_bytes) + c * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -400,14 +408,14 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     constexpr int kWarmMax = 16;
     int redo = 0;
     bool warm = !(PRAG_SH_DBG(a.dbg) & 1) && *s_slot_ok == 0u;   // (read after the barrier below the query tiles)
-    auto vtile = [&](int vt) {
+    auto vtile = [&](int vt) __attribute__((always_inline)) {
         int at = vt < n_my ? vt : vt - n_my;
         at = at < n_my ? at : n_my - 1;             // prefetch past the end: any valid tile
         return gw + at * nW;
     };
     int vt_cur = 0, c_cur = 0;
     int vt_nx = 0, c_nx = 0;
-    auto advance = [&](int& t, int& c) {
+    auto advance = [&](int& t, int& c) __attribute__((always_inline)) {
         const bool wrap = (c + 1 == NCH);
         c = wrap ? 0 : c + 1;
         t = wrap ? t + 1 : t;
@@ -415,14 +423,21 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     float m_s = 1.f, m_e = 0.f, m_x = 0.f;   // metadata of row (tile*32 + r), requested at the tile's first chunk
     int tiles_done = 0;
 
-    auto load_meta = [&](int tile) {
+    auto load_meta = [&](int tile) __attribute__((always_inline)) {
+        if (PRAG_SH_DBG(a.dbg) & 32768) return;         // timing only: no row metadata
         const int64_t row = (int64_t)tile * 32 + r;     // (arrays are padded to a multiple of 32 rows)
         m_s = a.sscale[row];
         m_e = a.serr[row];
         m_x = a.use_norm ? a.xnorm[row] : 0.f;
     };
     // stage one 4-KiB chunk (32 rows x 128 bytes), refill its registers with chunk (tile_nx, c_nx), 4 k-steps
-    auto chunk_step = [&](u32x4 (&ldr)[4], int c, int tile_nx, int c_nx) {
+    auto chunk_step = [&](u32x4 (&ldr)[4], int c, int tile_nx, int c_nx) __attribute__((always_inline)) {
+        if (PRAG_SH_DBG(a.dbg) & 4096) {      // timing only: the stream alone (loads into registers, nothing else)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ldr[i]));
+            issue(ldr, tile_nx, c_nx);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(s_st + st_dst[i]) = ldr[i];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (staged by some lanes, read as fragments by others)
@@ -433,28 +448,50 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
         int xq = xq0;
         // (unrolled chunks: hoisted out of the tile loop these offsets would be 4 NCHS registers)
         if constexpr (NCHS > 0) asm volatile("" : "+v"(xq));
+        if (PRAG_SH_DBG(a.dbg) & 2048) return;     // timing only: stream + staging writes, no fragment reads, no MFMAs
 #pragma unroll
         for (int s = 0; s < 4; ++s) {               // 4 k-steps of 32 elements per 128-byte chunk
             const i32x4 av = *reinterpret_cast<const i32x4*>(s_st + a_off + (((2 * s + hh) ^ a_sw) << 4));
             const int P0 = c * 8 + 2 * s;           // (bit 0 = hh lives in xq)
             const int q_sw = ((P0 & ~15) | (((P0 & 15) ^ xq))) << 4;
+            // the first k-step of a tile starts from the constant 0 (an inline operand of the MFMA): the epilogue does not
+            // clear 16 (32) accumulator registers per query column
+            if (s == 0 && c == 0) {
+                const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int t = 0; t < NQ; ++t) {
-                const int q_addr = q_base[t] + q_sw;
-                const i32x4 b1 = *reinterpret_cast<const i32x4*>(s_qa + q_addr);
-                acc1[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b1, acc1[t], 0, 0, 0);
-                if constexpr (TERMS == 2) {
-                    const i32x4 b2 = *reinterpret_cast<const i32x4*>(s_qb + q_addr);
-                    acc2[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b2, acc2[t], 0, 0, 0);
+                for (int t = 0; t < NQ; ++t) {
+                    const int q_addr = q_base[t] + q_sw;
+                    const i32x4 b1 = *reinterpret_cast<const i32x4*>(s_qa + q_addr);
+                    acc1[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b1, zero, 0, 0, 0);
+                    if constexpr (TERMS == 2) {
+                        const i32x4 b2 = *reinterpret_cast<const i32x4*>(s_qb + q_addr);
+                        acc2[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b2, zero, 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) {
+                    const int q_addr = q_base[t] + q_sw;
+                    const i32x4 b1 = *reinterpret_cast<const i32x4*>(s_qa + q_addr);
+                    acc1[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b1, acc1[t], 0, 0, 0);
+                    if constexpr (TERMS == 2) {
+                        const i32x4 b2 = *reinterpret_cast<const i32x4*>(s_qb + q_addr);
+                        acc2[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b2, acc2[t], 0, 0, 0);
+                    }
                 }
             }
         }
     };
     // ---- epilogue of a tile: 16 rows x this lane's queries ----------------------------------------
-    auto epilogue = [&](int tile_cur, bool second) {   // second visit of a warm-up tile: filter only
+    auto epilogue = [&](int tile_cur, bool second) __attribute__((always_inline)) {   // second visit of a warm-up tile: filter only
         {
             // ---- epilogue: 16 rows x this lane's queries ---------------------------------------
             const bool collect = (second || !warm) && !(PRAG_SH_DBG(a.dbg) & 2);
+            if (PRAG_SH_DBG(a.dbg) & 1024) {       // timing only: no epilogue arithmetic at all
+                ++tiles_done;
+                warm = false;
+                return;
+            }
             if (hh == 0) {
                 s_meta[r] = m_s;
                 s_meta[32 + r] = m_e;
@@ -466,13 +503,19 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
             __builtin_amdgcn_wave_barrier();
             const int64_t doc0 = (int64_t)tile_cur * 32;
             // one (row, query) pair: list / best-key update, filter, append
-            auto pair = [&](int t, int ge, int64_t doc, float rs_e, float re_e, float rx_e, float ks, float cA_t, float cC_t,
-                            float tau_t) {
-                const bool valid = doc < a.N;
+            // key of one (row, query) pair and its error bound - ONE definition for the group test and the per-pair code
+            auto key_eps = [&](int t, int ge, float rs_e, float re_e, float rx_e, float ks, float cA_t, float cC_t, float& mid,
+                               float& eps) __attribute__((always_inline)) {
                 float dq = (float)acc1[t][ge];
                 if constexpr (TERMS == 2) dq = fmaf((float)acc2[t][ge], 1.0f / 128.0f, dq);
-                const float mid = fmaf(ks * rs_e, dq, rx_e);
-                const float eps = fmaf(cA_t, re_e, cC_t);
+                mid = fmaf(ks * rs_e, dq, rx_e);
+                eps = fmaf(cA_t, re_e, cC_t);
+            };
+            auto pair = [&](int t, int ge, int64_t doc, float rs_e, float re_e, float rx_e, float ks, float cA_t, float cC_t,
+                            float tau_t) __attribute__((always_inline)) {
+                const bool valid = doc < a.N;
+                float mid, eps;
+                key_eps(t, ge, rs_e, re_e, rx_e, ks, cA_t, cC_t, mid, eps);
                 if (!second) {
                     if constexpr (LISTS) top[t].push(valid ? mid + eps : INFINITY, tau_t);
                     else top[t].k[0] = fminf(top[t].k[0], valid ? mid + eps : INFINITY);
@@ -488,8 +531,6 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                     if (slot < (uint32_t)a.cap)
                         a.cand[((int64_t)blockIdx.x * QT + 32 * t + r) * a.cap + slot] = int2{(int)doc, (int)__float_as_uint(lo)};
                 }
-                acc1[t][ge] = 0;
-                if constexpr (TERMS == 2) acc2[t][ge] = 0;
             };
             float tau[NQ];
             if constexpr (QT == 128) {
@@ -512,19 +553,69 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
             } else {
 #pragma unroll
                 for (int t = 0; t < NQ; ++t) tau[t] = unsortable_f32(s_tau[32 * t + r]);
+                // Quad test first: the smallest key - eps of four rows of one query column.  Above the bound none of
+                // the four is a candidate and none can enter the bound list either (key + eps >= key - eps > tau): the
+                // list push and the append - two compares and two branches per pair - run for the quads that hold
+                // something (a few per cent of them per wave; profiles/r04s_scan8_ablation.txt: every instruction of
+                // this epilogue is exposed - two waves per SIMD do not hide it).  Rows past N (last tile) take the
+                // per-pair code, which masks them.
+                constexpr bool kQuadTest = QUAD;   // (64 queries x 32-deep lists: no registers for it)
+                const bool partial = doc0 + 32 > a.N;
+                if (kQuadTest && !partial && !(PRAG_SH_DBG(a.dbg) & 65536)) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 rs = *reinterpret_cast<const f32x4*>(s_meta + 8 * g + 4 * hh);
-                    const f32x4 re = *reinterpret_cast<const f32x4*>(s_meta + 32 + 8 * g + 4 * hh);
-                    const f32x4 rx = *reinterpret_cast<const f32x4*>(s_meta + 64 + 8 * g + 4 * hh);
+                    for (int g = 0; g < 4; ++g) {
+                        // (the metadata of a row quad is read where it is used: without the clobber all four quads' 48
+                        //  values are loaded ahead of the first branch and the kernel spills)
+                        asm volatile("" ::: "memory");
+                        const f32x4 rs = *reinterpret_cast<const f32x4*>(s_meta + 8 * g + 4 * hh);
+                        const f32x4 re = *reinterpret_cast<const f32x4*>(s_meta + 32 + 8 * g + 4 * hh);
+                        const f32x4 rx = *reinterpret_cast<const f32x4*>(s_meta + 64 + 8 * g + 4 * hh);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                        for (int t = 0; t < NQ; ++t) {
+                            float mid[4], eps[4];
 #pragma unroll
-                        for (int t = 0; t < NQ; ++t)
-                            pair(t, 4 * g + e, doc0 + 8 * g + 4 * hh + e, rs[e], re[e], rx[e], kscale[t], cA[t], cC[t], tau[t]);
+                            for (int e = 0; e < 4; ++e) key_eps(t, 4 * g + e, rs[e], re[e], rx[e], kscale[t], cA[t], cC[t], mid[e], eps[e]);
+                            const float m = fminf(fminf(mid[0] - eps[0], mid[1] - eps[1]), fminf(mid[2] - eps[2], mid[3] - eps[3]));
+                            if (m <= tau[t]) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    if (!second) {
+                                        if constexpr (LISTS) top[t].push(mid[e] + eps[e], tau[t]);
+                                        else top[t].k[0] = fminf(top[t].k[0], mid[e] + eps[e]);
+                                    }
+                                    const float lo = mid[e] - eps[e];
+                                    if (collect && lo <= tau[t]) {
+                                        // (per-lane pieces rebuilt HERE from an opaque copy of the lane id: hoisted out of
+                                        //  the tile loop they are 20 registers the loop does not have - spilled, and a
+                                        //  reload waits for vmcnt(0), i.e. drains the prefetch queue)
+                                        int le = lane;
+                                        asm volatile("" : "+v"(le));
+                                        const int rq = le & 31, row_off = 4 * (le >> 5) + 8 * g + e;
+                                        const uint32_t slot = atomicAdd(&s_ccnt[32 * t + rq], 1u);
+                                        if (slot < (uint32_t)a.cap)
+                                            a.cand[((int64_t)blockIdx.x * QT + 32 * t + rq) * a.cap + slot] =
+                                                int2{(int)doc0 + row_off, (int)__float_as_uint(lo)};
+                                    }
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);   // (one quad at a time: all eight in flight spill)
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 rs = *reinterpret_cast<const f32x4*>(s_meta + 8 * g + 4 * hh);
+                        const f32x4 re = *reinterpret_cast<const f32x4*>(s_meta + 32 + 8 * g + 4 * hh);
+                        const f32x4 rx = *reinterpret_cast<const f32x4*>(s_meta + 64 + 8 * g + 4 * hh);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int t = 0; t < NQ; ++t)
+                                pair(t, 4 * g + e, doc0 + 8 * g + 4 * hh + e, rs[e], re[e], rx[e], kscale[t], cA[t], cC[t], tau[t]);
+                    }
                 }
             }
-            if (!second) {
+            if (!second && !(PRAG_SH_DBG(a.dbg) & 16384)) {     // (16384, timing only: no bound maintenance)
 #pragma unroll
                 for (int t = 0; t < NQ; ++t)
                     if constexpr (LISTS)
@@ -558,7 +649,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                             for (int qq = lane; qq < QT; qq += 64) {
                                 const uint32_t v = s_best[qq];
                                 if (v != 0xFFFFFFFFu)
-                                    (void)__hip_atomic_fetch_min(a.g_slot + (qq * kShadowSlotRows + 0) * 32 + (blockIdx.x % KC), v,
+                                    (void)__hip_atomic_fetch_min(a.g_slot + (qq * kShadowSlotRows + 0) * 32 + ((int)blockIdx.x % a.kslots), v,
                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
                         }
@@ -574,7 +665,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                         for (int qq = lane; qq < QT; qq += 64) {
                             const uint32_t v = s_best[qq];
                             if (v != 0xFFFFFFFFu)
-                                (void)__hip_atomic_fetch_min(a.g_slot + (qq * kShadowSlotRows + epoch) * 32 + (blockIdx.x % KC), v,
+                                (void)__hip_atomic_fetch_min(a.g_slot + (qq * kShadowSlotRows + epoch) * 32 + ((int)blockIdx.x % a.kslots), v,
                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
@@ -589,8 +680,11 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                                 for (int qq = lane; qq < QT; qq += 64) {
                                     const uint32_t* sl = a.g_slot + (qq * kShadowSlotRows + epoch) * 32;
                                     uint32_t m = 0u;
-#pragma unroll
-                                    for (int s2 = 0; s2 < KC; ++s2) {
+                                    // k slots, not KC: the maximum over m slots fed by disjoint sets of workgroups bounds
+                                    // the m-th best key, and it sits at about rank m H(m) of the rows seen - 29 for 10
+                                    // slots, 54 for 16.  The bound only has to cover the k-th best.
+#pragma unroll 4
+                                    for (int s2 = 0; s2 < a.kslots; ++s2) {
                                         const uint32_t v = __hip_atomic_load(sl + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                         m = v > m ? v : m;
                                     }
@@ -617,12 +711,12 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
             }
         }
     };
-    auto body = [&](u32x4 (&ldr)[4]) {
+    auto body = [&](u32x4 (&ldr)[4], bool may_end) __attribute__((always_inline)) {      // may_end: a constant at every call site
         const int tile_cur = vtile(vt_cur);
         if (c_cur == 0) load_meta(tile_cur);
         chunk_step(ldr, c_cur, vtile(vt_nx), c_nx);
         advance(vt_nx, c_nx);
-        if (c_cur == NCH - 1) epilogue(tile_cur, vt_cur >= n_my);
+        if (may_end && c_cur == NCH - 1) epilogue(tile_cur, vt_cur >= n_my);
         advance(vt_cur, c_cur);
     };
 
@@ -654,11 +748,32 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
         }
         // (`redo` grows during the first tiles only, long before the loop bound is reached - or, on a
         // shard of a few tiles, up to n_my: every tile is then visited twice)
-        for (int it = 0; it < (n_my + redo) * NCH; it += NLD) {
-#pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                if (u > 0 && it + u >= (n_my + redo) * NCH) break;
-                body(ld[u]);
+        // (`redo` grows during the first tiles only, long before the loop bound is reached - or, on a
+        // shard of a few tiles, up to n_my: every tile is then visited twice)
+        if constexpr (ALN > 0) {
+            // ALN: rows of a whole number of rounds (the host checks (d / 128) % ALN == 0): a tile can only end in the LAST staging set of a round - ONE copy of the
+            // epilogue in the loop instead of NLD (85 KB of code for 64-query tiles against a 64-KB instruction cache
+            // shared by two CUs; profiles/r04s_scan8_ablation.txt: code that was only skipped, not removed, made the
+            // loop faster)
+            for (int it = 0; it < (n_my + redo) * NCH; it += NLD) {
+                body(ld[0], NLD == 1);
+                if constexpr (NLD > 1) body(ld[1], NLD == 2);
+                if constexpr (NLD > 2) body(ld[2], NLD == 3);
+                if constexpr (NLD > 3) body(ld[3], NLD == 4);
+                if constexpr (NLD > 4) body(ld[4], NLD == 5);
+                if constexpr (NLD > 5) body(ld[5], NLD == 6);
+            }
+        } else {
+            // (written out: left to `#pragma unroll`, one instantiation came back with the loop over the staging sets
+            //  NOT unrolled - ld[u] indexed at run time, i.e. 320 B of scratch - without a diagnostic)
+            static_assert(NLD >= 2 && NLD <= 6, "staging sets written out below");
+            for (int it = 0; it < (n_my + redo) * NCH; it += NLD) {
+                body(ld[0], true);
+                if (it + 1 < (n_my + redo) * NCH) body(ld[1], true);
+                if constexpr (NLD > 2) { if (it + 2 < (n_my + redo) * NCH) body(ld[2], true); }
+                if constexpr (NLD > 3) { if (it + 3 < (n_my + redo) * NCH) body(ld[3], true); }
+                if constexpr (NLD > 4) { if (it + 4 < (n_my + redo) * NCH) body(ld[4], true); }
+                if constexpr (NLD > 5) { if (it + 5 < (n_my + redo) * NCH) body(ld[5], true); }
             }
         }
     }
@@ -1192,10 +1307,10 @@ size_t shadow_slot_words() { return kShadowSlotWords; }
 size_t shadow_q_bytes() { return sizeof(ShadowQ); }
 int shadow_split() { return kShSplit; }
 
-template <int QT, int KC, bool LISTS = true, int NCHS = 0>
+template <int QT, int KC, bool LISTS = true, int NCHS = 0, int ALN = 0, bool QUAD = false>
 static int launch_scan8(const Scan8Args& a, int grid, hipStream_t st, EventRing& prof) {
     const int lds = scan8_lds_bytes(QT, a.qstride);
-    auto kern = scan8_kernel<QT, KC, LISTS, NCHS>;
+    auto kern = scan8_kernel<QT, KC, LISTS, NCHS, ALN, QUAD>;
     static LdsOptIn lds_opt_in;
     {
         const int rc_ = lds_opt_in.ensure(reinterpret_cast<const void*>(kern), 160 * 1024);
@@ -1208,6 +1323,19 @@ static int launch_scan8(const Scan8Args& a, int grid, hipStream_t st, EventRing&
     return PRAG_OK;
 }
 
+// 64-query tiles, 16-deep lists, rows of a multiple of 384 elements, long shards: the quad-test epilogue with ONE copy
+// of it in the loop (three staging sets, a tile = two rounds).  Measured on one box, scan8 alone / shard pass
+// (profiles/r04t_scan8_quad_ab.txt): 21 M rows 2.68 -> 2.56 ms (0.76 -> 0.795 of 8 TB/s); 2.625 M rows the pass is
+// 0.469 -> 0.481-0.498 ms - short scans spend their time in the early tiles, where most quads hold a candidate and the
+// test is extra work - hence the row threshold.
+constexpr int kScan8Aln = 3;
+static int64_t scan8_quad_min_rows() {
+    static const int64_t v = [] {
+        const char* e = getenv("PRAG_SCAN8_QUAD_ROWS");      // experiment switch
+        return e ? atoll(e) : (int64_t)8 << 20;
+    }();
+    return v;
+}
 int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
     const int qstride = (s.d + 255) / 256 * 256;
     const bool wide = s.qt_max >= 64 && s.B > 32 && scan8_lds_bytes(64, qstride) <= 160 * 1024;
@@ -1227,6 +1355,7 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
     // (query terms, per-query constants, bound slots and overflow words were written by prep_queries_kernel)
     for (int p0 = 0; p0 < Bpad; p0 += QT) {
         Scan8Args a;
+        a.kslots = std::max(1, std::min(s.k, s.kc));
         a.rows8 = s.store.rows8;
         a.sscale = s.store.sscale;
         a.serr = s.store.serr;
@@ -1252,6 +1381,7 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         a.dbg = 0;
 #endif
         int rc;
+        const bool quad16 = (s.d / 128) % kScan8Aln == 0 && s.N >= scan8_quad_min_rows();
         if (QT == 128)
             rc = s.d == 768 ? (s.kc == 8 ? launch_scan8<128, 8, false, 6>(a, grid, st, prof)
                                          : launch_scan8<128, 16, false, 6>(a, grid, st, prof))
@@ -1259,7 +1389,9 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
                                          : launch_scan8<128, 16, false, 4>(a, grid, st, prof));
         else if (QT == 64)
             rc = s.kc == 8 ? launch_scan8<64, 8>(a, grid, st, prof)
-                           : s.kc == 16 ? launch_scan8<64, 16>(a, grid, st, prof) : launch_scan8<64, 32>(a, grid, st, prof);
+                 : s.kc == 16 ? (quad16 ? launch_scan8<64, 16, true, 0, kScan8Aln, true>(a, grid, st, prof)
+                                        : launch_scan8<64, 16>(a, grid, st, prof))
+                              : launch_scan8<64, 32>(a, grid, st, prof);
         else
             rc = s.kc == 8 ? launch_scan8<32, 8>(a, grid, st, prof)
                            : s.kc == 16 ? launch_scan8<32, 16>(a, grid, st, prof) : launch_scan8<32, 32>(a, grid, st, prof);
