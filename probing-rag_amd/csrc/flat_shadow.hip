@@ -570,13 +570,23 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                         const f32x4 rs = *reinterpret_cast<const f32x4*>(s_meta + 8 * g + 4 * hh);
                         const f32x4 re = *reinterpret_cast<const f32x4*>(s_meta + 32 + 8 * g + 4 * hh);
                         const f32x4 rx = *reinterpret_cast<const f32x4*>(s_meta + 64 + 8 * g + 4 * hh);
+                        // the test uses the quad's largest error bound for all four rows: min(key) - max(eps) <= every
+                        // key - eps (a few more quads take the exact per-pair code, none is missed), and a pair costs
+                        // convert, multiply, fma, min instead of two more fmas and a subtraction
+                        const float re_max = fmaxf(fmaxf(re[0], re[1]), fmaxf(re[2], re[3]));
 #pragma unroll
                         for (int t = 0; t < NQ; ++t) {
                             float mid[4], eps[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) key_eps(t, 4 * g + e, rs[e], re[e], rx[e], kscale[t], cA[t], cC[t], mid[e], eps[e]);
-                            const float m = fminf(fminf(mid[0] - eps[0], mid[1] - eps[1]), fminf(mid[2] - eps[2], mid[3] - eps[3]));
+                            for (int e = 0; e < 4; ++e) {
+                                float dq = (float)acc1[t][4 * g + e];
+                                if constexpr (TERMS == 2) dq = fmaf((float)acc2[t][4 * g + e], 1.0f / 128.0f, dq);
+                                mid[e] = fmaf(kscale[t] * rs[e], dq, rx[e]);          // (key_eps's arithmetic)
+                            }
+                            const float m = fminf(fminf(mid[0], mid[1]), fminf(mid[2], mid[3])) - fmaf(cA[t], re_max, cC[t]);
                             if (m <= tau[t]) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) eps[e] = fmaf(cA[t], re[e], cC[t]);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     if (!second) {
@@ -1336,6 +1346,9 @@ static int64_t scan8_quad_min_rows() {
     }();
     return v;
 }
+// (Also measured: the same kernel with the six chunks of a 768-element row unrolled - scan8_kernel<64,16,true,6,3,true>,
+// scalar instructions per tile 412 -> 129, vector 501 -> 421, active-issue cycles -31 % by the SQ counters - runs at the
+// SAME speed, 2.62-2.70 vs 2.58-2.66 ms on one box: at two waves per SIMD this loop is not bound by instruction issue.)
 int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
     const int qstride = (s.d + 255) / 256 * 256;
     const bool wide = s.qt_max >= 64 && s.B > 32 && scan8_lds_bytes(64, qstride) <= 160 * 1024;
