@@ -357,15 +357,9 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     // wave, 160 KiB per CU) - with the chunk-major row layout the fifth is worth 2-3 % at 64 queries (2.875 ->
     // 2.827 ms at 21 M rows, same box, alternating runs) and nothing at 32 or 1; with two the loop starved.
     // 64 queries x 32-deep lists have no registers beyond three.
-#ifndef PRAG_SCAN8_NLD64
-#define PRAG_SCAN8_NLD64 5
-#endif
-#ifndef PRAG_SCAN8_QUAD
-#define PRAG_SCAN8_QUAD 1
-#endif
     constexpr int NLD = ALN > 0 ? ALN :
                         NCHS > 0 ? 2 :   // (128-query tiles: three spill 13 registers and measured no faster: 3.85 vs 3.79 ms)
-                         QT == 64 ? (KC == 32 ? 3 : PRAG_SCAN8_NLD64) : 4;   // (six at 64 queries fit - 253 VGPRs - and are slower: 2.92 vs 2.89 ms)
+                         QT == 64 ? (KC == 32 ? 3 : 5) : 4;   // (six at 64 queries fit - 253 VGPRs - and are slower: 2.92 vs 2.89 ms)
     u32x4 ld[NLD][4];
     // wave-uniform tile base (scalar registers) + a per-lane 32-bit offset: no 64-bit vector address
     // arithmetic and no per-row clamp in the loop - the shadow is allocated in multiples of 256 rows, so
