@@ -290,6 +290,9 @@ int prag_merge_topk_packed_tagged(const void* parts_dev, int64_t part_stride_byt
  * (collective, on the current device). */
 int prag_rccl_unique_id(void* id_out_128);
 int prag_rccl_comm_init_rank(void** comm_out, int world, int rank, const void* id_128);
+/* ncclAllGather of `bytes_per_rank` device bytes per rank on `stream` (the exchange step of the sharded search by
+ * itself: ShardedFlatIndex checks a new communicator with it before any search relies on it). */
+int prag_rccl_all_gather(void* comm, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
 int prag_rccl_comm_destroy(void* comm);
 int prag_index_set_comm(prag_index_t* ix, void* nccl_comm, int rank, int world);
 int prag_index_search_sharded(prag_index_t* ix, const float* q_dev, int B, int k, int64_t id_offset,

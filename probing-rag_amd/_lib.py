@@ -87,6 +87,7 @@ SIGNATURES = {
     "prag_index_set_candidate_depth": (_I, [_P, _I]),
     "prag_rccl_unique_id": (_I, [_P]),
     "prag_rccl_comm_init_rank": (_I, [ctypes.POINTER(_P), _I, _I, _P]),
+    "prag_rccl_all_gather": (_I, [_P, _P, _P, ctypes.c_size_t, _P]),
     "prag_rccl_comm_destroy": (_I, [_P]),
     "prag_index_set_comm": (_I, [_P, _P, _I, _I]),
     "prag_index_search_sharded": (_I, [_P, _P, _I, _I, _L, _P, _P, _P]),

@@ -113,6 +113,11 @@ extern "C" int prag_rccl_comm_init_rank(void** comm_out, int world, int rank, co
     return PRAG_OK;
 }
 
+extern "C" int prag_rccl_all_gather(void* comm, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream) {
+    PRAG_REQUIRE(comm && send_dev && recv_dev && bytes_per_rank > 0, PRAG_EINVAL, "prag_rccl_all_gather: NULL argument");
+    return rccl_all_gather_bytes(comm, send_dev, recv_dev, bytes_per_rank, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int prag_rccl_comm_destroy(void* comm) {
     if (!comm) return PRAG_OK;
     const int rc = rccl_load();

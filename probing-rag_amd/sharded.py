@@ -142,6 +142,22 @@ class ShardedFlatIndex:
             except Exception as e:  # noqa: BLE001
                 ok = 0
                 print(f"ShardedFlatIndex: ncclCommInitRank failed on rank {self.rank} ({e})", flush=True)
+        if ok:
+            # the new communicator carries one all-gather before any search relies on it: a wrong answer (or an error
+            # from RCCL) sends every rank back to the torch.distributed exchange; it also takes RCCL's one-off channel
+            # set-up out of the first search
+            try:
+                with torch.cuda.device(self.engine.device):
+                    send = torch.full((4,), 1000 + self.rank, dtype=torch.int32, device=self.engine.device)
+                    recv = torch.zeros((self.world, 4), dtype=torch.int32, device=self.engine.device)
+                    _lib.check(lib.prag_rccl_all_gather(comm, send.data_ptr(), recv.data_ptr(), 16,
+                                                        torch.cuda.current_stream().cuda_stream))
+                    want = (1000 + torch.arange(self.world, dtype=torch.int32, device=self.engine.device))[:, None].expand(-1, 4)
+                    if not torch.equal(recv, want):
+                        raise RuntimeError(f"all-gather self-check returned {recv[:, 0].tolist()}")
+            except Exception as e:  # noqa: BLE001
+                ok = 0
+                print(f"ShardedFlatIndex: RCCL self-check failed on rank {self.rank} ({e})", flush=True)
         flag = torch.tensor([ok], dtype=torch.int32, device=self.engine.device)
         self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
         if int(flag.item()) == 1:
