@@ -358,7 +358,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     // 2.827 ms at 21 M rows, same box, alternating runs) and nothing at 32 or 1; with two the loop starved.
     // 64 queries x 32-deep lists have no registers beyond three.
     constexpr int NLD = ALN > 0 ? ALN :
-                        NCHS > 0 ? 2 :   // (128-query tiles: three spill 13 registers and measured no faster: 3.85 vs 3.79 ms)
+                        NCHS > 0 ? (QUAD ? (NCHS % 3 == 0 ? 3 : 4) : 2) :   // (128-query tiles; before the quad test freed registers: two)
                          QT == 64 ? (KC == 32 ? 3 : 5) : 4;   // (six at 64 queries fit - 253 VGPRs - and are slower: 2.92 vs 2.89 ms)
     u32x4 ld[NLD][4];
     // wave-uniform tile base (scalar registers) + a per-lane 32-bit offset: no 64-bit vector address
@@ -534,14 +534,31 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                 for (int t = 0; t < NQ; ++t) {
                     tau[t] = unsortable_f32(s_tau[32 * t + r]);
                     const float ks = s_sqc[3 * (32 * t + r)], cA_t = s_sqc[3 * (32 * t + r) + 1], cC_t = s_sqc[3 * (32 * t + r) + 2];
+                    const bool partial128 = doc0 + 32 > a.N;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 rs = *reinterpret_cast<const f32x4*>(s_meta + 8 * g + 4 * hh);
                         const f32x4 re = *reinterpret_cast<const f32x4*>(s_meta + 32 + 8 * g + 4 * hh);
                         const f32x4 rx = *reinterpret_cast<const f32x4*>(s_meta + 64 + 8 * g + 4 * hh);
+                        if (QUAD && !partial128) {
+                            // the quad test of the 64-query tiles (below).  List-less: a lane's best key + eps per query
+                            // is only refreshed in quads that hold something under the bound - a skipped value is above
+                            // the bound and could not have lowered any slot below it; the stale one stays valid (larger)
+                            const float re_max = fmaxf(fmaxf(re[0], re[1]), fmaxf(re[2], re[3]));
+                            float mid[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            pair(t, 4 * g + e, doc0 + 8 * g + 4 * hh + e, rs[e], re[e], rx[e], ks, cA_t, cC_t, tau[t]);
+                            for (int e = 0; e < 4; ++e) mid[e] = fmaf(ks * rs[e], (float)acc1[t][4 * g + e], rx[e]);
+                            const float m = fminf(fminf(mid[0], mid[1]), fminf(mid[2], mid[3])) - fmaf(cA_t, re_max, cC_t);
+                            if (m <= tau[t]) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    pair(t, 4 * g + e, doc0 + 8 * g + 4 * hh + e, rs[e], re[e], rx[e], ks, cA_t, cC_t, tau[t]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                pair(t, 4 * g + e, doc0 + 8 * g + 4 * hh + e, rs[e], re[e], rx[e], ks, cA_t, cC_t, tau[t]);
+                        }
                     }
                 }
             } else {
@@ -1390,10 +1407,10 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         int rc;
         const bool quad16 = (s.d / 128) % kScan8Aln == 0 && s.N >= scan8_quad_min_rows();
         if (QT == 128)
-            rc = s.d == 768 ? (s.kc == 8 ? launch_scan8<128, 8, false, 6>(a, grid, st, prof)
-                                         : launch_scan8<128, 16, false, 6>(a, grid, st, prof))
-                            : (s.kc == 8 ? launch_scan8<128, 8, false, 4>(a, grid, st, prof)
-                                         : launch_scan8<128, 16, false, 4>(a, grid, st, prof));
+            rc = s.d == 768 ? (s.kc == 8 ? launch_scan8<128, 8, false, 6, 0, true>(a, grid, st, prof)
+                                         : launch_scan8<128, 16, false, 6, 0, true>(a, grid, st, prof))
+                            : (s.kc == 8 ? launch_scan8<128, 8, false, 4, 0, true>(a, grid, st, prof)
+                                         : launch_scan8<128, 16, false, 4, 0, true>(a, grid, st, prof));
         else if (QT == 64)
             rc = s.kc == 8 ? launch_scan8<64, 8>(a, grid, st, prof)
                  : s.kc == 16 ? (quad16 ? launch_scan8<64, 16, true, 0, kScan8Aln, true>(a, grid, st, prof)

@@ -14,7 +14,8 @@ if len(sys.argv) > 1:
     ix.add_synthetic(42, 0, N)
     ix.set_shadow(1)
     ix.prepare()
-    q = torch.from_numpy(synth_rows(7, 0, 64, 768)).cuda()
+    nq = int(os.environ.get("PRAG_QUERIES", 64))
+    q = torch.from_numpy(synth_rows(7, 0, nq, 768)).cuda()
     for _ in range(5):
         ix.search(q, 10)
     torch.cuda.synchronize()
@@ -23,9 +24,15 @@ if len(sys.argv) > 1:
         ix.search(q, 10)
     torch.cuda.synchronize()
     ms = np.asarray(ix.profile_read())
+    import time as _t
+    t0 = _t.perf_counter()
+    for _ in range(20):
+        ix.search(q, 10)
+    torch.cuda.synchronize()
+    wall = (_t.perf_counter() - t0) / 20 * 1e3
     alg = N * (768 + 8)
     print(f"PRAG_SHADOW_DBG={os.environ.get('PRAG_SHADOW_DBG', '0'):>5s}: scan8 {ms.mean():.4f} ms -> {alg / ms.mean() / 1e9:.2f} TB/s "
-          f"({alg / ms.mean() / 1e9 / 8:.3f} of 8)", flush=True)
+          f"({alg / ms.mean() / 1e9 / 8:.3f} of 8); search {wall:.3f} ms", flush=True)
 else:
     env0 = dict(os.environ, PRAG_LIB=os.path.join(ROOT, "probing-rag_amd", "lib", "libprag_diag.so"))
     for dbg in [int(x) for x in os.environ.get('ABLATE', '0,1024,2048,3072,4096,5120').split(',')]:
