@@ -1406,19 +1406,23 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
 #endif
         int rc;
         const bool quad16 = (s.d / 128) % kScan8Aln == 0 && s.N >= scan8_quad_min_rows();
+        const bool quad32 = s.N >= scan8_quad_min_rows();
         if (QT == 128)
             rc = s.d == 768 ? (s.kc == 8 ? launch_scan8<128, 8, false, 6, 0, true>(a, grid, st, prof)
                                          : launch_scan8<128, 16, false, 6, 0, true>(a, grid, st, prof))
                             : (s.kc == 8 ? launch_scan8<128, 8, false, 4, 0, true>(a, grid, st, prof)
                                          : launch_scan8<128, 16, false, 4, 0, true>(a, grid, st, prof));
         else if (QT == 64)
-            rc = s.kc == 8 ? launch_scan8<64, 8>(a, grid, st, prof)
+            rc = s.kc == 8 ? (quad16 ? launch_scan8<64, 8, true, 0, kScan8Aln, true>(a, grid, st, prof) : launch_scan8<64, 8>(a, grid, st, prof))
                  : s.kc == 16 ? (quad16 ? launch_scan8<64, 16, true, 0, kScan8Aln, true>(a, grid, st, prof)
                                         : launch_scan8<64, 16>(a, grid, st, prof))
                               : launch_scan8<64, 32>(a, grid, st, prof);
         else
-            rc = s.kc == 8 ? launch_scan8<32, 8>(a, grid, st, prof)
-                           : s.kc == 16 ? launch_scan8<32, 16>(a, grid, st, prof) : launch_scan8<32, 32>(a, grid, st, prof);
+            rc = quad32 ? (s.kc == 8 ? launch_scan8<32, 8, true, 0, 0, true>(a, grid, st, prof)
+                           : s.kc == 16 ? launch_scan8<32, 16, true, 0, 0, true>(a, grid, st, prof)
+                                        : launch_scan8<32, 32, true, 0, 0, true>(a, grid, st, prof))
+                        : (s.kc == 8 ? launch_scan8<32, 8>(a, grid, st, prof)
+                           : s.kc == 16 ? launch_scan8<32, 16>(a, grid, st, prof) : launch_scan8<32, 32>(a, grid, st, prof));
         if (rc != PRAG_OK) return rc;
         const int nq = std::min(QT, s.B - p0);
         GatherArgs g;
