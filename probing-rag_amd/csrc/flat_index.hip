@@ -1364,6 +1364,7 @@ struct prag_index {
     size_t mm_c_entries = 0;      // entries of mm_ckey / mm_cidx, mm_wcnt words
     int mm_mode = 1;   // 0 = never take the MFMA-tiled path (PRAG_SCAN_MM=0)
     int shadow_bound_mode = -1;   // -1 auto, 0 off, 1 on (PRAG_SHADOW_BOUND)
+    int64_t scan8_quad_rows = (int64_t)8 << 20;   // PRAG_SCAN8_QUAD_ROWS (tests: 0 = the quad-test scans at every size)
     int mm_shape16 = 1;   // tiled scans on 16 x 16 MFMA tiles (PRAG_MM_SHAPE=32: the 32 x 32 form, A/B timing)
     // 8-bit selection for the MFMA-tiled scan (> 128 queries on an index that keeps a shadow): int8 MFMA over the
     // shadow, kMm8Kc candidates per query, the shadow's error bound in the certificate; the queries that fail that
@@ -1659,6 +1660,7 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
 #endif
     if (const char* e = getenv("PRAG_MM_SHAPE")) ix->mm_shape16 = atoi(e) != 32;
     if (const char* e = getenv("PRAG_SHADOW_BOUND")) ix->shadow_bound_mode = atoi(e);
+    if (const char* e = getenv("PRAG_SCAN8_QUAD_ROWS")) ix->scan8_quad_rows = atoll(e);
     if (const char* e = getenv("PRAG_MM8")) ix->mm8_mode = atoi(e) != 0;
     if (const char* e = getenv("PRAG_MM8_MIN_ROWS")) ix->mm8_min_rows = atoll(e);
     if (const char* e = getenv("PRAG_PREPASS")) ix->prepass_mode = atoi(e);
@@ -2670,6 +2672,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         ss.cert = cert;
         ss.gate = ix->gate;
         // one more small launch; pays once the candidate lists are long (measured: profiles/r04p_exact_bound_ab.txt)
+        ss.quad_min_rows = ix->scan8_quad_rows;
         ss.exact_bound = k <= 32 && (ix->shadow_bound_mode < 0 ? ix->ntotal >= (1ll << 19) : ix->shadow_bound_mode != 0);
         rc = shadow_search(ss, st, prof);
         if (rc != PRAG_OK) return rc;

@@ -521,6 +521,7 @@ struct ShadowSearch {
     CertArgs cert;           // flag list: queries whose candidate regions overflowed go to the exact scan
     Gate gate;
     bool exact_bound = false;   // lower g_tau to an exact k-th best before the gather (shadow_bound_kernel)
+    int64_t quad_min_rows = (int64_t)8 << 20;   // shards from this size on scan with the quad-test epilogue (flat_shadow.hip)
 };
 bool shadow_store_supported(int d);
 bool shadow_tile128_ok(int d, int kc);

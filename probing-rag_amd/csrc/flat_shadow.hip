@@ -1350,16 +1350,6 @@ static int launch_scan8(const Scan8Args& a, int grid, hipStream_t st, EventRing&
 // 0.469 -> 0.481-0.498 ms - short scans spend their time in the early tiles, where most quads hold a candidate and the
 // test is extra work - hence the row threshold.
 constexpr int kScan8Aln = 3;
-static int64_t scan8_quad_min_rows() {
-    static const int64_t v = [] {
-        const char* e = getenv("PRAG_SCAN8_QUAD_ROWS");      // experiment switch
-        return e ? atoll(e) : (int64_t)8 << 20;
-    }();
-    return v;
-}
-// (Also measured: the same kernel with the six chunks of a 768-element row unrolled - scan8_kernel<64,16,true,6,3,true>,
-// scalar instructions per tile 412 -> 129, vector 501 -> 421, active-issue cycles -31 % by the SQ counters - runs at the
-// SAME speed, 2.62-2.70 vs 2.58-2.66 ms on one box: at two waves per SIMD this loop is not bound by instruction issue.)
 int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
     const int qstride = (s.d + 255) / 256 * 256;
     const bool wide = s.qt_max >= 64 && s.B > 32 && scan8_lds_bytes(64, qstride) <= 160 * 1024;
@@ -1405,8 +1395,8 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         a.dbg = 0;
 #endif
         int rc;
-        const bool quad16 = (s.d / 128) % kScan8Aln == 0 && s.N >= scan8_quad_min_rows();
-        const bool quad32 = s.N >= scan8_quad_min_rows();
+        const bool quad16 = (s.d / 128) % kScan8Aln == 0 && s.N >= s.quad_min_rows;
+        const bool quad32 = s.N >= s.quad_min_rows;
         if (QT == 128)
             rc = s.d == 768 ? (s.kc == 8 ? launch_scan8<128, 8, false, 6, 0, true>(a, grid, st, prof)
                                          : launch_scan8<128, 16, false, 6, 0, true>(a, grid, st, prof))

@@ -13,10 +13,12 @@ METRICS = [onp.METRIC_L2, onp.METRIC_IP, onp.METRIC_COS]
 
 @pytest.fixture(params=[None, "1"], ids=["bound-auto", "bound-on"])
 def shadow_bound(request, monkeypatch):
-    """Second run with the exact-bound / finish kernel in front of the gather forced on (shadow_bound_kernel,
-    flat_shadow.hip; by itself it starts at 2^19 rows - the big-corpus tests and the bench riders cover that side)."""
+    """Second run with the exact-bound / finish kernel in front of the gather (shadow_bound_kernel; by itself from 2^19
+    rows) and the quad-test scan kernels (from 2^23 rows) forced on at every size - the big-corpus tests and the bench
+    riders cover the default side."""
     if request.param:
-        monkeypatch.setenv("PRAG_SHADOW_BOUND", request.param)     # read when the index is created
+        monkeypatch.setenv("PRAG_SHADOW_BOUND", request.param)     # both read when the index is created
+        monkeypatch.setenv("PRAG_SCAN8_QUAD_ROWS", "0")
     return request.param
 
 
