@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """MFMA-tiled scan (> 128 queries): parity against the oracle and the per-lane-list kernels, timing (diagnostic)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import probing_rag_amd as pra

@@ -2,7 +2,7 @@
 """Print max |logit error| of every prober mode against the float64 oracle on
 identical operands (diagnostic; GPU)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import probing_rag_amd as pra

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Query-stationary scan (65..128 queries): parity on small shards and speed at 128 x 21M (diagnostic)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import probing_rag_amd as pra

@@ -6,11 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import probing_rag_amd as pra
-from oracle import oracle_np as onp
+from probing_rag_amd.synth import synth_rows
 N, d, B, k = int(os.environ.get("C3_N", 1_000_000)), 768, int(os.environ.get("C3_B", 1000)), 10
 ix = pra.HipFlatIndex(d, "cos", "f16", capacity=N)
 ix.add_synthetic(42, 0, N)
-Q = torch.from_numpy(onp.synth_rows(7, 0, B, d)).cuda()
+Q = torch.from_numpy(synth_rows(7, 0, B, d)).cuda()
 n = int(os.environ.get("C3_REPS", 10))
 for shadow in ((0,) if os.environ.get("C3_ONLY16") else (0, 2)):       # 0: fp16 tiles; 2: int8 tiles over the 8-bit shadow first (PRAG_MM8=0 switches them off)
     ix.set_shadow(shadow)

@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--theta", type=float, default=0.0)
     args = ap.parse_args()
     import probing_rag_amd as pra
-    from oracle import oracle_np as onp
+    from probing_rag_amd.synth import synth_rows
     from tests.golden import cases
     from transformers import GemmaConfig, GemmaForCausalLM
 
@@ -77,7 +77,7 @@ def main():
             return int(dec[0])
 
         def retrieve(text, k):
-            q = torch.from_numpy(onp.synth_rows(900 + qi, len(ev["retrieve"]), 1, 768)).to(dev)
+            q = torch.from_numpy(synth_rows(900 + qi, len(ev["retrieve"]), 1, 768)).to(dev)
             return timed("retrieve", lambda: index.search(q, k))
 
         pred, rc = pra.retrieve_decide(

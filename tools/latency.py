@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import probing_rag_amd as pra
-from oracle import oracle_np as onp
+from probing_rag_amd.synth import synth_rows
 from tests.golden import cases
 
 
@@ -44,7 +44,7 @@ for N in (10_000, 1_000_000, 21_000_000):
     ix = pra.HipFlatIndex(768, "l2", "f16", capacity=N)
     ix.add_synthetic(42, 0, N)
     for B in (1, 32):
-        q = onp.synth_rows(7, 0, B, 768)
+        q = synth_rows(7, 0, B, 768)
         qd = torch.from_numpy(q).cuda()
         t_dev = timeit(lambda: ix.search(qd, 5), n=30, warm=3)
         t_host = timeit(lambda: ix.search(q, 5), n=30, warm=3)

@@ -8,12 +8,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import probing_rag_amd as pra
-from oracle import oracle_np as onp
+from probing_rag_amd.synth import synth_rows
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 21_000_000
 ix = pra.HipFlatIndex(768, "cos", "f16", capacity=N)
 ix.set_shadow(2)
 ix.add_synthetic(42, 0, N)
-Q = torch.from_numpy(onp.synth_rows(7, 0, 1000, 768)).cuda()
+Q = torch.from_numpy(synth_rows(7, 0, 1000, 768)).cuda()
 ix.profile(64)
 for _ in range(2):
     ix.search(Q, 10)

@@ -8,11 +8,11 @@ import os, sys, time
 sys.path.insert(0, %r)
 import numpy as np, torch
 import probing_rag_amd as pra
-from oracle import oracle_np as onp
+from probing_rag_amd.synth import synth_rows
 N, d, B, k = int(os.environ.get("MM_N", 1000000)), 768, int(os.environ.get("MM_B", 1000)), 10
 ix = pra.HipFlatIndex(d, "cos", "f16", capacity=N)
 ix.add_synthetic(42, 0, N)
-Q = torch.from_numpy(onp.synth_rows(7, 0, B, d)).cuda()
+Q = torch.from_numpy(synth_rows(7, 0, B, d)).cuda()
 ix.profile(64)
 for _ in range(3): ix.search(Q, k)
 torch.cuda.synchronize(); ix.profile_read()

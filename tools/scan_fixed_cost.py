@@ -5,10 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import probing_rag_amd as pra
-from oracle import oracle_np as onp
+from probing_rag_amd.synth import synth_rows
 d, k = 768, 10
 for B in (64, 32):
-    Q = torch.from_numpy(onp.synth_rows(7, 0, B, d)).cuda()
+    Q = torch.from_numpy(synth_rows(7, 0, B, d)).cuda()
     for N in (256, 8192, 65536, 100_000, 262_144, 2_625_000):
         ix = pra.HipFlatIndex(d, "cos", "f16", capacity=N)
         ix.add_synthetic(42, 0, N)

@@ -6,14 +6,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import probing_rag_amd as pra
-from oracle import oracle_np as onp
+from probing_rag_amd.synth import synth_rows
 N, d, B, k = int(sys.argv[1]) if len(sys.argv) > 1 else 21_000_000, 768, 1000, 10
 ix = pra.HipFlatIndex(d, "cos", "f16", capacity=N + 700)
 ix.add_synthetic(42, 0, N)
 g = torch.Generator(device="cuda").manual_seed(3)
 base = torch.randn((1, d), generator=g, device="cuda")
 ix.add(base + 2e-3 * torch.randn((700, d), generator=g, device="cuda"))
-Q = torch.from_numpy(onp.synth_rows(7, 0, B, d)).cuda()
+Q = torch.from_numpy(synth_rows(7, 0, B, d)).cuda()
 Qc = Q.clone()
 for i in (5, 500, 999):
     Qc[i] = (base + 2e-3 * torch.randn((1, d), generator=g, device="cuda"))[0]

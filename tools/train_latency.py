@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import probing_rag_amd as pra
-from oracle import oracle_np as onp
+from probing_rag_amd.synth import synth_rows
 from tests.golden import cases
 
 
@@ -24,7 +24,7 @@ F = torch.nn.functional
 for B in (8, 64):
     d = 2048
     st = cases.synth_state(900, d)
-    x = torch.from_numpy(onp.synth_rows(901, 0, B, d)).cuda()
+    x = torch.from_numpy(synth_rows(901, 0, B, d)).cuda()
     y = torch.from_numpy(np.arange(B) % 2).cuda()
     tr = pra.HipProberTrainer(d, 2, seed=1).load_state_dict(st)
     t_hip = timeit(lambda: tr.step(x, y), n=200)
