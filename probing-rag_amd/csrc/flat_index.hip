@@ -1364,6 +1364,7 @@ struct prag_index {
     size_t mm_c_entries = 0;      // entries of mm_ckey / mm_cidx, mm_wcnt words
     int mm_mode = 1;   // 0 = never take the MFMA-tiled path (PRAG_SCAN_MM=0)
     int shadow_bound_mode = -1;   // -1 auto, 0 off, 1 on (PRAG_SHADOW_BOUND)
+    int shadow_sample_mode = -1;  // -1 auto, 0 off, 1 on (PRAG_SHADOW_SAMPLE): the sampled pre-bound of the two-level search
     int64_t scan8_quad_rows = (int64_t)8 << 20;   // PRAG_SCAN8_QUAD_ROWS (tests: 0 = the quad-test scans at every size)
     int mm_shape16 = 1;   // tiled scans on 16 x 16 MFMA tiles (PRAG_MM_SHAPE=32: the 32 x 32 form, A/B timing)
     // 8-bit selection for the MFMA-tiled scan (> 128 queries on an index that keeps a shadow): int8 MFMA over the
@@ -1660,6 +1661,7 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
 #endif
     if (const char* e = getenv("PRAG_MM_SHAPE")) ix->mm_shape16 = atoi(e) != 32;
     if (const char* e = getenv("PRAG_SHADOW_BOUND")) ix->shadow_bound_mode = atoi(e);
+    if (const char* e = getenv("PRAG_SHADOW_SAMPLE")) ix->shadow_sample_mode = atoi(e);
     if (const char* e = getenv("PRAG_SCAN8_QUAD_ROWS")) ix->scan8_quad_rows = atoll(e);
     if (const char* e = getenv("PRAG_MM8")) ix->mm8_mode = atoi(e) != 0;
     if (const char* e = getenv("PRAG_MM8_MIN_ROWS")) ix->mm8_min_rows = atoll(e);
@@ -2608,7 +2610,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         // twice the error band - the candidates of the loosely bounded first tiles cost the scan and the gather
         // what the warm-up's second visits cost: prep +13 us, gather +6 us, scan +-0, and one query in a few
         // searches overflowed a region).  PRAG_SHADOW_SAMPLE=0|1 forces it off / on for A/B runs (exact either way).
-        static const int sample_env = getenv("PRAG_SHADOW_SAMPLE") ? atoi(getenv("PRAG_SHADOW_SAMPLE")) : -1;
+        const int sample_env = ix->shadow_sample_mode;
         // ... and on shards so small that a wave owns fewer than 6 tiles: the chip-wide bound reaches a wave
         // through the slot epochs it polls after its 2nd and 3rd tile, so without a starting bound such a wave
         // filters against its own lists only and nearly every row passes (65 537 rows, 64 queries: every query

@@ -30,7 +30,6 @@
 
 #include <algorithm>
 #include <cstdlib>
-#include <vector>
 
 #include "flat_internal.h"
 
@@ -838,12 +837,6 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
 #endif
     int64_t lo = 0;
     int64_t hi = first_rows;  // first segment: every row is a candidate
-    static const std::vector<int> sched_env = [] {   // experiment switch: "g1,g2,..." growth per boundary
-        std::vector<int> v;
-        if (const char* e = getenv("PRAG_MM_GROWTH_SCHED"))
-            for (const char* p = e; *p;) { v.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
-        return v;
-    }();
     int seg_i = 0;
     while (lo < s.N) {
         a.row0 = lo;
@@ -922,8 +915,7 @@ int mm_run(const MmSearch& s, hipStream_t st, EventRing& prof) {
                                s.wg_slots, s.Bpad, s.gate);
         PRAG_LAUNCH_CHECK();
         lo = hi;
-        int g_step = mm_growth_step(s.growth, seg_i, s.i8 != 0);
-        if (!sched_env.empty() && !s.i8) g_step = sched_env[std::min<size_t>(seg_i, sched_env.size() - 1)];
+        const int g_step = mm_growth_step(s.growth, seg_i, s.i8 != 0);
         ++seg_i;
         hi = std::min<int64_t>(s.N, hi * (int64_t)std::max(2, std::min(16, g_step)));
     }

@@ -1054,6 +1054,7 @@ struct prag_prober {
     // at one pooled state, profiles/r04c_latency.txt: a hand-off costs a write-through drain, an atomic, a poll and
     // a load from beyond L2, ~5 us, where a kernel boundary costs ~2 us and leaves the data in L2; kept for A/B)
     int small_mode = 1;
+    int ct_force = 0;            // PRAG_PROBER_CT at creation: row-tile height override (tuning runs)
     _Float16* ws_h = nullptr;  // [L][maxB][d] hi / lo workspace for fp32 activations
     _Float16* ws_l = nullptr;
     int64_t ws_rows = 0;
@@ -1195,6 +1196,7 @@ extern "C" int prag_prober_create(prag_prober_t** out, int n_layers, int d_model
     p->allocs.resize(n_layers);
     p->h_small.resize(n_layers);
     if (const char* ev = getenv("PRAG_PROBER_SMALL")) p->small_mode = atoi(ev);
+    if (const char* ev = getenv("PRAG_PROBER_CT")) p->ct_force = atoi(ev);
     if (const char* ev = getenv("PRAG_PROBER_SHAPE")) p->shape16 = atoi(ev) != 32;
     {
         int dev = 0;
@@ -1537,7 +1539,7 @@ static int forward_impl(prag_prober_t* p, const void* x_dev, int x_dtype, int64_
     }
     const int max_ct = (p->na == 1 && nb == 1) ? 4 : 2;
     int ct = pick_ct(B, n_run, max_ct, p->n_cu);
-    static const int ct_force = getenv("PRAG_PROBER_CT") ? atoi(getenv("PRAG_PROBER_CT")) : 0;  // tuning knob
+    const int ct_force = p->ct_force;
     if (ct_force == 1 || ct_force == 2 || (ct_force == 4 && max_ct >= 4)) ct = ct_force;
 #define PRAG_DISPATCH(NA_, NB_)                                                      \
     if (p->na == NA_ && nb == NB_) {                                                 \
