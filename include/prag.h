@@ -354,6 +354,12 @@ int prag_index_set_shadow(prag_index_t* ix, int mode);
  * build.) */
 int prag_index_prepare(prag_index_t* ix, void* stream);
 
+/* Allocate every per-search workspace a search of up to B queries and this k needs, now (one throw-away search of
+ * zero queries on `stream`, waited for).  The index otherwise grows its workspaces inside the first search of a
+ * larger shape - a hipFree / hipMalloc, i.e. a device synchronisation, and not capturable into a graph.  After this
+ * call searches of that shape allocate nothing.  (No reference counterpart; faiss allocates per call.) */
+int prag_index_reserve(prag_index_t* ix, int B, int k, void* stream);
+
 /* Cap the number of workgroups (= CUs) the scan kernels occupy; 0 = all CUs.  The scan is
  * HBM-bound, so leaving a few CUs free lets an independent kernel on another stream (e.g. the
  * prober gate of the next batch) run concurrently instead of queueing behind it. */

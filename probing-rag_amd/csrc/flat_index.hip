@@ -2226,6 +2226,39 @@ extern "C" int prag_index_search_tagged(prag_index_t* ix, const float* q, int B,
     return index_search_impl(ix, q, B, k, id_offset, D, I, io_is_device, stream, 1);
 }
 
+// Allocate every workspace a search of this shape needs NOW (the index grows its workspaces lazily, by shape class, with
+// hipFree / hipMalloc - i.e. a device synchronisation - inside the first search that needs more): one throw-away search
+// of B zero queries on `stream`, waited for.  Afterwards a search of up to B queries and this k allocates nothing,
+// never waits for the device on the device-io path, and can be captured into a graph from its first call.
+extern "C" int prag_index_reserve(prag_index_t* ix, int B, int k, void* stream) {
+    PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
+    PRAG_REQUIRE(B >= 1 && k >= 1, PRAG_EINVAL, "prag_index_reserve: B=%d k=%d", B, k);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float* q = nullptr;
+    float* D = nullptr;
+    int64_t* I = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&q), (size_t)B * ix->d * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&D), (size_t)B * k * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&I), (size_t)B * k * sizeof(int64_t));
+    int rc = PRAG_OK;
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("prag_index_reserve: %s", hipGetErrorString(e));
+        rc = e == hipErrorOutOfMemory ? PRAG_ENOMEM : PRAG_EHIP;
+    } else {
+        e = hipMemsetAsync(q, 0, (size_t)B * ix->d * sizeof(float), st);
+        if (e == hipSuccess) rc = index_search_impl(ix, q, B, k, 0, D, I, 1, stream, 0);
+        const hipError_t e2 = hipStreamSynchronize(st);
+        if (rc == PRAG_OK && (e != hipSuccess || e2 != hipSuccess)) {
+            set_error("prag_index_reserve: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+            rc = PRAG_EHIP;
+        }
+    }
+    for (void* p : {(void*)q, (void*)D, (void*)I})
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
 extern "C" int prag_index_set_comm(prag_index_t* ix, void* nccl_comm, int rank, int world) {
     PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
     PRAG_REQUIRE(world >= 1 && rank >= 0 && rank < world, PRAG_EINVAL, "rank %d of %d", rank, world);

@@ -362,8 +362,17 @@ def _ix_prepare(self):
         _lib.check(_lib.lib().prag_index_prepare(self._h, _lib.current_stream_ptr(self.device)))
 
 
+def _ix_reserve(self, B: int, k: int):
+    """Allocate the workspaces of a ``B``-query, top-``k`` search now (a throw-away search of zero queries): later
+    searches of that shape allocate nothing and can be captured into a graph from the first call."""
+    import torch
+    with torch.cuda.device(self.device):
+        _lib.check(_lib.lib().prag_index_reserve(self._h, int(B), int(k), _lib.current_stream_ptr(self.device)))
+
+
 HipFlatIndex.set_shadow = _ix_set_shadow
 HipFlatIndex.prepare = _ix_prepare
+HipFlatIndex.reserve = _ix_reserve
 HipFlatIndex.set_candidate_depth = _ix_set_candidate_depth
 HipFlatIndex.last_exact_fallbacks = _ix_last_exact_fallbacks
 HipFlatIndex.last_tiled8 = _ix_last_tiled8

@@ -622,3 +622,33 @@ def test_against_faiss_where_it_is_installed():
         D, I = ix.search(Q, 5)
         _check(D, I, D0, I0, metric)
         ix.close()
+
+
+def test_reserve_makes_the_first_search_of_a_shape_capturable():
+    """prag_index_reserve: after it, the FIRST search of that shape allocates nothing - it is captured into a graph
+    without a warm-up search and the replay gives the definition's result (two-level path, 64 queries, and the
+    direct scan of a smaller batch on the same index)."""
+    import probing_rag_amd as pra
+    import torch
+    N, d, k = 50_000, 768, 10
+    X = onp.synth_rows(42, 0, N, d)
+    ix = pra.HipFlatIndex(d, "cos", "f16")
+    ix.set_shadow(2)
+    ix.add(X)
+    for B in (64, 7):
+        Q = onp.synth_rows(70 + B, 0, B, d)
+        qd = torch.from_numpy(Q).cuda()
+        out = (torch.empty((B, k), dtype=torch.float32, device="cuda"), torch.empty((B, k), dtype=torch.int64, device="cuda"))
+        ix.reserve(B, k)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                ix.search(qd, k, out=out)                  # the first real search of this shape
+        out[1].fill_(-7)
+        g.replay()
+        torch.cuda.synchronize()
+        D0, I0 = oracle_c.flat_search(onp.store_round(onp.normalize_rows(X), "f16"), Q, k, onp.METRIC_COS)
+        assert np.array_equal(out[1].cpu().numpy(), I0)
+        np.testing.assert_allclose(out[0].cpu().numpy(), D0, atol=1e-4, rtol=0)
