@@ -151,6 +151,16 @@ int prag_pool_accumulate_layers(float* acc_dev, const void* const* h_dev_ptrs, i
 int prag_pool_ragged(const void* acts_dev, int dtype, int B, int T, int d,
                      const int64_t* pred_lens_dev, int scale_mean, float* out_dev, void* stream);
 
+/* Replaces `_input_tensor_method1` (train.py:153-162, utils.py:134-143) - the input of the `each_token` training
+ * method, train.py:354's default (method_1_train / method_1_eval, train.py:182-197): the last pred_lens[b] positions
+ * of every sample concatenated in sample order, out float32 [n_rows, d], and `torch.repeat_interleave(labels,
+ * pred_lens)` -> labels_out int32 [n_rows] (labels_dev int32 [B]; both may be NULL).  row_offsets_dev int64 [B+1] =
+ * exclusive prefix sums of pred_lens (clamped to [0, T]), row_offsets[B] = n_rows: the host knows them, it sizes
+ * `out`.  acts [B,T,d] of element type dtype. */
+int prag_pool_each_token(const void* acts_dev, int dtype, int B, int T, int d, const int64_t* row_offsets_dev,
+                         int64_t n_rows, const int32_t* labels_dev, float* out_dev, int32_t* labels_out_dev,
+                         void* stream);
+
 /* Replaces the attention-masked mean pooling at the end of
  * `SentenceTransformer('facebook/contriever-msmarco').encode` (utils.py:365-366,
  * make_indexer.py:447-455; third-party code, restated from its published

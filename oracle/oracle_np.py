@@ -306,6 +306,35 @@ def train_eval_forward(state: dict, acts: np.ndarray, pred_lens: np.ndarray,
     return p.astype(np.float32), np.float32(loss), acc
 
 
+def pool_each_token(acts: np.ndarray, pred_lens: np.ndarray, labels: np.ndarray = None):
+    """`_input_tensor_method1` (train.py:153-162, utils.py:134-143; the `each_token` method): the last
+    pred_lens[i] positions of every sample concatenated in sample order, and
+    `torch.repeat_interleave(labels, pred_lens)`."""
+    T = acts.shape[1]
+    rows = np.concatenate([acts[i, T - int(n):, :] for i, n in enumerate(pred_lens)], axis=0)
+    new_labels = None if labels is None else np.repeat(np.asarray(labels), np.asarray(pred_lens).astype(np.int64))
+    return rows.astype(np.float32), new_labels
+
+
+def pool_last_token(acts: np.ndarray) -> np.ndarray:
+    """`activations[:, -1, :]` (train.py:228, utils.py:206; the `last_token` method)."""
+    return np.ascontiguousarray(acts[:, -1, :], dtype=np.float32)
+
+
+def eval_forward_rows(state: dict, x: np.ndarray, labels: np.ndarray):
+    """make_loss + return_acc (train.py:141-151, 170-181) on already-pooled rows: the tail of
+    train_eval_forward, shared by method_1_eval / method_3_eval (utils.py:175-179, 222-226)."""
+    z = prober_forward(state, x).astype(np.float64)
+    z = z - z.max(axis=1, keepdims=True)
+    p = np.exp(z)
+    p = p / p.sum(axis=1, keepdims=True)
+    lse = np.log(np.exp(p).sum(axis=1))
+    lab = np.asarray(labels).astype(np.int64)
+    loss = float(np.mean(lse - p[np.arange(len(lab)), lab]))
+    acc = float((p.argmax(axis=1) == lab).sum()) / len(lab)
+    return p.astype(np.float32), np.float32(loss), acc
+
+
 # --------------------------------------------------------------------------
 # prober training step (train.py:141-151, 210-220 / utils.py:191-197:
 # method_2_train = forward in train mode -> CrossEntropyLoss on the softmax

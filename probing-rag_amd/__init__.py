@@ -13,9 +13,10 @@ from .index import (HipFlatIndex, IndexFlatIP, IndexFlatL2, batch_topk_sim, enco
                     find_topk_sim, merge_topk, plan_search, read_index, read_index_header, write_index)
 from .docstore import Docstore, lookup_passages, read_docstore, write_docstore  # noqa: F401
 from .sharded import ShardedFlatIndex, partition_rows, search_shards_on_one_gpu  # noqa: F401
-from .trainer import HipProberTrainer, method_2_train  # noqa: F401
+from .trainer import HipProberTrainer, method_1_train, method_2_train, method_3_train  # noqa: F401
 from .encoder import MeanPoolEncoder  # noqa: F401
-from .loop import HiddenStatePool, masked_mean_pool, method_2_eval, pool_ragged, retrieve_decide, return_evidences  # noqa: F401
+from .loop import (HiddenStatePool, masked_mean_pool, method_1_eval, method_2_eval, method_3_eval, pool_each_token,  # noqa: F401
+                   pool_last_token, pool_ragged, retrieve_decide, return_evidences)
 
 ImprovedProbe = HipProber  # utils.py:29
 __version__ = "0.1.0"

@@ -65,6 +65,7 @@ SIGNATURES = {
     "prag_pool_accumulate_layers": (_I, [_P, _P, _I, _I, _L, _I, _P]),
     "prag_pool_ragged": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "prag_pool_masked_mean": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
+    "prag_pool_each_token": (_I, [_P, _I, _I, _I, _I, _P, _L, _P, _P, _P, _P]),
     "prag_trainer_create": (_I, [ctypes.POINTER(_P), _I, _I, _I] + [ctypes.c_double] * 7 + [ctypes.c_uint32]),
     "prag_trainer_load": (_I, [_P] + [_FP] * 12),
     "prag_trainer_step": (_I, [_P, _P, _P, _I, _P, _P, _P]),

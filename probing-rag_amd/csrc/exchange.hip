@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <mutex>
 
 #include "prag_common.h"
 #include "exchange.h"
@@ -37,9 +38,11 @@ struct Rccl {
     fn_error_string error_string = nullptr;
     bool tried = false;
 };
-Rccl g_rccl;
+Rccl g_rccl;              // guarded by g_rccl_mu until `lib` is set; read-only afterwards
+std::mutex g_rccl_mu;
 
 int rccl_load() {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);     // two host threads creating sharded indexes at once
     if (g_rccl.lib) return PRAG_OK;
     if (g_rccl.tried) {
         set_error("RCCL is not available in this process (librccl.so could not be loaded)");

@@ -1025,6 +1025,40 @@ __global__ __launch_bounds__(256) void pool_ragged_kernel(const T* __restrict__ 
     *reinterpret_cast<f32x4*>(out + (int64_t)b * d + col) = s;
 }
 
+// train.py:153-162 / utils.py:134-143 (`input_tensor_method1`, the `each_token` method - train.py:354's default):
+// the last pred_lens[b] positions of every sample, concatenated in sample order -> out [n_rows][d] float32, and
+// the sample's label repeated for each of its rows (torch.repeat_interleave).  row_off[b] = rows of the samples
+// before b (row_off[B] = n_rows); blockIdx.x = output row, blockIdx.y = 1024-column chunk.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_each_token_kernel(const T* __restrict__ acts, int B, int Tlen, int d,
+                                                             const int64_t* __restrict__ row_off,
+                                                             const int32_t* __restrict__ labels, float* __restrict__ out,
+                                                             int32_t* __restrict__ labels_out) {
+    const int64_t r = blockIdx.x;
+    int lo = 0, hi = B;                         // the sample b with row_off[b] <= r < row_off[b + 1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (row_off[mid] <= r) lo = mid; else hi = mid;
+    }
+    const int b = lo;
+    const int64_t n = row_off[b + 1] - row_off[b];
+    const int64_t t = (int64_t)Tlen - n + (r - row_off[b]);
+    if (labels_out && labels && blockIdx.y == 0 && threadIdx.x == 0) labels_out[r] = labels[b];
+    const int col = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
+    if (col >= d) return;
+    const T* src = acts + ((int64_t)b * Tlen + t) * d + col;
+    f32x4 v;
+    if constexpr (sizeof(T) == 4) {
+        v = *reinterpret_cast<const f32x4*>(src);
+    } else if constexpr (std::is_same<T, _Float16>::value) {
+        const half4 hv = *reinterpret_cast<const half4*>(src);
+        v = {(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+    } else {   // bf16 bits
+        v = load4_as_f32(src);
+    }
+    *reinterpret_cast<f32x4*>(out + r * d + col) = v;
+}
+
 }  // namespace prag
 
 // ===========================================================================
@@ -1052,7 +1086,8 @@ struct prag_prober {
     // PRAG_PROBER_SMALL=0: always the MFMA-tiled kernel; 1 (default): three short launches; 3: the same stages in
     // ONE launch with in-launch hand-offs (round 4: built, bit-identical, and SLOWER - 30.2 against 25.2 us per gate
     // at one pooled state, profiles/r04c_latency.txt: a hand-off costs a write-through drain, an atomic, a poll and
-    // a load from beyond L2, ~5 us, where a kernel boundary costs ~2 us and leaves the data in L2; kept for A/B)
+    // a load from beyond L2, ~5 us, where a kernel boundary costs ~2 us and leaves the data in L2; since round 5 the
+    // kernel exists in the `make diag` build only - in libprag.so mode 3 runs the three launches)
     int small_mode = 1;
     int ct_force = 0;            // PRAG_PROBER_CT at creation: row-tile height override (tuning runs)
     _Float16* ws_h = nullptr;  // [L][maxB][d] hi / lo workspace for fp32 activations
@@ -1710,6 +1745,32 @@ extern "C" int prag_pool_ragged(const void* acts_dev, int dtype, int B, int T, i
         hipLaunchKernelGGL(pool_ragged_kernel<unsigned short>, grid, dim3(256), 0, st,
                            reinterpret_cast<const unsigned short*>(acts_dev), T, d, pred_lens_dev, scale_mean,
                            out_dev);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+extern "C" int prag_pool_each_token(const void* acts_dev, int dtype, int B, int T, int d, const int64_t* row_offsets_dev,
+                                    int64_t n_rows, const int32_t* labels_dev, float* out_dev, int32_t* labels_out_dev,
+                                    void* stream) {
+    PRAG_REQUIRE(acts_dev && row_offsets_dev && out_dev, PRAG_EINVAL, "prag_pool_each_token: NULL device pointer");
+    PRAG_REQUIRE(B >= 1 && T >= 1 && d >= 4 && d % 4 == 0, PRAG_EINVAL, "B=%d T=%d d=%d", B, T, d);
+    PRAG_REQUIRE(n_rows >= 0 && n_rows <= (int64_t)B * T && n_rows <= 0x7fffffff, PRAG_EINVAL,
+                 "n_rows=%lld outside [0, B*T]", (long long)n_rows);
+    PRAG_REQUIRE(dtype == PRAG_F32 || dtype == PRAG_F16 || dtype == PRAG_BF16, PRAG_EINVAL, "dtype=%d", dtype);
+    if (n_rows == 0) return PRAG_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)n_rows, (d / 4 + 255) / 256);
+    if (dtype == PRAG_F32)
+        hipLaunchKernelGGL(pool_each_token_kernel<float>, grid, dim3(256), 0, st, reinterpret_cast<const float*>(acts_dev),
+                           B, T, d, row_offsets_dev, labels_dev, out_dev, labels_out_dev);
+    else if (dtype == PRAG_F16)
+        hipLaunchKernelGGL(pool_each_token_kernel<_Float16>, grid, dim3(256), 0, st,
+                           reinterpret_cast<const _Float16*>(acts_dev), B, T, d, row_offsets_dev, labels_dev, out_dev,
+                           labels_out_dev);
+    else
+        hipLaunchKernelGGL(pool_each_token_kernel<unsigned short>, grid, dim3(256), 0, st,
+                           reinterpret_cast<const unsigned short*>(acts_dev), B, T, d, row_offsets_dev, labels_dev,
+                           out_dev, labels_out_dev);
     PRAG_LAUNCH_CHECK();
     return PRAG_OK;
 }

@@ -8,7 +8,7 @@
 //                       Used for fc1 (K = d_model, input = caller's activations) and fc2 (K = 512).
 //   small_head_kernel   one workgroup: LN2 + fc3 for every (layer, row), then - optionally - the gate
 //                       (softmax / sum over layers / threshold, float32 in layer order, exp_rag.py:407-415).
-//   small_fused_kernel  (round 4, PRAG_PROBER_SMALL=3) the three stages in ONE launch: 32 workgroups per layer run
+//   small_fused_kernel  (round 4; `make diag` build only since round 5, PRAG_PROBER_SMALL=3) the three stages in ONE launch: 32 workgroups per layer run
 //                       fc1, hand their 16 hidden units to the layer's other workgroups through global memory
 //                       (write-through stores, one arrival counter per layer), run fc2 the same way, and the workgroup
 //                       that arrives last at the final counter runs the head and the gate.  Same arithmetic, same
@@ -297,6 +297,14 @@ __global__ __launch_bounds__(256) void small_head_kernel(const SmallLayer* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+struct SmallSync {          // device words of one prober handle, zero between launches
+    uint32_t cnt1[64];      // per layer: workgroups whose fc1 outputs are stored
+    uint32_t cnt2;          // workgroups whose fc2 outputs are stored (all layers)
+    uint32_t giveup;        // != 0: a wait timed out (the outputs of that launch are not valid)
+    uint32_t pad[2];
+};
+
+#ifdef PRAG_MM_DIAG   // measured slower than three launches (profiles/r04c_latency.txt): kept for A/B in libprag_diag.so only
 // One launch for the whole small-batch gate.
 // Hand-offs follow cdna_hip_programming.md Guideline 16 in its counter form, with write-through payloads:
 //   producer: every value another workgroup will read is stored `sc1` (relaxed agent-scope atomic store = one
@@ -312,12 +320,6 @@ __global__ __launch_bounds__(256) void small_head_kernel(const SmallLayer* __res
 // The arrival counters return to zero inside the launch (the last arriver resets them after every poll and ticket
 // of this launch has happened), so a replayed graph node starts from clean state; they are zeroed once at creation.
 // ---------------------------------------------------------------------------------------------------------------
-struct SmallSync {          // device words of one prober handle, zero between launches
-    uint32_t cnt1[64];      // per layer: workgroups whose fc1 outputs are stored
-    uint32_t cnt2;          // workgroups whose fc2 outputs are stored (all layers)
-    uint32_t giveup;        // != 0: a wait timed out (the outputs of that launch are not valid)
-    uint32_t pad[2];
-};
 
 template <typename T, int B_MAX>
 __global__ __launch_bounds__(256) void small_fused_kernel(const SmallLayer* __restrict__ layers, int layer0, int n_run,
@@ -444,8 +446,11 @@ __global__ __launch_bounds__(256) void small_fused_kernel(const SmallLayer* __re
     }
 }
 
+#endif  // PRAG_MM_DIAG
+
 size_t small_sync_bytes() { return sizeof(SmallSync); }
 
+#ifdef PRAG_MM_DIAG
 template <typename T, int BM>
 static int launch_fused_small_bm(const SmallRun& r, hipStream_t st) {
     const dim3 grid(kSmH / 16, r.n_run), block(256);
@@ -471,6 +476,8 @@ static int launch_fused_small(const SmallRun& r, hipStream_t st) {
     return launch_fused_small_bm<T, 8>(r, st);
 }
 
+#endif  // PRAG_MM_DIAG
+
 template <typename T>
 static void launch_fc1(const SmallRun& r, hipStream_t st) {
     const dim3 grid(kSmH / 16, r.n_run), block(256);
@@ -488,11 +495,13 @@ static void launch_fc1(const SmallRun& r, hipStream_t st) {
 int small_run(const SmallRun& r, hipStream_t st) {
     PRAG_REQUIRE(small_supported(r.B, r.d) && r.n_run >= 1 && r.n_run <= 64 && r.d % 4 == 0, PRAG_EUNSUPPORTED,
                  "internal: small-batch prober called outside its envelope (B=%d d=%d)", r.B, r.d);
+#ifdef PRAG_MM_DIAG
     if (r.sync && r.fused) {        // one launch (PRAG_PROBER_SMALL=3: A/B timing; three launches are faster, prober.hip)
         if (r.x_dtype == PRAG_F32) return launch_fused_small<float>(r, st);
         if (r.x_dtype == PRAG_F16) return launch_fused_small<_Float16>(r, st);
         return launch_fused_small<unsigned short>(r, st);
     }
+#endif
     if (r.x_dtype == PRAG_F32) launch_fc1<float>(r, st);
     else if (r.x_dtype == PRAG_F16) launch_fc1<_Float16>(r, st);
     else launch_fc1<unsigned short>(r, st);

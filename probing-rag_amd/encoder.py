@@ -23,10 +23,12 @@ class MeanPoolEncoder:
         self.max_length = max_length
 
     def encode(self, sentences, convert_to_numpy: bool = False):
-        """list[str] (or one str) -> float32 [B,d] embeddings on the GPU
-        (``convert_to_numpy=True`` gives SentenceTransformer.encode's host array)."""
+        """list[str] -> float32 [B,d] embeddings on the GPU; ONE str -> [d], as ``SentenceTransformer.encode`` returns
+        it (``find_topk_sim``, utils.py:374-376, unsqueezes that itself).  ``convert_to_numpy=True`` gives
+        SentenceTransformer.encode's host array."""
         import torch
-        if isinstance(sentences, str):
+        single = isinstance(sentences, str)
+        if single:
             sentences = [sentences]
         enc = self.tokenizer(sentences, padding=True, truncation=True, max_length=self.max_length, return_tensors="pt")
         ids = enc["input_ids"].to(self.device)
@@ -35,4 +37,6 @@ class MeanPoolEncoder:
             out = self.model(input_ids=ids, attention_mask=mask)
         hidden = out.last_hidden_state if hasattr(out, "last_hidden_state") else out[0]
         emb = masked_mean_pool(hidden, mask)
+        if single:
+            emb = emb[0]
         return emb.cpu().numpy() if convert_to_numpy else emb

@@ -283,8 +283,14 @@ def encode_query(model_retr, query):
 
 
 def find_topk_sim(model_retr, query: str, index, k: int):
+    """utils.py:374-376: ONE query string; its [d] embedding is unsqueezed to [1,d].  A host array takes the
+    reference's route (torch.tensor -> unsqueeze -> np.array); an embedding that is already a CUDA tensor
+    (``MeanPoolEncoder``) stays on the device."""
     import torch
-    D, I = index.search(np.array(torch.tensor(encode_query(model_retr, query)).unsqueeze(0)), k=k)
+    emb = encode_query(model_retr, query)
+    if isinstance(emb, torch.Tensor) and emb.is_cuda:
+        return index.search(emb.unsqueeze(0), k=k)
+    D, I = index.search(torch.as_tensor(emb).unsqueeze(0).numpy(), k=k)
     return D, I
 
 

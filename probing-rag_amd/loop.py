@@ -137,6 +137,73 @@ def pool_ragged(acts, pred_lens, mean: bool = True):
     return out
 
 
+def pool_each_token(acts, pred_lens, labels=None):
+    """`_input_tensor_method1` (train.py:153-162, utils.py:134-143) on device: the last pred_lens[b] positions of every
+    sample of acts [B,T,d], concatenated -> float32 [sum(pred_lens), d], and (if `labels` is given)
+    ``torch.repeat_interleave(labels, pred_lens)`` as an int64 tensor.  `pred_lens` comes from the data loader (host):
+    the row offsets are a host prefix sum, like the reference's Python loop over samples."""
+    import numpy as np
+    import torch
+    _lib.require_gpu()
+    acts = acts.contiguous()
+    if acts.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        acts = acts.float()
+    B, T, d = acts.shape
+    lens = np.clip(np.asarray(torch.as_tensor(pred_lens).cpu(), dtype=np.int64).reshape(-1), 0, T)
+    if lens.shape[0] != B:
+        raise ValueError(f"expected {B} pred_lens, got {lens.shape[0]}")
+    off = np.zeros(B + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    n_rows = int(off[-1])
+    off_dev = torch.from_numpy(off).to(acts.device)
+    out = torch.empty((n_rows, d), dtype=torch.float32, device=acts.device)
+    lab_in = lab_out = None
+    if labels is not None:
+        lab_in = torch.as_tensor(labels).to(device=acts.device, dtype=torch.int32).contiguous()
+        lab_out = torch.empty((n_rows,), dtype=torch.int32, device=acts.device)
+    with torch.cuda.device(acts.device):
+        _lib.check(_lib.lib().prag_pool_each_token(
+            ctypes.c_void_p(acts.data_ptr()),
+            {torch.float32: _lib.PRAG_F32, torch.float16: _lib.PRAG_F16, torch.bfloat16: _lib.PRAG_BF16}[acts.dtype],
+            B, T, d, ctypes.c_void_p(off_dev.data_ptr()), n_rows,
+            ctypes.c_void_p(lab_in.data_ptr()) if lab_in is not None else None, ctypes.c_void_p(out.data_ptr()),
+            ctypes.c_void_p(lab_out.data_ptr()) if lab_out is not None else None, _lib.current_stream_ptr(acts.device)))
+    return out, (lab_out.long() if lab_out is not None else None)
+
+
+def pool_last_token(acts):
+    """`activations[:, -1, :]` (train.py:228, utils.py:206; the `last_token` method) as float32 [B,d] on device:
+    the ragged pool over ONE trailing position."""
+    import torch
+    return pool_ragged(acts, torch.ones((acts.shape[0],), dtype=torch.int64), mean=False)
+
+
+def _eval_forward(prober, x, labels):
+    """make_loss + return_acc (train.py:141-151, 170-181) on pooled rows: softmax(-1), CrossEntropyLoss applied to the
+    probabilities (the reference's double softmax), argmax accuracy."""
+    import torch
+    probs = torch.softmax(prober(x), dim=-1)
+    labels = torch.as_tensor(labels, device=probs.device).long()
+    loss = torch.nn.functional.cross_entropy(probs, labels)
+    correct = (torch.argmax(probs, dim=-1) == labels).sum().item()
+    return round(correct / labels.size(0), 4), loss, probs
+
+
+def method_1_eval(prober, activations, labels, pred_lens):
+    """train.py:193-197 / utils.py:175-179 (`each_token`): every one of the last pred_len tokens is a sample with its
+    sequence's label.  Returns (accuracy over the TOKEN rows rounded to 4 places, len(labels) - the number of
+    sequences, as the reference returns it -, loss, probs)."""
+    x, new_labels = pool_each_token(activations, pred_lens, labels)
+    acc, loss, probs = _eval_forward(prober, x, new_labels)
+    return acc, len(labels), loss, probs
+
+
+def method_3_eval(prober, activations, labels, pred_lens=None):
+    """train.py:245-249 / utils.py:222-226 (`last_token`): the prober on the last position only."""
+    acc, loss, probs = _eval_forward(prober, pool_last_token(activations), labels)
+    return acc, len(labels), loss, probs
+
+
 def method_2_eval(prober, activations, labels, pred_lens):
     """train.py:199-208, 222-225 / utils.py:181-203 (`_method_2_util` + `return_acc`), forward
     only: ragged last-`pred_len` MEAN pool (HIP) -> prober (HIP) -> softmax(-1) ->

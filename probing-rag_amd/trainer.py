@@ -5,6 +5,8 @@ Reference (paths relative to /root/reference):
     ``ExponentialLR(optimizer, gamma=0.995)``                      train.py:126-135
   * ``method_2_train(model, optim, scheduler, activations, labels, pred_lens, args)``
                                                                     utils.py:191-197, train.py:210-220
+  * ``method_1_train`` (`each_token`, the script's default) / ``method_3_train`` (`last_token`)
+                                                                    utils.py:164-173, 213-220; train.py:182-191, 235-243
   * ``torch.save(probe.state_dict(), path)``                        train.py (checkpoint per epoch)
 
 ``HipProberTrainer`` owns the parameters and both Adam moments on the GPU and runs the whole
@@ -132,4 +134,20 @@ def method_2_train(model: HipProberTrainer, optim, scheduler, activations, label
     from .loop import pool_ragged
     pooled = pool_ragged(activations, pred_lens, mean=True)
     loss, _ = model.step(pooled, labels)
+    return round(loss.item(), 4), model.lr
+
+
+def method_1_train(model: HipProberTrainer, optim, scheduler, activations, labels, pred_lens, args=None):
+    """utils.py:164-173 / train.py:182-191 (`--method each_token`, train.py:354's default): every one of the last
+    pred_lens[b] tokens is a training row carrying its sequence's label (`_input_tensor_method1`)."""
+    from .loop import pool_each_token
+    x, new_labels = pool_each_token(activations, pred_lens, labels)
+    loss, _ = model.step(x, new_labels)
+    return round(loss.item(), 4), model.lr
+
+
+def method_3_train(model: HipProberTrainer, optim, scheduler, activations, labels, pred_lens=None, args=None):
+    """utils.py:213-220 / train.py:235-243 (`--method last_token`): the last position of every sequence."""
+    from .loop import pool_last_token
+    loss, _ = model.step(pool_last_token(activations), labels)
     return round(loss.item(), 4), model.lr

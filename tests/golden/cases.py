@@ -74,6 +74,12 @@ TRAIN_CASES = [
     dict(name="train_B8_T24", d=2048, B=8, T=24, wseed=500, xseed=88, steps=3, seed=4242),
     dict(name="train_B3_T9_nodrop", d=2048, B=3, T=9, wseed=501, xseed=89, steps=2, seed=1, dropout_p=0.0),
 ]
+# the other two training methods of train.py:354 (`each_token` - the script's default -, utils.py:164-173, and
+# `last_token`, utils.py:213-220): same optimiser / scheduler, different rows
+TRAIN_METHOD_CASES = [
+    dict(name="train_each_token_B4_T12", method="each_token", d=2048, B=4, T=12, wseed=502, xseed=90, steps=2, seed=77),
+    dict(name="train_last_token_B8_T6", method="last_token", d=2048, B=8, T=6, wseed=503, xseed=91, steps=2, seed=78),
+]
 TRAIN_SAMPLE_STRIDE = 251   # fc1/fc2 weights are stored as every 251st element (+ their float64 sums)
 
 

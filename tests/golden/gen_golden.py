@@ -140,6 +140,21 @@ def main():
         out[f"{name}/probs"] = probs.numpy().astype(np.float32)
         out[f"{name}/loss"] = np.float32(loss.item())
         out[f"{name}/acc"] = np.float64(ru.return_acc(probs, torch.from_numpy(labels)))
+        # the other two eval methods on the same inputs: method_1_eval (`each_token`, utils.py:175-179) and
+        # method_3_eval (`last_token`, utils.py:222-226) - the reference functions themselves
+        with torch.no_grad():
+            a1, n1, l1 = ru.method_1_eval(m, torch.from_numpy(acts), torch.from_numpy(labels),
+                                          torch.from_numpy(pred_lens), args)
+            _, p1 = ru.make_loss(m, *ru._input_tensor_method1(torch.from_numpy(acts), torch.from_numpy(labels),
+                                                              torch.from_numpy(pred_lens), args))
+            a3, n3, l3 = ru.method_3_eval(m, torch.from_numpy(acts), torch.from_numpy(labels),
+                                          torch.from_numpy(pred_lens), args)
+            _, p3 = ru._method_3_util(m, torch.from_numpy(acts), torch.from_numpy(labels),
+                                      torch.from_numpy(pred_lens), args)
+        out[f"{name}/m1_acc"], out[f"{name}/m1_n"], out[f"{name}/m1_loss"] = np.float64(a1), np.int64(n1), np.float32(l1.item())
+        out[f"{name}/m1_probs"] = p1.numpy().astype(np.float32)
+        out[f"{name}/m3_acc"], out[f"{name}/m3_n"], out[f"{name}/m3_loss"] = np.float64(a3), np.int64(n3), np.float32(l3.item())
+        out[f"{name}/m3_probs"] = p3.numpy().astype(np.float32)
         # inference-time sum pool of the same tokens (exp_rag.py:385-387)
         with torch.no_grad():
             sums = torch.stack([torch.from_numpy(acts[i, T - int(n):, :]).sum(dim=0)
@@ -166,8 +181,18 @@ def main():
             self.site += 1
             return x * torch.from_numpy(keep.astype(np.float32)) * np.float32(1.0 / (1.0 - self.p))
 
-    for case in cases.TRAIN_CASES:
+    for case in cases.TRAIN_CASES + cases.TRAIN_METHOD_CASES:
         name, d = case["name"], case["d"]
+        method = case.get("method", "tokens_mean")
+        # train.py:268-279: each_token -> method_1_train, tokens_mean -> method_2_train, last_token -> method_3_train
+        train_fn = {"each_token": ru.method_1_train, "tokens_mean": ru.method_2_train, "last_token": ru.method_3_train}[method]
+
+        def raw_loss(m_, a_, l_, p_, args_):
+            if method == "each_token":
+                return ru.make_loss(m_, *ru._input_tensor_method1(a_, l_, p_, args_))[0]
+            if method == "last_token":
+                return ru._method_3_util(m_, a_, l_, p_, args_)[0]
+            return ru._method_2_util(m_, a_, l_, p_, args_)[0]
         pdrop = case.get("dropout_p", 0.1)
         st = cases.synth_state(case["wseed"], d)
         m = ru.ImprovedProbe(input_size=d, output_size=2)
@@ -188,11 +213,10 @@ def main():
             # loss of the same forward for a tighter comparison
             m.dropout.site = 0
             with torch.no_grad():
-                raw, _ = ru._method_2_util(m, torch.from_numpy(acts), torch.from_numpy(labels),
-                                           torch.from_numpy(pred_lens), args)
+                raw = raw_loss(m, torch.from_numpy(acts), torch.from_numpy(labels), torch.from_numpy(pred_lens), args)
             m.dropout.site = 0
-            lrnd, lr_next = ru.method_2_train(m, optim, sched, torch.from_numpy(acts), torch.from_numpy(labels),
-                                              torch.from_numpy(pred_lens), args)
+            lrnd, lr_next = train_fn(m, optim, sched, torch.from_numpy(acts), torch.from_numpy(labels),
+                                     torch.from_numpy(pred_lens), args)
             assert abs(lrnd - round(raw.item(), 4)) < 1e-9
             losses.append(raw.item())
             lrs.append(lr_used)

@@ -174,3 +174,10 @@ def test_device_resident_encoder_feeds_the_index():
     D0, I0 = onp.flat_search(docs, emb.cpu().numpy(), 5, onp.METRIC_L2)
     assert np.array_equal(I.cpu().numpy(), I0)
     np.testing.assert_allclose(D.cpu().numpy(), D0, rtol=1e-4, atol=1e-6)
+    # ONE string -> [d] like SentenceTransformer.encode; find_topk_sim (utils.py:374-376) unsqueezes it itself
+    one = enc.encode(queries[1])
+    assert one.is_cuda and one.shape == (D_EMB,)
+    np.testing.assert_allclose(one.cpu().numpy(), emb[1].cpu().numpy(), atol=2e-6, rtol=0)
+    D1, I1 = pra.find_topk_sim(enc, queries[1], ix, k=5)
+    assert I1.shape == (1, 5) and np.array_equal(I1.cpu().numpy()[0], I0[1])
+    assert enc.encode(queries[1], convert_to_numpy=True).shape == (D_EMB,)

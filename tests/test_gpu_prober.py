@@ -378,49 +378,6 @@ def test_gate_threshold_is_compared_in_double_like_python(torch_cuda):
             assert int(odec[b]) == want
 
 
-@pytest.mark.parametrize("weights,B", [("f32", 1), ("f32", 4), ("f16", 2), ("f32", 3)])
-def test_one_launch_gate_equals_the_three_launch_form(torch_cuda, golden, monkeypatch, weights, B):
-    """The reference's call shape (exp_rag.py:381-389, 406-415: ONE pooled state per probed layer).  The one-launch
-    form of the gate (PRAG_PROBER_SMALL=3: fc1 / fc2 hand their outputs across workgroups inside the launch) must
-    equal the default three launches bit for bit, call after call (the arrival counters return to zero inside the
-    launch), and replayed from a captured graph.  (It is measured slower and is not the default: prober.hip.)"""
-    torch = torch_cuda
-    import probing_rag_amd as pra
-    case = dict(cases.PROBER_CASES[1], B=B)
-    x = torch.from_numpy(cases.case_x(case)).cuda()
-    ens3, states = _ensemble(case, weights)
-    monkeypatch.setenv("PRAG_PROBER_SMALL", "3")        # read when a handle is created
-    ens, _ = _ensemble(case, weights)
-    monkeypatch.delenv("PRAG_PROBER_SMALL")
-    want = [t.cpu().numpy() for t in ens3.gate(x, 1, 0.5)]
-    for _ in range(5):
-        got = [t.cpu().numpy() for t in ens.gate(x, 1, 0.5)]
-        for g, w_ in zip(got, want):
-            assert np.array_equal(g, w_)
-    np.testing.assert_allclose(got[0], _oracle_effective(ens, cases.case_x(case)), atol=TOL, rtol=0)
-    # per-layer calls (n_run = 1) and a sub-range of layers go through the same kernel
-    one = ens.probers[2](x[2]).cpu().numpy()
-    assert np.array_equal(one, want[0][2])
-    # graph replay: nothing in the launch depends on host state
-    out = (torch.empty((case["L"], B, 2), device="cuda"), torch.empty((B, 2), device="cuda"),
-           torch.empty((B,), dtype=torch.int32, device="cuda"))
-    ens.gate(x, 1, 0.5, out=out)
-    torch.cuda.synchronize()
-    s = torch.cuda.Stream()
-    with torch.cuda.stream(s):
-        ens.gate(x, 1, 0.5, out=out)       # warm on the capture stream
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s):
-            ens.gate(x, 1, 0.5, out=out)
-    for _ in range(3):
-        for t in out:
-            t.zero_()
-        g.replay()
-        torch.cuda.synchronize()
-        for t, w_ in zip(out, want):
-            assert np.array_equal(t.cpu().numpy(), w_)
-
-
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
 def test_decode_step_of_all_layers_pools_in_one_launch(torch_cuda, dtype):
     """exp_rag.py:317-329 hooks six layers: the accumulator adds a decode step of all of them in one launch

@@ -31,7 +31,7 @@ def _batches(case):
     return out
 
 
-@pytest.mark.parametrize("case", cases.TRAIN_CASES, ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", cases.TRAIN_CASES + cases.TRAIN_METHOD_CASES, ids=lambda c: c["name"])
 def test_training_steps_match_reference_golden(golden, case):
     import torch
     import probing_rag_amd as pra
@@ -43,10 +43,20 @@ def test_training_steps_match_reference_golden(golden, case):
     for acts, pred_lens, labels in _batches(case):
         lrs.append(tr.lr)
         # the reference's call: method_2_train(model, optim, scheduler, activations, labels, pred_lens, args)
-        pooled = pra.pool_ragged(torch.from_numpy(acts).cuda(), pred_lens, mean=True)
-        loss, probs = tr.step(pooled, torch.from_numpy(labels))
+        method = case.get("method", "tokens_mean")
+        step_labels = torch.from_numpy(labels)
+        if method == "each_token":       # method_1_train (utils.py:164-173): every trailing token is a row
+            pooled, step_labels = pra.pool_each_token(torch.from_numpy(acts).cuda(), pred_lens, labels)
+            want_rows, want_labels = onp.pool_each_token(acts, pred_lens, labels)
+            assert np.array_equal(pooled.cpu().numpy(), want_rows) and np.array_equal(step_labels.cpu().numpy(), want_labels)
+        elif method == "last_token":     # method_3_train (utils.py:213-220)
+            pooled = pra.pool_last_token(torch.from_numpy(acts).cuda())
+            assert np.array_equal(pooled.cpu().numpy(), acts[:, -1, :])
+        else:
+            pooled = pra.pool_ragged(torch.from_numpy(acts).cuda(), pred_lens, mean=True)
+        loss, probs = tr.step(pooled, step_labels)
         losses.append(loss.item())
-        assert probs.shape == (case["B"], 2) and abs(probs.sum().item() - case["B"]) < 1e-4
+        assert probs.shape == (pooled.shape[0], 2) and abs(probs.sum().item() - pooled.shape[0]) < 1e-4
     np.testing.assert_allclose(losses, golden[f"{name}/losses"], atol=2e-6, rtol=0)
     np.testing.assert_allclose(lrs, golden[f"{name}/lrs"], rtol=1e-12)
     assert tr.steps == case["steps"]
@@ -156,3 +166,46 @@ def test_labels_are_validated_and_eval_mode_disables_dropout():
     tr2 = pra.HipProberTrainer(d, 2, seed=5).load_state_dict(st)
     _, p_train = tr2.train().step(x, labels)
     assert np.abs(p_train.cpu().numpy() - want).max() > 1e-4
+
+
+def test_each_token_and_last_token_methods_keep_the_reference_signatures(golden):
+    """method_1_train / method_3_train (utils.py:164-173, 213-220) and method_1_eval / method_3_eval (utils.py:175-179,
+    222-226) by their reference signatures: eval outputs against the golden vectors of the reference functions
+    themselves; the training wrappers against the explicit pool + step; half-precision activations pool exactly."""
+    import torch
+    import probing_rag_amd as pra
+    case = cases.POOL_CASES[0]
+    name = case["name"]
+    st = cases.synth_state(case["wseed"], case["d"])
+    acts, pred_lens, labels = cases.synth_pool_inputs(case)
+    prober = pra.HipProber(case["d"], 2)
+    prober.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    a = torch.from_numpy(acts).cuda()
+    for tag, fn in (("m1", pra.method_1_eval), ("m3", pra.method_3_eval)):
+        acc, n, loss, probs = fn(prober, a, torch.from_numpy(labels), torch.from_numpy(pred_lens))
+        np.testing.assert_allclose(probs.cpu().numpy(), golden[f"{name}/{tag}_probs"], atol=1e-4, rtol=0)
+        assert abs(loss.item() - float(golden[f"{name}/{tag}_loss"])) < 1e-4
+        assert acc == float(golden[f"{name}/{tag}_acc"]) and n == int(golden[f"{name}/{tag}_n"])
+    # fp16 / bf16 activations (a half-precision LM): the gather converts, nothing else
+    for dt in (torch.float16, torch.bfloat16):
+        ah = a.to(dt)
+        rows, lab = pra.pool_each_token(ah, pred_lens, labels)
+        want, wl = onp.pool_each_token(ah.float().cpu().numpy(), pred_lens, labels)
+        assert np.array_equal(rows.cpu().numpy(), want) and np.array_equal(lab.cpu().numpy(), wl)
+        assert np.array_equal(pra.pool_last_token(ah).cpu().numpy(), ah[:, -1, :].float().cpu().numpy())
+    # empty and full-length samples
+    lens = np.array([0, case["T"], 1, 0, 3, case["T"], 2, 0], dtype=np.int64)
+    rows, lab = pra.pool_each_token(a, lens, labels)
+    want, wl = onp.pool_each_token(acts, lens, labels)
+    assert rows.shape[0] == int(lens.sum()) and np.array_equal(rows.cpu().numpy(), want) and np.array_equal(lab.cpu().numpy(), wl)
+    # the training wrappers
+    for train_fn, pool in ((pra.method_1_train, lambda: pra.pool_each_token(a, pred_lens, labels)),
+                           (pra.method_3_train, lambda: (pra.pool_last_token(a), torch.from_numpy(labels)))):
+        t1 = pra.HipProberTrainer(case["d"], 2, seed=5).load_state_dict(st)
+        t2 = pra.HipProberTrainer(case["d"], 2, seed=5).load_state_dict(st)
+        lrnd, lr = train_fn(t1, None, None, a, torch.from_numpy(labels), torch.from_numpy(pred_lens), None)
+        x, lab = pool()
+        loss, _ = t2.step(x, lab)
+        assert lrnd == round(loss.item(), 4) and lr == t2.lr == pytest.approx(1e-4 * 0.995)
+        for k in onp.STATE_KEYS:
+            assert torch.equal(t1.state_dict()[k], t2.state_dict()[k])

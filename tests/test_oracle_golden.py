@@ -111,7 +111,33 @@ def test_synth_rows_is_shardable_and_normalish():
     assert abs(float(a.mean())) < 0.02 and abs(float(a.std()) - 1.0) < 0.02
 
 
-@pytest.mark.parametrize("case", cases.TRAIN_CASES, ids=lambda c: c["name"])
+def _method_rows(case, acts, pred_lens, labels):
+    """The rows each training method of train.py:268-279 feeds the prober."""
+    method = case.get("method", "tokens_mean")
+    if method == "each_token":
+        return onp.pool_each_token(acts, pred_lens, labels)
+    if method == "last_token":
+        return onp.pool_last_token(acts), labels
+    return onp.pool_ragged_mean(acts, pred_lens), labels
+
+
+@pytest.mark.parametrize("case", cases.POOL_CASES, ids=lambda c: c["name"])
+def test_each_token_and_last_token_eval_match_reference(golden, case):
+    """method_1_eval / method_3_eval (utils.py:175-179, 222-226) run as they are by the generator."""
+    name = case["name"]
+    st = cases.synth_state(case["wseed"], case["d"])
+    acts, pred_lens, labels = cases.synth_pool_inputs(case)
+    x1, l1 = onp.pool_each_token(acts, pred_lens, labels)
+    assert x1.shape[0] == int(pred_lens.sum()) and np.array_equal(l1, np.repeat(labels, pred_lens))
+    for tag, (x, lab) in (("m1", (x1, l1)), ("m3", (onp.pool_last_token(acts), labels))):
+        probs, loss, acc = onp.eval_forward_rows(st, x, lab)
+        np.testing.assert_allclose(probs, golden[f"{name}/{tag}_probs"], atol=1e-5, rtol=0)
+        assert abs(float(loss) - float(golden[f"{name}/{tag}_loss"])) < 1e-5
+        assert round(acc, 4) == float(golden[f"{name}/{tag}_acc"])
+        assert int(golden[f"{name}/{tag}_n"]) == len(labels)     # the reference returns the number of SEQUENCES
+
+
+@pytest.mark.parametrize("case", cases.TRAIN_CASES + cases.TRAIN_METHOD_CASES, ids=lambda c: c["name"])
 def test_training_steps_match_reference(golden, case):
     """Oracle forward/backward/AdamW/ExponentialLR against the reference's own method_2_train
     (utils.py:191-197) run with torch.optim.AdamW + ExponentialLR(0.995) (train.py:131-135) on
@@ -121,7 +147,7 @@ def test_training_steps_match_reference(golden, case):
     batches = []
     for t in range(1, case["steps"] + 1):
         acts, pred_lens, labels = cases.synth_train_batch(case, t)
-        batches.append((onp.pool_ragged_mean(acts, pred_lens), labels))
+        batches.append(_method_rows(case, acts, pred_lens, labels))
     final, losses, lrs = onp.train_steps(st, batches, case["seed"], {"dropout_p": case.get("dropout_p", 0.1)})
     np.testing.assert_allclose(losses, golden[f"{name}/losses"], atol=2e-6, rtol=0)
     np.testing.assert_allclose(lrs, golden[f"{name}/lrs"], rtol=1e-12)
