@@ -87,7 +87,7 @@ def _run_path(kind, torch, pra, lm, states, lock, my_queries, args, dev, cpu_sub
     clock = _Clock(torch)
     handles = []
     if kind == "hip":
-        pool = pra.HiddenStatePool(len(LAYERS), D_MODEL)
+        pool = pra.HiddenStatePool(len(LAYERS), D_MODEL, defer=True)    # HF decoder-layer outputs are fresh tensors
         ens = pra.HipProberEnsemble(len(LAYERS), D_MODEL, 2, weights="f32")
         for slot, st in enumerate(states):
             ens.load_layer(slot, st)
@@ -97,8 +97,8 @@ def _run_path(kind, torch, pra, lm, states, lock, my_queries, args, dev, cpu_sub
         reset = pool.reset
 
         def gate():
-            _, _, dec = ens.gate(pool.pooled(), ablation=0, threshold=args.e2e_theta)
-            return int(dec[0])
+            # one C call: gate kernels, the decision in host memory, the wait (prag_gate_decide)
+            return int(ens.decide(pool.pooled(), ablation=0, threshold=args.e2e_theta)[0])
     else:
         from oracle import torch_cpu                     # baseline leg: the reference-shaped eager modules
         probers = [m.to(dev) for m in torch_cpu.make_probers(states, D_MODEL)]

@@ -103,6 +103,16 @@ int prag_gate(prag_prober_t* p, const void* x_dev, int x_dtype, int64_t x_layer_
               int B, int ablation, double theta, float* logits_dev, float* probsum_dev,
               int32_t* decision_dev, void* stream);
 
+/* The gate as the retrieve-decide loop consumes it: exp_rag.py:393, 406-415 end with a HOST branch on the two sums
+ * (`if logit_sum[0] + theta < logit_sum[1]`), once per generation, on ONE pooled state per layer.  prag_gate followed
+ * by a device->host copy of the decision and a stream wait in one call: the logits stay in a buffer of the handle,
+ * decision_host int32 [B] (plain host memory, 1 = retrieve) is filled before the call returns; probsum_host float32
+ * [B,2] is optional (the sums the reference prints, exp_rag.py:420).  Nothing is allocated per call; for B <= 256 the
+ * gate's last kernel writes into pinned host memory itself and the call waits for those words only (the stream is
+ * not otherwise synchronised; with probsum_host the call waits for the stream). */
+int prag_gate_decide(prag_prober_t* p, const void* x_dev, int x_dtype, int64_t x_layer_stride, int B, int ablation,
+                     double theta, int32_t* decision_host, float* probsum_host, void* stream);
+
 /* The gate arithmetic alone (exp_rag.py:407-415) on existing logits. */
 int prag_gate_from_logits(const float* logits_dev, int L, int B, int ablation, double theta,
                           float* probsum_dev, int32_t* decision_dev, void* stream);
@@ -255,7 +265,10 @@ int prag_index_d(const prag_index_t* ix);
  * No host synchronisation on the device-io path: every fallback - the exact scan, the second tier of the
  * 8-bit tiled selection (prag_index_last_tiled8 below) - is enqueued unconditionally and switched by a word
  * on the device, so a search whose workspaces exist (any earlier search of the same shape made them) can be
- * captured into a HIP graph and replayed, and every rank of a lockstep retrieval issues the same launches.
+ * captured into a HIP graph and replayed, and every rank of a lockstep retrieval issues the same COLLECTIVES (one
+ * all-gather per sharded search).  The kernel sequence itself may differ between ranks and between runs of one input:
+ * whether a > 128-query search takes the int8 tiles is per-process host state fed by an asynchronous copy of the
+ * previous searches' failed counts (prag_index_last_tiled8) - results are the definition's either way.
  * With io_is_device == 0 the call copies in/out and synchronises `stream`. */
 int prag_index_search(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset,
                       float* D, int64_t* I, int io_is_device, void* stream);
@@ -364,10 +377,12 @@ int prag_index_set_shadow(prag_index_t* ix, int mode);
  * build.) */
 int prag_index_prepare(prag_index_t* ix, void* stream);
 
-/* Allocate every per-search workspace a search of up to B queries and this k needs, now (one throw-away search of
- * zero queries on `stream`, waited for).  The index otherwise grows its workspaces inside the first search of a
+/* Allocate every per-search workspace a search of up to B queries and this k needs, now (throw-away searches on
+ * `stream`, waited for).  The index otherwise grows its workspaces inside the first search of a
  * larger shape - a hipFree / hipMalloc, i.e. a device synchronisation, and not capturable into a graph.  After this
- * call searches of that shape allocate nothing.  (No reference counterpart; faiss allocates per call.) */
+ * call searches of that shape allocate nothing.  The sizing searches use a fixed pseudo-random query pattern, leave the
+ * statistics of the int8-tile heuristic untouched and cover both of its settings.  (No reference counterpart; faiss
+ * allocates per call.) */
 int prag_index_reserve(prag_index_t* ix, int B, int k, void* stream);
 
 /* Cap the number of workgroups (= CUs) the scan kernels occupy; 0 = all CUs.  The scan is
@@ -378,6 +393,9 @@ int prag_index_set_scan_workgroups(prag_index_t* ix, int n_workgroups);
 /* Measurement hook: as prag_prober_profile, around every scan_topk launch. */
 int prag_index_profile(prag_index_t* ix, int slots);
 int prag_index_profile_read(prag_index_t* ix, float* ms, int cap, int* n_out);
+/* The same ring around the ncclAllGather of every prag_index_search_sharded (enabled by prag_index_profile on an
+ * index that holds a communicator): the exchange step of the sharded search by itself, in ms per call. */
+int prag_index_profile_read_exchange(prag_index_t* ix, float* ms, int cap, int* n_out);
 
 void prag_index_destroy(prag_index_t* ix);
 

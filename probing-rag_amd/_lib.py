@@ -55,6 +55,7 @@ SIGNATURES = {
     "prag_prober_load_layer": (_I, [_P, _I] + [_FP] * 12),
     "prag_prober_forward": (_I, [_P, _P, _I, _L, _I, _I, _I, _P, _P]),
     "prag_gate": (_I, [_P, _P, _I, _L, _I, _I, ctypes.c_double, _P, _P, _P, _P]),
+    "prag_gate_decide": (_I, [_P, _P, _I, _L, _I, _I, ctypes.c_double, _P, _P, _P]),
     "prag_gate_from_logits": (_I, [_P, _I, _I, _I, ctypes.c_double, _P, _P, _P]),
     "prag_prober_effective_weights": (_I, [_P, _I] + [_FP] * 6),
     "prag_prober_reserve": (_I, [_P, _I]),
@@ -102,6 +103,7 @@ SIGNATURES = {
     "prag_index_set_scan_workgroups": (_I, [_P, _I]),
     "prag_index_profile": (_I, [_P, _I]),
     "prag_index_profile_read": (_I, [_P, _FP, _I, ctypes.POINTER(_I)]),
+    "prag_index_profile_read_exchange": (_I, [_P, _FP, _I, ctypes.POINTER(_I)]),
     "prag_index_destroy": (None, [_P]),
 }
 

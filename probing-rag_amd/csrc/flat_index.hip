@@ -1462,6 +1462,7 @@ struct prag_index {
     char* xch_send = nullptr;
     char* xch_recv = nullptr;
     size_t xch_send_cap = 0, xch_recv_cap = 0;
+    EventRing prof_xch;          // HIP events around the all-gather of prag_index_search_sharded (prag_index_profile)
     int last_flagged = -1;   // flag count of the last host-io search (-1: last search was device-io)
     std::string last_plan;   // plan_describe of the most recent search (prag_index_last_plan)
     EventRing prof;
@@ -1934,6 +1935,21 @@ constexpr int kMm8CapWg = 128;    // survivors one workgroup can hold per query 
 constexpr int kMm8Chunk = 1024;   // queries per mm_run call
 constexpr int kMm8Growth = 3;     // segment i+1 ends at 3 x the end of segment i (search_tiled)
 
+// Segment growth of the tiled scans (ONE place: plan_search prices the schedule, search_tiled runs it): keep the
+// expected survivors of a segment (~(growth-1) * KC per query) inside the per-workgroup regions (64 per query) and the
+// compaction's staging buffer (4096).  int8 tiles: a segment yields ~(growth - 1) * 256 survivors per query, each an
+// LDS atomic and two stores in the filter while the other wave group waits; short segments keep the bound fresh.
+// Measured, 1000 queries, growth 9 / 6 / 4 / 3 / 2: 2.625 M rows 3.81 / 3.66 / 3.57 / 3.39 / 3.96 ms, 21 M rows 19.1 /
+// 18.5 / 18.2 / 17.9 / 17.9, 1 M rows 2.13 / 1.95 / 1.97 / 1.90 / 1.94 (same box).
+static inline int mm_segment_growth(int Bpad, int chunk, int cap_wg, int cu_budget, int kc, bool i8) {
+    const int n_qb = std::max(1, std::min(Bpad, chunk) / 256);
+    const int g_wg = 1 + (cap_wg / 4) * cu_budget / std::max(1, kc * n_qb);
+    const int g_lds = 1 + 3000 / kc;
+    int g = std::max(2, std::min(16, std::min(g_wg, g_lds)));
+    if (i8) g = std::min(g, kMm8Growth);
+    return g;
+}
+
 struct PlanEnv {
     int d = 0, metric = PRAG_METRIC_L2, store = PRAG_F16;
     int64_t ntotal = 0;
@@ -1955,6 +1971,8 @@ struct SearchPlan {
     size_t part_need = 0, cand_need = 0;
     const char* family = "";      // kernel of the corpus pass
     int launches = 0;             // corpus passes per search (tiled scans: segments)
+    int mm_growth = 0;            // tiled scans: segment growth (first step; later steps: mm_growth_step)
+    int64_t last_seg_rows = 0;    // tiled scans: rows of the last (largest) corpus segment - the profiled launch
     int64_t bytes_per_launch = 0; // algorithmic bytes one pass over the shard reads, in the form that is scanned
     size_t ws_bytes = 0;          // device workspace of the groups this plan touches
 };
@@ -2028,11 +2046,18 @@ static SearchPlan plan_search(const PlanEnv& e) {
     else if (P.exact_only) { P.family = "exact_scan_kernel"; P.launches = B; P.bytes_per_launch = N * d * elt_b; }
     else if (P.use_mm) {
         P.family = P.use_mm8 ? "scan_mm_kernel<int8 tiles over the 8-bit shadow>" : "scan_mm_kernel";
-        const int growth = P.use_mm8 ? kMm8Growth : 16;      // (search_tiled lowers it for deep lists)
+        const int growth = mm_segment_growth(P.Bpad, P.mm_chunk, P.mm_cap_wg, P.cu_budget, kc, P.use_mm8);
+        P.mm_growth = growth;
+        // the schedule of mm_run (flat_mm.hip): [0, kMmFirstSeg), then every segment ends at g_step x its start
         int segs = 1;
-        for (int64_t hi = std::min<int64_t>(N, kMmFirstSeg); hi < N;
-             hi = std::min<int64_t>(N, hi * mm_growth_step(growth, segs - 2, P.use_mm8)))
+        int64_t lo = 0, hi = std::min<int64_t>(N, kMmFirstSeg);
+        while (hi < N) {
+            lo = hi;
+            const int g_step = mm_growth_step(growth, segs - 1, P.use_mm8);
+            hi = std::min<int64_t>(N, hi * (int64_t)std::max(2, std::min(16, g_step)));
             ++segs;
+        }
+        P.last_seg_rows = hi - lo;
         P.launches = segs * ((P.Bpad + P.mm_chunk - 1) / P.mm_chunk);
         P.bytes_per_launch = P.use_mm8 ? N * (d + 4) + l2 : N * d * 2 + l2;
     } else if (P.use_shadow) {
@@ -2069,10 +2094,12 @@ static SearchPlan plan_search(const PlanEnv& e) {
 static int plan_describe(const PlanEnv& e, const SearchPlan& P, char* out, int cap) {
     return snprintf(out, cap,
                     "family=%s QT=%d kc=%d Bpad=%d grid=%d launches=%d bytes_per_launch=%lld ws_bytes=%zu hp=%d slots=%d "
-                    "prepass=%d shadow=%d tiled=%d int8_tiles=%d exact_only=%d store=%s metric=%d d=%d rows=%lld queries=%d k=%d",
+                    "prepass=%d shadow=%d tiled=%d int8_tiles=%d exact_only=%d store=%s metric=%d d=%d rows=%lld queries=%d k=%d "
+                    "mm_growth=%d last_seg_rows=%lld",
                     P.family, P.QT, P.kc, P.Bpad, P.grid, P.launches, (long long)P.bytes_per_launch, P.ws_bytes, (int)P.use_hp,
                     (int)P.use_slots, (int)P.prepass, (int)P.use_shadow, (int)P.use_mm, (int)P.use_mm8, (int)P.exact_only,
-                    e.store == PRAG_F32 ? "f32" : "f16", e.metric, e.d, (long long)e.ntotal, e.B, e.k);
+                    e.store == PRAG_F32 ? "f32" : "f16", e.metric, e.d, (long long)e.ntotal, e.B, e.k, P.mm_growth,
+                    (long long)P.last_seg_rows);
 }
 
 extern "C" int prag_plan_search(int d, int metric, int store_dtype, int64_t ntotal, int B, int k, int shadow_ready, int n_cu,
@@ -2132,19 +2159,7 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
     m.max_wg = cu_budget;
     m.gate = ix->gate;
     m.shape16 = ix->mm_shape16 != 0;
-    // segment growth: keep the expected survivors of a segment (~(growth-1) * KC per query) inside the
-    // per-workgroup regions (64 per query) and the compaction's staging buffer (4096)
-    {
-        const int n_qb = std::min(Bpad, chunk) / 256;
-        const int g_wg = 1 + (cap_wg / 4) * cu_budget / std::max(1, kc * n_qb);
-        const int g_lds = 1 + 3000 / kc;
-        m.growth = std::max(2, std::min(16, std::min(g_wg, g_lds)));
-        // int8 tiles: a segment yields ~(growth - 1) * 256 survivors per query, each an LDS atomic and two stores in
-        // the filter while the other wave group waits; short segments keep the bound fresh.  Measured, 1000 queries,
-        // growth 9 / 6 / 4 / 3 / 2: 2.625 M rows 3.81 / 3.66 / 3.57 / 3.39 / 3.96 ms, 21 M rows 19.1 / 18.5 / 18.2 /
-        // 17.9 / 17.9, 1 M rows 2.13 / 1.95 / 1.97 / 1.90 / 1.94 (same box)
-        if (i8) m.growth = std::min(m.growth, kMm8Growth);
-    }
+    m.growth = mm_segment_growth(Bpad, chunk, cap_wg, cu_budget, kc, i8);     // (one place: the plan prices this schedule)
     int rc = PRAG_OK;
     for (int c0 = 0; c0 < B; c0 += chunk) {  // chunks of <= 4096 queries (LDS counters)
         m.B = std::min(B - c0, chunk);
@@ -2209,6 +2224,7 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
     return PRAG_OK;
 }
 
+static void consume_tier_stats(prag_index* ix, bool wait);
 static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D, int64_t* I,
                              int io_is_device, void* stream, int tag_ids, bool allow_mm8 = true);
 
@@ -2227,9 +2243,14 @@ extern "C" int prag_index_search_tagged(prag_index_t* ix, const float* q, int B,
 }
 
 // Allocate every workspace a search of this shape needs NOW (the index grows its workspaces lazily, by shape class, with
-// hipFree / hipMalloc - i.e. a device synchronisation - inside the first search that needs more): one throw-away search
-// of B zero queries on `stream`, waited for.  Afterwards a search of up to B queries and this k allocates nothing,
-// never waits for the device on the device-io path, and can be captured into a graph from its first call.
+// hipFree / hipMalloc - i.e. a device synchronisation - inside the first search that needs more): throw-away searches
+// of B pseudo-random queries on `stream`, waited for.  Afterwards a search of up to B queries and this k allocates
+// nothing, never waits for the device on the device-io path, and can be captured into a graph from its first call.
+// Round 5: the dummy queries are a fixed non-degenerate pattern - all-zero queries tie every row, no
+// certificate can pass, and every query went through the exact float64 scan of the whole shard (or failed the whole
+// int8 tier and fed the auto-off heuristic a synthetic whole-batch repeat).  The tier statistics are put back as they
+// were, and a shape that can take the int8 tiles is searched under BOTH settings of the auto-off switch, so that the
+// plan it flips to later finds its workspaces too.
 extern "C" int prag_index_reserve(prag_index_t* ix, int B, int k, void* stream) {
     PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
     PRAG_REQUIRE(B >= 1 && k >= 1, PRAG_EINVAL, "prag_index_reserve: B=%d k=%d", B, k);
@@ -2237,23 +2258,50 @@ extern "C" int prag_index_reserve(prag_index_t* ix, int B, int k, void* stream) 
     float* q = nullptr;
     float* D = nullptr;
     int64_t* I = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&q), (size_t)B * ix->d * sizeof(float));
+    const size_t nq = (size_t)B * ix->d;
+    std::vector<float> hq(nq);
+    uint32_t lcg = 0x9E3779B9u;
+    for (size_t i = 0; i < nq; ++i) {          // uniform in [-1, 1): distinct directions, no ties
+        lcg = lcg * 1664525u + 1013904223u;
+        hq[i] = (float)(int32_t)lcg * (1.0f / 2147483648.0f);
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&q), nq * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&D), (size_t)B * k * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&I), (size_t)B * k * sizeof(int64_t));
     int rc = PRAG_OK;
+    // the statistics of the int8-tile heuristic are the caller's searches' business, not a sizing run's
+    consume_tier_stats(ix, true);
+    const int sv_streak = ix->mm8_whole_batch_streak, sv_count = ix->mm8_off_count, sv_period = ix->mm8_off_period,
+              sv_failed = ix->mm8_last_failed;
+    const bool sv_off = ix->mm8_auto_off;
+    const std::string sv_plan = ix->last_plan;
     if (e != hipSuccess) {
         (void)hipGetLastError();
         set_error("prag_index_reserve: %s", hipGetErrorString(e));
         rc = e == hipErrorOutOfMemory ? PRAG_ENOMEM : PRAG_EHIP;
     } else {
-        e = hipMemsetAsync(q, 0, (size_t)B * ix->d * sizeof(float), st);
-        if (e == hipSuccess) rc = index_search_impl(ix, q, B, k, 0, D, I, 1, stream, 0);
-        const hipError_t e2 = hipStreamSynchronize(st);
-        if (rc == PRAG_OK && (e != hipSuccess || e2 != hipSuccess)) {
-            set_error("prag_index_reserve: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        e = hipMemcpyAsync(q, hq.data(), nq * sizeof(float), hipMemcpyHostToDevice, st);
+        for (int pass = 0; pass < 2 && e == hipSuccess && rc == PRAG_OK; ++pass) {
+            ix->mm8_auto_off = pass == 0 ? false : true;
+            ix->mm8_off_count = 0;             // (no probe flips the switch back inside the sizing search)
+            rc = index_search_impl(ix, q, B, k, 0, D, I, 1, stream, 0);
+            const hipError_t e2 = hipStreamSynchronize(st);
+            if (e2 != hipSuccess) e = e2;
+            ix->tier_pending = false;
+            if (ix->last_plan.find("int8_tiles=1") == std::string::npos && pass == 0) break;   // not an int8-tile shape
+        }
+        if (rc == PRAG_OK && e != hipSuccess) {
+            set_error("prag_index_reserve: %s", hipGetErrorString(e));
             rc = PRAG_EHIP;
         }
     }
+    ix->mm8_whole_batch_streak = sv_streak;
+    ix->mm8_off_count = sv_count;
+    ix->mm8_off_period = sv_period;
+    ix->mm8_auto_off = sv_off;
+    ix->mm8_last_failed = sv_failed;
+    ix->last_plan = sv_plan;
+    ix->tier_pending = false;
     for (void* p : {(void*)q, (void*)D, (void*)I})
         if (p) (void)hipFree(p);
     return rc;
@@ -2301,7 +2349,9 @@ extern "C" int prag_index_search_sharded(prag_index_t* ix, const float* q_dev, i
     if (rc != PRAG_OK) return rc;
     const char* parts = ix->xch_send;
     if (ix->comm) {      // also with one rank: the collective the multi-rank path issues, in its dtype and shape
+        ix->prof_xch.begin(st);
         rc = rccl_all_gather_bytes(ix->comm, ix->xch_send, ix->xch_recv, stride, st);
+        ix->prof_xch.end(st);
         if (rc != PRAG_OK) return rc;
         parts = ix->xch_recv;
     }
@@ -2997,9 +3047,19 @@ extern "C" int prag_index_profile(prag_index_t* ix, int slots) {
     PRAG_REQUIRE(ix != nullptr && slots >= 0 && slots <= 4096, PRAG_EINVAL, "prag_index_profile: bad argument");
     if (slots == 0) {
         ix->prof.disable();
+        ix->prof_xch.disable();
         return PRAG_OK;
     }
+    if (ix->comm) {                 // sharded searches: the exchange step gets a ring of its own
+        const int rc = ix->prof_xch.enable(slots);
+        if (rc != PRAG_OK) return rc;
+    }
     return ix->prof.enable(slots);
+}
+
+extern "C" int prag_index_profile_read_exchange(prag_index_t* ix, float* ms, int cap, int* n_out) {
+    PRAG_REQUIRE(ix != nullptr && ms != nullptr && cap >= 0, PRAG_EINVAL, "prag_index_profile_read_exchange: bad argument");
+    return ix->prof_xch.read(ms, cap, n_out);
 }
 
 extern "C" int prag_index_profile_read(prag_index_t* ix, float* ms, int cap, int* n_out) {
@@ -3010,6 +3070,7 @@ extern "C" int prag_index_profile_read(prag_index_t* ix, float* ms, int cap, int
 extern "C" void prag_index_destroy(prag_index_t* ix) {
     if (!ix) return;
     ix->prof.disable();
+    ix->prof_xch.disable();
     void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->q16lo, ix->g_tau, ix->part_key, ix->part_idx, ix->cand,
                     ix->io_q, ix->io_res, ix->mm_cnt, ix->mm_ovf, ix->mm_kq, ix->mm_ckey, ix->mm_cidx, ix->t2_list, ix->t2_q,
                     ix->t2_D, ix->t2_I, ix->t2_word, ix->xch_send, ix->xch_recv,

@@ -1096,7 +1096,17 @@ struct prag_prober {
     int n_cu = 256;            // compute units of the device the handle lives on (tile-height choice)
     int shape16 = 1;           // fp16 x fp16 mode on 16 x 16 MFMA tiles (PRAG_PROBER_SHAPE=32: the 32 x 32 kernel)
     EventRing prof;
+    // prag_gate_decide: outputs owned by the handle.  Up to kDecideDirect rows the kernels write probsum / decision
+    // straight into mapped, coherent host memory (no copy node, no second launch); larger batches go through device
+    // buffers and ONE copy into the same pinned block.
+    float* dec_logits = nullptr;        // device [L][dec_cap][2]
+    char* dec_host = nullptr;           // pinned + mapped: int32 decision[dec_cap] | float probsum[dec_cap][2]
+    char* dec_host_dev = nullptr;       // the same block as the device sees it
+    char* dec_dev = nullptr;            // device staging for batches beyond kDecideDirect
+    int dec_cap = 0;
+    int dec_spin = 1;                   // PRAG_DECIDE_SPIN=0 at creation: always hipStreamSynchronize
 };
+constexpr int kDecideDirect = 256;
 
 static int pick_scale_exp(double maxabs) {
     if (!(maxabs > 0.0)) return 0;
@@ -1233,6 +1243,7 @@ extern "C" int prag_prober_create(prag_prober_t** out, int n_layers, int d_model
     if (const char* ev = getenv("PRAG_PROBER_SMALL")) p->small_mode = atoi(ev);
     if (const char* ev = getenv("PRAG_PROBER_CT")) p->ct_force = atoi(ev);
     if (const char* ev = getenv("PRAG_PROBER_SHAPE")) p->shape16 = atoi(ev) != 32;
+    if (const char* ev = getenv("PRAG_DECIDE_SPIN")) p->dec_spin = atoi(ev) != 0;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -1628,6 +1639,65 @@ extern "C" int prag_gate(prag_prober_t* p, const void* x_dev, int x_dtype, int64
                                  stream);
 }
 
+// The gate as the retrieve-decide loop consumes it (exp_rag.py:393, 406-415: `logits = return_prober_logit_gemma_2b(...)`,
+// softmax / sum / threshold in Python, then `if logit_sum[0] + theta < logit_sum[1]` on the HOST): one call that ends
+// with the decisions in the caller's host memory.  Everything the call needs lives in the handle (device logits, a
+// pinned + mapped result block), so the host side allocates nothing per decision; for <= kDecideDirect rows the gate's
+// last kernel writes the decisions into the mapped block itself and the host waits for THOSE WORDS (a sentinel it put
+// there first) instead of for an interrupt - the stream is not otherwise synchronised.  probsum_host != NULL also
+// returns the two sums the reference prints (exp_rag.py:420): that variant waits for the stream.
+static int decide_reserve(prag_prober* p, int B) {
+    if (B <= p->dec_cap) return PRAG_OK;
+    const int cap = std::max(B, 64);
+    if (p->dec_logits) (void)hipFree(p->dec_logits);
+    if (p->dec_host) (void)hipHostFree(p->dec_host);
+    if (p->dec_dev) (void)hipFree(p->dec_dev);
+    p->dec_logits = nullptr; p->dec_host = nullptr; p->dec_host_dev = nullptr; p->dec_dev = nullptr; p->dec_cap = 0;
+    PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&p->dec_logits), (size_t)p->n_layers * cap * 2 * sizeof(float)));
+    PRAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->dec_host), (size_t)cap * 12,
+                           hipHostMallocMapped | hipHostMallocCoherent));
+    PRAG_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->dec_host_dev), p->dec_host, 0));
+    if (cap > kDecideDirect) PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&p->dec_dev), (size_t)cap * 12));
+    p->dec_cap = cap;
+    return PRAG_OK;
+}
+
+extern "C" int prag_gate_decide(prag_prober_t* p, const void* x_dev, int x_dtype, int64_t x_layer_stride, int B,
+                                int ablation, double theta, int32_t* decision_host, float* probsum_host, void* stream) {
+    PRAG_REQUIRE(p != nullptr, PRAG_EINVAL, "prober handle is NULL");
+    PRAG_REQUIRE(B >= 0 && (B == 0 || decision_host != nullptr), PRAG_EINVAL, "prag_gate_decide: B=%d, decision_host NULL", B);
+    if (B == 0) return PRAG_OK;
+    int rc = decide_reserve(p, B);
+    if (rc != PRAG_OK) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool direct = B <= kDecideDirect;
+    volatile int32_t* dec_h = reinterpret_cast<volatile int32_t*>(p->dec_host);
+    float* ps_h = reinterpret_cast<float*>(p->dec_host + (size_t)p->dec_cap * 4);
+    char* base = direct ? p->dec_host_dev : p->dec_dev;
+    int32_t* dec_d = reinterpret_cast<int32_t*>(base);
+    float* ps_d = reinterpret_cast<float*>(base + (size_t)p->dec_cap * 4);
+    const bool spin = direct && p->dec_spin && probsum_host == nullptr;
+    if (spin)
+        for (int b = 0; b < B; ++b) dec_h[b] = -1;           // no decision is -1: the kernel's store replaces it
+    rc = prag_gate(p, x_dev, x_dtype, x_layer_stride, B, ablation, theta, p->dec_logits, ps_d, dec_d, stream);
+    if (rc != PRAG_OK) return rc;
+    if (!direct) PRAG_HIP(hipMemcpyAsync(p->dec_host, p->dec_dev, (size_t)p->dec_cap * 12, hipMemcpyDeviceToHost, st));
+    bool done = false;
+    if (spin) {
+        // ~200 us of polling (a B = 1 gate is ~20 us of kernels), then the ordinary wait
+        for (int it = 0; it < 200000 && !done; ++it) {
+            done = true;
+            for (int b = 0; b < B; ++b)
+                if (dec_h[b] == -1) { done = false; break; }
+            if (!done) __builtin_ia32_pause();
+        }
+    }
+    if (!done) PRAG_HIP(hipStreamSynchronize(st));
+    for (int b = 0; b < B; ++b) decision_host[b] = dec_h[b];
+    if (probsum_host) memcpy(probsum_host, ps_h, (size_t)B * 2 * sizeof(float));
+    return PRAG_OK;
+}
+
 extern "C" int prag_prober_profile(prag_prober_t* p, int slots) {
     PRAG_REQUIRE(p != nullptr && slots >= 0 && slots <= 4096, PRAG_EINVAL, "prag_prober_profile: bad argument");
     if (slots == 0) {
@@ -1653,6 +1723,9 @@ extern "C" void prag_prober_destroy(prag_prober_t* p) {
     if (p->small_sync) (void)hipFree(p->small_sync);
     if (p->ws_h) (void)hipFree(p->ws_h);
     if (p->ws_l) (void)hipFree(p->ws_l);
+    if (p->dec_logits) (void)hipFree(p->dec_logits);
+    if (p->dec_host) (void)hipHostFree(p->dec_host);
+    if (p->dec_dev) (void)hipFree(p->dec_dev);
     delete p;
 }
 

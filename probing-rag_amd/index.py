@@ -369,7 +369,7 @@ def _ix_prepare(self):
 
 
 def _ix_reserve(self, B: int, k: int):
-    """Allocate the workspaces of a ``B``-query, top-``k`` search now (a throw-away search of zero queries): later
+    """Allocate the workspaces of a ``B``-query, top-``k`` search now (throw-away searches of a fixed query pattern): later
     searches of that shape allocate nothing and can be captured into a graph from the first call."""
     import torch
     with torch.cuda.device(self.device):
@@ -403,5 +403,12 @@ def _ix_profile_read(self):
     return _profile_read(_lib.lib().prag_index_profile_read, self._h)
 
 
+def _ix_profile_read_exchange(self):
+    """ms per all-gather of the sharded searches since ``profile(slots)`` (C-level exchange only)."""
+    from .prober import _profile_read
+    return _profile_read(_lib.lib().prag_index_profile_read_exchange, self._h)
+
+
 HipFlatIndex.profile = _ix_profile
 HipFlatIndex.profile_read = _ix_profile_read
+HipFlatIndex.profile_read_exchange = _ix_profile_read_exchange

@@ -19,22 +19,25 @@ from . import _lib
 class HiddenStatePool:
     """acc[l] = sum over all positions of every forward pass after the first.
 
-    A decode step (one position per pass, KV cache on) of ALL hooked layers is added in ONE launch
-    (``prag_pool_accumulate_layers``): each layer's hook only notes where the model left its activations, the
-    last layer's hook - or ``pooled()`` / ``reset()`` - flushes the set.  The noted tensors are kept alive until
-    then and must not be overwritten in place by the model meanwhile (TransformerLens hook points and HF hidden
-    states are not); ``defer=False`` adds every layer at once in its own launch, as round 3 did."""
+    Every hook call adds its activations at once, in its own launch (``defer=False``, the default: the tensor is read
+    while the model still holds it unchanged, whatever the model does with that buffer afterwards).
+    ``defer=True`` adds a decode step (one position per pass, KV cache on) of ALL hooked layers in ONE launch
+    (``prag_pool_accumulate_layers``): each layer's hook only notes where the model left its activations, the last
+    layer's hook - or ``pooled()`` - flushes the set.  The noted tensors are kept alive until then and must not be
+    overwritten in place meanwhile: TransformerLens hook points and HF decoder-layer outputs are fresh tensors (the
+    call sites that opt in: bench_e2e.py, tests), static / compiled output buffers or an in-place residual add are
+    not - a tensor whose version counter moved between the note and the flush raises instead of being summed wrong."""
 
-    def __init__(self, n_layers: int, d_model: int, batch: int = 1, device=None, defer: bool = True):
+    def __init__(self, n_layers: int, d_model: int, batch: int = 1, device=None, defer: bool = False):
         _lib.require_gpu()
         import torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.acc = torch.zeros((n_layers, batch, d_model), dtype=torch.float32, device=self.device)
         self.passes = [0] * n_layers
         self.defer = bool(defer) and n_layers <= 64
-        self._pending = {}      # slot -> (tensor [B,1,d], assign)
+        self._pending = {}      # slot -> (tensor [B,1,d], assign, tensor._version when noted)
 
-    def reset(self):            # `cache = {}` exp_rag.py:397, 423
+    def reset(self):            # `cache = {}` exp_rag.py:397, 423: noted-but-unflushed activations are DROPPED with it
         self._pending = {}
         self.passes = [0] * len(self.passes)
 
@@ -45,7 +48,11 @@ class HiddenStatePool:
             return
         pend, self._pending = self._pending, {}
         L = len(self.passes)
-        items = [pend.get(s) for s in range(L)]
+        for s_, (a_, _, ver) in pend.items():
+            if a_._version != ver:
+                raise RuntimeError(f"HiddenStatePool(defer=True): the activations noted for layer slot {s_} were modified "
+                                   "in place before they were pooled; use defer=False with this model")
+        items = [(pend[s][0], pend[s][1]) if s in pend else None for s in range(L)]
         dts = {torch.float32: _lib.PRAG_F32, torch.float16: _lib.PRAG_F16, torch.bfloat16: _lib.PRAG_BF16}
         full = all(it is not None for it in items)
         if full:
@@ -92,7 +99,7 @@ class HiddenStatePool:
         if T == 1 and self.defer and (Bt * d) % 4 == 0:
             if slot in self._pending:        # a second pass of this layer before the others caught up
                 self._flush()
-            self._pending[slot] = (a, 1 if n == 1 else 0)
+            self._pending[slot] = (a, 1 if n == 1 else 0, a._version)
             if len(self._pending) == len(self.passes):
                 self._flush()
             return

@@ -177,6 +177,29 @@ class HipProberEnsemble:
                                             _lib.current_stream_ptr(x.device)))
         return logits, probsum, decision
 
+    def decide(self, x, ablation: int = 0, threshold: float = 0.0, with_probsum: bool = False):
+        """The gate as the loop consumes it (exp_rag.py:393, 406-415: a host `if` on the two sums): x [L,B,d] on the
+        device -> decisions as a host int32 array [B] (1 = retrieve), in ONE C call - gate, copy-out and wait
+        (``prag_gate_decide``; nothing is allocated on the device per call).  ``with_probsum`` also returns the sums
+        float32 [B,2] the reference prints (exp_rag.py:420)."""
+        x = self._check_x(x, 3)
+        L, B = x.shape[0], x.shape[1]
+        if L != self.n_layers:
+            raise RuntimeError(f"expected {self.n_layers} layers of activations, got {L}")
+        buf = self._decide_buf
+        if buf is None or buf[0].shape[0] < B:
+            buf = self._decide_buf = (np.empty((max(B, 8),), np.int32), np.empty((max(B, 8), 2), np.float32))
+        dec, ps = buf
+        import torch
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().prag_gate_decide(self._h, x.data_ptr(), _x_dtype(x), B * self.d_model, B, int(ablation),
+                                                   float(threshold), dec.ctypes.data,
+                                                   ps.ctypes.data if with_probsum else None,
+                                                   torch.cuda.current_stream(x.device).cuda_stream))
+        return (dec[:B].copy(), ps[:B].copy()) if with_probsum else dec[:B].copy()
+
+    _decide_buf = None
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             _lib.lib().prag_prober_destroy(self._h)

@@ -3,12 +3,14 @@ contiguously across ranks, local fused top-k, then ONE exchange step — an
 all-gather of the per-rank (D, I) [B,k] blocks over RCCL (xGMI) — and a
 (score, id) merge on every rank.
 
-Under the "nccl" backend (= RCCL on ROCm) the whole search is ONE C call,
-``prag_index_search_sharded``: local search, ``ncclAllGather`` on the caller's
-stream, merge (include/prag.h; a communicator of the library's own is created
-with ``prag_rccl_*`` because torch.distributed does not expose its ncclComm_t).
-This class is then a thin caller.  Under gloo (CPU tests, ranks sharing a GPU)
-the exchange goes through ``torch.distributed.all_gather_into_tensor``.
+The exchange goes through ``torch.distributed.all_gather_into_tensor`` (RCCL under the
+"nccl" backend, gloo in the CPU tests).  With ``PRAG_C_EXCHANGE=1`` the whole search
+is ONE C call instead, ``prag_index_search_sharded``: local search, ``ncclAllGather``
+on the caller's stream, merge (include/prag.h; a communicator of the library's own is
+created with ``prag_rccl_*`` because torch.distributed does not expose its
+ncclComm_t).  That path is opt-in until a multi-GPU run has validated it; asked for
+and unavailable, it raises on every rank - it never falls back silently.
+``index.exchange`` / ``index.exchange_note`` say which one runs.
 
 The reference has no distributed code (single process, faiss-cpu on one host:
 exp_rag.py:248, 432-436); this is the MI355X-native scaling of that call.
@@ -108,19 +110,38 @@ class ShardedFlatIndex:
         self.ntotal = 0
         self._synced = True
         self._comm = None           # ncclComm_t of the C-level exchange (enable_c_exchange)
+        # Which exchange runs, and why (bench.py prints both): "none" (one rank), "torch.distributed" or "prag_rccl".
+        # The C-level exchange (one C call per sharded search, a communicator of the library's own) is OPT-IN until a
+        # multi-GPU run has validated it: PRAG_C_EXCHANGE=1 asks for it and RAISES on every rank when any
+        # rank cannot have it; unset / "auto" / "0" exchange through torch.distributed (RCCL under the "nccl" backend).
         import os
         want = os.environ.get("PRAG_C_EXCHANGE", "auto")
-        if engine is None and self.distributed and want != "0" and \
-                (want == "1" or (self.world > 1 and dist.get_backend(group) == "nccl")):
-            self.enable_c_exchange()
+        self.exchange = "none" if self.world == 1 else "torch.distributed"
+        self.exchange_note = "PRAG_C_EXCHANGE=%s: torch.distributed.all_gather_into_tensor (%s)" % (
+            want, dist.get_backend(group) if self.distributed else "no process group")
+        if engine is None and self.distributed and want == "1":
+            ok, why = self.enable_c_exchange()
+            if not ok:
+                raise RuntimeError(f"PRAG_C_EXCHANGE=1 but the C-level RCCL exchange is unavailable: {why}")
 
     # ---- exchange in C ---------------------------------------------------------
+    def _all_ok(self, ok: int) -> bool:
+        """Collective vote: True only if EVERY rank of the group passed `ok` != 0."""
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.engine.device)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+        return int(flag.item()) == 1
+
     def enable_c_exchange(self):
         """Collective.  Creates an RCCL communicator of the library's own over the ranks of this group (rank 0's
         ncclGetUniqueId travels through torch.distributed) and hands it to the local index; `search` is then one
-        C call.  Every rank falls back to the torch.distributed exchange together if any rank fails."""
+        C call.  Returns (ok, reason).  The ranks VOTE after every step that can fail on one rank alone - the id,
+        ncclCommInitRank, the self-check all-gather - and before the next collective on the new communicator, so no
+        rank ever enters a collective that a failed peer skips (a rank whose init failed went to the
+        final vote while its peers blocked in the self-check).  torch's own collectives and the library's run on
+        different communicators: the device is drained between them (torch.cuda.synchronize) so they never overlap."""
         import ctypes
         lib = _lib.lib()
+        why = ""
         ok, comm = 1, ctypes.c_void_p()
         ident = [None]
         try:
@@ -129,43 +150,50 @@ class ShardedFlatIndex:
                 _lib.check(lib.prag_rccl_unique_id(buf))
                 ident = [bytes(buf.raw)]
         except Exception as e:      # noqa: BLE001 - reported, then every rank falls back together
-            ok, ident = 0, [b""]
-            print(f"ShardedFlatIndex: C-level exchange unavailable on rank 0 ({e})", flush=True)
+            ok, ident, why = 0, [b""], f"ncclGetUniqueId on rank 0: {e}"
         self.dist.broadcast_object_list(ident, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                                         group=self.group)
         if len(ident[0]) != 128:
-            ok = 0
-        if ok:
-            try:
-                with torch.cuda.device(self.engine.device):
-                    _lib.check(lib.prag_rccl_comm_init_rank(ctypes.byref(comm), self.world, self.rank, ident[0]))
-            except Exception as e:  # noqa: BLE001
-                ok = 0
-                print(f"ShardedFlatIndex: ncclCommInitRank failed on rank {self.rank} ({e})", flush=True)
-        if ok:
-            # the new communicator carries one all-gather before any search relies on it: a wrong answer (or an error
-            # from RCCL) sends every rank back to the torch.distributed exchange; it also takes RCCL's one-off channel
-            # set-up out of the first search
-            try:
-                with torch.cuda.device(self.engine.device):
-                    send = torch.full((4,), 1000 + self.rank, dtype=torch.int32, device=self.engine.device)
-                    recv = torch.zeros((self.world, 4), dtype=torch.int32, device=self.engine.device)
-                    _lib.check(lib.prag_rccl_all_gather(comm, send.data_ptr(), recv.data_ptr(), 16,
-                                                        torch.cuda.current_stream().cuda_stream))
-                    want = (1000 + torch.arange(self.world, dtype=torch.int32, device=self.engine.device))[:, None].expand(-1, 4)
-                    if not torch.equal(recv, want):
-                        raise RuntimeError(f"all-gather self-check returned {recv[:, 0].tolist()}")
-            except Exception as e:  # noqa: BLE001
-                ok = 0
-                print(f"ShardedFlatIndex: RCCL self-check failed on rank {self.rank} ({e})", flush=True)
-        flag = torch.tensor([ok], dtype=torch.int32, device=self.engine.device)
-        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
-        if int(flag.item()) == 1:
-            self._comm = comm.value
-            self.engine.index.set_comm(self._comm, self.rank, self.world)
-        elif comm.value:
+            return False, why or "rank 0 could not create an RCCL unique id (librccl not loadable?)"   # same on every rank
+        try:
+            with torch.cuda.device(self.engine.device):
+                _lib.check(lib.prag_rccl_comm_init_rank(ctypes.byref(comm), self.world, self.rank, ident[0]))
+        except Exception as e:  # noqa: BLE001
+            ok, why = 0, f"ncclCommInitRank on rank {self.rank}: {e}"
+        if not self._all_ok(ok):            # vote BEFORE the first collective on the new communicator
+            if comm.value:
+                lib.prag_rccl_comm_destroy(comm)
+            return False, why or "ncclCommInitRank failed on another rank"
+        # the new communicator carries one all-gather before any search relies on it: a wrong answer (or an error
+        # from RCCL) is voted on too; it also takes RCCL's one-off channel set-up out of the first search
+        torch.cuda.synchronize(self.engine.device)     # torch's all_reduce above is done before ours starts
+        try:
+            with torch.cuda.device(self.engine.device):
+                send = torch.full((4,), 1000 + self.rank, dtype=torch.int32, device=self.engine.device)
+                recv = torch.zeros((self.world, 4), dtype=torch.int32, device=self.engine.device)
+                _lib.check(lib.prag_rccl_all_gather(comm, send.data_ptr(), recv.data_ptr(), 16,
+                                                    torch.cuda.current_stream().cuda_stream))
+                torch.cuda.synchronize(self.engine.device)
+                want = (1000 + torch.arange(self.world, dtype=torch.int32, device=self.engine.device))[:, None].expand(-1, 4)
+                if not torch.equal(recv, want):
+                    raise RuntimeError(f"all-gather self-check returned {recv[:, 0].tolist()}")
+        except Exception as e:  # noqa: BLE001
+            ok, why = 0, f"RCCL self-check on rank {self.rank}: {e}"
+        if not self._all_ok(ok):
             lib.prag_rccl_comm_destroy(comm)
-        return self._comm is not None
+            return False, why or "the RCCL self-check failed on another rank"
+        torch.cuda.synchronize(self.engine.device)
+        self._comm = comm.value
+        self.engine.index.set_comm(self._comm, self.rank, self.world)
+        self.exchange = "prag_rccl"
+        self.exchange_note = "prag_index_search_sharded: local search + ncclAllGather + merge in one C call (own communicator)"
+        return True, ""
+
+    def disable_c_exchange(self):
+        """Back to the torch.distributed exchange (collective only in the sense that every rank must do the same)."""
+        self.close()
+        self.exchange = "none" if self.world == 1 else "torch.distributed"
+        self.exchange_note = "torch.distributed.all_gather_into_tensor"
 
     def close(self):
         if self._comm:

@@ -35,9 +35,15 @@ def main():
     # the exchange in C (include/prag.h: prag_rccl_* + prag_index_set_comm + prag_index_search_sharded): a
     # communicator of the library's own over the one rank, then the whole sharded search as ONE call - local search
     # with tagged ids, ncclAllGather on the current stream, merge
-    assert ix._comm is None                                    # one rank: not enabled by itself
-    assert ix.enable_c_exchange(), "RCCL communicator of the library's own could not be created"
+    assert ix._comm is None and ix.exchange == "none"          # opt-in (PRAG_C_EXCHANGE=1), never by itself
+    ok, why = ix.enable_c_exchange()
+    assert ok and ix.exchange == "prag_rccl", "RCCL communicator of the library's own could not be created: " + why
+    ix.engine.index.profile(16)                                # the exchange step has an event ring of its own
     D2, I2 = ix.search(q, k)
+    torch.cuda.synchronize()
+    xms = ix.engine.index.profile_read_exchange()
+    assert len(xms) == 1 and 0.0 < xms[0] < 50.0, xms
+    ix.engine.index.profile(0)
     assert torch.equal(I2, I0) and torch.equal(D2, D0)
     for B2 in (1, 300):                                        # the reference's call shape, and the tiled scans
         q2 = torch.from_numpy(onp.synth_rows(8, 0, B2, d)).cuda()
@@ -59,8 +65,19 @@ def main():
     torch.cuda.synchronize()
     assert torch.equal(out[1], I0) and torch.equal(out[0], D0)
     del g
-    ix.close()
-    assert ix._comm is None
+    ix.disable_c_exchange()
+    assert ix._comm is None and ix.exchange == "none"
+    # PRAG_C_EXCHANGE=1 at construction: the C exchange or an exception, never a silent fallback
+    os.environ["PRAG_C_EXCHANGE"] = "1"
+    ix2 = pra.ShardedFlatIndex(d, "cos", "f16")
+    assert ix2.exchange == "prag_rccl" and ix2._comm is not None
+    ix2.add_synthetic_local(42, 0, 5000)
+    ix2.sync()
+    D3, I3 = ix2.search(q, k)
+    Dl, Il = ix2.engine.index.search(q, k)
+    assert torch.equal(I3, Il) and torch.equal(D3, Dl)
+    ix2.close()
+    del os.environ["PRAG_C_EXCHANGE"]
     # shard sizes (ShardedFlatIndex.sync), timing reduction and device list (bench.py)
     counts = torch.zeros(1, dtype=torch.int64, device="cuda")
     dist.all_gather_into_tensor(counts, torch.tensor([N], dtype=torch.int64, device="cuda"))

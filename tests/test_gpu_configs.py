@@ -240,7 +240,7 @@ def test_c5_gemma2b_shaped_loop_matches_the_reference_style_path():
 
     # exp_rag.py:317-329: one forward hook per probed layer.  The HIP path accumulates on the device;
     # the reference-style cache is filled by the same hooks (activations.detach().cpu()).
-    pool = pra.HiddenStatePool(len(layers), 2048)
+    pool = pra.HiddenStatePool(len(layers), 2048, defer=True)
     cache = {}
 
     def make_hook(slot):

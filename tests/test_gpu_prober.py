@@ -388,7 +388,8 @@ def test_decode_step_of_all_layers_pools_in_one_launch(torch_cuda, dtype):
     L, Bt, d = 6, 2, 256
     rng = np.random.default_rng(3)
     dt = getattr(torch, dtype)
-    a, b = pra.HiddenStatePool(L, d, batch=Bt), pra.HiddenStatePool(L, d, batch=Bt, defer=False)
+    a, b = pra.HiddenStatePool(L, d, batch=Bt, defer=True), pra.HiddenStatePool(L, d, batch=Bt)
+    assert a.defer and not b.defer       # immediate adds are the default
     steps = [torch.from_numpy(rng.standard_normal((L, Bt, 9 if t in (0, 4) else 1, d)).astype(np.float32)).cuda().to(dt)
              for t in range(8)]
     for t, st in enumerate(steps):
@@ -402,6 +403,15 @@ def test_decode_step_of_all_layers_pools_in_one_launch(torch_cuda, dtype):
     want = sum(st.float().sum(dim=2) for st in steps[1:]) + steps[3][0].float().sum(dim=1)[None] * \
         torch.tensor([1.0] + [0.0] * (L - 1), device="cuda")[:, None, None]
     np.testing.assert_allclose(a.pooled().cpu().numpy(), want.cpu().numpy(), atol=1e-4)
+    # a noted tensor that is modified in place before the flush is an error, not a wrong sum
+    c = pra.HiddenStatePool(2, d, batch=Bt, defer=True)
+    h = [torch.ones((Bt, 1, d), device="cuda") for _ in range(2)]
+    for l in range(2):
+        c.observe(l, h[l])                  # prompt pass (skipped)
+    c.observe(0, h[0])                      # noted, waiting for layer 1
+    h[0].add_(1.0)                          # e.g. an in-place residual add into a static buffer
+    with pytest.raises(RuntimeError, match="modified in place"):
+        c.observe(1, h[1])
 
 
 @pytest.mark.parametrize("d", [2048, 320])
@@ -435,3 +445,32 @@ def test_fp16_mode_on_both_mfma_shapes(torch_cuda, monkeypatch, d):
     sub = np.array([0, 1, 31, 32, 63, 64, 100, 127, 128, 1500, 2999])
     small = ens16.forward(x[:, sub].contiguous()).cpu().numpy()
     np.testing.assert_allclose(small, big[:, sub], atol=2e-6, rtol=0)
+
+
+@pytest.mark.parametrize("weights,B", [("f32", 1), ("f32", 3), ("f16", 2), ("f16", 40), ("f32", 300)])
+def test_decide_returns_the_gate_decisions_in_host_memory(torch_cuda, golden, monkeypatch, weights, B):
+    """exp_rag.py:393, 406-415 end in a host branch: `ens.decide` (prag_gate_decide) is gate + copy-out + wait in one
+    call and must give exactly what `ens.gate` writes on the device - on the small-batch path (B = 1, the reference's
+    call shape), the tiled path, beyond the 256 rows the kernels write into host memory themselves, with the spin
+    wait and with the plain stream wait, with and without the sums, and call after call on one handle."""
+    torch = torch_cuda
+    import probing_rag_amd as pra
+    case = dict(cases.PROBER_CASES[1], B=B)
+    x_np = cases.synth_x(case["xseed"], case["L"], B, case["d"], case["sigma"])
+    x = torch.from_numpy(x_np).cuda()
+    for spin in ("1", "0"):
+        monkeypatch.setenv("PRAG_DECIDE_SPIN", spin)
+        ens, _ = _ensemble(case, weights)
+        monkeypatch.delenv("PRAG_DECIDE_SPIN")
+        for ab, th in ((0, 0.0), (2, -1.0), (5, 1.5)):
+            _, ps_dev, dec_dev = ens.gate(x, ab, th)
+            for _ in range(3):
+                dec = ens.decide(x, ab, th)
+                assert dec.dtype == np.int32 and dec.shape == (B,)
+                assert np.array_equal(dec, dec_dev.cpu().numpy())
+            dec2, ps = ens.decide(x, ab, th, with_probsum=True)
+            assert np.array_equal(dec2, dec) and np.array_equal(ps, ps_dev.cpu().numpy())
+        # a smaller batch after a larger one reuses the handle's buffers
+        d1 = ens.decide(x[:, :1].contiguous(), 0, 0.0)
+        assert np.array_equal(d1, ens.gate(x[:, :1].contiguous(), 0, 0.0)[2].cpu().numpy())
+        ens.close()

@@ -283,6 +283,19 @@ def test_search_plan_over_the_shape_grid():
     assert (ref["family"], ref["QT"], ref["kc"], ref["hp"], ref["bytes_per_launch"]) == ("scan_topk_kernel", 32, 8, 1, 21_000_000 * 3076)
     c3 = pra.plan_search(768, "cos", "f16", 1_000_000, 1000, 10, 0)
     assert (c3["family"], c3["Bpad"], c3["launches"]) == ("scan_mm_kernel", 1024, 5)      # 2048 -> x16 -> x4 -> x4 -> the rest
+    # the segment schedule of the tiled scans is priced where it is decided (bench.py re-derived x16
+    # everywhere): 2048, x16, then x4 per segment on the fp16 tiles; x3 everywhere on the int8 tiles
+    assert (c3["mm_growth"], c3["last_seg_rows"]) == (16, 1_000_000 - 524_288)
+    m3 = pra.plan_search(768, "cos", "f16", 3_000_000, 1000, 10, 0)
+    assert (m3["launches"], m3["last_seg_rows"]) == (6, 3_000_000 - 2_097_152)       # not the 2.47 M of a x16 schedule
+    m21 = pra.plan_search(768, "cos", "f16", 21_000_000, 1000, 10, 0)
+    assert m21["last_seg_rows"] == 21_000_000 - 8_388_608
+    i8 = pra.plan_search(768, "cos", "f16", 21_000_000, 1000, 10, 1)
+    seg, prev = 2048, 0
+    while seg < 21_000_000:
+        prev, seg = seg, seg * 3
+    assert (i8["int8_tiles"], i8["mm_growth"], i8["last_seg_rows"]) == (1, 3, 21_000_000 - prev)
+    assert pra.plan_search(768, "cos", "f16", 1000, 300, 10, 0)["last_seg_rows"] == 1000     # one segment
     assert pra.plan_search(768, "cos", "f16", 2_625_000, 1000, 10, 1)["int8_tiles"] == 1
     assert pra.plan_search(768, "cos", "f16", 1_000_000, 1000, 10, 1)["int8_tiles"] == 0       # below 2 Mi rows
     with __import__("pytest").raises(pra.PragError, match="911"):

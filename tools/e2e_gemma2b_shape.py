@@ -43,7 +43,7 @@ def main():
           f"({time.perf_counter()-t0:.1f} s)", flush=True)
 
     layers = list(range(6, 17, 2))                                  # exp_rag.py:311
-    pool = pra.HiddenStatePool(len(layers), 2048)
+    pool = pra.HiddenStatePool(len(layers), 2048, defer=True)
     for slot, l in enumerate(layers):                               # 'blocks.{l}.hook_resid_post' = layer output
         lm.model.layers[l].register_forward_hook(
             lambda mod, inp, out, slot=slot: pool.observe(slot, out[0] if isinstance(out, tuple) else out))
