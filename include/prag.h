@@ -334,6 +334,13 @@ int prag_index_set_candidate_depth(prag_index_t* ix, int depth);
  * certified and went through the exact float64 scan.  Synchronises `stream`. */
 int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out);
 
+/* Measurement hook: how many rows the proof-carrying filter of the most recent two-level search let through to the
+ * exact rerank (the last query tile of that search: total over its queries, the largest count of one query, the
+ * number of queries counted; 0 queries: that search scanned the rows directly).  Synchronises `stream`.  (No reference
+ * counterpart: faiss.IndexFlat scores every row, make_indexer.py:449-450.) */
+int prag_index_last_survivors(prag_index_t* ix, void* stream, int64_t* total_out, int* max_per_query_out,
+                              int* n_queries_out);
+
 /* The search plan - which kernel family makes the corpus pass, query-tile height, candidate depth, grid, corpus
  * passes per search, algorithmic bytes per pass, workspace bytes - is a pure function of the request shape and the
  * index state.  prag_plan_search describes the plan of a hypothetical index (no GPU needed: d, metric, store_dtype,

@@ -285,6 +285,53 @@ def synth_rows(seed: int, row0: int, nrows: int, d: int) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------
+# Embedding-shaped synthetic corpus: the reference indexes UN-NORMALISED contriever output under
+# L2 (make_indexer.py:447-456) - rows that share a mean direction, with a power-law spectrum around it and a few
+# outlier coordinates.  NumPy restatement of probing_rag_amd/synth.py (same structure; the normals come from
+# NumPy's generator here, so the two streams agree in distribution, not bit for bit - parity tests feed the
+# oracle the rows the index actually stores).
+# --------------------------------------------------------------------------
+def embedding_structure(seed: int, d: int, mean_frac: float = 0.8, alpha: float = 0.5, n_outlier: int = 6,
+                        outlier_ratio=(10.0, 30.0), resid_norm: float = 0.6):
+    rng = np.random.default_rng(int(seed) * 7919 + 13)
+    U, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    lam = (np.arange(1, d + 1, dtype=np.float64)) ** (-float(alpha))
+    lam *= resid_norm / np.sqrt((lam ** 2).sum())
+    cols = np.sort(rng.choice(d, size=n_outlier, replace=False)) if n_outlier else np.zeros((0,), np.int64)
+    signs = rng.choice([-1.0, 1.0], size=n_outlier)
+    ratios = np.linspace(outlier_ratio[0], outlier_ratio[1], n_outlier) if n_outlier else np.zeros((0,))
+    dense = rng.standard_normal(d)
+    dense[cols] = 0.0
+    dense /= np.linalg.norm(dense)
+    mu2 = mean_frac ** 2 * resid_norm ** 2 / (1.0 - mean_frac ** 2)
+    kappa = (ratios ** 2).sum() * 0.6745 ** 2 / d
+    mb2 = max(0.0, (mu2 - kappa * resid_norm ** 2) / (1.0 + kappa))
+    med = 0.6745 * np.sqrt((resid_norm ** 2 + mb2) / d)
+    mu = np.sqrt(mb2) * dense
+    mu[cols] = signs * ratios * med
+    return U.astype(np.float32), lam.astype(np.float32), mu.astype(np.float32), cols.astype(np.int64)
+
+
+def embedding_like_rows(seed: int, row0: int, n: int, d: int, structure=None, chunk: int = 1 << 18, **kw) -> np.ndarray:
+    """float32 [n,d]: rows = mu (1 + 0.1 z' on the outlier coordinates) + U diag(lambda) z."""
+    U, lam, mu, cols = structure if structure is not None else embedding_structure(seed, d, **kw)
+    M = np.ascontiguousarray((U * lam[None, :]).T)
+    jit = np.zeros((d,), np.float32)
+    jit[cols] = 0.1
+    out = np.empty((n, d), np.float32)
+    done = 0
+    while done < n:
+        c = (row0 + done) // chunk
+        lo = c * chunk
+        z = np.random.default_rng((int(seed) << 20) + c).standard_normal((chunk, d + 1), dtype=np.float32)
+        a, b = row0 + done - lo, min(chunk, row0 + n - lo)
+        zz = z[a:b]
+        out[done:done + (b - a)] = zz[:, :d] @ M + mu[None, :] * (1.0 + jit[None, :] * zz[:, d:])
+        done += b - a
+    return out
+
+
+# --------------------------------------------------------------------------
 # train/eval-time forward (train.py:141-151, 199-208, 170-181; utils.py:122-189)
 # --------------------------------------------------------------------------
 def train_eval_forward(state: dict, acts: np.ndarray, pred_lens: np.ndarray,

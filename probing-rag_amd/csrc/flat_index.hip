@@ -206,6 +206,29 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
         r1 += __shfl_xor(r1, o, 64);
         r2 += __shfl_xor(r2, o, 64);
     }
+    // the two-level search over an affine image of the rows (flat_shadow.hip): its int8 terms approximate p = q c
+    // (c: powers of two, exact), and K_q = alpha q.mu moves an exact key into the scan's key space
+    if (sp.q8a && sp.aff) {
+        double kq = 0.0;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int c = lane * 4 + it * 256;
+            if (c < d) {
+                const f32x4 m4 = *reinterpret_cast<const f32x4*>(sp.aff + c);
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(sp.aff + d + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    kq = fma((double)v[it][e], (double)m4[e], kq);
+                    v[it][e] *= c4[e];
+                }
+            }
+        }
+        if (!sampler) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) kq += __shfl_xor(kq, o, 64);
+            if (lane == 0 && sp.kshift) sp.kshift[b] = (double)sp.alpha * kq;
+        }
+    }
     if (sampler) {
         shadow_prebound_wave(sp, b, d, (int)blockIdx.y - 1, v, lane, s_q8[threadIdx.x >> 6], sm);
         return;
@@ -1443,6 +1466,13 @@ struct prag_index {
     float* serr = nullptr;
     int64_t shadow_cap = 0, shadow_rows = 0;
     uint32_t* shadow_err_max = nullptr;
+    // the shadow's affine map y = (x - mu) / c (flat_shadow.hip): [mu | c | 1/c] d floats each, a [2][d] float64
+    // scratch for the column sums behind it, the word max ||y||^2; fitted whenever the shadow is (re)built from row 0
+    float* sh_aff = nullptr;
+    double* sh_aff_sums = nullptr;
+    uint32_t* sh_yn_max = nullptr;
+    int shadow_affine_mode = 1;        // PRAG_SHADOW_AFFINE=0 at creation: identity map (the round 2-4 shadow)
+    double* sh_kshift = nullptr;       // [sh_q_cap] K_q = alpha q.mu of the queries of the running search
     signed char* sh_q8 = nullptr;      // [2][q_cap][d]
     void* sh_sq = nullptr;
     uint32_t* sh_slots = nullptr;
@@ -1584,6 +1614,11 @@ static int shadow_ensure(prag_index* ix, hipStream_t st) {
             e = hipMalloc(reinterpret_cast<void**>(&ix->shadow_err_max), sizeof(uint32_t));
             if (e == hipSuccess) e = hipMemsetAsync(ix->shadow_err_max, 0, sizeof(uint32_t), st);
         }
+        if (e == hipSuccess && !ix->sh_aff) {
+            e = hipMalloc(reinterpret_cast<void**>(&ix->sh_aff), (size_t)3 * ix->d * sizeof(float));
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ix->sh_aff_sums), (size_t)2 * ix->d * sizeof(double));
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ix->sh_yn_max), sizeof(uint32_t));
+        }
         if (e != hipSuccess) {   // nothing half-allocated is left behind; rows are scanned directly from now on
             for (void* p : {(void*)ix->rows8, (void*)ix->sscale, (void*)ix->serr})
                 if (p) (void)hipFree(p);
@@ -1604,6 +1639,16 @@ static int shadow_ensure(prag_index* ix, hipStream_t st) {
         ss.sscale = ix->sscale;
         ss.serr = ix->serr;
         ss.err_max = ix->shadow_err_max;
+        ss.aff = ix->sh_aff;
+        ss.yn_max = ix->sh_yn_max;
+        if (ix->shadow_rows == 0) {
+            // a shadow built from its first row: fit the affine map to the rows that are there (frozen for the rows
+            // added later - any map is valid, the fit only decides how tight the filter is)
+            PRAG_HIP(hipMemsetAsync(ix->sh_yn_max, 0, sizeof(uint32_t), st));
+            PRAG_HIP(hipMemsetAsync(ix->shadow_err_max, 0, sizeof(uint32_t), st));
+            const int rc_a = shadow_affine_fit(ss, ix->ntotal, ix->shadow_affine_mode == 0, ix->sh_aff_sums, st);
+            if (rc_a != PRAG_OK) return rc_a;
+        }
         const int rc = shadow_build(ss, ix->shadow_rows, ix->ntotal, st);
         if (rc != PRAG_OK) return rc;
         ix->shadow_rows = ix->ntotal;
@@ -1656,6 +1701,7 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
     // MFMA-tiled scan, PRAG_PREPASS, PRAG_SHADOW.  The switches that trade exactness for a timing
     // experiment (certificate off, tiled-scan overflow left unrepaired) exist only in `make diag`.
     if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e) != 0;
+    if (const char* e = getenv("PRAG_SHADOW_AFFINE")) ix->shadow_affine_mode = atoi(e) != 0;
 #ifdef PRAG_MM_DIAG
     if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e);
     if (const char* e = getenv("PRAG_CERT")) ix->cert_mode = atoi(e);
@@ -2619,6 +2665,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     cert.tag_ids = tag_ids;
     cert.sq8 = nullptr;        // (set below, once the query workspace of the 8-bit selection exists)
     cert.e_max = ix->shadow_err_max;
+    cert.kshift = nullptr;
     cert.gate = ix->gate;
     static EventRing no_prof_gated;   // a gated second-tier search is not part of the profiled launches
     EventRing& prof = ix->gate.word ? no_prof_gated : ix->prof;
@@ -2653,6 +2700,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
             ix->sh_q_cap = 0;
             const int rc_ws = ws_regrow({{vpp(&ix->sh_q8), (size_t)2 * BpadS * ix->d},
                                          {&ix->sh_sq, (size_t)BpadS * shadow_q_bytes()},
+                                         {vpp(&ix->sh_kshift), (size_t)BpadS * sizeof(double)},
                                          {vpp(&ix->sh_slots), (size_t)BpadS * shadow_slot_words() * sizeof(uint32_t)},
                                          {vpp(&ix->sh_ovf), (size_t)2 * BpadS * sizeof(uint32_t)}});   // + arrival counters
             if (rc_ws != PRAG_OK) return rc_ws;
@@ -2681,6 +2729,9 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         sprep.done = ix->sh_ovf + ix->sh_q_cap;
         sprep.xn_max = ix->cert_words + 1;
         sprep.alpha = metric_l2 ? -2.0f : -1.0f;
+        sprep.aff = ix->sh_aff;
+        sprep.yn_max = ix->sh_yn_max;
+        sprep.kshift = ix->sh_kshift;
         // sample for the pre-bound: kShadowSampleSlices x kShadowSampleTiles whole tiles spread over the shard
         sprep.rows8 = ix->rows8;
         sprep.sscale = ix->sscale;
@@ -2704,6 +2755,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
             sprep.sample_stride = 0;
             sprep.kq = ix->mm_kq;
             cert.sq8 = reinterpret_cast<const ShadowQ*>(ix->sh_sq);
+            cert.kshift = ix->sh_kshift;
         }
     }
     hipLaunchKernelGGL(prep_queries_kernel, dim3((Bpad + 3) / 4, sprep.sample_stride > 0 ? 1 + kShadowSampleSlices : 1), dim3(256), 0,
@@ -2725,6 +2777,9 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         ss.store.sscale = ix->sscale;
         ss.store.serr = ix->serr;
         ss.store.err_max = ix->shadow_err_max;
+        ss.store.aff = ix->sh_aff;
+        ss.store.yn_max = ix->sh_yn_max;
+        ss.kshift = ix->sh_kshift;
         ss.xnorm = ix->xnorm;
         ss.N = ix->ntotal;
         ss.d = ix->d;
@@ -3043,6 +3098,44 @@ extern "C" int prag_index_set_scan_workgroups(prag_index_t* ix, int n_workgroups
     return PRAG_OK;
 }
 
+// Measurement hook: candidates the scan of the most recent two-level search (<= 128 queries: its LAST query tile)
+// handed to the exact rerank - per query, summed over the scan's workgroups - i.e. how tight the proof-carrying filter
+// was on this corpus.  Synchronises `stream`.  n_queries_out = 0: the last search did not take the two-level path.
+extern "C" int prag_index_last_survivors(prag_index_t* ix, void* stream, int64_t* total_out, int* max_per_query_out,
+                                         int* n_queries_out) {
+    PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
+    if (total_out) *total_out = 0;
+    if (max_per_query_out) *max_per_query_out = 0;
+    if (n_queries_out) *n_queries_out = 0;
+    if (ix->last_plan.find("family=scan8_kernel") == std::string::npos || !ix->sh_ccnt) return PRAG_OK;
+    int QT = 64, grid = 0, B = 0;
+    {
+        const char* p = strstr(ix->last_plan.c_str(), " QT=");
+        if (p) QT = atoi(p + 4);
+        p = strstr(ix->last_plan.c_str(), " grid=");
+        if (p) grid = atoi(p + 6);
+        p = strstr(ix->last_plan.c_str(), " queries=");
+        if (p) B = atoi(p + 9);
+    }
+    PRAG_REQUIRE(grid >= 1 && grid <= ix->n_cu && (QT == 32 || QT == 64 || QT == 128), PRAG_ESTATE, "unreadable plan");
+    PRAG_HIP(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    std::vector<uint32_t> h((size_t)grid * QT);
+    PRAG_HIP(hipMemcpy(h.data(), ix->sh_ccnt, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const int nq = std::min(QT, B - (B - 1) / QT * QT);       // real queries of the last tile
+    int64_t total = 0;
+    int mx = 0;
+    for (int q = 0; q < nq; ++q) {
+        int64_t c = 0;
+        for (int g = 0; g < grid; ++g) c += h[(size_t)g * QT + q];
+        total += c;
+        mx = (int)std::max<int64_t>(mx, c);
+    }
+    if (total_out) *total_out = total;
+    if (max_per_query_out) *max_per_query_out = mx;
+    if (n_queries_out) *n_queries_out = nq;
+    return PRAG_OK;
+}
+
 extern "C" int prag_index_profile(prag_index_t* ix, int slots) {
     PRAG_REQUIRE(ix != nullptr && slots >= 0 && slots <= 4096, PRAG_EINVAL, "prag_index_profile: bad argument");
     if (slots == 0) {
@@ -3075,7 +3168,7 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
                     ix->io_q, ix->io_res, ix->mm_cnt, ix->mm_ovf, ix->mm_kq, ix->mm_ckey, ix->mm_cidx, ix->t2_list, ix->t2_q,
                     ix->t2_D, ix->t2_I, ix->t2_word, ix->xch_send, ix->xch_recv,
                     ix->mm_wcnt, ix->mm_wkey, ix->mm_widx, ix->rows16, ix->qinfo, ix->qn2, ix->flag_list, ix->g_slot,
-                    ix->cert_words, ix->ex_key, ix->ex_id, ix->rows8, ix->sscale, ix->serr, ix->shadow_err_max, ix->sh_q8,
+                    ix->cert_words, ix->ex_key, ix->ex_id, ix->rows8, ix->sscale, ix->serr, ix->shadow_err_max, ix->sh_aff, ix->sh_aff_sums, ix->sh_yn_max, ix->sh_kshift, ix->sh_q8,
                     ix->sh_sq, ix->sh_slots, ix->sh_ovf, ix->sh_cand, ix->sh_ccnt, ix->sh_pkey, ix->sh_pid, ix->ex_done};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

@@ -198,6 +198,8 @@ struct CertArgs {
     // within A1 e_i + C1 of its exact key (ShadowQ, same bound as the two-level search), so eps = A1 max_i e_i + C1
     const ShadowQ* sq8;       // [B] or null (fp16 selection: the model above)
     const uint32_t* e_max;    // float bits of max_i e_i
+    const double* kshift;     // [B] with sq8: K_q = alpha q.mu of the shadow's affine map (exact key - K_q is the
+                              // selection's key space, flat_shadow.hip); null: 0
     Gate gate;                // the rerank / merge-rerank / gather kernels return at once when it is closed
 };
 
@@ -219,7 +221,8 @@ __device__ __forceinline__ bool cert_ok(const CertArgs& c, int b, int metric_l2,
                                         float kth_sel) {
     if (c.force && c.force[b]) return false;
     if (!(kth_sel < INFINITY)) return true;   // the candidate list is not full: every row is in it
-    const double e = metric_l2 ? kth_exact_score - c.qn2[b] : -kth_exact_score;
+    double e = metric_l2 ? kth_exact_score - c.qn2[b] : -kth_exact_score;
+    if (c.sq8 && c.kshift) e -= c.kshift[b];      // 8-bit selection over an affine shadow: same key space first
     return e < (double)kth_sel - cert_eps(c, b, metric_l2);
 }
 
@@ -277,6 +280,9 @@ struct ShadowPrep {
     float* kq;               // optional [Bpad]: kscale of every query, contiguous (MFMA-tiled scan over the shadow)
     const uint32_t* xn_max;  // bits of max ||x||^2
     float alpha;
+    const float* aff;        // [mu | c | 1/c] of the shadow's affine map (d floats each) or null
+    const uint32_t* yn_max;  // bits of max ||y||^2, y = (x - mu) / c (aff null: xn_max is used)
+    double* kshift;          // [Bpad] out: K_q = alpha q.mu
     // sample for the pre-bound (sample_stride == 0: none, the slots of the pre-epoch stay +inf)
     const signed char* rows8;
     const float* sscale;
@@ -342,10 +348,13 @@ __device__ __forceinline__ ShadowTerms shadow_terms_wave(int d, const f32x4 (&v)
     return t;
 }
 // constants of eps_i = A e_i + C (every lane computes the same values)
-__device__ __forceinline__ ShadowQ shadow_consts(const ShadowTerms& t, float alpha, const uint32_t* xn_max) {
+__device__ __forceinline__ ShadowQ shadow_consts(const ShadowTerms& t, float alpha, const uint32_t* xn_max,
+                                                 const uint32_t* yn_max = nullptr) {
     const double aa = fabs((double)alpha);
     const double xn = (double)__uint_as_float(*xn_max) * (1.0 + 1e-6);
-    const double nx = sqrt(xn);
+    // the dot product the int8 terms approximate is p.y (p = q c, y = (x - mu) / c): its residual term and its
+    // float32 roundings scale with max ||y||; the L2 key also carries ||x||^2 (the xn term of the rounding slack)
+    const double nx = yn_max ? sqrt((double)__uint_as_float(*yn_max) * (1.0 + 1e-6)) : sqrt(xn);
     ShadowQ o;
     o.kscale = alpha * t.s1;
     // eps = A e_i + C;  C = query residual against the largest row + float32 roundings of key / eps
@@ -376,12 +385,13 @@ __device__ __forceinline__ void shadow_prep_wave(const ShadowPrep& p, int b, int
         if (lane == 0) {
             p.sq[b] = ShadowQ{0.f, 0.f, 0.f, 0.f, 0.f, {0.f, 0.f, 0.f}};
             if (p.kq) p.kq[b] = 0.f;
+            if (p.kshift) p.kshift[b] = 0.0;
         }
         return;
     }
     const ShadowTerms t = shadow_terms_wave(d, v, lane, p.q8a + (int64_t)b * d, p.q8b + (int64_t)b * d);
     if (lane == 0) {
-        const ShadowQ c = shadow_consts(t, p.alpha, p.xn_max);
+        const ShadowQ c = shadow_consts(t, p.alpha, p.xn_max, p.aff ? p.yn_max : nullptr);
         p.sq[b] = c;
         if (p.kq) p.kq[b] = c.kscale;
     }
@@ -435,7 +445,7 @@ __device__ __forceinline__ void shadow_prebound_wave(const ShadowPrep& p, int b,
                                                      int lane, signed char* q8_lds, ShadowSample& sm) {
     uint32_t* slot = p.slots + (int64_t)b * kShadowSlotWords + kShadowPreEpoch * 32 + slice;
     const ShadowTerms t = shadow_terms_wave(d, v, lane, q8_lds, nullptr);
-    const ShadowQ c = shadow_consts(t, p.alpha, p.xn_max);
+    const ShadowQ c = shadow_consts(t, p.alpha, p.xn_max, p.aff ? p.yn_max : nullptr);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     shadow_sample_issue(p, d, slice, lane, sm);
@@ -491,6 +501,8 @@ struct ShadowStore {
     float* sscale;           // [cap] s_i
     float* serr;             // [cap] e_i = ||x_i - s_i x^_i||, rounded up
     uint32_t* err_max;       // float bits of max_i e_i (diagnostic)
+    const float* aff = nullptr;   // [mu | c | 1/c] of the affine map y = (x - mu) / c the shadow quantises (null: y = x)
+    uint32_t* yn_max = nullptr;   // float bits of max_i ||y_i||^2
 };
 struct ShadowSearch {
     ShadowStore store;
@@ -520,6 +532,7 @@ struct ShadowSearch {
     uint32_t* done;          // [Bpad]
     CertArgs cert;           // flag list: queries whose candidate regions overflowed go to the exact scan
     Gate gate;
+    const double* kshift = nullptr;   // [Bpad] K_q of every query (prep_queries_kernel) or null
     bool exact_bound = false;   // lower g_tau to an exact k-th best before the gather (shadow_bound_kernel)
     int64_t quad_min_rows = (int64_t)8 << 20;   // shards from this size on scan with the quad-test epilogue (flat_shadow.hip)
 };
@@ -530,6 +543,7 @@ size_t shadow_slot_words();
 size_t shadow_q_bytes();
 int shadow_split();
 int shadow_build(const ShadowStore& s, int64_t row0, int64_t row1, hipStream_t st);
+int shadow_affine_fit(const ShadowStore& s, int64_t n_rows, int identity, double* sums, hipStream_t st);
 int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof);
 
 bool mm_supported(int d, int store_dtype, int kc);

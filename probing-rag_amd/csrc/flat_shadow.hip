@@ -4,13 +4,21 @@
 // the stored rows.  Results are the definition's (faiss.IndexFlat semantics; /root/reference:
 // make_indexer.py:449-450, utils.py:378-380) - the shadow only decides which rows need not be looked at.
 //
-// Shadow (built on the device from the stored rows, one wave per row):
-//   x^_i = rint(x_i / s_i) in [-127,127], s_i = max|x_i| / 127 ;  e_i = ||x_i - s_i x^_i|| (float64, rounded up)
-// Query (per search): two int8 terms, q ~ sq (q^1 + q^2 / 128), residual rq = ||q - q~|| ~ 2^-15 ||q||.
-// Selection score  sel = sq s_i (q^1.x^_i + q^2.x^_i / 128)   (v_mfma_i32_32x32x32_i8: exact integers)
-// differs from the exact q.x_i by at most
-//   eps_i = ||q~|| e_i + rq ||x_i||      (Cauchy-Schwarz; ~0.8 % of ||q|| ||x|| for 768 Gaussian elements)
-// so with key = -sel (IP, COS) or ||x_i||^2 - 2 sel (L2):  key - a eps_i <= exact key <= key + a eps_i.
+// Shadow (built on the device from the stored rows):
+//   y_i = (x_i - mu) / c   (round 5: a per-INDEX affine map, mu = column means, c = column scales - powers of two - of a
+//                           sample of the rows, frozen when the shadow is first built: real embeddings share a mean
+//                           direction and carry a few outlier coordinates, and a per-row abs-max int8 grid spent its
+//                           levels on those instead of on what separates one row from another)
+//   y^_i = rint(y_i / s_i) in [-127,127], s_i = max|y_i| / 127 ;  e_i = ||y_i - s_i y^_i|| (rounded up)
+// Query (per search): p = q * c (exact: powers of two), so that q.x_i = q.mu + p.y_i; two int8 terms,
+// p ~ sp (p^1 + p^2 / 128), residual rq = ||p - p~|| ~ 2^-15 ||p||.
+// Selection score  sel = sp s_i (p^1.y^_i + p^2.y^_i / 128)   (v_mfma_i32_32x32x32_i8: exact integers)
+// differs from p.y_i = q.x_i - q.mu by at most
+//   eps_i = ||p~|| e_i + rq max||y||     (Cauchy-Schwarz; ~0.8 % of ||p|| ||y|| for 768 Gaussian elements)
+// so with key = -sel (IP, COS) or ||x_i||^2 - 2 sel (L2):  key - a eps_i <= exact key - K_q <= key + a eps_i, where
+// K_q = alpha q.mu is one constant per query (alpha = -1 / -2): every comparison inside the scan is between keys of
+// the same query, and the two places where an EXACT key meets the scan's key space (shadow_bound_kernel, the
+// certificate of the int8 tiles) subtract K_q first.  mu = 0, c = 1 is the round 2-4 shadow.
 // Filter: tau is an upper bound on the k-th best EXACT key as soon as k rows with key + a eps <= tau
 // have been seen (per-lane lists of key_hi = key + a eps, shared through LDS and the chip-wide bound
 // slots, exactly as the fp16 scan shares its bound).  A row is dropped only if key - a eps_i > tau,
@@ -28,6 +36,8 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 #include "flat_internal.h"
 
@@ -59,8 +69,10 @@ template <bool F32, int NCH>
 __global__ __launch_bounds__(256) void shadow_build_kernel(const void* __restrict__ rows, int64_t tile0, int64_t n_rows,
                                                           signed char* __restrict__ rows8,
                                                           float* __restrict__ sscale, float* __restrict__ serr,
-                                                          uint32_t* __restrict__ err_max) {
+                                                          uint32_t* __restrict__ err_max, const float* __restrict__ aff,
+                                                          uint32_t* __restrict__ yn_max) {
     constexpr int d = NCH * 128;
+    // aff = [mu | c | 1/c] (d floats each) or null: y = (x - mu) * (1/c), one float32 rounding (the subtraction)
     const int tid = threadIdx.x;
     const int row_in = tid >> 3, piece = tid & 7;
     const int64_t tile = tile0 + blockIdx.x;
@@ -88,13 +100,32 @@ __global__ __launch_bounds__(256) void shadow_build_kernel(const void* __restric
                 }
             }
         }
+        if (aff) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const f32x4* pm = reinterpret_cast<const f32x4*>(aff + c * 128 + piece * 16);
+                const f32x4* pi = reinterpret_cast<const f32x4*>(aff + 2 * d + c * 128 + piece * 16);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 m4 = pm[u], i4 = pi[u];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[c][4 * u + e] = (v[c][4 * u + e] - m4[e]) * i4[e];
+                }
+            }
+        }
     } else {
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[c][e] = 0.f;
     }
-    float mx = 0.f;
+    float mx = 0.f, yn2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) yn2 = fmaf(v[c][e], v[c][e], yn2);
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) yn2 += __shfl_xor(yn2, o, 64);
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
@@ -140,6 +171,67 @@ __global__ __launch_bounds__(256) void shadow_build_kernel(const void* __restric
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) e_row = fmaxf(e_row, __shfl_xor(e_row, o, 64));
     if ((tid & 63) == 0 && e_row > 0.f) atomicMax(err_max, __float_as_uint(e_row));
+    // max_i ||y_i||^2 (rounded up: <= 1024 float32 squares): what the query-residual term of eps multiplies
+    float yn = valid ? yn2 * (1.0f + 2e-4f) : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) yn = fmaxf(yn, __shfl_xor(yn, o, 64));
+    if ((tid & 63) == 0 && yn > 0.f && yn_max) atomicMax(yn_max, __float_as_uint(yn));
+}
+
+// ---------------------------------------------------------------------------
+// The affine map of the shadow: column sums of a sample of the stored rows (float64), then mu_j = mean,
+// c_j = the power of two nearest to the column's standard deviation (1 for a constant column).  Valid for ANY mu and
+// c (the filter's bound does not depend on how they were chosen); these make the int8 grid of a row cover what
+// differs between rows.
+// ---------------------------------------------------------------------------
+template <bool F32>
+__global__ __launch_bounds__(256) void shadow_colsum_kernel(const void* __restrict__ rows, int d, int64_t n_rows,
+                                                           int64_t stride, int64_t n_take, double* __restrict__ sums) {
+    // thread t owns columns t, t + 256, ... (d <= 1024); block b takes sample rows b, b + grid, ...
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    for (int64_t j = blockIdx.x; j < n_take; j += gridDim.x) {
+        const int64_t row = j * stride;
+        if (row >= n_rows) break;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = threadIdx.x + 256 * u;
+            if (c < d) {
+                const float x = F32 ? reinterpret_cast<const float*>(rows)[row * d + c]
+                                    : (float)reinterpret_cast<const _Float16*>(rows)[row * d + c];
+                s1[u] += (double)x;
+                s2[u] = fma((double)x, (double)x, s2[u]);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = threadIdx.x + 256 * u;
+        if (c < d) {
+            atomicAdd(sums + c, s1[u]);
+            atomicAdd(sums + d + c, s2[u]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void shadow_affine_kernel(const double* __restrict__ sums, int d, double n, int identity,
+                                                           float* __restrict__ aff) {
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float mu = 0.f, sc = 1.f;
+        if (!identity && n > 0.0) {
+            const double m = sums[c] / n;
+            const double var = sums[d + c] / n - m * m;
+            mu = (float)m;
+            if (var > 0.0) {
+                int ex = (int)lrint(log2(sqrt(var)));
+                ex = ex < -30 ? -30 : ex > 30 ? 30 : ex;
+                sc = ldexpf(1.0f, ex);
+            }
+            if (!(fabsf(mu) < 3.0e38f)) mu = 0.f;      // (inf / nan rows: no centring on that column)
+        }
+        aff[c] = mu;
+        aff[d + c] = sc;
+        aff[2 * d + c] = 1.0f / sc;                    // exact: a power of two
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -173,7 +265,14 @@ struct Scan8Args {
     int dbg;                    // timing experiments only (PRAG_SHADOW_DBG; results are WRONG): bit 0 no warm-up
                                 // (no second visits), bit 1 nothing is collected
     Gate gate;
+#ifdef PRAG_MM_DIAG
+    unsigned long long* stamps; // [grid][8 waves][kScan8Stamps] wall-clock stamps (PRAG_SCAN8_STAMPS=1, `make diag` only)
+#endif
 };
+// stamps of one wave: 0 kernel entry, 1 prologue done (queries in LDS, first loads issued), 2..9 after its tile 1, 2, 4,
+// 8, 16, 32, 64, 128, 10 after its last first-visit tile, 11 after the second visits, 12 kernel exit, 13 = redo,
+// 14 = n_my, 15 = candidates appended by the workgroup (wave 0)
+constexpr int kScan8Stamps = 16;
 
 // (kShadowEpochs = 9 in flat_internal.h: bound slots refreshed after tiles 1, 2, 4, ..., 256; per query
 // kShadowEpochs + 1 rows of 32 words, the last one the sample slots written by prep_queries_kernel)
@@ -220,6 +319,16 @@ template <int QT, int KC, bool LISTS = true, int NCHS = 0, int ALN = 0, bool QUA
 __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (gate_closed(a.gate)) return;
+#ifdef PRAG_MM_DIAG
+    const unsigned long long stamp_entry = a.stamps ? wall_clock64() : 0ull;
+#define S8_STAMP(i) do { if (a.stamps && (threadIdx.x & 63) == 0) \
+        a.stamps[((int64_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * kScan8Stamps + (i)] = wall_clock64(); } while (0)
+#define S8_VALUE(i, v) do { if (a.stamps && (threadIdx.x & 63) == 0) \
+        a.stamps[((int64_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * kScan8Stamps + (i)] = (unsigned long long)(v); } while (0)
+#else
+#define S8_STAMP(i) do {} while (0)
+#define S8_VALUE(i, v) do {} while (0)
+#endif
     constexpr int NQ = QT / 32;
     // 32-query tiles carry the query as two int8 terms (the HBM-bound loop has matrix-pipe slack for the
     // second MFMA); 64-query tiles use the first term only and pay with a wider eps (more candidates)
@@ -642,6 +751,10 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                     if constexpr (LISTS)
                         if (top[t].k[KC - 1] < tau[t]) atomicMin(&s_tau[32 * t + r], sortable_u32(top[t].k[KC - 1]));
                 ++tiles_done;
+#ifdef PRAG_MM_DIAG
+                if (a.stamps && (tiles_done & (tiles_done - 1)) == 0 && tiles_done <= 128) S8_STAMP(2 + (31 - __builtin_clz(tiles_done)));
+                if (a.stamps && tiles_done == n_my) S8_STAMP(10);
+#endif
                 if (warm) {
                     ++redo;
                     // leave the warm-up when a chip-wide slot bound has arrived for every query (a lane's own
@@ -741,6 +854,10 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
         advance(vt_cur, c_cur);
     };
 
+#ifdef PRAG_MM_DIAG
+    if (a.stamps && lane == 0) a.stamps[((int64_t)blockIdx.x * 8 + w) * kScan8Stamps + 0] = stamp_entry;
+    S8_STAMP(1);
+#endif
     if constexpr (NCHS > 0) {
         static_assert(NCHS == 0 || NCHS % NLD == 0, "staging buffers rotate with the chunks of a tile");
         if (n_my > 0) {
@@ -798,12 +915,25 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
             }
         }
     }
+    S8_STAMP(11);
+    S8_VALUE(13, redo);
+    S8_VALUE(14, n_my);
     __syncthreads();
     if (tid < QT) {
         a.ccnt[(int64_t)blockIdx.x * QT + tid] = s_ccnt[tid];
         // the final bound of this workgroup: the gather drops candidates that a later, tighter bound excludes
         (void)__hip_atomic_fetch_min(a.g_tau + tid, s_tau[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifdef PRAG_MM_DIAG
+    if (a.stamps && tid == 0) {
+        unsigned long long tot = 0;
+        for (int i = 0; i < QT; ++i) tot += s_ccnt[i];
+        a.stamps[((int64_t)blockIdx.x * 8) * kScan8Stamps + 15] = tot;
+    }
+#endif
+    S8_STAMP(12);
+#undef S8_STAMP
+#undef S8_VALUE
 }
 
 // ---------------------------------------------------------------------------
@@ -890,6 +1020,7 @@ struct GatherArgs {
     uint32_t* ovf;          // [B] set when a region overflowed (or the id stage did)
     CertArgs cert;          // flag list for the exact fallback
     int dbg;                // timing experiments only (PRAG_SHADOW_DBG bits 32 / 64 / 128; results are WRONG)
+    const double* kshift;   // [B] K_q = alpha q.mu: exact key - K_q is the scan's key space (null: 0)
 };
 
 // Exact float64 score of one stored row against the staged query: 16 lanes per row (sub = lane & 15), every lane of
@@ -1068,9 +1199,11 @@ __global__ __launch_bounds__(kShThreads) void shadow_bound_kernel(GatherArgs a, 
         if (rank == a.k - 1 && kv != ~0ull) {
             const double sc = unsortable_f64(a.metric_l2 ? kv : ~kv);
             // the scan's key space: -score (inner product, cosine), ||x||^2 - 2 q.x = ||q - x||^2 - ||q||^2 (L2)
-            const double t = a.metric_l2 ? sc - s_qn2 : -sc;
+            // (minus K_q = alpha q.mu when the shadow is an affine image of the rows: see the file comment)
+            const double kq = a.kshift ? a.kshift[b] : 0.0;
+            const double t = (a.metric_l2 ? sc - s_qn2 : -sc) - kq;
             float tf = __double2float_ru(t);
-            tf = fmaf(2.4e-7f, fabsf(tf) + (a.metric_l2 ? (float)s_qn2 : 0.f), tf) + 1e-37f;   // upward only: never excludes
+            tf = fmaf(2.4e-7f, fabsf(tf) + (a.metric_l2 ? (float)s_qn2 : 0.f) + (float)fabs(kq), tf) + 1e-37f;   // upward only: never excludes
             const uint32_t v = sortable_u32(tf);
             if (v < tau_bits) {
                 g_tau_w[qi] = v;
@@ -1306,7 +1439,7 @@ bool shadow_supported(int d, int kc, int k, int B) {
 template <bool F32>
 static void launch_build(int nch, dim3 grid, hipStream_t st, const ShadowStore& s, int64_t tile0, int64_t n_rows) {
 #define PRAG_SB(N_) case N_: hipLaunchKernelGGL((shadow_build_kernel<F32, N_>), grid, dim3(256), 0, st, s.rows, tile0, \
-                                                n_rows, s.rows8, s.sscale, s.serr, s.err_max); break;
+                                                n_rows, s.rows8, s.sscale, s.serr, s.err_max, s.aff, s.yn_max); break;
     switch (nch) { PRAG_SB(1) PRAG_SB(2) PRAG_SB(3) PRAG_SB(4) PRAG_SB(5) PRAG_SB(6) PRAG_SB(7) PRAG_SB(8) }
 #undef PRAG_SB
 }
@@ -1320,6 +1453,27 @@ int shadow_build(const ShadowStore& s, int64_t row0, int64_t row1, hipStream_t s
     const dim3 grid((unsigned)(tile1 - tile0));
     if (s.store_f32) launch_build<true>(s.d / 128, grid, st, s, tile0, row1);
     else launch_build<false>(s.d / 128, grid, st, s, tile0, row1);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
+// mu / c / 1/c of the shadow's affine map from a sample of rows [0, n_rows) (at most 2^18 of them, evenly spread) ->
+// aff [3][d]; `sums` is a [2][d] float64 scratch.  identity: mu = 0, c = 1 (PRAG_SHADOW_AFFINE=0).
+int shadow_affine_fit(const ShadowStore& s, int64_t n_rows, int identity, double* sums, hipStream_t st) {
+    PRAG_REQUIRE(shadow_store_supported(s.d) && s.aff && sums, PRAG_EUNSUPPORTED, "internal: affine map of d=%d rows", s.d);
+    const int64_t n_take = std::min<int64_t>(n_rows, (int64_t)1 << 18);
+    const int64_t stride = n_take > 0 ? std::max<int64_t>(1, n_rows / n_take) : 1;
+    PRAG_HIP(hipMemsetAsync(sums, 0, (size_t)2 * s.d * sizeof(double), st));
+    if (!identity && n_take > 0) {
+        const dim3 grid((unsigned)std::min<int64_t>(n_take, 2048));
+        if (s.store_f32)
+            hipLaunchKernelGGL(shadow_colsum_kernel<true>, grid, dim3(256), 0, st, s.rows, s.d, n_rows, stride, n_take, sums);
+        else
+            hipLaunchKernelGGL(shadow_colsum_kernel<false>, grid, dim3(256), 0, st, s.rows, s.d, n_rows, stride, n_take, sums);
+        PRAG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(shadow_affine_kernel, dim3(1), dim3(256), 0, st, sums, s.d, (double)n_take,
+                       identity, const_cast<float*>(s.aff));
     PRAG_LAUNCH_CHECK();
     return PRAG_OK;
 }
@@ -1391,6 +1545,14 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
 #ifdef PRAG_MM_DIAG
         static const int dbg_env = getenv("PRAG_SHADOW_DBG") ? atoi(getenv("PRAG_SHADOW_DBG")) : 0;
         a.dbg = dbg_env;
+        static const int stamps_env = getenv("PRAG_SCAN8_STAMPS") ? atoi(getenv("PRAG_SCAN8_STAMPS")) : 0;
+        static unsigned long long* stamps_dev = nullptr;
+        a.stamps = nullptr;
+        if (stamps_env) {
+            if (!stamps_dev) PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&stamps_dev), (size_t)1024 * 8 * kScan8Stamps * 8));
+            PRAG_HIP(hipMemsetAsync(stamps_dev, 0, (size_t)1024 * 8 * kScan8Stamps * 8, st));
+            a.stamps = stamps_dev;
+        }
 #else
         a.dbg = 0;
 #endif
@@ -1414,6 +1576,41 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
                         : (s.kc == 8 ? launch_scan8<32, 8>(a, grid, st, prof)
                            : s.kc == 16 ? launch_scan8<32, 16>(a, grid, st, prof) : launch_scan8<32, 32>(a, grid, st, prof));
         if (rc != PRAG_OK) return rc;
+#ifdef PRAG_MM_DIAG
+        {
+            static int stamp_calls = 0;
+            if (a.stamps && ++stamp_calls % stamps_env == 0) {      // PRAG_SCAN8_STAMPS=n: every n-th search prints
+                PRAG_HIP(hipStreamSynchronize(st));
+                std::vector<unsigned long long> h((size_t)grid * 8 * kScan8Stamps);
+                PRAG_HIP(hipMemcpy(h.data(), a.stamps, h.size() * 8, hipMemcpyDeviceToHost));
+                unsigned long long t0 = ~0ull;
+                for (int i = 0; i < grid * 8; ++i)
+                    if (h[(size_t)i * kScan8Stamps + 14]) t0 = std::min(t0, h[(size_t)i * kScan8Stamps]);
+                const char* names[13] = {"entry", "prologue", "tile1", "tile2", "tile4", "tile8", "tile16", "tile32", "tile64",
+                                         "tile128", "last_first_visit", "loop_end", "exit"};
+                fprintf(stderr, "[scan8 stamps] grid %d QT %d rows %lld: us since the first wave's entry (min / median / max over waves)\n",
+                        grid, QT, (long long)s.N);
+                for (int k_ = 0; k_ < 13; ++k_) {
+                    std::vector<double> v;
+                    for (int i = 0; i < grid * 8; ++i) {
+                        const unsigned long long x = h[(size_t)i * kScan8Stamps + k_];
+                        if (x && h[(size_t)i * kScan8Stamps + 14]) v.push_back((double)(x - t0) / 100.0);   // 100 MHz wall clock
+                    }
+                    if (v.empty()) continue;
+                    std::sort(v.begin(), v.end());
+                    fprintf(stderr, "  %-17s %8.1f %8.1f %8.1f   (%zu waves)\n", names[k_], v.front(), v[v.size() / 2], v.back(), v.size());
+                }
+                double redo = 0, nmy = 0, cand = 0;
+                for (int i = 0; i < grid * 8; ++i) {
+                    redo += (double)h[(size_t)i * kScan8Stamps + 13];
+                    nmy += (double)h[(size_t)i * kScan8Stamps + 14];
+                    if (i % 8 == 0) cand += (double)h[(size_t)i * kScan8Stamps + 15];
+                }
+                fprintf(stderr, "  tiles %.0f, second visits %.0f (%.1f %%), candidates appended %.0f (%.0f per query)\n", nmy, redo,
+                        100.0 * redo / std::max(1.0, nmy), cand, cand / QT);
+            }
+        }
+#endif
         const int nq = std::min(QT, s.B - p0);
         GatherArgs g;
         g.rows = s.store.rows;
@@ -1438,6 +1635,7 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         g.cert = s.cert;
         g.cert.gate = s.gate;
         g.dbg = a.dbg;
+        g.kshift = s.kshift;
         if (s.exact_bound) {     // (k <= 32: the kernel scores 32 rows)
             if (s.store.store_f32)
                 hipLaunchKernelGGL(shadow_bound_kernel<true>, dim3(nq), dim3(kShThreads), 0, st, g, s.g_tau + p0);

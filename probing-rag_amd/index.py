@@ -314,6 +314,15 @@ def _ix_last_exact_fallbacks(self) -> int:
     return n.value
 
 
+def _ix_last_survivors(self) -> dict:
+    """Rows the filter of the most recent two-level search handed to the exact rerank (its last query tile):
+    {"queries", "total", "per_query", "max_per_query"}; queries = 0 when that search scanned the rows directly."""
+    tot, mx, nq = ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(_lib.lib().prag_index_last_survivors(self._h, _lib.current_stream_ptr(self.device), ctypes.byref(tot),
+                                                    ctypes.byref(mx), ctypes.byref(nq)))
+    return {"queries": nq.value, "total": tot.value, "per_query": tot.value / max(1, nq.value), "max_per_query": mx.value}
+
+
 def parse_plan(line: str) -> dict:
     """`key=value` fields of a plan line -> dict (ints where they parse)."""
     out = {}
@@ -383,6 +392,7 @@ HipFlatIndex.set_candidate_depth = _ix_set_candidate_depth
 HipFlatIndex.last_exact_fallbacks = _ix_last_exact_fallbacks
 HipFlatIndex.last_tiled8 = _ix_last_tiled8
 HipFlatIndex.last_plan = _ix_last_plan
+HipFlatIndex.last_survivors = _ix_last_survivors
 
 
 def _ix_set_scan_workgroups(self, n: int):

@@ -237,3 +237,77 @@ def test_sliced_gather_merge_never_reads_a_stale_list(monkeypatch):
             bad += int(not (torch.equal(I, I0) and torch.equal(D, D0)))
     torch.cuda.synchronize()
     assert bad == 0
+
+
+@pytest.mark.parametrize("metric,store", [("cos", "f16"), ("l2", "f16"), ("l2", "f32")])
+@pytest.mark.parametrize("kw", [{}, {"n_outlier": 4, "outlier_ratio": (10.0, 14.0)}], ids=["6_outliers_10-30x", "4_outliers_dense_mean"])
+def test_embedding_shaped_corpus_is_searched_exactly_and_tightly(metric, store, kw):
+    """un-normalised sentence-embedding geometry (make_indexer.py:447-456 indexes contriever output under
+    L2): rows share a mean at 0.8 of their norm, a power-law spectrum, outlier coordinates at 10-30 x the median.
+    1 Mi rows, ids bit-exact against the C oracle on the stored rows for 64 queries and for the reference's single
+    query; the two-level search must stay a FILTER on such rows - no exact fallback, survivors per query in the
+    hundreds, not the tens of thousands a per-row abs-max grid let through (the shadow quantises (x - mu) / c)."""
+    import torch
+    import probing_rag_amd as pra
+    from probing_rag_amd.synth import embedding_like_rows, embedding_structure
+    N, d, k = 1 << 20, 768, 10
+    st = embedding_structure(5, d, **kw)
+    ix = pra.HipFlatIndex(d, metric, store, capacity=N)
+    for lo in range(0, N, 1 << 18):
+        ix.add(embedding_like_rows(5, lo, 1 << 18, d, structure=st))
+    q = embedding_like_rows(1005, 0, 64, d, structure=st)
+    mid = {"l2": onp.METRIC_L2, "cos": onp.METRIC_COS}[metric]
+    stored = ix.reconstruct_n(0, N)                         # what the index holds (normalised / rounded)
+    D0, I0 = oracle_c.flat_search(stored, q.cpu().numpy(), k, mid)
+    ix.set_shadow(2)
+    ix.prepare()
+    for B in (64, 1):
+        D, I = ix.search(q[:B], k)
+        assert ix.last_plan()["family"] == "scan8_kernel"
+        _check(D.cpu().numpy(), I.cpu().numpy(), D0[:B], I0[:B], mid)
+        assert ix.last_exact_fallbacks() == 0
+        sv = ix.last_survivors()
+        assert sv["queries"] == B and sv["max_per_query"] < 20_000, sv     # (regions hold 131 072 per query)
+        assert sv["per_query"] < 6_000, sv
+    # the direct scan of the stored rows agrees too (its certificate has to cope with the common mean)
+    ix.set_shadow(0)
+    D, I = ix.search(q, k)
+    _check(D.cpu().numpy(), I.cpu().numpy(), D0, I0, mid)
+    # > 128 queries on the int8 tiles over the same shadow: the certificate compares keys in the shifted key space
+    ix.set_shadow(2)
+    q300 = embedding_like_rows(1006, 0, 300, d, structure=st)
+    D3, I3 = ix.search(q300, k)
+    D30, I30 = oracle_c.flat_search(stored, q300.cpu().numpy(), k, mid)
+    _check(D3.cpu().numpy(), I3.cpu().numpy(), D30, I30, mid)
+    ix.close()
+
+
+def test_affine_shadow_map_is_a_performance_choice_only(monkeypatch):
+    """PRAG_SHADOW_AFFINE=0 keeps the round 2-4 shadow (mu = 0, c = 1): same ids, same scores - on rows with a common
+    mean and outlier coordinates it lets far more rows through; rows added AFTER the map was fitted (a different
+    distribution, even) are still searched exactly, and so is a shadow rebuilt when the capacity grows."""
+    import torch
+    import probing_rag_amd as pra
+    from probing_rag_amd.synth import embedding_like_rows, embedding_structure
+    N, d, k = 200_000, 768, 10
+    st = embedding_structure(9, d)
+    X = embedding_like_rows(9, 0, N, d, structure=st)
+    q = embedding_like_rows(1009, 0, 40, d, structure=st)
+    res, surv = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PRAG_SHADOW_AFFINE", mode)
+        ix = pra.HipFlatIndex(d, "l2", "f16")           # capacity grows: the shadow is rebuilt from row 0 on the way
+        monkeypatch.delenv("PRAG_SHADOW_AFFINE")
+        ix.set_shadow(2)
+        ix.add(X[: N // 2])
+        ix.add(X[N // 2:])
+        ix.add(torch.from_numpy(onp.synth_rows(3, 0, 5000, d)).cuda() * 0.05)     # iid rows: not what the map was fitted on
+        res[mode] = ix.search(q, k)
+        surv[mode] = ix.last_survivors()["per_query"]
+        if mode == "1":
+            stored = ix.reconstruct_n(0, ix.ntotal)
+            D0, I0 = oracle_c.flat_search(stored, q.cpu().numpy(), k, onp.METRIC_L2)
+            _check(res[mode][0].cpu().numpy(), res[mode][1].cpu().numpy(), D0, I0, onp.METRIC_L2)
+        ix.close()
+    assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][0], res["0"][0])
+    assert surv["1"] * 3 < surv["0"], surv          # centring + column scales: the filter is several times tighter

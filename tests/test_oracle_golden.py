@@ -211,3 +211,35 @@ def test_topk_wrappers_hand_the_index_what_the_reference_does():
     np.testing.assert_array_equal(D, g["batch/D"])
     np.testing.assert_array_equal(D1, g["find/D"])
     assert int(g["batch/I"][1, 0]) == 17                      # the planted neighbour
+
+
+@pytest.mark.parametrize("kw", [{}, {"n_outlier": 4, "outlier_ratio": (10.0, 14.0)}], ids=["6_outliers_10-30x", "4_outliers_dense_mean"])
+def test_embedding_shaped_generators_meet_their_specification(kw):
+    """a corpus with the geometry of un-normalised sentence embeddings (make_indexer.py:447-456):
+    ||mu|| ~ 0.8 of the row norm, power-law spectrum around it, outlier coordinates at 10-30 x the median |x_j|.
+    The oracle's NumPy restatement and the product's generator (probing_rag_amd/synth.py, run on the CPU device here)
+    must both meet the specification and describe the SAME distribution; any shard regenerates its own rows."""
+    from probing_rag_amd import synth
+    d, n = 768, 10000
+    st_o = onp.embedding_structure(5, d, **kw)
+    st_p = synth.embedding_structure(5, d, **kw)
+    for a, b in zip(st_o, st_p):
+        assert np.array_equal(a, b)                      # one structure (U, lambda, mu, outlier columns)
+    xo = onp.embedding_like_rows(5, 1000, n, d, structure=st_o)
+    xp = synth.embedding_like_rows(5, 1000, n, d, device="cpu", structure=st_p).numpy()
+    cols = st_o[3]
+    for x in (xo, xp):
+        mu, nrm = x.mean(0), np.linalg.norm(x, axis=1)
+        assert abs(np.linalg.norm(mu) / nrm.mean() - 0.8) < 0.01 and abs(nrm.mean() - 1.0) < 0.02
+        med = np.median(np.abs(np.delete(x, cols, axis=1)))
+        ratios = np.abs(x[:, cols]).mean(0) / med
+        lo, hi = kw.get("outlier_ratio", (10.0, 30.0))
+        assert ratios.min() > 0.9 * lo and ratios.max() < 1.1 * hi and len(cols) == kw.get("n_outlier", 6)
+        # power-law spectrum of the centred rows: the top 10 of 768 directions carry > 35 % of the variance
+        ev = np.linalg.eigvalsh(np.cov((x - mu).T))[::-1]
+        assert ev[:10].sum() / ev.sum() > 0.35 and ev[0] / ev[99] > 50
+    # same distribution: column means and the spectrum agree between the two streams
+    assert np.abs(xo.mean(0) - xp.mean(0)).max() < 0.02
+    # shards regenerate their own rows
+    assert np.array_equal(onp.embedding_like_rows(5, 8000, 300, d, structure=st_o), xo[7000:7300])
+    assert np.array_equal(synth.embedding_like_rows(5, 8000, 300, d, device="cpu", structure=st_p).numpy(), xp[7000:7300])
