@@ -230,7 +230,7 @@ def scan_model(ix):
     read from the plan the library executed (prag_index_last_plan: the dispatch is decided in ONE place,
     plan_search in flat_index.hip; round 3 re-derived it here).  Algorithmic bytes = what one pass over the shard
     has to read: the rows in the form that is scanned (+4 B of ||x||^2 per row for L2; the 8-bit shadow carries
-    8 B of scale and error bound per row)."""
+    12 B per row: scale, error bound and the additive part of the key)."""
     plan = ix.last_plan()
     return plan["family"], plan["bytes_per_launch"], plan["launches"], bool(plan["tiled"])
 
@@ -242,7 +242,7 @@ def stored_row_bytes(store, metric, n_local):
 
 ROOFLINE_DEFINITION = (
     "frac = frac_bytes_moved = bytes the scan kernel has to read per launch (the rows in the form it scans: "
-    "the 8-bit shadow + 8 B/row of scale and error bound for scan8_kernel, the stored rows otherwise) / kernel "
+    "the 8-bit shadow + 12 B/row of scale, error bound and additive key term for scan8_kernel, the stored rows otherwise) / kernel "
     "time / 8 TB/s.  frac_stored_rows = SURVEY 8(d)'s N*d*s of the rows as stored / the same kernel time / 8 TB/s: "
     "above the bytes-moved fraction (and possibly above 1) exactly when the two-level search avoids reading the "
     "stored rows; for a direct scan the two are equal.")
@@ -483,10 +483,13 @@ def shard_variant(torch, pra, ens, k, metric, ms_per_pass_full, passes=300):
       eager        gate then search on one stream, one host call each (rounds 1-4)
       graph        the same pass captured into ONE HIP graph and replayed (every piece is capturable: no host
                    synchronisation, no allocation after the first pass of a shape)
-      graph_2s     the captured pass with the gate on a second stream BESIDE the search: the gate belongs to the next
-                   batch of states and depends on nothing in the search; its 96 workgroups run in the search's
-                   low-occupancy phases (prep, the 64-workgroup bound kernel, the tails) - fork / join inside the graph
-      eager_2s     the two-stream form without the graph
+      tail_2s      the gate of the NEXT batch of states (it depends on nothing in the search) on a second stream that waits
+                   for the search's CORPUS SCAN only (prag_index_stream_wait_scan): its 96 workgroups run beside the
+                   search's tail - the 64-workgroup bound kernel, the rerank, the fallback probes.  (Beside the scan
+                   itself it cannot run: scan8 holds all of a CU's LDS.  Round 5 measured that form too - the gate issued
+                   at the head of the pass on a second stream: 0.472 eager / 0.519 captured against 0.465 on one stream,
+                   profiles/r05a_bench.json.)
+      graph_tail_2s  the same, captured (fork / join inside the graph)
     pass_ms = the fastest of them (named in pass_mode).  predicted_strong_scaling_eff = ms_per_pass(21 M rows, this
     run) / 8 / pass_ms: the efficiency an 8-GPU run can reach at best (fixed costs do not shrink with the shard)."""
     from probing_rag_amd.synth import synth_rows
@@ -523,22 +526,24 @@ def shard_variant(torch, pra, ens, k, metric, ms_per_pass_full, passes=300):
     main_s = torch.cuda.current_stream()
     side = torch.cuda.Stream()
 
-    def one_pass_2s():
-        side.wait_stream(torch.cuda.current_stream())
+    def one_pass_tail():
+        ix.search(q, k, out=out)
+        ix.stream_wait_scan(side)                    # the side stream waits for scan8, not for the whole search
         with torch.cuda.stream(side):
             ens.gate(x, 0, 0.0, out=gate_out)
-        ix.search(q, k, out=out)
         torch.cuda.current_stream().wait_stream(side)
+
+    ix.stream_wait_scan(side)                        # (first call: switches the event recording on)
 
     modes = {}
     modes["eager"] = timed(one_pass, passes)                       # no event rings inside the timed loop
     I_eager, dec_eager = out[1].clone(), gate_out[2].clone()
     search_ms = timed(lambda: ix.search(q, k, out=out), passes)
     gate_ms = timed(lambda: ens.gate(x, 0, 0.0, out=gate_out), passes)
-    modes["eager_2s"] = timed(one_pass_2s, passes)
-    same = {"eager_2s": bool(torch.equal(out[1], I_eager) and torch.equal(gate_out[2], dec_eager))}
+    modes["tail_2s"] = timed(one_pass_tail, passes)
+    same = {"tail_2s": bool(torch.equal(out[1], I_eager) and torch.equal(gate_out[2], dec_eager))}
     graph_err = None
-    for name, fn in (("graph", one_pass), ("graph_2s", one_pass_2s)):
+    for name, fn in (("graph", one_pass), ("graph_tail_2s", one_pass_tail)):
         try:
             cs = torch.cuda.Stream()
             cs.wait_stream(torch.cuda.current_stream())
@@ -575,7 +580,7 @@ def shard_variant(torch, pra, ens, k, metric, ms_per_pass_full, passes=300):
     _, I_direct = ix.search(q, k)
     scan_k = float(np.mean(scan_ms)) if scan_ms else float("nan")
     gate_k = float(np.mean(gk_ms)) if gk_ms else float("nan")
-    alg = SHARD_ROWS * (d_emb + 8)
+    alg = SHARD_ROWS * (d_emb + 12)
     rec = {"what": "one rank's pass of the 8-GPU job on this GPU: gate over 512 x 6 x 2048 fp16 states, then %s top-%d of "
                    "64 queries over 2 625 000 x 768 fp16 rows (two-level search); host-timed back to back, "
                    "no event records in the timed loops" % (metric, k),

@@ -334,6 +334,14 @@ int prag_index_set_candidate_depth(prag_index_t* ix, int depth);
  * certified and went through the exact float64 scan.  Synchronises `stream`. */
 int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out);
 
+/* Pipelining hook: make `other_stream` wait until the CORPUS SCAN of the most recent search enqueued on this handle
+ * has finished - not the whole search.  What follows the scan (the exact bound / rerank of the survivors, the fallback
+ * probes) runs on a few dozen workgroups; independent work of the caller - exp_rag.py's gate for the NEXT batch of
+ * generations (exp_rag.py:406-415) - launched on `other_stream` after this call runs beside that tail instead of behind
+ * it.  The first call on a handle only switches the recording on (searches enqueued afterwards record an event behind
+ * their scan) and waits for nothing.  Capturable: inside a stream capture the wait becomes a fork edge. */
+int prag_index_stream_wait_scan(prag_index_t* ix, void* other_stream);
+
 /* Measurement hook: how many rows the proof-carrying filter of the most recent two-level search let through to the
  * exact rerank (the last query tile of that search: total over its queries, the largest count of one query, the
  * number of queries counted; 0 queries: that search scanned the rows directly).  Synchronises `stream`.  (No reference
@@ -365,7 +373,7 @@ int prag_index_last_plan(prag_index_t* ix, char* out, int cap);
  * utils.py:378-380 (batch_topk_sim -> IndexFlat.search); results are the definition's either way. */
 int prag_index_last_tiled8(prag_index_t* ix, int* n_failed_out);
 
-/* Two-level exact search: keep an 8-bit shadow of the stored rows (+d+8 bytes per row, built on the
+/* Two-level exact search: keep an 8-bit shadow of the stored rows (+d+12 bytes per row, built on the
  * device as rows are added - `prag_index_add*` extend it before they return, so no search pays for
  * the build) and scan IT for batches of <= 128 queries (d a multiple of 128, <= 1024,
  * k <= 26; larger batches: prag_index_last_tiled8 above): half the bytes of fp16 storage, a quarter of float32.  Results do not change: a

@@ -219,7 +219,8 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     kq = fma((double)v[it][e], (double)m4[e], kq);
-                    v[it][e] *= c4[e];
+                    // (centre_query: the rows carry alpha mu.(x - mu) themselves, the int8 terms see q - mu)
+                    v[it][e] = (sp.centre_query ? v[it][e] - m4[e] : v[it][e]) * c4[e];
                 }
             }
         }
@@ -1471,6 +1472,8 @@ struct prag_index {
     float* sh_aff = nullptr;
     double* sh_aff_sums = nullptr;
     uint32_t* sh_yn_max = nullptr;
+    float* sbias = nullptr;            // [shadow_cap] per-row additive part of the two-level scan's key
+    uint32_t* sh_bias_max = nullptr;   // float bits of max |sbias_i|
     int shadow_affine_mode = 1;        // PRAG_SHADOW_AFFINE=0 at creation: identity map (the round 2-4 shadow)
     double* sh_kshift = nullptr;       // [sh_q_cap] K_q = alpha q.mu of the queries of the running search
     signed char* sh_q8 = nullptr;      // [2][q_cap][d]
@@ -1493,6 +1496,11 @@ struct prag_index {
     char* xch_recv = nullptr;
     size_t xch_send_cap = 0, xch_recv_cap = 0;
     EventRing prof_xch;          // HIP events around the all-gather of prag_index_search_sharded (prag_index_profile)
+    // prag_index_stream_wait_scan: an event recorded right behind the corpus scan of every search (two-level search:
+    // after scan8, before the bound kernel / gather / fallback probes), so that independent work of the caller - the
+    // gate of the next batch - can start beside the search's low-occupancy tail on another stream
+    hipEvent_t scan_done_ev = nullptr;
+    bool scan_done_recorded = false;
     int last_flagged = -1;   // flag count of the last host-io search (-1: last search was device-io)
     std::string last_plan;   // plan_describe of the most recent search (prag_index_last_plan)
     EventRing prof;
@@ -1564,16 +1572,16 @@ static void** vpp(T** p) { return reinterpret_cast<void**>(p); }
 constexpr int64_t kShadowMinRows = 1 << 20;
 
 // Does this index keep a shadow at its current size / mode?  (mode 1: shards of >= 2^20 rows when the
-// device has room for d + 8 more bytes per row with 2 GB to spare; mode 2: any size)
+// device has room for d + 12 more bytes per row with 2 GB to spare; mode 2: any size)
 static bool shadow_wanted(prag_index* ix) {
     if (!ix->shadow_mode || ix->ntotal == 0 || !shadow_store_supported(ix->d) || ix->shadow_failed) return false;
     if (ix->shadow_mode >= 2) return true;
     if (ix->ntotal < kShadowMinRows || ix->shadow_no_room) return false;
     if (ix->shadow_cap < ix->cap) {
         size_t free_b = 0, total_b = 0;
-        const size_t have = ix->rows8 ? (size_t)ix->shadow_cap * (ix->d + 8) : 0;
+        const size_t have = ix->rows8 ? (size_t)ix->shadow_cap * (ix->d + 12) : 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
-            free_b + have < (size_t)ix->cap * (ix->d + 8) + ((size_t)2 << 30)) {
+            free_b + have < (size_t)ix->cap * (ix->d + 12) + ((size_t)2 << 30)) {
             ix->shadow_no_room = true;
             return false;
         }
@@ -1596,20 +1604,21 @@ static int shadow_ensure(prag_index* ix, hipStream_t st) {
     if (!shadow_wanted(ix)) {
         if ((ix->shadow_no_room || ix->shadow_failed) && ix->rows8) {   // an undersized shadow nobody will read again
             PRAG_HIP(hipStreamSynchronize(st));                          // (a search may still be reading it)
-            for (void* p : {(void*)ix->rows8, (void*)ix->sscale, (void*)ix->serr})
+            for (void* p : {(void*)ix->rows8, (void*)ix->sscale, (void*)ix->serr, (void*)ix->sbias})
                 if (p) (void)hipFree(p);
-            ix->rows8 = nullptr; ix->sscale = nullptr; ix->serr = nullptr; ix->shadow_cap = 0; ix->shadow_rows = 0;
+            ix->rows8 = nullptr; ix->sscale = nullptr; ix->serr = nullptr; ix->sbias = nullptr; ix->shadow_cap = 0; ix->shadow_rows = 0;
         }
         return PRAG_OK;
     }
     if (ix->shadow_cap < ix->cap) {    // (re)allocate with the rows; rebuilt from row 0
         PRAG_HIP(hipStreamSynchronize(st));   // a search may still be reading the old shadow on this stream
-        for (void* p : {(void*)ix->rows8, (void*)ix->sscale, (void*)ix->serr})
+        for (void* p : {(void*)ix->rows8, (void*)ix->sscale, (void*)ix->serr, (void*)ix->sbias})
             if (p) (void)hipFree(p);
-        ix->rows8 = nullptr; ix->sscale = nullptr; ix->serr = nullptr; ix->shadow_cap = 0; ix->shadow_rows = 0;
+        ix->rows8 = nullptr; ix->sscale = nullptr; ix->serr = nullptr; ix->sbias = nullptr; ix->shadow_cap = 0; ix->shadow_rows = 0;
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&ix->rows8), (size_t)ix->cap * ix->d);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ix->sscale), (size_t)ix->cap * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ix->serr), (size_t)ix->cap * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ix->sbias), (size_t)ix->cap * sizeof(float));
         if (e == hipSuccess && !ix->shadow_err_max) {
             e = hipMalloc(reinterpret_cast<void**>(&ix->shadow_err_max), sizeof(uint32_t));
             if (e == hipSuccess) e = hipMemsetAsync(ix->shadow_err_max, 0, sizeof(uint32_t), st);
@@ -1618,11 +1627,12 @@ static int shadow_ensure(prag_index* ix, hipStream_t st) {
             e = hipMalloc(reinterpret_cast<void**>(&ix->sh_aff), (size_t)3 * ix->d * sizeof(float));
             if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ix->sh_aff_sums), (size_t)2 * ix->d * sizeof(double));
             if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ix->sh_yn_max), sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ix->sh_bias_max), sizeof(uint32_t));
         }
         if (e != hipSuccess) {   // nothing half-allocated is left behind; rows are scanned directly from now on
-            for (void* p : {(void*)ix->rows8, (void*)ix->sscale, (void*)ix->serr})
+            for (void* p : {(void*)ix->rows8, (void*)ix->sscale, (void*)ix->serr, (void*)ix->sbias})
                 if (p) (void)hipFree(p);
-            ix->rows8 = nullptr; ix->sscale = nullptr; ix->serr = nullptr;
+            ix->rows8 = nullptr; ix->sscale = nullptr; ix->serr = nullptr; ix->sbias = nullptr;
             (void)hipGetLastError();
             if (ix->shadow_mode == 1) { ix->shadow_no_room = true; return PRAG_OK; }
             set_error("prag_index: allocating the 8-bit shadow failed: %s", hipGetErrorString(e));
@@ -1641,7 +1651,12 @@ static int shadow_ensure(prag_index* ix, hipStream_t st) {
         ss.err_max = ix->shadow_err_max;
         ss.aff = ix->sh_aff;
         ss.yn_max = ix->sh_yn_max;
+        ss.sbias = ix->sbias;
+        ss.bias_max = ix->sh_bias_max;
+        ss.xnorm_l2 = ix->metric == PRAG_METRIC_L2 ? ix->xnorm : nullptr;
+        ss.alpha = ix->metric == PRAG_METRIC_L2 ? -2.0f : -1.0f;
         if (ix->shadow_rows == 0) {
+            PRAG_HIP(hipMemsetAsync(ix->sh_bias_max, 0, sizeof(uint32_t), st));
             // a shadow built from its first row: fit the affine map to the rows that are there (frozen for the rows
             // added later - any map is valid, the fit only decides how tight the filter is)
             PRAG_HIP(hipMemsetAsync(ix->sh_yn_max, 0, sizeof(uint32_t), st));
@@ -2109,7 +2124,7 @@ static SearchPlan plan_search(const PlanEnv& e) {
     } else if (P.use_shadow) {
         P.family = "scan8_kernel";
         P.launches = P.Bpad / P.QT;
-        P.bytes_per_launch = N * (d + 8) + l2;
+        P.bytes_per_launch = N * (d + 12);     // 8-bit row + scale, error bound and the additive part of the key
     } else if (P.use_qs) {
         P.family = "scan_qs_kernel";
         P.launches = P.Bpad / 128;
@@ -2731,14 +2746,19 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         sprep.alpha = metric_l2 ? -2.0f : -1.0f;
         sprep.aff = ix->sh_aff;
         sprep.yn_max = ix->sh_yn_max;
+        sprep.bias_max = ix->sh_bias_max;
+        sprep.centre_query = use_shadow ? 1 : 0;     // (the int8 tiles keep the query as it is: their rows carry no bias term)
         sprep.kshift = ix->sh_kshift;
         // sample for the pre-bound: kShadowSampleSlices x kShadowSampleTiles whole tiles spread over the shard
         sprep.rows8 = ix->rows8;
         sprep.sscale = ix->sscale;
         sprep.serr = ix->serr;
-        sprep.xnorm = metric_l2 ? ix->xnorm : nullptr;
+        sprep.sbias = ix->sbias;
         const int64_t whole_tiles = ix->ntotal / 32;
-        sprep.sample_stride = whole_tiles / (kShadowSampleSlices * kShadowSampleTiles);   // 0: shard too small
+        // (PRAG_SHADOW_SAMPLE=2: > 32 queries sample ONE tile per slice - a quarter of the sampling work for a bound
+        //  at the ~1 % quantile instead of the 0.25 % one; <= 32 queries keep four)
+        sprep.sample_tiles = (ix->shadow_sample_mode == 2 && B > 32) ? 1 : kShadowSampleTiles;
+        sprep.sample_stride = whole_tiles / (kShadowSampleSlices * sprep.sample_tiles);   // 0: shard too small
         // The sampled bound is used for batches of <= 32 queries (kernel trace at 2.6 M rows: the sampling waves
         // take the prep kernel from 7 to 19 us and the scan from 399 to 376 us; at 64 queries - one query term,
         // twice the error band - the candidates of the loosely bounded first tiles cost the scan and the gather
@@ -2779,6 +2799,8 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         ss.store.err_max = ix->shadow_err_max;
         ss.store.aff = ix->sh_aff;
         ss.store.yn_max = ix->sh_yn_max;
+        ss.store.sbias = ix->sbias;
+        ss.store.bias_max = ix->sh_bias_max;
         ss.kshift = ix->sh_kshift;
         ss.xnorm = ix->xnorm;
         ss.N = ix->ntotal;
@@ -2813,6 +2835,8 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         ss.gate = ix->gate;
         // one more small launch; pays once the candidate lists are long (measured: profiles/r04p_exact_bound_ab.txt)
         ss.quad_min_rows = ix->scan8_quad_rows;
+        ss.scan_done = allow_mm8 && !ix->gate.word ? ix->scan_done_ev : nullptr;   // (not the gated inner searches)
+        if (ss.scan_done) ix->scan_done_recorded = true;
         ss.exact_bound = k <= 32 && (ix->shadow_bound_mode < 0 ? ix->ntotal >= (1ll << 19) : ix->shadow_bound_mode != 0);
         rc = shadow_search(ss, st, prof);
         if (rc != PRAG_OK) return rc;
@@ -2906,6 +2930,10 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
             hipLaunchKernelGGL(rerank_kernel<false>, dim3(B), dim3(64 * std::min(kc, 16)), 0, st, ix->rows, ix->d, metric_l2,
                                ix->q32, ix->cand, kc, k, id_offset, D_dev, I_dev, rc_, kth);
         PRAG_LAUNCH_CHECK();
+    }
+    if (ix->scan_done_ev && !use_shadow && allow_mm8 && !ix->gate.word) {    // (the two-level search recorded it behind scan8)
+        PRAG_HIP(hipEventRecord(ix->scan_done_ev, st));
+        ix->scan_done_recorded = true;
     }
     // ---- exact float64 scan for the queries on the flag list --------------------------------------
     // Device i/o: always enqueued, the kernels return at once when the list is empty (~3 us each, no
@@ -3098,6 +3126,18 @@ extern "C" int prag_index_set_scan_workgroups(prag_index_t* ix, int n_workgroups
     return PRAG_OK;
 }
 
+extern "C" int prag_index_stream_wait_scan(prag_index_t* ix, void* other_stream) {
+    PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
+    if (!ix->scan_done_ev) {     // first call: searches record the event from now on; nothing to wait for yet
+        PRAG_HIP(hipEventCreateWithFlags(&ix->scan_done_ev, hipEventDisableTiming));
+        ix->scan_done_recorded = false;
+        return PRAG_OK;
+    }
+    if (ix->scan_done_recorded)
+        PRAG_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(other_stream), ix->scan_done_ev, 0));
+    return PRAG_OK;
+}
+
 // Measurement hook: candidates the scan of the most recent two-level search (<= 128 queries: its LAST query tile)
 // handed to the exact rerank - per query, summed over the scan's workgroups - i.e. how tight the proof-carrying filter
 // was on this corpus.  Synchronises `stream`.  n_queries_out = 0: the last search did not take the two-level path.
@@ -3164,11 +3204,12 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
     if (!ix) return;
     ix->prof.disable();
     ix->prof_xch.disable();
+    if (ix->scan_done_ev) (void)hipEventDestroy(ix->scan_done_ev);
     void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->q16lo, ix->g_tau, ix->part_key, ix->part_idx, ix->cand,
                     ix->io_q, ix->io_res, ix->mm_cnt, ix->mm_ovf, ix->mm_kq, ix->mm_ckey, ix->mm_cidx, ix->t2_list, ix->t2_q,
                     ix->t2_D, ix->t2_I, ix->t2_word, ix->xch_send, ix->xch_recv,
                     ix->mm_wcnt, ix->mm_wkey, ix->mm_widx, ix->rows16, ix->qinfo, ix->qn2, ix->flag_list, ix->g_slot,
-                    ix->cert_words, ix->ex_key, ix->ex_id, ix->rows8, ix->sscale, ix->serr, ix->shadow_err_max, ix->sh_aff, ix->sh_aff_sums, ix->sh_yn_max, ix->sh_kshift, ix->sh_q8,
+                    ix->cert_words, ix->ex_key, ix->ex_id, ix->rows8, ix->sscale, ix->serr, ix->shadow_err_max, ix->sh_aff, ix->sh_aff_sums, ix->sh_yn_max, ix->sh_bias_max, ix->sbias, ix->sh_kshift, ix->sh_q8,
                     ix->sh_sq, ix->sh_slots, ix->sh_ovf, ix->sh_cand, ix->sh_ccnt, ix->sh_pkey, ix->sh_pid, ix->ex_done};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

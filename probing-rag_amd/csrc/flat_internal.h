@@ -267,7 +267,7 @@ constexpr int kShadowEpochs = 9;
 constexpr int kShadowPreEpoch = kShadowEpochs;                 // index of the sample slots
 constexpr int kShadowSlotWords = (kShadowEpochs + 1) * 32;
 constexpr int kShadowSampleSlices = 32;                        // one slot each
-constexpr int kShadowSampleTiles = 4;                          // 32-row tiles per slice: 4096 sample rows
+constexpr int kShadowSampleTiles = 4;                          // 32-row tiles per slice at most: 4096 sample rows (ShadowPrep::sample_tiles)
 
 // what prep_queries_kernel writes for the two-level search (q8a == nullptr: nothing)
 struct ShadowPrep {
@@ -282,13 +282,17 @@ struct ShadowPrep {
     float alpha;
     const float* aff;        // [mu | c | 1/c] of the shadow's affine map (d floats each) or null
     const uint32_t* yn_max;  // bits of max ||y||^2, y = (x - mu) / c (aff null: xn_max is used)
+    const uint32_t* bias_max;   // bits of max |sbias_i| (null: xn_max stands in)
+    int centre_query;        // 1: the int8 terms approximate (q - mu) c (<= 128-query scans, rows carry sbias_i);
+                             // 0: q c (int8 tiles of the > 128-query scans)
     double* kshift;          // [Bpad] out: K_q = alpha q.mu
     // sample for the pre-bound (sample_stride == 0: none, the slots of the pre-epoch stay +inf)
     const signed char* rows8;
     const float* sscale;
     const float* serr;
-    const float* xnorm;      // nullptr unless L2
-    int64_t sample_stride;   // in tiles: slice s, j-th tile = (s * kShadowSampleTiles + j) * sample_stride
+    const float* sbias;      // per-row additive part of the key (the scan's own array)
+    int64_t sample_stride;   // in tiles: slice s, j-th tile = (s * sample_tiles + j) * sample_stride
+    int sample_tiles;        // 32-row tiles per slice (1 .. kShadowSampleTiles)
 };
 
 #ifdef __HIPCC__
@@ -349,12 +353,15 @@ __device__ __forceinline__ ShadowTerms shadow_terms_wave(int d, const f32x4 (&v)
 }
 // constants of eps_i = A e_i + C (every lane computes the same values)
 __device__ __forceinline__ ShadowQ shadow_consts(const ShadowTerms& t, float alpha, const uint32_t* xn_max,
-                                                 const uint32_t* yn_max = nullptr) {
+                                                 const uint32_t* yn_max = nullptr, const uint32_t* bias_max = nullptr) {
     const double aa = fabs((double)alpha);
-    const double xn = (double)__uint_as_float(*xn_max) * (1.0 + 1e-6);
+    // the additive part of a key (||x||^2 for L2, plus alpha mu.(x - mu) under the affine map): its float32 rounding
+    // and the rounding of key = bias + scale * acc are inside 1e-6 of its largest magnitude
+    const double xn0 = (double)__uint_as_float(*xn_max) * (1.0 + 1e-6);
+    const double xn = fmax(xn0, bias_max ? (double)__uint_as_float(*bias_max) * (1.0 + 1e-6) : 0.0);
     // the dot product the int8 terms approximate is p.y (p = q c, y = (x - mu) / c): its residual term and its
     // float32 roundings scale with max ||y||; the L2 key also carries ||x||^2 (the xn term of the rounding slack)
-    const double nx = yn_max ? sqrt((double)__uint_as_float(*yn_max) * (1.0 + 1e-6)) : sqrt(xn);
+    const double nx = yn_max ? sqrt((double)__uint_as_float(*yn_max) * (1.0 + 1e-6)) : sqrt(xn0);
     ShadowQ o;
     o.kscale = alpha * t.s1;
     // eps = A e_i + C;  C = query residual against the largest row + float32 roundings of key / eps
@@ -391,7 +398,7 @@ __device__ __forceinline__ void shadow_prep_wave(const ShadowPrep& p, int b, int
     }
     const ShadowTerms t = shadow_terms_wave(d, v, lane, p.q8a + (int64_t)b * d, p.q8b + (int64_t)b * d);
     if (lane == 0) {
-        const ShadowQ c = shadow_consts(t, p.alpha, p.xn_max, p.aff ? p.yn_max : nullptr);
+        const ShadowQ c = shadow_consts(t, p.alpha, p.xn_max, p.aff ? p.yn_max : nullptr, p.bias_max);
         p.sq[b] = c;
         if (p.kq) p.kq[b] = c.kscale;
     }
@@ -408,21 +415,21 @@ struct ShadowSample {        // what a sampling wave requests before it even loo
     float rs[4], re[4], rx[4];     // scale, error bound, ||x||^2 of the tile being scored (4 rows per lane group)
 };
 __device__ __forceinline__ void shadow_sample_meta(const ShadowPrep& p, int slice, int j, int lane, ShadowSample& sm) {
-    const int jc = j < kShadowSampleTiles ? j : kShadowSampleTiles - 1;
-    const int64_t tile = ((int64_t)slice * kShadowSampleTiles + jc) * p.sample_stride;
+    const int jc = j < p.sample_tiles ? j : p.sample_tiles - 1;
+    const int64_t tile = ((int64_t)slice * p.sample_tiles + jc) * p.sample_stride;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t row = tile * 32 + 8 * i + (lane >> 3);       // (whole tiles below N only)
         sm.rs[i] = p.sscale[row];
         sm.re[i] = p.serr[row];
-        sm.rx[i] = p.xnorm ? p.xnorm[row] : 0.f;
+        sm.rx[i] = p.sbias ? p.sbias[row] : 0.f;
     }
 }
 __device__ __forceinline__ const signed char* shadow_sample_chunk(const ShadowPrep& p, int d, int slice, int lane, int sidx) {
-    const int nch = d >> 7, total = kShadowSampleTiles * nch;
+    const int nch = d >> 7, total = p.sample_tiles * nch;
     const int sc = sidx < total ? sidx : total - 1;
     const int j = sc / nch, ch = sc - j * nch;
-    const int64_t tile = ((int64_t)slice * kShadowSampleTiles + j) * p.sample_stride;
+    const int64_t tile = ((int64_t)slice * p.sample_tiles + j) * p.sample_stride;
     return p.rows8 + tile * (32 * (int64_t)d) + ch * 4096 + lane * 16;
 }
 // The sample tiles are cold (the scan of the previous search has been through every cache since) and scattered
@@ -445,7 +452,7 @@ __device__ __forceinline__ void shadow_prebound_wave(const ShadowPrep& p, int b,
                                                      int lane, signed char* q8_lds, ShadowSample& sm) {
     uint32_t* slot = p.slots + (int64_t)b * kShadowSlotWords + kShadowPreEpoch * 32 + slice;
     const ShadowTerms t = shadow_terms_wave(d, v, lane, q8_lds, nullptr);
-    const ShadowQ c = shadow_consts(t, p.alpha, p.xn_max, p.aff ? p.yn_max : nullptr);
+    const ShadowQ c = shadow_consts(t, p.alpha, p.xn_max, p.aff ? p.yn_max : nullptr, p.bias_max);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     shadow_sample_issue(p, d, slice, lane, sm);
@@ -454,7 +461,7 @@ __device__ __forceinline__ void shadow_prebound_wave(const ShadowPrep& p, int b,
     float best = INFINITY;
     // the slice as one stream of 4-KiB chunks (tile-major, chunk-minor), a ring of them in flight
     constexpr int kRing = kShadowSampleRing;
-    const int total = kShadowSampleTiles * nch;
+    const int total = p.sample_tiles * nch;
     int acc[4] = {0, 0, 0, 0};
     int ch = 0, j = 0;
     for (int s0 = 0; s0 < total; s0 += kRing) {
@@ -503,6 +510,10 @@ struct ShadowStore {
     uint32_t* err_max;       // float bits of max_i e_i (diagnostic)
     const float* aff = nullptr;   // [mu | c | 1/c] of the affine map y = (x - mu) / c the shadow quantises (null: y = x)
     uint32_t* yn_max = nullptr;   // float bits of max_i ||y_i||^2
+    float* sbias = nullptr;       // [cap] per-row additive part of the scan's key: alpha mu.(x_i - mu) [+ ||x_i||^2, L2]
+    uint32_t* bias_max = nullptr; // float bits of max_i |sbias_i|
+    const float* xnorm_l2 = nullptr;   // ||x_i||^2 of the stored rows when the metric is L2 (build time), else null
+    float alpha = -1.0f;          // key = alpha * dot (+ ||x||^2 for L2)
 };
 struct ShadowSearch {
     ShadowStore store;
@@ -533,6 +544,7 @@ struct ShadowSearch {
     CertArgs cert;           // flag list: queries whose candidate regions overflowed go to the exact scan
     Gate gate;
     const double* kshift = nullptr;   // [Bpad] K_q of every query (prep_queries_kernel) or null
+    hipEvent_t scan_done = nullptr;   // recorded behind the scan of the last query tile (prag_index_stream_wait_scan)
     bool exact_bound = false;   // lower g_tau to an exact k-th best before the gather (shadow_bound_kernel)
     int64_t quad_min_rows = (int64_t)8 << 20;   // shards from this size on scan with the quad-test epilogue (flat_shadow.hip)
 };

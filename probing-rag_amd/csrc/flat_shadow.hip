@@ -19,6 +19,13 @@
 // K_q = alpha q.mu is one constant per query (alpha = -1 / -2): every comparison inside the scan is between keys of
 // the same query, and the two places where an EXACT key meets the scan's key space (shadow_bound_kernel, the
 // certificate of the int8 tiles) subtract K_q first.  mu = 0, c = 1 is the round 2-4 shadow.
+// The <= 128-query scans also take the mean out of the QUERY: q.x_i = q.mu + mu.(x_i - mu) + (q - mu).(x_i - mu); the
+// middle term is a per-ROW constant (sbias_i = alpha mu.(x_i - mu) [+ ||x_i||^2 for L2], float64 at build time,
+// stored as float32 next to s_i and e_i) and only p' = (q - mu) c meets the int8 rows.  Queries live in the rows'
+// space (the same encoder made both, utils.py:365-366, make_indexer.py:447-456): without this a query's own outlier
+// coordinates set its int8 scale and the 64-query tiles (ONE query term) resolved the other 760 coordinates with
+// three levels - measured on embedding-shaped rows: 180 000 - 870 000 survivors per query of 1 M rows and every query in
+// the exact scan (profiles/r05b_embedding_probe_centred_rows_only.txt).
 // Filter: tau is an upper bound on the k-th best EXACT key as soon as k rows with key + a eps <= tau
 // have been seen (per-lane lists of key_hi = key + a eps, shared through LDS and the chip-wide bound
 // slots, exactly as the fp16 scan shares its bound).  A row is dropped only if key - a eps_i > tau,
@@ -70,15 +77,19 @@ __global__ __launch_bounds__(256) void shadow_build_kernel(const void* __restric
                                                           signed char* __restrict__ rows8,
                                                           float* __restrict__ sscale, float* __restrict__ serr,
                                                           uint32_t* __restrict__ err_max, const float* __restrict__ aff,
-                                                          uint32_t* __restrict__ yn_max) {
+                                                          uint32_t* __restrict__ yn_max, float* __restrict__ sbias,
+                                                          const float* __restrict__ xnorm, float alpha,
+                                                          uint32_t* __restrict__ bias_max) {
     constexpr int d = NCH * 128;
     // aff = [mu | c | 1/c] (d floats each) or null: y = (x - mu) * (1/c), one float32 rounding (the subtraction)
+    // sbias_i = alpha mu.(x_i - mu) (float64 sum, rounded once) + ||x_i||^2 when xnorm is given (L2)
     const int tid = threadIdx.x;
     const int row_in = tid >> 3, piece = tid & 7;
     const int64_t tile = tile0 + blockIdx.x;
     const int64_t i = tile * 32 + row_in;
     const bool valid = i < n_rows;                 // rows past the end of the shard quantise to zeros
     float v[NCH][16];
+    double mdot = 0.0;                             // this thread's part of mu.(x - mu)
     if (valid) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -109,7 +120,11 @@ __global__ __launch_bounds__(256) void shadow_build_kernel(const void* __restric
                 for (int u = 0; u < 4; ++u) {
                     const f32x4 m4 = pm[u], i4 = pi[u];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[c][4 * u + e] = (v[c][4 * u + e] - m4[e]) * i4[e];
+                    for (int e = 0; e < 4; ++e) {
+                        const float ctr = v[c][4 * u + e] - m4[e];
+                        mdot = fma((double)m4[e], (double)ctr, mdot);
+                        v[c][4 * u + e] = ctr * i4[e];
+                    }
                 }
             }
         }
@@ -172,6 +187,18 @@ __global__ __launch_bounds__(256) void shadow_build_kernel(const void* __restric
     for (int o = 32; o > 0; o >>= 1) e_row = fmaxf(e_row, __shfl_xor(e_row, o, 64));
     if ((tid & 63) == 0 && e_row > 0.f) atomicMax(err_max, __float_as_uint(e_row));
     // max_i ||y_i||^2 (rounded up: <= 1024 float32 squares): what the query-residual term of eps multiplies
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) mdot += __shfl_xor(mdot, o, 64);
+    float b_row = 0.f;
+    if (sbias && piece == 0) {
+        // one rounding: |sbias_i - exact| <= 2^-24 |sbias_i|, inside the 1e-6 |bias|max slack of the eps constants
+        b_row = valid ? (float)((double)alpha * mdot + (xnorm ? (double)xnorm[i] : 0.0)) : 0.f;
+        sbias[i] = b_row;
+    }
+    b_row = fabsf(b_row);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b_row = fmaxf(b_row, __shfl_xor(b_row, o, 64));
+    if ((tid & 63) == 0 && b_row > 0.f && bias_max) atomicMax(bias_max, __float_as_uint(b_row));
     float yn = valid ? yn2 * (1.0f + 2e-4f) : 0.f;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) yn = fmaxf(yn, __shfl_xor(yn, o, 64));
@@ -247,7 +274,7 @@ struct Scan8Args {
     const signed char* rows8;   // [N/32][d/128][32][128]: chunk-major inside 32-row tiles
     const float* sscale;        // [roundup(N,32)]
     const float* serr;
-    const float* xnorm;
+    const float* sbias;         // [roundup(N,32)] per-row additive part of the key: alpha mu.(x_i - mu) [+ ||x_i||^2 for L2]
     const signed char* q8a;     // [QT][d] this pass's query tile
     const signed char* q8b;
     const ShadowQ* sq;          // [QT]
@@ -255,7 +282,6 @@ struct Scan8Args {
     int d;
     int qstride;                // LDS bytes per query row (multiple of 256)
     int n_tiles;                // ceil(N / 32)
-    int use_norm;               // L2: key includes ||x||^2
     uint32_t* g_tau;            // [QT] chip-wide bound (sortable), +inf at start, -inf for padding
     uint32_t* g_slot;           // [QT][kShadowEpochs + 1][32]
     int2* cand;                 // [grid][QT][cap]  (row id, bits of key - a eps)
@@ -272,7 +298,7 @@ struct Scan8Args {
 // stamps of one wave: 0 kernel entry, 1 prologue done (queries in LDS, first loads issued), 2..9 after its tile 1, 2, 4,
 // 8, 16, 32, 64, 128, 10 after its last first-visit tile, 11 after the second visits, 12 kernel exit, 13 = redo,
 // 14 = n_my, 15 = candidates appended by the workgroup (wave 0)
-constexpr int kScan8Stamps = 16;
+[[maybe_unused]] constexpr int kScan8Stamps = 16;
 
 // (kShadowEpochs = 9 in flat_internal.h: bound slots refreshed after tiles 1, 2, 4, ..., 256; per query
 // kShadowEpochs + 1 rows of 32 words, the last one the sample slots written by prep_queries_kernel)
@@ -531,7 +557,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
         const int64_t row = (int64_t)tile * 32 + r;     // (arrays are padded to a multiple of 32 rows)
         m_s = a.sscale[row];
         m_e = a.serr[row];
-        m_x = a.use_norm ? a.xnorm[row] : 0.f;
+        m_x = a.sbias[row];
     };
     // stage one 4-KiB chunk (32 rows x 128 bytes), refill its registers with chunk (tile_nx, c_nx), 4 k-steps
     auto chunk_step = [&](u32x4 (&ldr)[4], int c, int tile_nx, int c_nx) __attribute__((always_inline)) {
@@ -1439,7 +1465,7 @@ bool shadow_supported(int d, int kc, int k, int B) {
 template <bool F32>
 static void launch_build(int nch, dim3 grid, hipStream_t st, const ShadowStore& s, int64_t tile0, int64_t n_rows) {
 #define PRAG_SB(N_) case N_: hipLaunchKernelGGL((shadow_build_kernel<F32, N_>), grid, dim3(256), 0, st, s.rows, tile0, \
-                                                n_rows, s.rows8, s.sscale, s.serr, s.err_max, s.aff, s.yn_max); break;
+                                                n_rows, s.rows8, s.sscale, s.serr, s.err_max, s.aff, s.yn_max, s.sbias, s.xnorm_l2, s.alpha, s.bias_max); break;
     switch (nch) { PRAG_SB(1) PRAG_SB(2) PRAG_SB(3) PRAG_SB(4) PRAG_SB(5) PRAG_SB(6) PRAG_SB(7) PRAG_SB(8) }
 #undef PRAG_SB
 }
@@ -1527,7 +1553,7 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         a.rows8 = s.store.rows8;
         a.sscale = s.store.sscale;
         a.serr = s.store.serr;
-        a.xnorm = s.xnorm;
+        a.sbias = s.store.sbias;
         a.q8a = s.q8a + (size_t)p0 * s.d;
         a.q8b = s.q8b + (size_t)p0 * s.d;
         a.sq = reinterpret_cast<const ShadowQ*>(s.sq) + p0;
@@ -1535,7 +1561,6 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         a.d = s.d;
         a.qstride = qstride;
         a.n_tiles = n_tiles;
-        a.use_norm = s.metric_l2;
         a.g_tau = s.g_tau + p0;
         a.g_slot = s.slots + (size_t)p0 * kShadowSlotWords;
         a.cand = reinterpret_cast<int2*>(s.cand);
@@ -1576,6 +1601,7 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
                         : (s.kc == 8 ? launch_scan8<32, 8>(a, grid, st, prof)
                            : s.kc == 16 ? launch_scan8<32, 16>(a, grid, st, prof) : launch_scan8<32, 32>(a, grid, st, prof));
         if (rc != PRAG_OK) return rc;
+        if (s.scan_done && p0 + QT >= Bpad) PRAG_HIP(hipEventRecord(s.scan_done, st));
 #ifdef PRAG_MM_DIAG
         {
             static int stamp_calls = 0;

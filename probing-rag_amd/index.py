@@ -314,6 +314,13 @@ def _ix_last_exact_fallbacks(self) -> int:
     return n.value
 
 
+def _ix_stream_wait_scan(self, stream):
+    """Make `stream` (a torch.cuda.Stream) wait for the corpus scan of the most recent search on this index - not for
+    the search's tail (bound kernel, exact rerank, fallback probes): work launched on `stream` afterwards, e.g. the
+    gate of the next batch, runs beside that tail.  The first call only switches the event recording on."""
+    _lib.check(_lib.lib().prag_index_stream_wait_scan(self._h, ctypes.c_void_p(stream.cuda_stream)))
+
+
 def _ix_last_survivors(self) -> dict:
     """Rows the filter of the most recent two-level search handed to the exact rerank (its last query tile):
     {"queries", "total", "per_query", "max_per_query"}; queries = 0 when that search scanned the rows directly."""
@@ -393,6 +400,7 @@ HipFlatIndex.last_exact_fallbacks = _ix_last_exact_fallbacks
 HipFlatIndex.last_tiled8 = _ix_last_tiled8
 HipFlatIndex.last_plan = _ix_last_plan
 HipFlatIndex.last_survivors = _ix_last_survivors
+HipFlatIndex.stream_wait_scan = _ix_stream_wait_scan
 
 
 def _ix_set_scan_workgroups(self, n: int):

@@ -311,3 +311,64 @@ def test_affine_shadow_map_is_a_performance_choice_only(monkeypatch):
         ix.close()
     assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][0], res["0"][0])
     assert surv["1"] * 3 < surv["0"], surv          # centring + column scales: the filter is several times tighter
+
+
+def test_work_beside_the_tail_of_a_search():
+    """prag_index_stream_wait_scan: a second stream waits for the corpus scan of the latest search only, so the gate of
+    the next batch can run beside the bound kernel / rerank.  Results of both are what one stream gives, eagerly and
+    replayed from a captured graph (the wait becomes a fork edge); the first call only switches the recording on."""
+    import torch
+    import probing_rag_amd as pra
+    from tests.golden import cases
+    N, d, k = 300_000, 768, 10
+    ix = pra.HipFlatIndex(d, "cos", "f16", capacity=N)
+    ix.add_synthetic(42, 0, N)
+    ix.set_shadow(2)
+    ix.prepare()
+    q = torch.from_numpy(onp.synth_rows(7, 0, 64, d)).cuda()
+    case = dict(cases.PROBER_CASES[1], B=96)
+    ens = pra.HipProberEnsemble(case["L"], case["d"], 2, weights="f16")
+    for l in range(case["L"]):
+        ens.load_layer(l, cases.synth_state(case["wseed"] + l, case["d"]))
+    x = torch.from_numpy(cases.synth_x(case["xseed"], case["L"], 96, case["d"], 1.0)).cuda().half()
+    D0, I0 = ix.search(q, k)
+    want = [t.clone() for t in ens.gate(x, 0, 0.0)]
+    out = (torch.empty_like(D0), torch.empty_like(I0))
+    gout = tuple(torch.empty_like(t) for t in want)
+    side = torch.cuda.Stream()
+
+    def one_pass():
+        ix.search(q, k, out=out)
+        ix.stream_wait_scan(side)
+        with torch.cuda.stream(side):
+            ens.gate(x, 0, 0.0, out=gout)
+        torch.cuda.current_stream().wait_stream(side)
+
+    ix.stream_wait_scan(side)             # recording on; nothing to wait for
+    for _ in range(5):
+        for t in (*out, *gout):
+            t.zero_()
+        one_pass()
+        torch.cuda.synchronize()
+        assert torch.equal(out[1], I0) and torch.equal(out[0], D0)
+        assert all(torch.equal(a, b) for a, b in zip(gout, want))
+    # direct scans record the event too (behind their scan + rerank launches)
+    ix.set_shadow(0)
+    one_pass()
+    torch.cuda.synchronize()
+    assert torch.equal(out[1], I0)
+    ix.set_shadow(2)
+    cs = torch.cuda.Stream()
+    cs.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cs):
+        one_pass()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cs):
+            one_pass()
+    for _ in range(3):
+        for t in (*out, *gout):
+            t.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out[1], I0) and all(torch.equal(a, b) for a, b in zip(gout, want))

@@ -269,7 +269,7 @@ def test_search_plan_over_the_shape_grid():
                                     assert p["QT"] == 32
                                 elt = 4 if store == "f32" else 2
                                 norms = 4 * N if metric == "l2" else 0
-                                want = {"scan8_kernel": N * (d + 8) + norms, "scan_topk_kernel": N * d * elt + norms,
+                                want = {"scan8_kernel": N * (d + 12), "scan_topk_kernel": N * d * elt + norms,
                                         "scan_qs_kernel": N * d * 2 + norms, "scan_mm_kernel": N * d * 2 + norms,
                                         "exact_scan_kernel": N * d * elt}.get(p["family"])
                                 if want is not None:

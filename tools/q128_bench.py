@@ -26,4 +26,4 @@ for B in (128, 96, 65):
         res[mode] = (out, dt, kern, ix.last_exact_fallbacks())
     same = torch.equal(res[0][0][1], res[1][0][1])
     print(f"N={N} B={B}: fp16 rows {res[0][1]:.3f} ms (kernel {res[0][2]:.3f}) | two-level {res[1][1]:.3f} ms (kernel {res[1][2]:.3f}, "
-          f"{N * (d + 8) / res[1][2] / 1e6 / 8000:.3f} of 8 TB/s) fallbacks {res[1][3]} ids_equal {same}", flush=True)
+          f"{N * (d + 12) / res[1][2] / 1e6 / 8000:.3f} of 8 TB/s) fallbacks {res[1][3]} ids_equal {same}", flush=True)

@@ -28,6 +28,6 @@ for N in sizes:
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps * 1e3
         kern = float(np.median(ix.profile_read())); ix.profile(0)
-        print(f"{tag} N={N} B={B:3d}: search {dt:7.4f} ms, scan8 {kern:7.4f} ms = {N * (d + 8) / kern / 1e6 / 8000:.3f} of 8 TB/s, "
+        print(f"{tag} N={N} B={B:3d}: search {dt:7.4f} ms, scan8 {kern:7.4f} ms = {N * (d + 12) / kern / 1e6 / 8000:.3f} of 8 TB/s, "
               f"fallbacks {ix.last_exact_fallbacks()}, add+build {t_add*1e3:.0f} ms, first search {t_first*1e3:.2f} ms", flush=True)
     ix.close()

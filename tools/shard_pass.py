@@ -25,9 +25,20 @@ gate_out = (torch.empty((L, Bg, 2), dtype=torch.float32, device="cuda"), torch.e
             torch.empty((Bg,), dtype=torch.int32, device="cuda"))
 out = (torch.empty((bench.SHARD_QUERIES, 10), dtype=torch.float32, device="cuda"),
        torch.empty((bench.SHARD_QUERIES, 10), dtype=torch.int64, device="cuda"))
+side = torch.cuda.Stream()
+TAIL = os.environ.get("SHARD_TAIL") == "1"      # the gate beside the search's tail (prag_index_stream_wait_scan)
+if TAIL:
+    ix.stream_wait_scan(side)
 def one():
-    ens.gate(x, 0, 0.0, out=gate_out)
+    if not TAIL:
+        ens.gate(x, 0, 0.0, out=gate_out)
+        ix.search(q, 10, out=out)
+        return
     ix.search(q, 10, out=out)
+    ix.stream_wait_scan(side)
+    with torch.cuda.stream(side):
+        ens.gate(x, 0, 0.0, out=gate_out)
+    torch.cuda.current_stream().wait_stream(side)
 for _ in range(20):
     one()
 torch.cuda.synchronize()
