@@ -74,11 +74,13 @@ def parse(argv=None):
     ap.add_argument("--shadow", type=int, default=1,
                     help="1: two-level exact search through the 8-bit shadow of the rows (prag_index_set_shadow); "
                          "0: scan the stored rows themselves")
-    ap.add_argument("--overlap-gate", type=int, default=0,
-                    help="1: run the gate on a second stream beside the HBM-bound scan (scan capped at "
-                         "n_cu-16 workgroups); 0 (default): one stream.  Round 3 measured both at the 8-GPU shard "
-                         "size with the 8-GPU gate share (2.6 M rows, 512 gate rows): 0.537 ms per pass on one "
-                         "stream, 0.542 overlapped (the scan loses to the gate what the gate's latency saves)")
+    ap.add_argument("--overlap-gate", type=int, default=2,
+                    help="2 (default): the gate of the NEXT batch on a second stream that waits for the search's corpus "
+                         "scan only (prag_index_stream_wait_scan): it runs beside the search's tail - bound kernel, exact "
+                         "rerank, fallback probes - measured 0.459 -> 0.454 ms per pass at the 8-GPU shard size, 0.420 "
+                         "with the sampled pre-bound (profiles/r05c_shard_ab.txt); 0: one stream; 1: the gate on a second "
+                         "stream beside the scan itself (scan capped at n_cu-16 workgroups; measured slower in rounds 3 "
+                         "and 5: scan8 holds all of a CU's LDS)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("PRAG_BENCH_LAUNCH_TIMEOUT", "1800")),
                     help="`--gpus N` without a launcher: seconds after which the torch.distributed.run child (its whole "
@@ -740,14 +742,26 @@ def main(argv=None):
     main_stream = torch.cuda.current_stream()
     side_stream = torch.cuda.Stream()
     n_cu = torch.cuda.get_device_properties(dev_index).multi_processor_count
-    if args.overlap_gate:
+    if args.overlap_gate == 1:
         local.set_scan_workgroups(n_cu - 16)
     local.set_shadow(1 if args.shadow else 0)
+
+    if args.overlap_gate == 2:
+        local.stream_wait_scan(side_stream)       # (first call: switches the event recording on)
 
     def one_pass():
         if not args.overlap_gate:
             ens.gate(x, 0, 0.0, out=gate_out)
             return index.search(q, args.k)
+        if args.overlap_gate == 2:
+            # the search first; the gate (independent work: the decisions of the NEXT batch of generations) starts on
+            # the side stream as soon as the search's corpus scan is done and runs beside its low-occupancy tail
+            out = index.search(q, args.k)
+            local.stream_wait_scan(side_stream)
+            with torch.cuda.stream(side_stream):
+                ens.gate(x, 0, 0.0, out=gate_out)
+            main_stream.wait_stream(side_stream)      # the pass ends when both are done
+            return out
         # the search goes first so the scan's persistent workgroups settle on their CUs; the gate
         # (independent work: the decisions of the NEXT batch) fills the CUs left free
         start = torch.cuda.Event()
@@ -892,6 +906,14 @@ def main(argv=None):
     if args.measure_traffic and world == 1 and not args.no_variants:     # (shard / diagnostic runs skip the two passes)
         gate_mfma_busy, gate_mfma_note = measure_gate_mfma(Bg)
     gate_avg_ms = float(np.mean(gate_ms)) if gate_ms else float("nan")
+    # the same kernel with the chip to itself (in the pass it runs beside the search's tail when --overlap-gate 2)
+    ens.profile(64)
+    for _ in range(50):
+        ens.gate(x, 0, 0.0, out=gate_out)
+    torch.cuda.synchronize()
+    gate_alone = ens.profile_read()
+    ens.profile(0)
+    gate_alone_ms = float(np.mean(gate_alone)) if gate_alone else None
     gate_flops = 2.0 * L * (d_model * 512 + 512 * 512 + 512 * 2) * Bg
     out = {
         "metric": "probe-decisions/sec + query*doc scores/sec/GPU (value = query*doc scores/sec, whole job)",
@@ -914,7 +936,7 @@ def main(argv=None):
                    "docs_total": args.docs, "docs_per_gpu": n_local, "d_emb": d_emb, "queries": args.queries,
                    "k": args.k, "gate_batch": args.gate_batch, "gate_batch_per_gpu": Bg, "d_model": d_model,
                    "parallelism": f"corpus rows sharded x{world}; gate rows split x{world}",
-                   "gate_overlapped_with_scan": bool(args.overlap_gate),
+                   "gate_overlap": {0: "none (one stream)", 1: "beside the scan", 2: "beside the search's tail (second stream waits for the scan only)"}[args.overlap_gate],
                    "two_level_shadow": scan_kernel == "scan8_kernel"},
         "probe_decisions_per_s": args.gate_batch / (gate_avg_ms * 1e-3) if gate_ms else None,
         "scores_per_s_per_gpu": value / world,
@@ -942,7 +964,7 @@ def main(argv=None):
         "roofline_gate": {"bound": "mfma", "kernel": GATE_KERNELS[1 if os.environ.get("PRAG_PROBER_SHAPE") == "32" else 0], "achieved": gate_flops / (gate_avg_ms * 1e-3) / 1e12,
                           "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                           "frac": gate_flops / (gate_avg_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF,
-                          "avg_launch_ms": gate_avg_ms,
+                          "avg_launch_ms": gate_avg_ms, "avg_launch_ms_back_to_back_alone": gate_alone_ms,
                           "matrix_pipe_busy_frac_of_cu_busy": gate_mfma_busy, "matrix_pipe_busy_source": gate_mfma_note,
                           "hbm_GBs": (L * Bg * d_model * 2 + L * 1318914 * 2) / (gate_avg_ms * 1e-3) / 1e9},
     }

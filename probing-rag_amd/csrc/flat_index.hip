@@ -1474,7 +1474,7 @@ struct prag_index {
     uint32_t* sh_yn_max = nullptr;
     float* sbias = nullptr;            // [shadow_cap] per-row additive part of the two-level scan's key
     uint32_t* sh_bias_max = nullptr;   // float bits of max |sbias_i|
-    int shadow_affine_mode = 1;        // PRAG_SHADOW_AFFINE=0 at creation: identity map (the round 2-4 shadow)
+    int shadow_affine_mode = 1;        // PRAG_SHADOW_AFFINE at creation: 0 identity map (the round 2-4 shadow), 1 centre + column scales, 2 centre only
     double* sh_kshift = nullptr;       // [sh_q_cap] K_q = alpha q.mu of the queries of the running search
     signed char* sh_q8 = nullptr;      // [2][q_cap][d]
     void* sh_sq = nullptr;
@@ -1661,7 +1661,7 @@ static int shadow_ensure(prag_index* ix, hipStream_t st) {
             // added later - any map is valid, the fit only decides how tight the filter is)
             PRAG_HIP(hipMemsetAsync(ix->sh_yn_max, 0, sizeof(uint32_t), st));
             PRAG_HIP(hipMemsetAsync(ix->shadow_err_max, 0, sizeof(uint32_t), st));
-            const int rc_a = shadow_affine_fit(ss, ix->ntotal, ix->shadow_affine_mode == 0, ix->sh_aff_sums, st);
+            const int rc_a = shadow_affine_fit(ss, ix->ntotal, ix->shadow_affine_mode == 0 ? 1 : ix->shadow_affine_mode == 2 ? 2 : 0, ix->sh_aff_sums, st);
             if (rc_a != PRAG_OK) return rc_a;
         }
         const int rc = shadow_build(ss, ix->shadow_rows, ix->ntotal, st);
@@ -1716,7 +1716,7 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
     // MFMA-tiled scan, PRAG_PREPASS, PRAG_SHADOW.  The switches that trade exactness for a timing
     // experiment (certificate off, tiled-scan overflow left unrepaired) exist only in `make diag`.
     if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e) != 0;
-    if (const char* e = getenv("PRAG_SHADOW_AFFINE")) ix->shadow_affine_mode = atoi(e) != 0;
+    if (const char* e = getenv("PRAG_SHADOW_AFFINE")) ix->shadow_affine_mode = atoi(e);
 #ifdef PRAG_MM_DIAG
     if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e);
     if (const char* e = getenv("PRAG_CERT")) ix->cert_mode = atoi(e);
@@ -2770,7 +2770,12 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         // filters against its own lists only and nearly every row passes (65 537 rows, 64 queries: every query
         // overflowed the gather's staging and went to the exact scan; found by tools/fuzz_shadow.py)
         const bool few_tiles = n_tiles < 48 * cu_budget;
-        if (sample_env == 0 || (sample_env < 0 && B > 32 && !few_tiles)) sprep.sample_stride = 0;
+        // Round 5 (profiles/r05b_scan8_stamps_shard.txt, r05c_shard_ab.txt): at the 8-GPU shard size a wave owns 40
+        // tiles and re-visits 3 of them when the scan opens without a bound (7.8 % of the scan, 18 us); with the gate
+        // of the next batch running beside the search's tail the sampling waves' 13 us are off the critical path -
+        // 0.459 -> 0.420 ms per pass.  > 32 queries sample when a wave owns fewer than 128 tiles (~8 M rows).
+        const bool short_scan = n_tiles < 128 * 8 * cu_budget;
+        if (sample_env == 0 || (sample_env < 0 && B > 32 && !few_tiles && !short_scan)) sprep.sample_stride = 0;
         if (use_mm8) {   // the tiled scan wants the first int8 term, the key scales as one array, and no sample
             sprep.sample_stride = 0;
             sprep.kq = ix->mm_kq;

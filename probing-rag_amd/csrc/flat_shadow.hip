@@ -244,11 +244,11 @@ __global__ __launch_bounds__(256) void shadow_affine_kernel(const double* __rest
                                                            float* __restrict__ aff) {
     for (int c = threadIdx.x; c < d; c += 256) {
         float mu = 0.f, sc = 1.f;
-        if (!identity && n > 0.0) {
+        if (identity != 1 && n > 0.0) {
             const double m = sums[c] / n;
             const double var = sums[d + c] / n - m * m;
             mu = (float)m;
-            if (var > 0.0) {
+            if (var > 0.0 && identity != 2) {        // (identity == 2: centre only, c = 1)
                 int ex = (int)lrint(log2(sqrt(var)));
                 ex = ex < -30 ? -30 : ex > 30 ? 30 : ex;
                 sc = ldexpf(1.0f, ex);
@@ -1484,13 +1484,14 @@ int shadow_build(const ShadowStore& s, int64_t row0, int64_t row1, hipStream_t s
 }
 
 // mu / c / 1/c of the shadow's affine map from a sample of rows [0, n_rows) (at most 2^18 of them, evenly spread) ->
-// aff [3][d]; `sums` is a [2][d] float64 scratch.  identity: mu = 0, c = 1 (PRAG_SHADOW_AFFINE=0).
+// aff [3][d]; `sums` is a [2][d] float64 scratch.  identity 1: mu = 0, c = 1 (PRAG_SHADOW_AFFINE=0); 2: c = 1, rows
+// centred only (PRAG_SHADOW_AFFINE=2).
 int shadow_affine_fit(const ShadowStore& s, int64_t n_rows, int identity, double* sums, hipStream_t st) {
     PRAG_REQUIRE(shadow_store_supported(s.d) && s.aff && sums, PRAG_EUNSUPPORTED, "internal: affine map of d=%d rows", s.d);
     const int64_t n_take = std::min<int64_t>(n_rows, (int64_t)1 << 18);
     const int64_t stride = n_take > 0 ? std::max<int64_t>(1, n_rows / n_take) : 1;
     PRAG_HIP(hipMemsetAsync(sums, 0, (size_t)2 * s.d * sizeof(double), st));
-    if (!identity && n_take > 0) {
+    if (identity != 1 && n_take > 0) {
         const dim3 grid((unsigned)std::min<int64_t>(n_take, 2048));
         if (s.store_f32)
             hipLaunchKernelGGL(shadow_colsum_kernel<true>, grid, dim3(256), 0, st, s.rows, s.d, n_rows, stride, n_take, sums);

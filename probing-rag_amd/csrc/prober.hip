@@ -1552,7 +1552,7 @@ static int forward_impl(prag_prober_t* p, const void* x_dev, int x_dtype, int64_
         return rc;
     }
 
-    ProberArgs a;
+    ProberArgs a{};
     a.layers = p->d_layers;
     a.layer0 = layer0;
     a.B = B;

@@ -41,8 +41,10 @@ __device__ unsigned long long g_pstamp16[2 * 3 * 8 * 32];
             g_pstamp16[3 * 8 * 32 + (ps_sel * 8 + w) * 32 + (i)] = r_;                                             \
         }                                                                                                          \
     }
+#define P16_ABL(bit) (a.ablate & (bit))
 #else
 #define PSTAMP(i)
+#define P16_ABL(bit) 0
 #endif
 
 template <int CT16>
@@ -316,6 +318,7 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
     // epilogue 1 on column tiles [c0, c0 + nc): LN0 fold, bias, SiLU in place, partial LN1 sums -> bufS; up to four
     // column tiles at a time (sixteen independent SiLU chains per hidden tile)
     auto ep1_cols = [&](const int c0, const int nc) {
+        if (P16_ABL(1)) return;
         constexpr int E1 = CT16 < 4 ? CT16 : 4;
 #pragma unroll
         for (int cb = 0; cb < CT16; cb += E1) {
@@ -375,6 +378,7 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
     // lane carries twice as many per-row values as with 32-row tiles, and 16 of them live across both fc2 loops were
     // registers the 128-row tile does not have.  Every wave writes the same bits and reads them back itself.
     auto mean_cols = [&](const int c0, const int nc) {
+        if (P16_ABL(8)) return;
         P16_LOCAL_LANE()
 #pragma unroll
         for (int c = 0; c < CT16; ++c)
@@ -418,6 +422,7 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
     // publish this wave's SiLU outputs of pass g: two K-32 hi fragments per column tile (tiles 2 p, 2 p + 1 of the
     // wave; rounded to nearest, so |lo| <= 2^-12 |s|) and the wave's half of a k block's fp8 lo operand
     auto publish = [&](const int g) {
+        if (P16_ABL(2)) return;
         int lane_p = lane;
         asm volatile("" : "+v"(lane_p));
 #pragma unroll
@@ -543,6 +548,15 @@ __global__ __launch_bounds__(512, 2) void prober16_kernel(ProberArgs a) {
     // epilogue 2 of pass g: LN1 fold, bias, SiLU, one-pass LN2 sums, fc3 partial dot products -> set.  Column tiles in
     // groups of EG (per-row running sums are registers: two groups of two instead of one of four)
     auto ep2 = [&](const int g, f32x4 (&acc2)[HT][GC], float* set) {
+        if (P16_ABL(4)) {          // (the accumulators must stay live: one cheap store of their sum)
+            float keep = 0.f;
+#pragma unroll
+            for (int i = 0; i < HT; ++i)
+#pragma unroll
+                for (int c = 0; c < GC; ++c) keep += acc2[i][c][0] + acc2[i][c][3];
+            if (keep == 12345.678f) set[lane] = keep;
+            return;
+        }
         constexpr int EG = GC;      // (two groups of two re-read the per-hidden constants: +1.3 k cycles per call)
 #pragma unroll
         for (int cg = 0; cg < GC; cg += EG) {
@@ -708,6 +722,7 @@ static int launch_p16(const ProberArgs& a, int n_run, hipStream_t st, EventRing&
     ProberArgs b = a;
 #ifdef PRAG_MM_DIAG
     b.stamps = getenv("PRAG_PROBER_STAMPS") ? atoi(getenv("PRAG_PROBER_STAMPS")) : 0;
+    b.ablate = getenv("PRAG_PROBER_ABLATE") ? atoi(getenv("PRAG_PROBER_ABLATE")) : 0;
 #endif
     b.n_tiles = (a.B + 16 * CT16 - 1) / (16 * CT16);
     b.n_run = n_run;

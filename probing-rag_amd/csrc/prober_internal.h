@@ -45,6 +45,9 @@ struct ProberArgs {
     float* logits;  // [n_run][B][2]
 #ifdef PRAG_MM_DIAG
     int stamps;     // 1: phase stamps of three workgroups
+    int ablate;     // PRAG_PROBER_ABLATE, timing only (WRONG results): bit 0 no epilogue-1 arithmetic, bit 1 no
+                    // publish (hi / lo split + LDS stores), bit 2 no epilogue-2 arithmetic, bit 3 no LN statistics /
+                    // logits - what is left is the loads, the LDS staging and every MFMA
 #endif
 };
 
