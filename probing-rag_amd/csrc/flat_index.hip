@@ -1351,6 +1351,40 @@ __global__ __launch_bounds__(64) void mm8_tier_plan_kernel(const uint32_t* __res
     for (int i = threadIdx.x; i < cap; i += 64) t2_list[i] = (uint32_t)i < n ? flag_list[i] : first;
 }
 
+// Retry tier of the <= 128-query searches (round 5): the queries on the flag list - a candidate region of the two-level
+// search overflowed, or the certificate of a 33-128-query direct scan did not clear - are searched again 32 at a time by
+// the <= 32-query kernels (BOTH int8 query terms over the shadow / hi + lo fp16 terms over the rows: a far tighter
+// filter and certificate) before anything goes to the exact float64 scan.  r2_word[0] = flagged count, r2_list = the
+// flagged batch rows padded with the first one to a multiple of 32; [1] accumulates what the inner searches still flag.
+__global__ __launch_bounds__(128) void retry_plan_kernel(uint32_t* __restrict__ n_flag, const int* __restrict__ flag_list,
+                                                        uint32_t* __restrict__ r2_word, int* __restrict__ r2_list, int cap) {
+    const uint32_t n = *n_flag;
+    if (threadIdx.x == 0) {
+        r2_word[0] = n;
+        r2_word[1] = 0u;
+    }
+    if (n == 0) return;
+    const int first = flag_list[0];
+    for (int i = threadIdx.x; i < cap; i += 128) r2_list[i] = (uint32_t)i < n ? flag_list[i] : first;
+}
+__global__ __launch_bounds__(64) void retry_scatter_kernel(const float* __restrict__ Ds, const int64_t* __restrict__ Is,
+                                                          const int* __restrict__ list, uint32_t* __restrict__ r2_word,
+                                                          const uint32_t* __restrict__ n_flag_inner, int part0, int k,
+                                                          float* __restrict__ D, int64_t* __restrict__ I, prag::Gate gate) {
+    const int i = blockIdx.x;
+    if (prag::gate_closed(gate)) return;
+    if (i == 0 && threadIdx.x == 0) r2_word[1] += *n_flag_inner;     // (one part at a time on the stream: no race)
+    if ((uint32_t)(part0 + i) >= r2_word[0]) return;                  // padding rows
+    const int64_t b = list[part0 + i];
+    for (int j = threadIdx.x; j < k; j += 64) {
+        D[b * k + j] = Ds[(int64_t)i * k + j];
+        I[b * k + j] = Is[(int64_t)i * k + j];
+    }
+}
+__global__ void retry_finish_kernel(const uint32_t* __restrict__ r2_word, uint32_t* __restrict__ n_flag) {
+    if (r2_word[0] != 0u) *n_flag = r2_word[1];       // what the exact scan recomputed in the end
+}
+
 // ===========================================================================
 // host side
 // ===========================================================================
@@ -1474,7 +1508,15 @@ struct prag_index {
     uint32_t* sh_yn_max = nullptr;
     float* sbias = nullptr;            // [shadow_cap] per-row additive part of the two-level scan's key
     uint32_t* sh_bias_max = nullptr;   // float bits of max |sbias_i|
-    int shadow_affine_mode = 1;        // PRAG_SHADOW_AFFINE at creation: 0 identity map (the round 2-4 shadow), 1 centre + column scales, 2 centre only
+    // PRAG_SHADOW_AFFINE at creation: 0 identity map (the round 2-4 shadow), 1 (default) rows and queries centred on the
+    // column means, c = 1; 2 centred + power-of-two column scales c_j ~ the column's standard deviation.  Measured on
+    // embedding-shaped rows, 64 queries x 1 M rows, survivors per query mean / max (profiles/r05c_*, r05d_*):
+    // mode 0: 180 000 - 870 000 (every query in the exact scan); mode 2: 1 450 / 2 700 (cosine), 11 200 / 113 000 (L2,
+    // one region overflow); mode 1: 2 400 / 3 800 and 4 100 / 10 100.  Why scales lose with ONE int8 query term: queries
+    // live in the rows' space, so c_j = sigma_j evens out the rows' grid and squares the disparity on the query's
+    // (p_j = q'_j c_j ~ sigma_j^2); with both sides on one grid each, eps ~ ||p|| max|y| + max|p| ||y|| is symmetric
+    // under c <-> 1/c and c = 1 is its minimum.  (The 32-query tiles - two query terms - would prefer mode 2 by ~25 %.)
+    int shadow_affine_mode = 1;
     double* sh_kshift = nullptr;       // [sh_q_cap] K_q = alpha q.mu of the queries of the running search
     signed char* sh_q8 = nullptr;      // [2][q_cap][d]
     void* sh_sq = nullptr;
@@ -1496,6 +1538,20 @@ struct prag_index {
     char* xch_recv = nullptr;
     size_t xch_send_cap = 0, xch_recv_cap = 0;
     EventRing prof_xch;          // HIP events around the all-gather of prag_index_search_sharded (prag_index_profile)
+    // retry tier (retry_tier below): armed by what recent searches flagged - the count travels to the host
+    // asynchronously and is looked at when the NEXT search is planned, never waited for
+    uint32_t* r2_word = nullptr;          // device [4]
+    int* r2_list = nullptr;               // [128]
+    float* r2_q = nullptr;                // [32][d]
+    float* r2_D = nullptr;
+    int64_t* r2_I = nullptr;
+    int r2_k = 0;
+    uint32_t* r2_word_host = nullptr;     // pinned
+    hipEvent_t r2_event = nullptr;
+    bool r2_pending = false;
+    bool retry_armed = false;
+    int retry_clean = 0;                  // armed searches in a row that flagged nothing
+    int retry_mode = -1;                  // PRAG_RETRY_TIER at creation: -1 adaptive, 0 never, 1 always armed
     // prag_index_stream_wait_scan: an event recorded right behind the corpus scan of every search (two-level search:
     // after scan8, before the bound kernel / gather / fallback probes), so that independent work of the caller - the
     // gate of the next batch - can start beside the search's low-occupancy tail on another stream
@@ -1661,7 +1717,7 @@ static int shadow_ensure(prag_index* ix, hipStream_t st) {
             // added later - any map is valid, the fit only decides how tight the filter is)
             PRAG_HIP(hipMemsetAsync(ix->sh_yn_max, 0, sizeof(uint32_t), st));
             PRAG_HIP(hipMemsetAsync(ix->shadow_err_max, 0, sizeof(uint32_t), st));
-            const int rc_a = shadow_affine_fit(ss, ix->ntotal, ix->shadow_affine_mode == 0 ? 1 : ix->shadow_affine_mode == 2 ? 2 : 0, ix->sh_aff_sums, st);
+            const int rc_a = shadow_affine_fit(ss, ix->ntotal, ix->shadow_affine_mode == 0 ? 1 : ix->shadow_affine_mode == 1 ? 2 : 0, ix->sh_aff_sums, st);
             if (rc_a != PRAG_OK) return rc_a;
         }
         const int rc = shadow_build(ss, ix->shadow_rows, ix->ntotal, st);
@@ -1717,6 +1773,7 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
     // experiment (certificate off, tiled-scan overflow left unrepaired) exist only in `make diag`.
     if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e) != 0;
     if (const char* e = getenv("PRAG_SHADOW_AFFINE")) ix->shadow_affine_mode = atoi(e);
+    if (const char* e = getenv("PRAG_RETRY_TIER")) ix->retry_mode = atoi(e);
 #ifdef PRAG_MM_DIAG
     if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e);
     if (const char* e = getenv("PRAG_CERT")) ix->cert_mode = atoi(e);
@@ -2342,6 +2399,9 @@ extern "C" int prag_index_reserve(prag_index_t* ix, int B, int k, void* stream) 
         rc = e == hipErrorOutOfMemory ? PRAG_ENOMEM : PRAG_EHIP;
     } else {
         e = hipMemcpyAsync(q, hq.data(), nq * sizeof(float), hipMemcpyHostToDevice, st);
+        const int sv_retry = ix->retry_mode;
+        const bool sv_armed = ix->retry_armed;
+        if (ix->retry_mode != 0) ix->retry_mode = 1;       // a 33-128-query shape also sizes its retry tier (retry_tier)
         for (int pass = 0; pass < 2 && e == hipSuccess && rc == PRAG_OK; ++pass) {
             ix->mm8_auto_off = pass == 0 ? false : true;
             ix->mm8_off_count = 0;             // (no probe flips the switch back inside the sizing search)
@@ -2349,8 +2409,11 @@ extern "C" int prag_index_reserve(prag_index_t* ix, int B, int k, void* stream) 
             const hipError_t e2 = hipStreamSynchronize(st);
             if (e2 != hipSuccess) e = e2;
             ix->tier_pending = false;
+            ix->r2_pending = false;
             if (ix->last_plan.find("int8_tiles=1") == std::string::npos && pass == 0) break;   // not an int8-tile shape
         }
+        ix->retry_mode = sv_retry;
+        ix->retry_armed = sv_armed;
         if (rc == PRAG_OK && e != hipSuccess) {
             set_error("prag_index_reserve: %s", hipGetErrorString(e));
             rc = PRAG_EHIP;
@@ -2513,6 +2576,64 @@ static int mm8_second_tier(prag_index* ix, const float* q_dev, int B, int k, int
     return rc;
 }
 
+// The flag count of the previous <= 128-query search, if it has arrived: something flagged arms the retry tier, 64 armed
+// searches in a row without a flag disarm it (an armed search with nothing flagged pays ~7 early-exit launches per 32
+// queries, ~40 us at 64 queries: not something the common case should carry).
+static void consume_retry_stats(prag_index* ix, bool wait) {
+    if (!ix->r2_pending) return;
+    if (wait) {
+        if (hipEventSynchronize(ix->r2_event) != hipSuccess) return;
+    } else if (hipEventQuery(ix->r2_event) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    ix->r2_pending = false;
+    if (*ix->r2_word_host > 0u) {
+        ix->retry_armed = true;
+        ix->retry_clean = 0;
+    } else if (ix->retry_armed && ++ix->retry_clean >= 64) {
+        ix->retry_armed = false;
+    }
+}
+
+static int retry_tier(prag_index* ix, const float* q_dev, int B, int k, int64_t id_offset, float* D_dev, int64_t* I_dev,
+                      void* stream, int tag_ids, uint32_t* flag_word) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    constexpr int kPart = 32, kMaxB = 128;
+    if (!ix->r2_word || ix->r2_k < k) {
+        const int nk = std::max(k, ix->r2_k);
+        ix->r2_k = 0;
+        const int rc_ws = ws_regrow({{vpp(&ix->r2_list), (size_t)kMaxB * sizeof(int)},
+                                     {vpp(&ix->r2_q), (size_t)kPart * ix->d * sizeof(float)},
+                                     {vpp(&ix->r2_D), (size_t)kPart * nk * sizeof(float)},
+                                     {vpp(&ix->r2_I), (size_t)kPart * nk * sizeof(int64_t)},
+                                     {vpp(&ix->r2_word), 4 * sizeof(uint32_t)}});
+        if (rc_ws != PRAG_OK) return rc_ws;
+        ix->r2_k = nk;
+    }
+    hipLaunchKernelGGL(retry_plan_kernel, dim3(1), dim3(128), 0, st, flag_word, ix->flag_list, ix->r2_word, ix->r2_list, kMaxB);
+    PRAG_LAUNCH_CHECK();
+    GateScope scope{ix};
+    const int n_parts = (std::min(B, kMaxB) + kPart - 1) / kPart;
+    for (int p = 0; p < n_parts; ++p) {
+        ix->gate = Gate{ix->r2_word, (uint32_t)(kPart * p) + 1u, 0xFFFFFFFFu};
+        hipLaunchKernelGGL(gather_queries_kernel, dim3(kPart), dim3(256), 0, st, q_dev, ix->r2_list + kPart * p, kPart, ix->d,
+                           ix->r2_q, ix->gate);
+        PRAG_LAUNCH_CHECK();
+        // (32 queries: two-term tiles over the shadow / high-precision list scan over the rows, its own certificate and -
+        //  for what even that cannot clear - its own exact scan; the inner search resets and refills the flag list)
+        const int rc = index_search_impl(ix, ix->r2_q, kPart, k, id_offset, ix->r2_D, ix->r2_I, 1, stream, tag_ids, false);
+        if (rc != PRAG_OK) return rc;
+        hipLaunchKernelGGL(retry_scatter_kernel, dim3(kPart), dim3(64), 0, st, ix->r2_D, ix->r2_I, ix->r2_list, ix->r2_word,
+                           ix->cert_words /* the inner (device-io) search's flag count */, kPart * p, k, D_dev, I_dev, ix->gate);
+        PRAG_LAUNCH_CHECK();
+    }
+    ix->gate = Gate{};
+    hipLaunchKernelGGL(retry_finish_kernel, dim3(1), dim3(1), 0, st, ix->r2_word, flag_word);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+
 static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D, int64_t* I,
                              int io_is_device, void* stream, int tag_ids, bool allow_mm8) {
     PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
@@ -2527,6 +2648,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     env.shadow_mode = ix->shadow_mode; env.mm8_min_rows = ix->mm8_min_rows; env.allow_mm8 = allow_mm8;
     env.shadow_ready = ix->ntotal > 0 && ix->rows8 != nullptr && ix->shadow_rows == ix->ntotal && shadow_wanted(ix);
     if (allow_mm8) consume_tier_stats(ix, false);     // the previous search's failed count, if it has arrived
+    if (allow_mm8) consume_retry_stats(ix, false);    // ... and the flag count of the previous <= 128-query search
     env.mm8_auto_off = ix->mm8_auto_off;
     SearchPlan P = plan_search(env);
     PRAG_REQUIRE(P.kc != 0, PRAG_EUNSUPPORTED, "k=%d: at most 911 results per query", k);
@@ -2980,9 +3102,31 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         memcpy(D, ix->io_res_host + (size_t)B * k * 8, (size_t)B * k * sizeof(float));
         return PRAG_OK;
     }
+    // Retry tier (retry_tier above): 33-128 queries, outer searches only.  Device i/o: armed by what earlier searches
+    // flagged (the count travels back asynchronously); host i/o: decided on the count that came back with the results.
+    const bool retry_shape = allow_mm8 && !ix->gate.word && may_flag && !exact_only && !use_mm && B > 32 && B <= 128 &&
+                             ix->retry_mode != 0;
     if (io_is_device) {
         ix->last_flagged = -1;
-        if (may_flag) {
+        const bool retry_now = retry_shape && (ix->retry_armed || ix->retry_mode == 1);
+        if (retry_shape) {      // statistics for the next search's decision; never waited for, nothing while capturing
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+            ix->r2_pending = false;
+            if (!capturing) {
+                if (!ix->r2_word_host) {
+                    PRAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->r2_word_host), 4 * sizeof(uint32_t)));
+                    PRAG_HIP(hipEventCreateWithFlags(&ix->r2_event, hipEventDisableTiming));
+                }
+                PRAG_HIP(hipMemcpyAsync(ix->r2_word_host, flag_word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                PRAG_HIP(hipEventRecord(ix->r2_event, st));
+                ix->r2_pending = true;
+            }
+        }
+        if (retry_now) {
+            const int rc = retry_tier(ix, q_dev, B, k, id_offset, D_dev, I_dev, stream, tag_ids, flag_word);
+            if (rc != PRAG_OK) return rc;
+        } else if (may_flag) {
             const int rc = exact_run(er, st);
             if (rc != PRAG_OK) return rc;
         }
@@ -3000,10 +3144,21 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     memcpy(&n_flag, ix->io_res_host + (size_t)B * k * 12, sizeof(n_flag));
     ix->last_flagged = (int)n_flag;
     if (may_flag && n_flag > 0) {
-        const int rc = exact_run(er, st);
-        if (rc != PRAG_OK) return rc;
+        if (retry_shape) {
+            ix->retry_armed = true;        // (device-io searches on this handle start armed too)
+            ix->retry_clean = 0;
+            const int rc = retry_tier(ix, q_dev, B, k, id_offset, D_dev, I_dev, stream, tag_ids, flag_word);
+            if (rc != PRAG_OK) return rc;
+        } else {
+            const int rc = exact_run(er, st);
+            if (rc != PRAG_OK) return rc;
+        }
         rc_io = fetch();
         if (rc_io != PRAG_OK) return rc_io;
+        if (retry_shape) {      // what the exact scan recomputed in the end (retry_finish_kernel)
+            memcpy(&n_flag, ix->io_res_host + (size_t)B * k * 12, sizeof(n_flag));
+            ix->last_flagged = (int)n_flag;
+        }
     }
     memcpy(I, ix->io_res_host, (size_t)B * k * sizeof(int64_t));
     memcpy(D, ix->io_res_host + (size_t)B * k * 8, (size_t)B * k * sizeof(float));
@@ -3210,6 +3365,10 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
     ix->prof.disable();
     ix->prof_xch.disable();
     if (ix->scan_done_ev) (void)hipEventDestroy(ix->scan_done_ev);
+    if (ix->r2_event) (void)hipEventDestroy(ix->r2_event);
+    if (ix->r2_word_host) (void)hipHostFree(ix->r2_word_host);
+    for (void* p : {(void*)ix->r2_word, (void*)ix->r2_list, (void*)ix->r2_q, (void*)ix->r2_D, (void*)ix->r2_I})
+        if (p) (void)hipFree(p);
     void* ptrs[] = {ix->rows, ix->xnorm, ix->q32, ix->q16, ix->q16lo, ix->g_tau, ix->part_key, ix->part_idx, ix->cand,
                     ix->io_q, ix->io_res, ix->mm_cnt, ix->mm_ovf, ix->mm_kq, ix->mm_ckey, ix->mm_cidx, ix->t2_list, ix->t2_q,
                     ix->t2_D, ix->t2_I, ix->t2_word, ix->xch_send, ix->xch_recv,

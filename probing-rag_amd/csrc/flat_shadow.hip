@@ -5,10 +5,11 @@
 // make_indexer.py:449-450, utils.py:378-380) - the shadow only decides which rows need not be looked at.
 //
 // Shadow (built on the device from the stored rows):
-//   y_i = (x_i - mu) / c   (round 5: a per-INDEX affine map, mu = column means, c = column scales - powers of two - of a
-//                           sample of the rows, frozen when the shadow is first built: real embeddings share a mean
-//                           direction and carry a few outlier coordinates, and a per-row abs-max int8 grid spent its
-//                           levels on those instead of on what separates one row from another)
+//   y_i = (x_i - mu) / c   (round 5: a per-INDEX affine map, mu = column means of a sample of the rows, frozen when the
+//                           shadow is first built: real embeddings share a mean direction and carry a few outlier
+//                           coordinates, and a per-row abs-max int8 grid spent its levels on those instead of on what
+//                           separates one row from another.  c = 1 by default; PRAG_SHADOW_AFFINE=2 adds power-of-two
+//                           column scales - see shadow_affine_mode in flat_index.hip for why that is not the default)
 //   y^_i = rint(y_i / s_i) in [-127,127], s_i = max|y_i| / 127 ;  e_i = ||y_i - s_i y^_i|| (rounded up)
 // Query (per search): p = q * c (exact: powers of two), so that q.x_i = q.mu + p.y_i; two int8 terms,
 // p ~ sp (p^1 + p^2 / 128), residual rq = ||p - p~|| ~ 2^-15 ||p||.
@@ -1485,7 +1486,7 @@ int shadow_build(const ShadowStore& s, int64_t row0, int64_t row1, hipStream_t s
 
 // mu / c / 1/c of the shadow's affine map from a sample of rows [0, n_rows) (at most 2^18 of them, evenly spread) ->
 // aff [3][d]; `sums` is a [2][d] float64 scratch.  identity 1: mu = 0, c = 1 (PRAG_SHADOW_AFFINE=0); 2: c = 1, rows
-// centred only (PRAG_SHADOW_AFFINE=2).
+// centred only (PRAG_SHADOW_AFFINE=1, the default); 0: centred + column scales (PRAG_SHADOW_AFFINE=2).
 int shadow_affine_fit(const ShadowStore& s, int64_t n_rows, int identity, double* sums, hipStream_t st) {
     PRAG_REQUIRE(shadow_store_supported(s.d) && s.aff && sums, PRAG_EUNSUPPORTED, "internal: affine map of d=%d rows", s.d);
     const int64_t n_take = std::min<int64_t>(n_rows, (int64_t)1 << 18);

@@ -285,7 +285,7 @@ def test_embedding_shaped_corpus_is_searched_exactly_and_tightly(metric, store, 
 
 
 def test_affine_shadow_map_is_a_performance_choice_only(monkeypatch):
-    """PRAG_SHADOW_AFFINE=0 keeps the round 2-4 shadow (mu = 0, c = 1): same ids, same scores - on rows with a common
+    """PRAG_SHADOW_AFFINE=0 keeps the round 2-4 shadow (mu = 0, c = 1), 2 adds column scales: same ids, same scores - on rows with a common
     mean and outlier coordinates it lets far more rows through; rows added AFTER the map was fitted (a different
     distribution, even) are still searched exactly, and so is a shadow rebuilt when the capacity grows."""
     import torch
@@ -296,7 +296,7 @@ def test_affine_shadow_map_is_a_performance_choice_only(monkeypatch):
     X = embedding_like_rows(9, 0, N, d, structure=st)
     q = embedding_like_rows(1009, 0, 40, d, structure=st)
     res, surv = {}, {}
-    for mode in ("1", "0"):
+    for mode in ("1", "0", "2"):
         monkeypatch.setenv("PRAG_SHADOW_AFFINE", mode)
         ix = pra.HipFlatIndex(d, "l2", "f16")           # capacity grows: the shadow is rebuilt from row 0 on the way
         monkeypatch.delenv("PRAG_SHADOW_AFFINE")
@@ -312,7 +312,8 @@ def test_affine_shadow_map_is_a_performance_choice_only(monkeypatch):
             _check(res[mode][0].cpu().numpy(), res[mode][1].cpu().numpy(), D0, I0, onp.METRIC_L2)
         ix.close()
     assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][0], res["0"][0])
-    assert surv["1"] * 3 < surv["0"], surv          # centring + column scales: the filter is several times tighter
+    assert torch.equal(res["1"][1], res["2"][1]) and torch.equal(res["1"][0], res["2"][0])
+    assert surv["1"] * 3 < surv["0"], surv          # rows and queries centred on the column means: several times tighter
 
 
 def test_work_beside_the_tail_of_a_search():
@@ -374,3 +375,61 @@ def test_work_beside_the_tail_of_a_search():
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(out[1], I0) and all(torch.equal(a, b) for a, b in zip(gout, want))
+
+
+def test_flagged_queries_are_retried_32_at_a_time_before_the_exact_scan(monkeypatch):
+    """Round 5 retry tier: on rows with outlier coordinates and the round 2-4 shadow (PRAG_SHADOW_AFFINE=0) the 64-query
+    tiles - one int8 query term - overflow their candidate regions for nearly every query; the 32-query tiles - both
+    terms - do not.  With the tier (armed by the first search's flag count, or forced) the flagged queries are searched
+    again 32 at a time and hardly any reaches the exact float64 scan; results are the definition's either way, for
+    device and host i/o, and the tier disarms nothing it should not (a clean corpus stays unarmed)."""
+    import torch
+    import probing_rag_amd as pra
+    from probing_rag_amd.synth import embedding_like_rows, embedding_structure
+    N, d, k = 300_000, 768, 10
+    st = embedding_structure(11, d)
+    X = embedding_like_rows(11, 0, N, d, structure=st)
+    q = embedding_like_rows(1011, 0, 64, d, structure=st)
+    monkeypatch.setenv("PRAG_SHADOW_AFFINE", "0")
+    counts = {}
+    for mode in ("0", "1", "auto"):
+        if mode == "auto":
+            monkeypatch.delenv("PRAG_RETRY_TIER", raising=False)
+        else:
+            monkeypatch.setenv("PRAG_RETRY_TIER", mode)
+        ix = pra.HipFlatIndex(d, "l2", "f16", capacity=N)
+        ix.set_shadow(2)
+        ix.add(X)
+        if mode == "0":
+            stored = ix.reconstruct_n(0, N)
+            D0, I0 = oracle_c.flat_search(stored, q.cpu().numpy(), k, onp.METRIC_L2)
+        D, I = ix.search(q, k)
+        _check(D.cpu().numpy(), I.cpu().numpy(), D0, I0, onp.METRIC_L2)
+        counts[mode] = [ix.last_exact_fallbacks()]
+        torch.cuda.synchronize()
+        D, I = ix.search(q, k)                      # (adaptive: armed by the first search's count)
+        _check(D.cpu().numpy(), I.cpu().numpy(), D0, I0, onp.METRIC_L2)
+        counts[mode].append(ix.last_exact_fallbacks())
+        Dn, In = ix.search(q.cpu().numpy(), k)      # host i/o: decided on the count that came back with the results
+        _check(Dn, In, D0, I0, onp.METRIC_L2)
+        counts[mode].append(ix.last_exact_fallbacks())
+        # 70 queries: three parts of 32 (the last one padded)
+        q70 = embedding_like_rows(1012, 0, 70, d, structure=st)
+        D7, I7 = ix.search(q70, k)
+        D70, I70 = oracle_c.flat_search(stored, q70.cpu().numpy(), k, onp.METRIC_L2)
+        _check(D7.cpu().numpy(), I7.cpu().numpy(), D70, I70, onp.METRIC_L2)
+        ix.close()
+    assert counts["0"][0] > 32 and counts["0"][1] > 32, counts             # the cliff: most queries in the exact scan
+    assert max(counts["1"]) <= 8, counts                                    # forced: the two-term tiles clear them
+    assert counts["auto"][0] > 32 and counts["auto"][1] <= 8 and counts["auto"][2] <= 8, counts
+    # a clean corpus never arms the tier (and pays nothing for it)
+    monkeypatch.delenv("PRAG_SHADOW_AFFINE")
+    ix = pra.HipFlatIndex(d, "cos", "f16", capacity=N)
+    ix.set_shadow(2)
+    ix.add_synthetic(42, 0, N)
+    qq = torch.from_numpy(onp.synth_rows(7, 0, 64, d)).cuda()
+    for _ in range(3):
+        ix.search(qq, k)
+        torch.cuda.synchronize()
+        assert ix.last_exact_fallbacks() == 0
+    ix.close()
