@@ -251,11 +251,213 @@ __global__ __launch_bounds__(kExThreads) void exact_scan_kernel(ExactArgs a) {
 }
 
 
-// Tried in round 3 and dropped: a batched form that takes up to 8 flagged queries through one pass over the rows
-// (rows loaded once per step, queries in LDS, one threshold list per query).  The scan is bound by float64 issue,
-// not by HBM (8 M x 640 fp16 rows: 2.6 ms per query = 3.9 TB/s): four flagged queries cost 10.2 ms batched against
-// 10.4 ms one by one, and ONE flagged query - the common case - 6.1 ms instead of 2.6 (74 KB of LDS leave one
-// workgroup per CU).
+// ---------------------------------------------------------------------------------------------------------------
+// Grouped form (round 5): up to kExGroup flagged queries per pass over the rows.  A row is loaded and converted to
+// float64 ONCE per pass; the queries of the group sit in LDS as float64 (no conversion per use: four ds_read_b128 - the
+// same 64 bytes in each of the wave's four 16-lane groups, a broadcast - feed eight v_fma_f64); the per-(element, query)
+// work is ONE fma (inner product) or a subtraction and an fma (L2).  tools/micro/f64_valu_probe.hip
+// (profiles/r05d_f64_valu_rates.txt): v_fma_f64, v_add_f64, v_cvt_f64_f32 all issue at ~2.3-2.8 ns per wave instruction
+// per SIMD and the shared LDS reads hide behind the fmas - 2.6e13 lane-fmas/s over the chip, i.e. eight queries x 21 M x
+// 768 in ~6 ms against 8 x 5 ms one by one.  Every lane forms the sums of the single-query kernel in the same order:
+// the float64 scores - and D / I - are bit-identical.  One small threshold list per query (kExGroupCap slots, k <=
+// kExGroupCap / 4); the group's lists alias the big list the merge of a query needs afterwards.
+// The single-query kernel stays: ONE flagged query is the common case, and 100 KB of LDS per workgroup would halve its
+// occupancy (what round 3's batched attempt - float32 queries in LDS, a conversion per use - paid: 6.1 ms instead of
+// 2.6 for one query).  exact_run takes the grouped kernel when the caller expects several flagged queries
+// (ExactRun::grouped: every query flagged by construction, or flags seen in recent searches).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kExGroup = 8;
+constexpr int kExGroupCap = 512;
+
+struct ExSmallTopK {
+    unsigned long long key[kExGroupCap];
+    int id[kExGroupCap];
+};
+
+// sort list g of the group by (key, id), keep the k best, tighten its bound.  All threads.
+__device__ __forceinline__ void exg_cut(ExSmallTopK& t, int& cnt, unsigned long long& bound, int k) {
+    __syncthreads();
+    const int n = cnt;
+    int n_pad = 2;
+    while (n_pad < n) n_pad <<= 1;
+    for (int i = n + threadIdx.x; i < n_pad; i += kExThreads) {
+        t.key[i] = ~0ull;
+        t.id[i] = 0x7fffffff;
+    }
+    for (int size = 2; size <= n_pad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int p = threadIdx.x; p < (n_pad >> 1); p += kExThreads) {
+                const int i = ((p / stride) * 2 * stride) + (p % stride), j = i + stride;
+                const unsigned long long ka = t.key[i], kb = t.key[j];
+                const int ia = t.id[i], ib = t.id[j];
+                const bool gt = ka > kb || (ka == kb && ia > ib);
+                if (gt == ((i & size) == 0)) {
+                    t.key[i] = kb;
+                    t.key[j] = ka;
+                    t.id[i] = ib;
+                    t.id[j] = ia;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt = n < k ? n : k;
+        if (n >= k) bound = t.key[k - 1];
+    }
+    __syncthreads();
+}
+
+template <bool F32>
+__global__ __launch_bounds__(kExThreads) void exact_group_kernel(ExactArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char ex_smem[];
+    // [kExGroup][d] float64 queries | kExGroup small lists (aliased by the merge's big list) | counters
+    double* s_qd = reinterpret_cast<double*>(ex_smem);
+    char* s_lists = ex_smem + (size_t)kExGroup * a.d * sizeof(double);
+    ExSmallTopK* tks = reinterpret_cast<ExSmallTopK*>(s_lists);
+    ExTopK& tk_big = *reinterpret_cast<ExTopK*>(s_lists);
+    static_assert(sizeof(ExTopK) <= kExGroup * sizeof(ExSmallTopK), "the merge list aliases the group's lists");
+    // (counters BEHIND the dynamic region's arrays: a static __shared__ object would sit in front of it and move its base
+    //  off the 16-byte alignment the ds_read_b128 of the queries needs - cdna_hip_programming.md Guideline 17)
+    unsigned long long* s_bound = reinterpret_cast<unsigned long long*>(s_lists + (size_t)kExGroup * sizeof(ExSmallTopK));
+    int* s_cnt = reinterpret_cast<int*>(s_bound + kExGroup);
+    int& s_last = s_cnt[kExGroup];
+    if (gate_closed(a.gate)) return;
+    const uint32_t nf = *a.n_flag;
+    if ((uint32_t)a.f0 >= nf) return;
+    const int f1 = (int)std::min<uint32_t>(nf, (uint32_t)(a.f0 + a.f_cap));
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int sub = lane & 15, slot = lane >> 4;
+    const int d = a.d;
+    const int64_t n_tiles = (a.N + 31) / 32;
+    for (int fg = a.f0; fg < f1; fg += kExGroup) {
+        const int ng = min(kExGroup, f1 - fg);
+        __syncthreads();
+        for (int i = tid; i < kExGroup * d; i += kExThreads) {
+            const int g = i / d, c = i - g * d;
+            // (slots past the group's last query repeat the first one: same work, results never written)
+            const int b = a.flag_list[fg + (g < ng ? g : 0)];
+            s_qd[i] = (double)a.q32[(int64_t)b * d + c];
+        }
+        if (tid < kExGroup) {
+            s_cnt[tid] = 0;
+            s_bound[tid] = ~0ull;
+        }
+        __syncthreads();
+        int since = 0;
+        for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+            const int64_t row = t * 32 + w * 4 + slot;
+            double acc[kExGroup];
+#pragma unroll
+            for (int g = 0; g < kExGroup; ++g) acc[g] = 0.0;
+            if (row < a.N) {
+                constexpr int MAXS = 12;   // d <= 1536
+                u32x4 v0[MAXS], v1[F32 ? MAXS : 1];
+#pragma unroll
+                for (int it = 0; it < MAXS; ++it) {
+                    const int e = sub * 8 + it * 128;
+                    if (e < d) {
+                        if constexpr (F32) {
+                            const float* p = reinterpret_cast<const float*>(a.rows) + row * d + e;
+                            v0[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+                            v1[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 4));
+                        } else {
+                            v0[it] = __builtin_nontemporal_load(
+                                reinterpret_cast<const u32x4*>(reinterpret_cast<const _Float16*>(a.rows) + row * d + e));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < MAXS; ++it) {
+                    const int e = sub * 8 + it * 128;
+                    if (e < d) {
+                        double xd[8];
+                        if constexpr (F32) {
+                            const f32x4 x0 = __builtin_bit_cast(f32x4, v0[it]);
+                            const f32x4 x1 = __builtin_bit_cast(f32x4, v1[it]);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { xd[j] = (double)x0[j]; xd[4 + j] = (double)x1[j]; }
+                        } else {
+                            const half8 h = __builtin_bit_cast(half8, v0[it]);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) xd[j] = (double)(float)h[j];
+                        }
+#pragma unroll
+                        for (int g = 0; g < kExGroup; ++g) {
+                            typedef double d2 __attribute__((ext_vector_type(2)));
+                            const d2* qp = reinterpret_cast<const d2*>(s_qd + (size_t)g * d + e);
+                            double s = acc[g];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const d2 qv = qp[u];
+                                if (a.metric_l2) {
+                                    const double d0 = qv[0] - xd[2 * u], d1 = qv[1] - xd[2 * u + 1];
+                                    s = fma(d0, d0, s);
+                                    s = fma(d1, d1, s);
+                                } else {
+                                    s = fma(qv[0], xd[2 * u], s);
+                                    s = fma(qv[1], xd[2 * u + 1], s);
+                                }
+                            }
+                            acc[g] = s;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < kExGroup; ++g) {
+                const double s = dpp_add16_f64(acc[g]);
+                if (sub == 0 && row < a.N && g < ng) {
+                    const unsigned long long key = a.metric_l2 ? sortable_u64(s) : ~sortable_u64(s);
+                    if (key <= s_bound[g]) {
+                        const int sl = atomicAdd(&s_cnt[g], 1);
+                        tks[g].key[sl] = key;       // (<= 32 pushes per list and tile; checked every kExCheck tiles)
+                        tks[g].id[sl] = (int)row;
+                    }
+                }
+            }
+            if (++since == kExCheck) {
+                since = 0;
+                __syncthreads();
+                for (int g = 0; g < ng; ++g) {        // (uniform: s_cnt is read behind the barrier by every thread)
+                    const int c = s_cnt[g];
+                    if (c > kExGroupCap - 32 * kExCheck) exg_cut(tks[g], s_cnt[g], s_bound[g], a.k);
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        for (int g = 0; g < ng; ++g) {
+            exg_cut(tks[g], s_cnt[g], s_bound[g], a.k);
+            const int64_t o = ((int64_t)(fg + g - a.f0) * a.n_lists + blockIdx.x) * a.k;
+            for (int j = tid; j < a.k; j += kExThreads) {
+                const bool ok = j < s_cnt[g];
+                a.part_key[o + j] = ok ? tks[g].key[j] : ~0ull;
+                a.part_id[o + j] = ok ? tks[g].id[j] : 0x7fffffff;
+            }
+        }
+        // the LAST workgroup to finish a query folds its per-workgroup lists (as in the single-query kernel)
+        __threadfence();
+        __syncthreads();
+        for (int g = 0; g < ng; ++g) {
+            const int fs = fg + g - a.f0;
+            if (tid == 0) s_last = atomicAdd(a.done + fs, 1u) == gridDim.x - 1 ? 1 : 0;
+            __syncthreads();
+            if (s_last) {
+                __threadfence();
+                exact_merge_lists(a, tk_big, fs, a.flag_list[fg + g]);
+                if (tid == 0) a.done[fs] = 0u;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// (Round 3's batched attempt, for the record: rows loaded once per step, float32 queries in LDS, one threshold list per
+// query - four flagged queries cost 10.2 ms batched against 10.4 ms one by one at 8 M x 640 fp16 rows, and ONE flagged
+// query 6.1 ms instead of 2.6: 74 KB of LDS left one workgroup per CU.  The grouped kernel above keeps float64 queries
+// in LDS and is only taken when several flagged queries are expected.)
 size_t exact_part_entries(int f_cap, int grid, int k) { return (size_t)f_cap * grid * k; }
 
 int exact_run(const ExactRun& r, hipStream_t st) {
@@ -280,9 +482,24 @@ int exact_run(const ExactRun& r, hipStream_t st) {
     a.done = r.done;
     a.tag_ids = r.tag_ids;
     a.gate = r.gate;
+    // several flagged queries expected, and the group's lists hold them: eight queries per pass over the rows
+    const bool grouped = r.grouped && r.k <= kExGroupCap / 4 && r.d % 16 == 0;
+    const size_t g_lds = (size_t)kExGroup * r.d * sizeof(double) + (size_t)kExGroup * sizeof(ExSmallTopK) + kExGroup * 12 + 16;
+    if (grouped) {
+        static LdsOptIn opt_in[2];
+        const int rc_ = opt_in[r.store_f32 ? 1 : 0].ensure(
+            r.store_f32 ? reinterpret_cast<const void*>(exact_group_kernel<true>) : reinterpret_cast<const void*>(exact_group_kernel<false>),
+            160 * 1024);
+        if (rc_ != PRAG_OK) return rc_;
+    }
     for (int f0 = 0; f0 < r.B; f0 += r.f_cap) {
         a.f0 = f0;
-        if (r.store_f32)
+        if (grouped) {
+            if (r.store_f32)
+                hipLaunchKernelGGL(exact_group_kernel<true>, dim3(r.grid), dim3(kExThreads), g_lds, st, a);
+            else
+                hipLaunchKernelGGL(exact_group_kernel<false>, dim3(r.grid), dim3(kExThreads), g_lds, st, a);
+        } else if (r.store_f32)
             hipLaunchKernelGGL(exact_scan_kernel<true>, dim3(r.grid), dim3(kExThreads), 0, st, a);
         else
             hipLaunchKernelGGL(exact_scan_kernel<false>, dim3(r.grid), dim3(kExThreads), 0, st, a);

@@ -1552,6 +1552,7 @@ struct prag_index {
     bool retry_armed = false;
     int retry_clean = 0;                  // armed searches in a row that flagged nothing
     int retry_mode = -1;                  // PRAG_RETRY_TIER at creation: -1 adaptive, 0 never, 1 always armed
+    int exact_group_mode = -1;            // PRAG_EXACT_GROUP at creation: -1 adaptive, 0 never, 1 always (exact_group_kernel)
     // prag_index_stream_wait_scan: an event recorded right behind the corpus scan of every search (two-level search:
     // after scan8, before the bound kernel / gather / fallback probes), so that independent work of the caller - the
     // gate of the next batch - can start beside the search's low-occupancy tail on another stream
@@ -1774,6 +1775,7 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
     if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e) != 0;
     if (const char* e = getenv("PRAG_SHADOW_AFFINE")) ix->shadow_affine_mode = atoi(e);
     if (const char* e = getenv("PRAG_RETRY_TIER")) ix->retry_mode = atoi(e);
+    if (const char* e = getenv("PRAG_EXACT_GROUP")) ix->exact_group_mode = atoi(e);
 #ifdef PRAG_MM_DIAG
     if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e);
     if (const char* e = getenv("PRAG_CERT")) ix->cert_mode = atoi(e);
@@ -2647,8 +2649,17 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     env.cert_mode = ix->cert_mode; env.prepass_mode = ix->prepass_mode; env.wg_cap = ix->wg_cap; env.n_cu = ix->n_cu;
     env.shadow_mode = ix->shadow_mode; env.mm8_min_rows = ix->mm8_min_rows; env.allow_mm8 = allow_mm8;
     env.shadow_ready = ix->ntotal > 0 && ix->rows8 != nullptr && ix->shadow_rows == ix->ntotal && shadow_wanted(ix);
-    if (allow_mm8) consume_tier_stats(ix, false);     // the previous search's failed count, if it has arrived
-    if (allow_mm8) consume_retry_stats(ix, false);    // ... and the flag count of the previous <= 128-query search
+    if (allow_mm8) {
+        // (not while `stream` is being captured: hipEventQuery is not a capture-safe call - it invalidated the capture of
+        //  a search that followed an uncaptured one; the statistics wait for the next uncaptured search)
+        hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
+        const bool capturing0 = hipStreamIsCapturing(reinterpret_cast<hipStream_t>(stream), &cs0) == hipSuccess &&
+                                cs0 != hipStreamCaptureStatusNone;
+        if (!capturing0) {
+            consume_tier_stats(ix, false);     // the previous search's failed count, if it has arrived
+            consume_retry_stats(ix, false);    // ... and the flag count of the previous <= 128-query search
+        }
+    }
     env.mm8_auto_off = ix->mm8_auto_off;
     SearchPlan P = plan_search(env);
     PRAG_REQUIRE(P.kc != 0, PRAG_EUNSUPPORTED, "k=%d: at most 911 results per query", k);
@@ -3087,6 +3098,9 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     er.done = ix->ex_done;
     er.tag_ids = tag_ids;
     er.gate = ix->gate;
+    // several flagged queries expected - every query goes to the exact scan by construction, or recent searches on this
+    // handle flagged some (the armed retry tier's inner searches included): eight queries per pass over the rows
+    er.grouped = ix->exact_group_mode != 0 && (ix->exact_group_mode == 1 || (exact_only && B >= 2) || ix->retry_armed);
     const bool may_flag = certify && ix->ntotal > 0;
     if (use_mm8) {
         // second tier, decided on the device (mm8_second_tier): no read-back, no host branch

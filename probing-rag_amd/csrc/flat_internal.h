@@ -252,6 +252,7 @@ struct ExactRun {
     uint32_t* done;         // [f_cap] zero-initialised arrival counters (the kernel leaves them zero)
     int tag_ids;
     Gate gate;
+    bool grouped = false;   // several flagged queries expected: eight per pass over the rows (exact_group_kernel)
 };
 size_t exact_part_entries(int f_cap, int grid, int k);
 // Enqueue ceil(B / f_cap) launches of the exact scan (list merge folded in); each exits at once when no query is flagged.

@@ -652,3 +652,38 @@ def test_reserve_makes_the_first_search_of_a_shape_capturable():
         D0, I0 = oracle_c.flat_search(onp.store_round(onp.normalize_rows(X), "f16"), Q, k, onp.METRIC_COS)
         assert np.array_equal(out[1].cpu().numpy(), I0)
         np.testing.assert_allclose(out[0].cpu().numpy(), D0, atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("store,metric", [("f16", onp.METRIC_L2), ("f32", onp.METRIC_COS), ("f32", onp.METRIC_L2), ("f16", onp.METRIC_IP)])
+def test_grouped_exact_scan_is_bit_identical_to_the_single_query_scan(monkeypatch, store, metric):
+    """Round 5: eight flagged queries per pass over the rows (exact_group_kernel: rows converted to float64 once,
+    float64 queries in LDS).  Every lane forms the single-query kernel's sums in the same order, so D and I must be
+    IDENTICAL - on a corpus of dense near-duplicates (squared-L2 cancellation, the certificate's worst case), for 1, 5,
+    21 and 40 flagged queries (partial groups, several groups), with ties across workgroups, and against the oracle."""
+    import torch
+    import probing_rag_amd as pra
+    N, d, k = 9000, 640, 30                       # d = 640 with k > 26: every query goes straight to the exact scan
+    rng = np.random.default_rng(17)
+    base = onp.synth_rows(93, 0, 1, d)[0]
+    X = (base[None, :] + 2e-3 * rng.standard_normal((N, d))).astype(np.float32)
+    X[N - 1] = X[17]
+    X[N // 2] = X[17]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PRAG_EXACT_GROUP", mode)
+        ix = pra.HipFlatIndex(d, metric, store)
+        monkeypatch.delenv("PRAG_EXACT_GROUP")
+        ix.add(X)
+        out = []
+        for B in (1, 5, 21, 40):
+            Q = (base[None, :] + 2e-3 * np.random.default_rng(100 + B).standard_normal((B, d))).astype(np.float32)
+            Q[0] = X[17]
+            D, I = ix.search(torch.from_numpy(Q).cuda(), k)
+            assert ix.last_exact_fallbacks() == B
+            out.append((D.cpu().numpy(), I.cpu().numpy(), Q))
+        res[mode] = out
+        ix.close()
+    for (D0, I0, Q), (D1, I1, _) in zip(res["0"], res["1"]):
+        assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
+        Dw, Iw = onp.flat_search(_stored(X, metric, store), Q, k, metric)
+        _check(D1, I1, Dw, Iw, metric)

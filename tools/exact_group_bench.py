@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Exact float64 fallback, one query per pass against eight per pass (exact_group_kernel): every query flagged by
+construction (k = 30 on d = 640 goes straight to the exact scan) - ms per search for 1 ... 64 queries, both kernels."""
+import os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    sys.path.insert(0, ROOT)
+    import torch
+    import probing_rag_amd as pra
+    N, d, k = int(sys.argv[2]), 640, 30
+    for metric, store in (("l2", "f16"), ("ip", "f16"), ("l2", "f32")):
+        ix = pra.HipFlatIndex(d, metric, store, capacity=N)
+        ix.add_synthetic(42, 0, N)
+        out = []
+        for B in (1, 2, 8, 16, 64):
+            q = torch.randn(B, d, device="cuda")
+            for _ in range(2):
+                ix.search(q, k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 3
+            for _ in range(n):
+                ix.search(q, k)
+            torch.cuda.synchronize()
+            out.append(f"B={B}: {(time.perf_counter() - t0) / n * 1e3:8.2f} ms")
+        print(f"{metric} {store} {N} x {d}: " + " | ".join(out), flush=True)
+        ix.close()
+    sys.exit(0)
+for N in (4_000_000,):
+    for mode, name in (("0", "one query per pass"), ("1", "eight queries per pass")):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "child", str(N)], env=dict(os.environ, PRAG_EXACT_GROUP=mode),
+                           capture_output=True, text=True)
+        print(f"== {name}\n{r.stdout.strip() or r.stderr.strip()[-400:]}", flush=True)
