@@ -2636,59 +2636,68 @@ static int retry_tier(prag_index* ix, const float* q_dev, int B, int k, int64_t 
     return PRAG_OK;
 }
 
-static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D, int64_t* I,
-                             int io_is_device, void* stream, int tag_ids, bool allow_mm8) {
-    PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
-    PRAG_REQUIRE(B >= 0 && k >= 1, PRAG_EINVAL, "B=%d k=%d", B, k);
-    if (B == 0) return PRAG_OK;
-    PRAG_REQUIRE(q && D && I, PRAG_EINVAL, "prag_index_search: NULL pointer");
-    // ---- plan: every dispatch decision, as a pure function of the shape and the index state (plan_search) --------
-    PlanEnv env;
-    env.d = ix->d; env.metric = ix->metric; env.store = ix->store; env.ntotal = ix->ntotal; env.B = B; env.k = k;
-    env.kc_min = ix->kc_min; env.hp_mode = ix->hp_mode; env.mm_mode = ix->mm_mode; env.mm8_mode = ix->mm8_mode;
-    env.cert_mode = ix->cert_mode; env.prepass_mode = ix->prepass_mode; env.wg_cap = ix->wg_cap; env.n_cu = ix->n_cu;
-    env.shadow_mode = ix->shadow_mode; env.mm8_min_rows = ix->mm8_min_rows; env.allow_mm8 = allow_mm8;
-    env.shadow_ready = ix->ntotal > 0 && ix->rows8 != nullptr && ix->shadow_rows == ix->ntotal && shadow_wanted(ix);
-    if (allow_mm8) {
-        // (not while `stream` is being captured: hipEventQuery is not a capture-safe call - it invalidated the capture of
-        //  a search that followed an uncaptured one; the statistics wait for the next uncaptured search)
-        hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
-        const bool capturing0 = hipStreamIsCapturing(reinterpret_cast<hipStream_t>(stream), &cs0) == hipSuccess &&
-                                cs0 != hipStreamCaptureStatusNone;
-        if (!capturing0) {
-            consume_tier_stats(ix, false);     // the previous search's failed count, if it has arrived
-            consume_retry_stats(ix, false);    // ... and the flag count of the previous <= 128-query search
-        }
-    }
-    env.mm8_auto_off = ix->mm8_auto_off;
-    SearchPlan P = plan_search(env);
-    PRAG_REQUIRE(P.kc != 0, PRAG_EUNSUPPORTED, "k=%d: at most 911 results per query", k);
-    if (P.mm8_eligible && ix->mm8_auto_off && ++ix->mm8_off_count >= ix->mm8_off_period) {
-        // one probe after a while: a serving index must not lose the 8-bit tiles for good over two bad batches
-        ix->mm8_auto_off = false;
-        ix->mm8_whole_batch_streak = 1;      // a single whole-batch repeat switches them off again ...
-        ix->mm8_off_period = std::min(4096, ix->mm8_off_period * 2);   // ... for twice as long
-        ix->mm8_off_count = 0;
-        env.mm8_auto_off = false;
-        P = plan_search(env);
-    }
-    if (allow_mm8) {                         // (second-tier inner searches keep the outer search's plan on record)
-        char buf[640];
-        plan_describe(env, P, buf, (int)sizeof(buf));
-        ix->last_plan = buf;
-        if (!P.use_mm8) {
-            ix->tier_pending = false;
-            ix->mm8_last_failed = P.mm8_eligible ? -2 : -1;
-        }
-    }
-    const int kc = P.kc;
-    const bool exact_only = P.exact_only, use_mm8 = P.use_mm8;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+// ---------------------------------------------------------------------------------------------------------------
+// One search = a plan (plan_search) and the stages below, each a function of its own (round 5; rounds 1-4 grew one
+// 600-line function).  SearchRun is what the stages share.  Every workspace a search needs is sized BEFORE its first
+// launch, in two places: search_workspaces (query block, lists, candidates, tiled-scan stores, exact-scan lists) and
+// search_shadow_args (the two-level search's query terms, regions and slice lists); the tiers that run a search of
+// their own (mm8_second_tier, retry_tier) size theirs where they start.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kShadowCap = 512;   // candidates per (scan workgroup, query) region of the two-level search (search_shadow_args)
 
+struct SearchRun {
+    prag_index* ix;
+    SearchPlan P;
+    int B, k;
+    int64_t id_offset;
+    int io_is_device;
+    void* stream;
+    int tag_ids;
+    bool allow_mm8;
+    hipStream_t st;
+    const float* q_dev;        // device views of the caller's queries / results (host i/o: the staging blocks)
+    float* D_dev;
+    int64_t* I_dev;
+    CertArgs cert;
+    uint32_t* flag_word;       // flag count of this search (device i/o: cert_words[0]; host i/o: behind the results)
+    EventRing* prof;
+    ShadowPrep sprep;
+    bool reranked;             // the executor wrote D / I itself (two-level search, list scan)
+};
+// the names the stages were written with
+#define SEARCH_BASE(r)                                                                                               \
+    [[maybe_unused]] prag_index* const ix = (r).ix;                                                                  \
+    [[maybe_unused]] const SearchPlan& P = (r).P;                                                                    \
+    [[maybe_unused]] const int B = (r).B, k = (r).k, io_is_device = (r).io_is_device, tag_ids = (r).tag_ids;         \
+    [[maybe_unused]] const int64_t id_offset = (r).id_offset;                                                        \
+    [[maybe_unused]] void* const stream = (r).stream;                                                                \
+    [[maybe_unused]] const bool allow_mm8 = (r).allow_mm8;                                                           \
+    [[maybe_unused]] hipStream_t const st = (r).st;                                                                  \
+    [[maybe_unused]] const float*& q_dev = (r).q_dev;                                                                \
+    [[maybe_unused]] float*& D_dev = (r).D_dev;                                                                      \
+    [[maybe_unused]] int64_t*& I_dev = (r).I_dev;
+#define SEARCH_PLAN(r)                                                                                               \
+    [[maybe_unused]] const int kc = P.kc, qstride = P.qstride, QT = P.QT, Bpad = P.Bpad, n_tiles = P.n_tiles,        \
+                               cu_budget = P.cu_budget, grid = P.grid, n_lists = P.grid, mm_chunk = P.mm_chunk,      \
+                               mm_cap_wg = P.mm_cap_wg, ex_grid = P.ex_grid, ex_fcap = P.ex_fcap;                    \
+    [[maybe_unused]] const bool exact_only = P.exact_only, use_mm8 = P.use_mm8, use_mm = P.use_mm, use_qs = P.use_qs, \
+                                use_hp = P.use_hp, certify = P.certify, use_shadow = P.use_shadow;                   \
+    [[maybe_unused]] const size_t part_need = P.part_need, cand_need = P.cand_need;                                  \
+    [[maybe_unused]] const int metric_l2 = (r).ix->metric == PRAG_METRIC_L2;
+#define SEARCH_CERT(r)                                                                                               \
+    [[maybe_unused]] CertArgs& cert = (r).cert;                                                                      \
+    [[maybe_unused]] uint32_t* const flag_word = (r).flag_word;                                                      \
+    [[maybe_unused]] EventRing& prof = *(r).prof;                                                                    \
+    [[maybe_unused]] ShadowPrep& sprep = (r).sprep;                                                                  \
+    [[maybe_unused]] bool& reranked = (r).reranked;
+
+// host i/o: queries into the pinned / device staging block, results come back through it (search_finish)
+static int search_stage_io(SearchRun& r, const float* q, float* D, int64_t* I) {
+    SEARCH_BASE(r)
     // ---- host i/o staging -----------------------------------------------------
-    const float* q_dev = q;
-    float* D_dev = D;
-    int64_t* I_dev = I;
+    q_dev = q;
+    D_dev = D;
+    I_dev = I;
     if (!io_is_device) {
         if (B > ix->io_B || k > ix->io_k) {
             if (ix->io_q) (void)hipFree(ix->io_q);
@@ -2713,10 +2722,14 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         D_dev = reinterpret_cast<float*>(ix->io_res + (size_t)B * k * 8);
     }
 
-    // ---- workspace --------------------------------------------------------------
-    const int qstride = P.qstride, QT = P.QT, Bpad = P.Bpad;
-    const bool use_mm = P.use_mm, shadow128 = P.shadow128, use_qs = P.use_qs, use_hp = P.use_hp;
-    (void)shadow128;
+    return PRAG_OK;
+}
+
+// every per-search workspace of the plan's kernel family (and of the exact scan behind it), before the first launch
+static int search_workspaces(SearchRun& r) {
+    SEARCH_BASE(r)
+    const int Bpad = P.Bpad;
+    const bool use_mm = P.use_mm;
     if (Bpad > ix->q_cap) {
         ix->q_cap = 0;
         const int rc_ws = ws_regrow({{vpp(&ix->qinfo), (size_t)Bpad * 4 * sizeof(float)},
@@ -2730,9 +2743,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         if (rc_ws != PRAG_OK) return rc_ws;
         ix->q_cap = Bpad;
     }
-    const int n_tiles = P.n_tiles, cu_budget = P.cu_budget, grid = P.grid;
-    const int n_lists = grid;  // one merged list per workgroup and query
-    const size_t part_need = P.part_need;
+    const size_t part_need = P.part_need;      // one merged list per workgroup and query
     if (part_need > ix->part_cap) {
         ix->part_cap = 0;
         const int rc_ws = ws_regrow({{vpp(&ix->part_key), part_need * sizeof(float)}, {vpp(&ix->part_idx), part_need * sizeof(int)}});
@@ -2777,8 +2788,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         }
     }
 
-    const int metric_l2 = ix->metric == PRAG_METRIC_L2;
-    // ---- exactness certificate: error model of the scan that will run, exact-scan workspace -------
+    // ---- exact-scan workspace (the certificate's fallback) --------------------------------------------------------
     const bool certify = P.certify;
     const int ex_grid = P.ex_grid, ex_fcap = P.ex_fcap;
     if (certify && ix->ntotal > 0) {
@@ -2797,10 +2807,13 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
             ix->ex_done_cap = ex_fcap;
         }
     }
-    {   // max ||x||^2 and the shadow are kept up to date by add / prepare: a no-op unless set_shadow changed the mode
-        const int rc = shadow_ensure(ix, st);
-        if (rc != PRAG_OK) return rc;
-    }
+    return PRAG_OK;
+}
+
+// the certificate's error model for the scan that will run (flat_internal.h "Exactness certificate")
+static void search_certificate(SearchRun& r) {
+    SEARCH_BASE(r)
+    SEARCH_PLAN(r)
     CertArgs cert;
     cert.qinfo = ix->qinfo;
     cert.qn2 = ix->qn2;
@@ -2832,16 +2845,24 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
             cert.c_row = cert.c_abs = cert.c_acc = -1e30f;
         }
     }
+    r.cert = cert;
+    r.flag_word = flag_word;
+    r.prof = &prof;
+}
+
+// the two-level search's (and the int8 tiles') query-side workspace and what prep_queries_kernel writes into it
+static int search_shadow_args(SearchRun& r) {
+    SEARCH_BASE(r)
+    SEARCH_PLAN(r)
+    SEARCH_CERT(r)
     // ---- two-level search through the 8-bit shadow (HBM-bound batches on large shards) --------------
     // candidates per (scan workgroup, query) region: 64 MB at 256 workgroups x 64 queries.  128 (round 2) sent
     // every query of a corpus with contiguous clusters to the exact scan (104 ms per search against 1.1 ms for
     // the direct scan: whole tiles of a loosely bounded query's look-alikes arrive at once); 512 holds them
     // (0.77 ms) and costs nothing on the i.i.d. corpus (same box: 2.84 / 2.85 / 2.84 ms at 128 / 256 / 512)
-    constexpr int kShadowCap = 512;
     // (the shadow's eps constants read max ||x||^2 and its overflow path needs the exact scan: both exist
     // only with the certificate on - a diag build with PRAG_CERT=0 scans the rows directly)
-    const bool use_shadow = P.use_shadow;
-    ShadowPrep sprep{};
+    sprep = ShadowPrep{};
     if (use_shadow || use_mm8) {   // workspace of the two-level search; its query terms come out of prep_queries_kernel
         const int BpadS = use_mm8 ? Bpad : (B + 63) / 64 * 64;
         if (BpadS > ix->sh_q_cap) {
@@ -2916,6 +2937,13 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
             cert.kshift = ix->sh_kshift;
         }
     }
+    return PRAG_OK;
+}
+
+static int search_prep(SearchRun& r) {
+    SEARCH_BASE(r)
+    SEARCH_PLAN(r)
+    SEARCH_CERT(r)
     hipLaunchKernelGGL(prep_queries_kernel, dim3((Bpad + 3) / 4, sprep.sample_stride > 0 ? 1 + kShadowSampleSlices : 1), dim3(256), 0,
                        st, q_dev, B, Bpad, ix->d,
                        ix->metric == PRAG_METRIC_COS ? 1 : 0, ix->q32, ix->q16, ix->q16lo, ix->g_tau,
@@ -2924,129 +2952,144 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
                        ix->flag_list, exact_only && ix->ntotal > 0 ? 1 : 0, ix->g_slot, sprep, ix->gate);
     PRAG_LAUNCH_CHECK();
 
-    bool reranked = false;
-    if (use_shadow) {
-        int rc = PRAG_OK;
-        ShadowSearch ss;
-        ss.store.rows = ix->rows;
-        ss.store.store_f32 = ix->store == PRAG_F32;
-        ss.store.d = ix->d;
-        ss.store.rows8 = ix->rows8;
-        ss.store.sscale = ix->sscale;
-        ss.store.serr = ix->serr;
-        ss.store.err_max = ix->shadow_err_max;
-        ss.store.aff = ix->sh_aff;
-        ss.store.yn_max = ix->sh_yn_max;
-        ss.store.sbias = ix->sbias;
-        ss.store.bias_max = ix->sh_bias_max;
-        ss.kshift = ix->sh_kshift;
-        ss.xnorm = ix->xnorm;
-        ss.N = ix->ntotal;
-        ss.d = ix->d;
-        ss.metric_l2 = metric_l2;
-        ss.alpha = metric_l2 ? -2.0f : -1.0f;
-        ss.q32 = ix->q32;
-        ss.xn_max = ix->cert_words + 1;
-        ss.B = B;
-        ss.Bpad_ws = std::min(ix->sh_q_cap, Bpad);
-        ss.qt_max = QT;
-        ss.k = k;
-        ss.kc = kc;
-        ss.id_offset = id_offset;
-        ss.D = D_dev;
-        ss.I = I_dev;
-        ss.g_tau = ix->g_tau;
-        ss.q8a = ix->sh_q8;
-        ss.q8b = ix->sh_q8 + (size_t)ix->sh_q_cap * ix->d;
-        ss.sq = ix->sh_sq;
-        ss.slots = ix->sh_slots;
-        ss.cand = ix->sh_cand;
-        ss.ccnt = ix->sh_ccnt;
-        ss.cap = kShadowCap;
-        ss.wg_slots = ix->n_cu;
-        ss.max_wg = cu_budget;
-        ss.part_key = ix->sh_pkey;
-        ss.part_id = ix->sh_pid;
-        ss.ovf = ix->sh_ovf;
-        ss.done = ix->sh_ovf + ix->sh_q_cap;
-        ss.cert = cert;
-        ss.gate = ix->gate;
-        // one more small launch; pays once the candidate lists are long (measured: profiles/r04p_exact_bound_ab.txt)
-        ss.quad_min_rows = ix->scan8_quad_rows;
-        ss.scan_done = allow_mm8 && !ix->gate.word ? ix->scan_done_ev : nullptr;   // (not the gated inner searches)
-        if (ss.scan_done) ix->scan_done_recorded = true;
-        ss.exact_bound = k <= 32 && (ix->shadow_bound_mode < 0 ? ix->ntotal >= (1ll << 19) : ix->shadow_bound_mode != 0);
-        rc = shadow_search(ss, st, prof);
-        if (rc != PRAG_OK) return rc;
-        reranked = true;
-    } else if (ix->ntotal == 0 || exact_only) {
-        PRAG_HIP(hipMemsetAsync(ix->cand, 0xFF, cand_need * sizeof(int), st));  // all -1
-    } else if (use_mm) {
-        const int rc = search_tiled(ix, B, Bpad, kc, qstride, n_tiles, cu_budget, mm_chunk, mm_cap_wg, st, use_mm8);
-        if (rc != PRAG_OK) return rc;
-    } else {
-        ScanArgs a;
-        a.rows = ix->rows;
-        a.xnorm = ix->xnorm;
-        a.N = ix->ntotal;
-        a.d = ix->d;
-        a.qstride = qstride;
-        a.n_tiles = n_tiles;
-        a.alpha = metric_l2 ? -2.0f : -1.0f;
-        a.use_norm = metric_l2;
-        a.out_key = ix->part_key;
-        a.out_idx = ix->part_idx;
-        a.gate = ix->gate;
-        auto run_scan = [&](const ScanArgs& sa, int g, EventRing& ring) -> int {
-            if (use_qs) return dispatch_qs(ix->d, kc, sa, g, st, ring);
-            if (QT == 32 && use_hp)
-                return ix->store == PRAG_F32 ? dispatch_scan_kc<32, true, true>(kc, sa, g, st, ring)
-                                             : dispatch_scan_kc<32, false, true>(kc, sa, g, st, ring);
-            if (QT == 32)
-                return ix->store == PRAG_F32 ? dispatch_scan_kc<32, true>(kc, sa, g, st, ring)
-                                             : dispatch_scan_kc<32, false>(kc, sa, g, st, ring);
-            return ix->store == PRAG_F32 ? dispatch_scan_kc<64, true>(kc, sa, g, st, ring)
-                                         : dispatch_scan_kc<64, false>(kc, sa, g, st, ring);
-        };
-        // Pre-pass over the first kSample rows (same kernels, a few workgroups): per query, the
-        // KC-th best key of that SUBSET is a valid upper bound on the shard's KC-th best, so the
-        // full scan starts pruned (~0.2 % quantile) instead of inserting at every slot while its
-        // per-lane lists warm up.  Only worth it when the shard is much larger than the sample.
-        constexpr int64_t kSample = 8192;
-        // (the list scan now gets its bound from the slots filled inside the launch; the pre-pass remains
-        // for the query-stationary kernel and behind PRAG_PREPASS=1 for A/B timing)
-        // Bound for the list scan: slots filled inside the launch (no extra launches: best on shards
-        // of a few million rows, where two launches are ~6 % of the search) or the pre-pass (its bound
-        // is there from the first tile: measured 1.5 % faster at 21 M rows).  Crossover ~8 M rows.
-        const bool use_slots = P.use_slots, prepass = P.prepass;
-        static EventRing no_prof;  // the pre-pass is not part of the profiled scan launches
-        for (int p0 = 0; p0 < Bpad; p0 += QT) {
-            a.q16 = ix->q16 + (size_t)p0 * ix->d;
-            a.q16lo = ix->q16lo + (size_t)p0 * ix->d;
-            a.g_tau = ix->g_tau + p0;
-            a.g_slot = use_slots ? ix->g_slot + (size_t)p0 * kSlotWords : nullptr;
-            const int nq = std::min(QT, B - p0);
-            int rc;
-            if (prepass) {
-                ScanArgs pre = a;
-                pre.N = kSample;
-                pre.n_tiles = (int)(kSample / 32);
-                const int pre_grid = use_qs ? (int)(kSample / 128) : (int)(kSample / 256);
-                rc = run_scan(pre, pre_grid, no_prof);
-                if (rc != PRAG_OK) return rc;
-                rc = launch_merge(kc, ix->part_key, ix->part_idx, pre_grid, QT, nq, ix->cand + (size_t)p0 * kc,
-                                  ix->g_tau + p0, st, nullptr, 0, 0, ix->gate);
-                if (rc != PRAG_OK) return rc;
-            }
-            rc = run_scan(a, grid, prof);
+    return PRAG_OK;
+}
+
+// <= 128 queries over the 8-bit shadow: scan8 -> exact bound -> gather (flat_shadow.hip)
+static int exec_two_level(SearchRun& r) {
+    SEARCH_BASE(r)
+    SEARCH_PLAN(r)
+    SEARCH_CERT(r)
+    int rc = PRAG_OK;
+    ShadowSearch ss;
+    ss.store.rows = ix->rows;
+    ss.store.store_f32 = ix->store == PRAG_F32;
+    ss.store.d = ix->d;
+    ss.store.rows8 = ix->rows8;
+    ss.store.sscale = ix->sscale;
+    ss.store.serr = ix->serr;
+    ss.store.err_max = ix->shadow_err_max;
+    ss.store.aff = ix->sh_aff;
+    ss.store.yn_max = ix->sh_yn_max;
+    ss.store.sbias = ix->sbias;
+    ss.store.bias_max = ix->sh_bias_max;
+    ss.kshift = ix->sh_kshift;
+    ss.xnorm = ix->xnorm;
+    ss.N = ix->ntotal;
+    ss.d = ix->d;
+    ss.metric_l2 = metric_l2;
+    ss.alpha = metric_l2 ? -2.0f : -1.0f;
+    ss.q32 = ix->q32;
+    ss.xn_max = ix->cert_words + 1;
+    ss.B = B;
+    ss.Bpad_ws = std::min(ix->sh_q_cap, Bpad);
+    ss.qt_max = QT;
+    ss.k = k;
+    ss.kc = kc;
+    ss.id_offset = id_offset;
+    ss.D = D_dev;
+    ss.I = I_dev;
+    ss.g_tau = ix->g_tau;
+    ss.q8a = ix->sh_q8;
+    ss.q8b = ix->sh_q8 + (size_t)ix->sh_q_cap * ix->d;
+    ss.sq = ix->sh_sq;
+    ss.slots = ix->sh_slots;
+    ss.cand = ix->sh_cand;
+    ss.ccnt = ix->sh_ccnt;
+    ss.cap = kShadowCap;
+    ss.wg_slots = ix->n_cu;
+    ss.max_wg = cu_budget;
+    ss.part_key = ix->sh_pkey;
+    ss.part_id = ix->sh_pid;
+    ss.ovf = ix->sh_ovf;
+    ss.done = ix->sh_ovf + ix->sh_q_cap;
+    ss.cert = cert;
+    ss.gate = ix->gate;
+    // one more small launch; pays once the candidate lists are long (measured: profiles/r04p_exact_bound_ab.txt)
+    ss.quad_min_rows = ix->scan8_quad_rows;
+    ss.scan_done = allow_mm8 && !ix->gate.word ? ix->scan_done_ev : nullptr;   // (not the gated inner searches)
+    if (ss.scan_done) ix->scan_done_recorded = true;
+    ss.exact_bound = k <= 32 && (ix->shadow_bound_mode < 0 ? ix->ntotal >= (1ll << 19) : ix->shadow_bound_mode != 0);
+    rc = shadow_search(ss, st, prof);
+    if (rc != PRAG_OK) return rc;
+    reranked = true;
+    return PRAG_OK;
+}
+
+// <= 128 queries over the stored rows: per-lane-list scan (or the query-stationary kernel) + merge / rerank / certificate
+static int exec_list_scan(SearchRun& r) {
+    SEARCH_BASE(r)
+    SEARCH_PLAN(r)
+    SEARCH_CERT(r)
+    ScanArgs a;
+    a.rows = ix->rows;
+    a.xnorm = ix->xnorm;
+    a.N = ix->ntotal;
+    a.d = ix->d;
+    a.qstride = qstride;
+    a.n_tiles = n_tiles;
+    a.alpha = metric_l2 ? -2.0f : -1.0f;
+    a.use_norm = metric_l2;
+    a.out_key = ix->part_key;
+    a.out_idx = ix->part_idx;
+    a.gate = ix->gate;
+    auto run_scan = [&](const ScanArgs& sa, int g, EventRing& ring) -> int {
+        if (use_qs) return dispatch_qs(ix->d, kc, sa, g, st, ring);
+        if (QT == 32 && use_hp)
+            return ix->store == PRAG_F32 ? dispatch_scan_kc<32, true, true>(kc, sa, g, st, ring)
+                                         : dispatch_scan_kc<32, false, true>(kc, sa, g, st, ring);
+        if (QT == 32)
+            return ix->store == PRAG_F32 ? dispatch_scan_kc<32, true>(kc, sa, g, st, ring)
+                                         : dispatch_scan_kc<32, false>(kc, sa, g, st, ring);
+        return ix->store == PRAG_F32 ? dispatch_scan_kc<64, true>(kc, sa, g, st, ring)
+                                     : dispatch_scan_kc<64, false>(kc, sa, g, st, ring);
+    };
+    // Pre-pass over the first kSample rows (same kernels, a few workgroups): per query, the
+    // KC-th best key of that SUBSET is a valid upper bound on the shard's KC-th best, so the
+    // full scan starts pruned (~0.2 % quantile) instead of inserting at every slot while its
+    // per-lane lists warm up.  Only worth it when the shard is much larger than the sample.
+    constexpr int64_t kSample = 8192;
+    // (the list scan now gets its bound from the slots filled inside the launch; the pre-pass remains
+    // for the query-stationary kernel and behind PRAG_PREPASS=1 for A/B timing)
+    // Bound for the list scan: slots filled inside the launch (no extra launches: best on shards
+    // of a few million rows, where two launches are ~6 % of the search) or the pre-pass (its bound
+    // is there from the first tile: measured 1.5 % faster at 21 M rows).  Crossover ~8 M rows.
+    const bool use_slots = P.use_slots, prepass = P.prepass;
+    static EventRing no_prof;  // the pre-pass is not part of the profiled scan launches
+    for (int p0 = 0; p0 < Bpad; p0 += QT) {
+        a.q16 = ix->q16 + (size_t)p0 * ix->d;
+        a.q16lo = ix->q16lo + (size_t)p0 * ix->d;
+        a.g_tau = ix->g_tau + p0;
+        a.g_slot = use_slots ? ix->g_slot + (size_t)p0 * kSlotWords : nullptr;
+        const int nq = std::min(QT, B - p0);
+        int rc;
+        if (prepass) {
+            ScanArgs pre = a;
+            pre.N = kSample;
+            pre.n_tiles = (int)(kSample / 32);
+            const int pre_grid = use_qs ? (int)(kSample / 128) : (int)(kSample / 256);
+            rc = run_scan(pre, pre_grid, no_prof);
             if (rc != PRAG_OK) return rc;
-            // the end of the search for this query tile: list merge + exact rerank + certificate in one launch
-            rc = launch_merge_rerank(kc, ix->store == PRAG_F32, ix->part_key, ix->part_idx, n_lists, QT, nq, p0,
-                                     ix->rows, ix->d, metric_l2, ix->q32, k, id_offset, D_dev, I_dev, cert, st);
+            rc = launch_merge(kc, ix->part_key, ix->part_idx, pre_grid, QT, nq, ix->cand + (size_t)p0 * kc,
+                              ix->g_tau + p0, st, nullptr, 0, 0, ix->gate);
             if (rc != PRAG_OK) return rc;
         }
-        reranked = true;
+        rc = run_scan(a, grid, prof);
+        if (rc != PRAG_OK) return rc;
+        // the end of the search for this query tile: list merge + exact rerank + certificate in one launch
+        rc = launch_merge_rerank(kc, ix->store == PRAG_F32, ix->part_key, ix->part_idx, n_lists, QT, nq, p0,
+                                 ix->rows, ix->d, metric_l2, ix->q32, k, id_offset, D_dev, I_dev, cert, st);
+        if (rc != PRAG_OK) return rc;
     }
+    reranked = true;
+    return PRAG_OK;
+}
+
+// candidates (tiled scans, deep lists, the all -1 list of an empty / exact-only search) -> float64 scores, D / I, flags
+static int exec_rerank(SearchRun& r) {
+    SEARCH_BASE(r)
+    SEARCH_PLAN(r)
+    SEARCH_CERT(r)
     if (!reranked && kc > 32) {  // deep lists (k > 26): scores + sort in one 1024-thread block per query
         CertArgs dc = cert;
         dc.force = ix->mm_ovf;   // a query whose candidate store overflowed is recomputed by the exact scan
@@ -3069,6 +3112,14 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
                                ix->q32, ix->cand, kc, k, id_offset, D_dev, I_dev, rc_, kth);
         PRAG_LAUNCH_CHECK();
     }
+    return PRAG_OK;
+}
+
+// what follows the scan: second tier of the int8 tiles, retry tier, exact scan of the flagged queries, host copy-out
+static int search_finish(SearchRun& r, float* D, int64_t* I) {
+    SEARCH_BASE(r)
+    SEARCH_PLAN(r)
+    SEARCH_CERT(r)
     if (ix->scan_done_ev && !use_shadow && allow_mm8 && !ix->gate.word) {    // (the two-level search recorded it behind scan8)
         PRAG_HIP(hipEventRecord(ix->scan_done_ev, st));
         ix->scan_done_recorded = true;
@@ -3177,6 +3228,81 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     memcpy(I, ix->io_res_host, (size_t)B * k * sizeof(int64_t));
     memcpy(D, ix->io_res_host + (size_t)B * k * 8, (size_t)B * k * sizeof(float));
     return PRAG_OK;
+}
+
+static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D, int64_t* I,
+                             int io_is_device, void* stream, int tag_ids, bool allow_mm8) {
+    PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
+    PRAG_REQUIRE(B >= 0 && k >= 1, PRAG_EINVAL, "B=%d k=%d", B, k);
+    if (B == 0) return PRAG_OK;
+    PRAG_REQUIRE(q && D && I, PRAG_EINVAL, "prag_index_search: NULL pointer");
+    // ---- plan: every dispatch decision, as a pure function of the shape and the index state (plan_search) --------
+    PlanEnv env;
+    env.d = ix->d; env.metric = ix->metric; env.store = ix->store; env.ntotal = ix->ntotal; env.B = B; env.k = k;
+    env.kc_min = ix->kc_min; env.hp_mode = ix->hp_mode; env.mm_mode = ix->mm_mode; env.mm8_mode = ix->mm8_mode;
+    env.cert_mode = ix->cert_mode; env.prepass_mode = ix->prepass_mode; env.wg_cap = ix->wg_cap; env.n_cu = ix->n_cu;
+    env.shadow_mode = ix->shadow_mode; env.mm8_min_rows = ix->mm8_min_rows; env.allow_mm8 = allow_mm8;
+    env.shadow_ready = ix->ntotal > 0 && ix->rows8 != nullptr && ix->shadow_rows == ix->ntotal && shadow_wanted(ix);
+    if (allow_mm8) {
+        // (not while `stream` is being captured: hipEventQuery is not a capture-safe call - it invalidated the capture of
+        //  a search that followed an uncaptured one; the statistics wait for the next uncaptured search)
+        hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
+        const bool capturing0 = hipStreamIsCapturing(reinterpret_cast<hipStream_t>(stream), &cs0) == hipSuccess &&
+                                cs0 != hipStreamCaptureStatusNone;
+        if (!capturing0) {
+            consume_tier_stats(ix, false);     // the previous search's failed count, if it has arrived
+            consume_retry_stats(ix, false);    // ... and the flag count of the previous <= 128-query search
+        }
+    }
+    env.mm8_auto_off = ix->mm8_auto_off;
+    SearchPlan P = plan_search(env);
+    PRAG_REQUIRE(P.kc != 0, PRAG_EUNSUPPORTED, "k=%d: at most 911 results per query", k);
+    if (P.mm8_eligible && ix->mm8_auto_off && ++ix->mm8_off_count >= ix->mm8_off_period) {
+        // one probe after a while: a serving index must not lose the 8-bit tiles for good over two bad batches
+        ix->mm8_auto_off = false;
+        ix->mm8_whole_batch_streak = 1;      // a single whole-batch repeat switches them off again ...
+        ix->mm8_off_period = std::min(4096, ix->mm8_off_period * 2);   // ... for twice as long
+        ix->mm8_off_count = 0;
+        env.mm8_auto_off = false;
+        P = plan_search(env);
+    }
+    if (allow_mm8) {                         // (second-tier inner searches keep the outer search's plan on record)
+        char buf[640];
+        plan_describe(env, P, buf, (int)sizeof(buf));
+        ix->last_plan = buf;
+        if (!P.use_mm8) {
+            ix->tier_pending = false;
+            ix->mm8_last_failed = P.mm8_eligible ? -2 : -1;
+        }
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+
+    SearchRun r{};
+    r.ix = ix; r.P = P; r.B = B; r.k = k; r.id_offset = id_offset; r.io_is_device = io_is_device; r.stream = stream;
+    r.tag_ids = tag_ids; r.allow_mm8 = allow_mm8; r.st = st; r.prof = &ix->prof; r.reranked = false;
+    int rc = search_stage_io(r, q, D, I);
+    if (rc == PRAG_OK) rc = search_workspaces(r);
+    // max ||x||^2 and the shadow are kept up to date by add / prepare: a no-op unless set_shadow changed the mode
+    if (rc == PRAG_OK) rc = shadow_ensure(ix, st);
+    if (rc != PRAG_OK) return rc;
+    search_certificate(r);
+    rc = search_shadow_args(r);
+    if (rc == PRAG_OK) rc = search_prep(r);
+    if (rc != PRAG_OK) return rc;
+    // ---- the corpus pass of the plan's kernel family ------------------------------------------------------------------
+    if (P.use_shadow) {
+        rc = exec_two_level(r);
+    } else if (ix->ntotal == 0 || P.exact_only) {
+        PRAG_HIP(hipMemsetAsync(ix->cand, 0xFF, P.cand_need * sizeof(int), st));  // all -1
+    } else if (P.use_mm) {
+        rc = search_tiled(ix, B, P.Bpad, P.kc, P.qstride, P.n_tiles, P.cu_budget, P.mm_chunk, P.mm_cap_wg, st, P.use_mm8);
+    } else {
+        rc = exec_list_scan(r);
+    }
+    if (rc == PRAG_OK) rc = exec_rerank(r);
+    if (rc != PRAG_OK) return rc;
+    return search_finish(r, D, I);
 }
 
 static int merge_topk_impl(const float* Dp, const int64_t* Ip, int64_t d_stride, int64_t i_stride, int n_parts,

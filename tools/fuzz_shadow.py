@@ -21,7 +21,7 @@ while time.time() - t0 < budget:
     k = int(rng.choice([1, 5, 10, 12, 13, 26]))
     metric = str(rng.choice(["l2", "ip", "cos"]))
     store = str(rng.choice(["f16", "f32"]))
-    kind = str(rng.choice(["iid", "clustered", "dups", "scaled"]))
+    kind = str(rng.choice(["iid", "clustered", "dups", "scaled", "embedded"]))
     g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
     X = torch.randn((N, d), generator=g, device="cuda")
     if kind == "clustered" and N >= 64:
@@ -33,6 +33,17 @@ while time.time() - t0 < budget:
     elif kind == "scaled":
         X = X * torch.exp(torch.randn((N, 1), generator=g, device="cuda"))
     Q = torch.randn((B, d), generator=g, device="cuda")
+    if kind == "embedded":
+        # a common mean direction and a few outlier coordinates (the geometry of real sentence embeddings): the shadow's
+        # affine map, the per-row bias term and the centred queries carry this case; queries share the structure
+        mu = torch.randn((d,), generator=g, device="cuda") * float(rng.choice([0.5, 2.0, 8.0]))
+        cols = torch.randperm(d, generator=g, device="cuda")[: int(rng.integers(1, 8))]
+        mu[cols] = mu[cols].sign() * float(rng.choice([10.0, 30.0, 100.0]))
+        jit = torch.zeros((d,), device="cuda")
+        jit[cols] = float(rng.choice([0.0, 0.1, 0.5]))
+        X = X + mu * (1.0 + jit * torch.randn((N, 1), generator=g, device="cuda"))
+        if rng.random() < 0.7:
+            Q = Q + mu * (1.0 + jit * torch.randn((B, 1), generator=g, device="cuda"))
     if N >= 4:
         Q[0] = X[N // 3]
         Q[B - 1] = X[N - 1] + 0.01 * Q[B - 1]
