@@ -309,7 +309,7 @@ __device__ __forceinline__ void exg_cut(ExSmallTopK& t, int& cnt, unsigned long 
     __syncthreads();
 }
 
-template <bool F32>
+template <bool F32, int NS>
 __global__ __launch_bounds__(kExThreads) void exact_group_kernel(ExactArgs a) {
     extern __shared__ __attribute__((aligned(16))) char ex_smem[];
     // [kExGroup][d] float64 queries | kExGroup small lists (aliased by the merge's big list) | counters
@@ -346,28 +346,36 @@ __global__ __launch_bounds__(kExThreads) void exact_group_kernel(ExactArgs a) {
         }
         __syncthreads();
         int since = 0;
+        // the next tile's row is requested before this tile's is used (one wave holds 8 KB of the stream in flight while
+        // its ~700 float64 instructions per tile run: with two waves per SIMD and no prefetch the pass was latency-bound)
+        constexpr int MAXS = NS;        // 128-element steps per row: d <= 128 NS
+        u32x4 v0[MAXS], v1[F32 ? MAXS : 1], vn0[MAXS], vn1[F32 ? MAXS : 1];
+        auto load_row = [&](u32x4 (&r0)[MAXS], u32x4 (&r1)[F32 ? MAXS : 1], int64_t row) __attribute__((always_inline)) {
+            const int64_t rc = row < a.N ? row : a.N - 1;          // (past the end: any valid row, never pushed)
+#pragma unroll
+            for (int it = 0; it < MAXS; ++it) {
+                const int e = sub * 8 + it * 128;
+                if (e < d) {
+                    if constexpr (F32) {
+                        const float* p = reinterpret_cast<const float*>(a.rows) + rc * d + e;
+                        r0[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+                        r1[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 4));
+                    } else {
+                        r0[it] = __builtin_nontemporal_load(
+                            reinterpret_cast<const u32x4*>(reinterpret_cast<const _Float16*>(a.rows) + rc * d + e));
+                    }
+                }
+            }
+        };
+        if ((int64_t)blockIdx.x < n_tiles) load_row(v0, v1, (int64_t)blockIdx.x * 32 + w * 4 + slot);
         for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
             const int64_t row = t * 32 + w * 4 + slot;
+            const int64_t t_next = t + gridDim.x < n_tiles ? t + gridDim.x : t;
+            load_row(vn0, vn1, t_next * 32 + w * 4 + slot);
             double acc[kExGroup];
 #pragma unroll
             for (int g = 0; g < kExGroup; ++g) acc[g] = 0.0;
             if (row < a.N) {
-                constexpr int MAXS = 12;   // d <= 1536
-                u32x4 v0[MAXS], v1[F32 ? MAXS : 1];
-#pragma unroll
-                for (int it = 0; it < MAXS; ++it) {
-                    const int e = sub * 8 + it * 128;
-                    if (e < d) {
-                        if constexpr (F32) {
-                            const float* p = reinterpret_cast<const float*>(a.rows) + row * d + e;
-                            v0[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-                            v1[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 4));
-                        } else {
-                            v0[it] = __builtin_nontemporal_load(
-                                reinterpret_cast<const u32x4*>(reinterpret_cast<const _Float16*>(a.rows) + row * d + e));
-                        }
-                    }
-                }
 #pragma unroll
                 for (int it = 0; it < MAXS; ++it) {
                     const int e = sub * 8 + it * 128;
@@ -416,6 +424,11 @@ __global__ __launch_bounds__(kExThreads) void exact_group_kernel(ExactArgs a) {
                         tks[g].id[sl] = (int)row;
                     }
                 }
+            }
+#pragma unroll
+            for (int it = 0; it < MAXS; ++it) {
+                v0[it] = vn0[it];
+                if constexpr (F32) v1[it] = vn1[it];
             }
             if (++since == kExCheck) {
                 since = 0;
@@ -483,22 +496,28 @@ int exact_run(const ExactRun& r, hipStream_t st) {
     a.tag_ids = r.tag_ids;
     a.gate = r.gate;
     // several flagged queries expected, and the group's lists hold them: eight queries per pass over the rows
-    const bool grouped = r.grouped && r.k <= kExGroupCap / 4 && r.d % 16 == 0;
+    // (float32 rows of more than 768 elements: the prefetched row is 96 more registers - that instantiation spilled)
+    const bool grouped = r.grouped && r.k <= kExGroupCap / 4 && r.d % 16 == 0 && !(r.store_f32 && r.d > 768);
     const size_t g_lds = (size_t)kExGroup * r.d * sizeof(double) + (size_t)kExGroup * sizeof(ExSmallTopK) + kExGroup * 12 + 16;
+    // (rows of <= 768 elements keep six 128-element steps in registers, twice: the prefetch; longer rows twelve)
+    const bool short_rows = r.d <= 768;
+    const void* gk = r.store_f32 ? reinterpret_cast<const void*>(exact_group_kernel<true, 6>)
+                                 : (short_rows ? reinterpret_cast<const void*>(exact_group_kernel<false, 6>)
+                                               : reinterpret_cast<const void*>(exact_group_kernel<false, 12>));
     if (grouped) {
-        static LdsOptIn opt_in[2];
-        const int rc_ = opt_in[r.store_f32 ? 1 : 0].ensure(
-            r.store_f32 ? reinterpret_cast<const void*>(exact_group_kernel<true>) : reinterpret_cast<const void*>(exact_group_kernel<false>),
-            160 * 1024);
+        static LdsOptIn opt_in[4];
+        const int rc_ = opt_in[(r.store_f32 ? 2 : 0) + (short_rows ? 1 : 0)].ensure(gk, 160 * 1024);
         if (rc_ != PRAG_OK) return rc_;
     }
     for (int f0 = 0; f0 < r.B; f0 += r.f_cap) {
         a.f0 = f0;
         if (grouped) {
-            if (r.store_f32)
-                hipLaunchKernelGGL(exact_group_kernel<true>, dim3(r.grid), dim3(kExThreads), g_lds, st, a);
-            else
-                hipLaunchKernelGGL(exact_group_kernel<false>, dim3(r.grid), dim3(kExThreads), g_lds, st, a);
+            if (r.store_f32) {
+                hipLaunchKernelGGL((exact_group_kernel<true, 6>), dim3(r.grid), dim3(kExThreads), g_lds, st, a);
+            } else {
+                if (short_rows) hipLaunchKernelGGL((exact_group_kernel<false, 6>), dim3(r.grid), dim3(kExThreads), g_lds, st, a);
+                else hipLaunchKernelGGL((exact_group_kernel<false, 12>), dim3(r.grid), dim3(kExThreads), g_lds, st, a);
+            }
         } else if (r.store_f32)
             hipLaunchKernelGGL(exact_scan_kernel<true>, dim3(r.grid), dim3(kExThreads), 0, st, a);
         else

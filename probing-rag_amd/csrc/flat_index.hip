@@ -1322,7 +1322,23 @@ __global__ __launch_bounds__(256) void gather_queries_kernel(const float* __rest
                                                             int d, float* __restrict__ out, prag::Gate gate) {
     const int i = blockIdx.x;
     if (i >= n || prag::gate_closed(gate)) return;
-    const float* src = q + (int64_t)list[i] * d;
+    const int b = list[i];
+    if (b < 0) {
+        // padding slot of the retry tier: a fixed pseudo-random query (any ordinary query certifies like the unflagged
+        // ones of the batch did; a COPY of a flagged query would be flagged again and cost an exact pass of its own)
+        for (int c = threadIdx.x * 4; c < d; c += 1024) {
+            prag::f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t h = (uint32_t)(i * 8191 + c + e) * 2654435761u;
+                h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+                v[e] = (float)(int32_t)h * (1.0f / 2147483648.0f);
+            }
+            *reinterpret_cast<prag::f32x4*>(out + (int64_t)i * d + c) = v;
+        }
+        return;
+    }
+    const float* src = q + (int64_t)b * d;
     for (int c = threadIdx.x * 4; c < d; c += 1024)
         *reinterpret_cast<prag::f32x4*>(out + (int64_t)i * d + c) = *reinterpret_cast<const prag::f32x4*>(src + c);
 }
@@ -1355,7 +1371,8 @@ __global__ __launch_bounds__(64) void mm8_tier_plan_kernel(const uint32_t* __res
 // search overflowed, or the certificate of a 33-128-query direct scan did not clear - are searched again 32 at a time by
 // the <= 32-query kernels (BOTH int8 query terms over the shadow / hi + lo fp16 terms over the rows: a far tighter
 // filter and certificate) before anything goes to the exact float64 scan.  r2_word[0] = flagged count, r2_list = the
-// flagged batch rows padded with the first one to a multiple of 32; [1] accumulates what the inner searches still flag.
+// flagged batch rows, padded with -1 (gather_queries_kernel writes a fixed pseudo-random query there) to a multiple of 32;
+// [1] accumulates what the inner searches still flag.
 __global__ __launch_bounds__(128) void retry_plan_kernel(uint32_t* __restrict__ n_flag, const int* __restrict__ flag_list,
                                                         uint32_t* __restrict__ r2_word, int* __restrict__ r2_list, int cap) {
     const uint32_t n = *n_flag;
@@ -1364,8 +1381,7 @@ __global__ __launch_bounds__(128) void retry_plan_kernel(uint32_t* __restrict__ 
         r2_word[1] = 0u;
     }
     if (n == 0) return;
-    const int first = flag_list[0];
-    for (int i = threadIdx.x; i < cap; i += 128) r2_list[i] = (uint32_t)i < n ? flag_list[i] : first;
+    for (int i = threadIdx.x; i < cap; i += 128) r2_list[i] = (uint32_t)i < n ? flag_list[i] : -1;   // -1: padding query
 }
 __global__ __launch_bounds__(64) void retry_scatter_kernel(const float* __restrict__ Ds, const int64_t* __restrict__ Is,
                                                           const int* __restrict__ list, uint32_t* __restrict__ r2_word,
@@ -1381,7 +1397,8 @@ __global__ __launch_bounds__(64) void retry_scatter_kernel(const float* __restri
         I[b * k + j] = Is[(int64_t)i * k + j];
     }
 }
-__global__ void retry_finish_kernel(const uint32_t* __restrict__ r2_word, uint32_t* __restrict__ n_flag) {
+__global__ void retry_finish_kernel(uint32_t* __restrict__ r2_word, uint32_t* __restrict__ n_flag) {
+    r2_word[2] = r2_word[0] != 0u ? 1u : 0u;          // the tier did something in this search
     if (r2_word[0] != 0u) *n_flag = r2_word[1];       // what the exact scan recomputed in the end
 }
 
@@ -1553,6 +1570,7 @@ struct prag_index {
     int retry_clean = 0;                  // armed searches in a row that flagged nothing
     int retry_mode = -1;                  // PRAG_RETRY_TIER at creation: -1 adaptive, 0 never, 1 always armed
     int exact_group_mode = -1;            // PRAG_EXACT_GROUP at creation: -1 adaptive, 0 never, 1 always (exact_group_kernel)
+    bool exact_group_hint = false;        // recent retry tiers left >= 4 queries for the exact scan
     // prag_index_stream_wait_scan: an event recorded right behind the corpus scan of every search (two-level search:
     // after scan8, before the bound kernel / gather / fallback probes), so that independent work of the caller - the
     // gate of the next batch - can start beside the search's low-occupancy tail on another stream
@@ -2590,11 +2608,16 @@ static void consume_retry_stats(prag_index* ix, bool wait) {
         return;
     }
     ix->r2_pending = false;
-    if (*ix->r2_word_host > 0u) {
+    if (ix->r2_word_host[0] > 0u) {
         ix->retry_armed = true;
         ix->retry_clean = 0;
     } else if (ix->retry_armed && ++ix->retry_clean >= 64) {
         ix->retry_armed = false;
+        ix->exact_group_hint = false;
+    }
+    if (ix->r2_word_host[2] != 0u) {        // the tier ran in that search: [1] = what its inner searches still flagged
+        ix->exact_group_hint = ix->r2_word_host[1] >= 4u;
+        ix->r2_word_host[2] = 0u;
     }
 }
 
@@ -3151,7 +3174,10 @@ static int search_finish(SearchRun& r, float* D, int64_t* I) {
     er.gate = ix->gate;
     // several flagged queries expected - every query goes to the exact scan by construction, or recent searches on this
     // handle flagged some (the armed retry tier's inner searches included): eight queries per pass over the rows
-    er.grouped = ix->exact_group_mode != 0 && (ix->exact_group_mode == 1 || (exact_only && B >= 2) || ix->retry_armed);
+    // (one flagged query is the common case and the single-query kernel is 3.7x faster for it - profiles/
+    //  r05f_exact_group_bench.txt -, so "several" means: by construction, or the retry tier's inner searches have been
+    //  leaving >= 4 queries flagged lately)
+    er.grouped = ix->exact_group_mode != 0 && (ix->exact_group_mode == 1 || (exact_only && B >= 2) || ix->exact_group_hint);
     const bool may_flag = certify && ix->ntotal > 0;
     if (use_mm8) {
         // second tier, decided on the device (mm8_second_tier): no read-back, no host branch
@@ -3181,6 +3207,7 @@ static int search_finish(SearchRun& r, float* D, int64_t* I) {
             if (!capturing) {
                 if (!ix->r2_word_host) {
                     PRAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->r2_word_host), 4 * sizeof(uint32_t)));
+                    memset(ix->r2_word_host, 0, 4 * sizeof(uint32_t));
                     PRAG_HIP(hipEventCreateWithFlags(&ix->r2_event, hipEventDisableTiming));
                 }
                 PRAG_HIP(hipMemcpyAsync(ix->r2_word_host, flag_word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -3191,6 +3218,10 @@ static int search_finish(SearchRun& r, float* D, int64_t* I) {
         if (retry_now) {
             const int rc = retry_tier(ix, q_dev, B, k, id_offset, D_dev, I_dev, stream, tag_ids, flag_word);
             if (rc != PRAG_OK) return rc;
+            if (ix->r2_pending) {       // (not capturing) the tier's own outcome travels back with the flag count
+                PRAG_HIP(hipMemcpyAsync(ix->r2_word_host + 1, ix->r2_word + 1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                PRAG_HIP(hipEventRecord(ix->r2_event, st));
+            }
         } else if (may_flag) {
             const int rc = exact_run(er, st);
             if (rc != PRAG_OK) return rc;
@@ -3223,6 +3254,7 @@ static int search_finish(SearchRun& r, float* D, int64_t* I) {
         if (retry_shape) {      // what the exact scan recomputed in the end (retry_finish_kernel)
             memcpy(&n_flag, ix->io_res_host + (size_t)B * k * 12, sizeof(n_flag));
             ix->last_flagged = (int)n_flag;
+            ix->exact_group_hint = n_flag >= 4u;
         }
     }
     memcpy(I, ix->io_res_host, (size_t)B * k * sizeof(int64_t));
