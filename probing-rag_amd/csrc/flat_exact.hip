@@ -391,24 +391,32 @@ __global__ __launch_bounds__(kExThreads) void exact_group_kernel(ExactArgs a) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) xd[j] = (double)(float)h[j];
                         }
+                        // element pair u of all eight queries before pair u + 1: eight independent fma chains side by
+                        // side (per query the summation order is the single-query kernel's: e, e + 1, ... in turn)
+                        typedef double d2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                        for (int g = 0; g < kExGroup; ++g) {
-                            typedef double d2 __attribute__((ext_vector_type(2)));
-                            const d2* qp = reinterpret_cast<const d2*>(s_qd + (size_t)g * d + e);
-                            double s = acc[g];
+                        for (int u = 0; u < 4; ++u) {
+                            d2 qv[kExGroup];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const d2 qv = qp[u];
-                                if (a.metric_l2) {
-                                    const double d0 = qv[0] - xd[2 * u], d1 = qv[1] - xd[2 * u + 1];
-                                    s = fma(d0, d0, s);
-                                    s = fma(d1, d1, s);
-                                } else {
-                                    s = fma(qv[0], xd[2 * u], s);
-                                    s = fma(qv[1], xd[2 * u + 1], s);
+                            for (int g = 0; g < kExGroup; ++g)
+                                qv[g] = *reinterpret_cast<const d2*>(s_qd + (size_t)g * d + e + 2 * u);
+                            if (a.metric_l2) {
+#pragma unroll
+                                for (int g = 0; g < kExGroup; ++g) {
+                                    const double d0 = qv[g][0] - xd[2 * u];
+                                    acc[g] = fma(d0, d0, acc[g]);
                                 }
+#pragma unroll
+                                for (int g = 0; g < kExGroup; ++g) {
+                                    const double d1 = qv[g][1] - xd[2 * u + 1];
+                                    acc[g] = fma(d1, d1, acc[g]);
+                                }
+                            } else {
+#pragma unroll
+                                for (int g = 0; g < kExGroup; ++g) acc[g] = fma(qv[g][0], xd[2 * u], acc[g]);
+#pragma unroll
+                                for (int g = 0; g < kExGroup; ++g) acc[g] = fma(qv[g][1], xd[2 * u + 1], acc[g]);
                             }
-                            acc[g] = s;
                         }
                     }
                 }

@@ -2933,8 +2933,8 @@ static int search_shadow_args(SearchRun& r) {
         sprep.sbias = ix->sbias;
         const int64_t whole_tiles = ix->ntotal / 32;
         // (PRAG_SHADOW_SAMPLE=2: > 32 queries sample ONE tile per slice - a quarter of the sampling work for a bound
-        //  at the ~1 % quantile instead of the 0.25 % one; <= 32 queries keep four)
-        sprep.sample_tiles = (ix->shadow_sample_mode == 2 && B > 32) ? 1 : kShadowSampleTiles;
+        //  at the ~1 % quantile instead of the 0.25 % one; 3: two tiles; <= 32 queries keep four)
+        sprep.sample_tiles = (ix->shadow_sample_mode == 2 && B > 32) ? 1 : (ix->shadow_sample_mode == 3 && B > 32) ? 2 : kShadowSampleTiles;
         sprep.sample_stride = whole_tiles / (kShadowSampleSlices * sprep.sample_tiles);   // 0: shard too small
         // The sampled bound is used for batches of <= 32 queries (kernel trace at 2.6 M rows: the sampling waves
         // take the prep kernel from 7 to 19 us and the scan from 399 to 376 us; at 64 queries - one query term,

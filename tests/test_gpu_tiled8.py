@@ -95,10 +95,13 @@ def test_first_tier_answers_a_random_corpus(metric):
 
 @pytest.mark.parametrize("store", ["f16", "f32"])
 @pytest.mark.parametrize("metric", METRICS)
-def test_second_tier_on_a_corpus_of_look_alikes(metric, store):
+def test_second_tier_on_a_corpus_of_look_alikes(metric, store, monkeypatch):
     """Thousands of rows inside the 8-bit error band of every query's k-th score: 256 candidates cannot clear
     the certificate, the batch is repeated on the fp16 tiles (and their exact fallback) - results still the
-    definition's, through host arrays and through device tensors."""
+    definition's, through host arrays and through device tensors.  (Rows = one base vector + noise: with the shadow
+    centred on the column means - round 5 - the int8 grid resolves the noise itself and the first tier answers such a
+    corpus; the second tier is exercised on the round 2-4 shadow, PRAG_SHADOW_AFFINE=0, and the default is checked for
+    the definition's results next to it.)"""
     import probing_rag_amd as pra
     import torch
     N, d, B, k = 20_000, 768, 150, 10
@@ -106,10 +109,19 @@ def test_second_tier_on_a_corpus_of_look_alikes(metric, store):
     base = onp.synth_rows(5, 0, 1, d)[0]
     X = (base[None, :] + 2e-3 * rng.standard_normal((N, d))).astype(np.float32)
     Q = (base[None, :] + 2e-3 * rng.standard_normal((B, d))).astype(np.float32)
+    D0, I0 = oracle_c.flat_search(_stored(X, metric, store), Q, k, metric)
+    ixc = pra.HipFlatIndex(d, metric, store)          # the default (centred) shadow: whichever tier answers, exact
+    ixc.set_shadow(2)
+    ixc.add(X)
+    Dc, Ic = ixc.search(Q, k)
+    assert ixc.last_tiled8() >= 0
+    _check(Dc, Ic, D0, I0, metric)
+    ixc.close()
+    monkeypatch.setenv("PRAG_SHADOW_AFFINE", "0")     # read when the index is created
     ix = pra.HipFlatIndex(d, metric, store)
+    monkeypatch.delenv("PRAG_SHADOW_AFFINE")
     ix.set_shadow(2)
     ix.add(X)
-    D0, I0 = oracle_c.flat_search(_stored(X, metric, store), Q, k, metric)
     D, I = ix.search(Q, k)
     assert ix.last_tiled8() > 0
     _check(D, I, D0, I0, metric)
