@@ -9,6 +9,7 @@ for sw in "SHARD_TAIL=1" "PRAG_SHADOW_SAMPLE=3 SHARD_TAIL=1" "SHARD_TAIL=1" "PRA
   env $sw SHARD_REPS=400 timeout 200 python tools/shard_pass.py 2>&1 | grep "shard pass" | cut -c1-60 >> $OUT/${TAG}_shard_ab.txt
 done
 cat $OUT/${TAG}_shard_ab.txt
+timeout 400 python tools/exact_group_bench.py > $OUT/${TAG}_exact_group_bench.txt 2>&1; cat $OUT/${TAG}_exact_group_bench.txt
 timeout 600 python bench.py --e2e --e2e-queries 200 --no-cpu-baseline > $OUT/${TAG}_e2e_200q.json 2> $OUT/${TAG}_e2e.err; tail -c 1200 $OUT/${TAG}_e2e_200q.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $R/bench.py --no-variants --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_stats.log
