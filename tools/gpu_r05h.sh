@@ -16,4 +16,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- pyt
 f=$(ls $OUT/${TAG}_stats/*/*kernel_stats.csv | head -1); cp $f $OUT/${TAG}_bench_kernel_stats.csv; head -8 $OUT/${TAG}_bench_kernel_stats.csv | cut -c1-160
 SHARD_TAIL=1 SHARD_REPS=200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_shard_stats -- python3 $R/tools/shard_pass.py > $OUT/${TAG}_shard_pass_under_rocprof.txt 2>&1
 f=$(ls $OUT/${TAG}_shard_stats/*/*kernel_stats.csv | head -1); cp $f $OUT/${TAG}_shard_pass_kernel_stats.csv; head -12 $OUT/${TAG}_shard_pass_kernel_stats.csv | cut -c1-160
+python3 $R/tools/tail_overlap_trace.py $OUT/${TAG}_shard_stats > $OUT/${TAG}_tail_overlap_trace.txt 2>&1; cat $OUT/${TAG}_tail_overlap_trace.txt
 rm -rf $OUT/${TAG}_stats $OUT/${TAG}_shard_stats
