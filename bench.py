@@ -492,6 +492,9 @@ def shard_variant(torch, pra, ens, k, metric, ms_per_pass_full, passes=300):
                    at the head of the pass on a second stream: 0.472 eager / 0.519 captured against 0.465 on one stream,
                    profiles/r05a_bench.json.)
       graph_tail_2s  the same, captured (fork / join inside the graph)
+      fused        prag_search_and_gate: one C call; the gate's prober workgroups ride in the launch of the search's bound
+                   kernel (bound_gate_kernel) - no second stream, no cross-stream dependency
+      graph_fused  the same, captured
     pass_ms = the fastest of them (named in pass_mode).  predicted_strong_scaling_eff = ms_per_pass(21 M rows, this
     run) / 8 / pass_ms: the efficiency an 8-GPU run can reach at best (fixed costs do not shrink with the shard)."""
     from probing_rag_amd.synth import synth_rows
@@ -535,6 +538,9 @@ def shard_variant(torch, pra, ens, k, metric, ms_per_pass_full, passes=300):
             ens.gate(x, 0, 0.0, out=gate_out)
         torch.cuda.current_stream().wait_stream(side)
 
+    def one_pass_fused():                            # one C call: the gate's workgroups in the bound kernel's launch
+        pra.search_and_gate(ix, q, k, ens, x, 0, 0.0, out=out, gate_out=gate_out)
+
     ix.stream_wait_scan(side)                        # (first call: switches the event recording on)
 
     modes = {}
@@ -544,8 +550,12 @@ def shard_variant(torch, pra, ens, k, metric, ms_per_pass_full, passes=300):
     gate_ms = timed(lambda: ens.gate(x, 0, 0.0, out=gate_out), passes)
     modes["tail_2s"] = timed(one_pass_tail, passes)
     same = {"tail_2s": bool(torch.equal(out[1], I_eager) and torch.equal(gate_out[2], dec_eager))}
+    out[1].zero_()
+    gate_out[2].zero_()
+    modes["fused"] = timed(one_pass_fused, passes)
+    same["fused"] = bool(torch.equal(out[1], I_eager) and torch.equal(gate_out[2], dec_eager))
     graph_err = None
-    for name, fn in (("graph", one_pass), ("graph_tail_2s", one_pass_tail)):
+    for name, fn in (("graph", one_pass), ("graph_tail_2s", one_pass_tail), ("graph_fused", one_pass_fused)):
         try:
             cs = torch.cuda.Stream()
             cs.wait_stream(torch.cuda.current_stream())
@@ -746,14 +756,18 @@ def main(argv=None):
         local.set_scan_workgroups(n_cu - 16)
     local.set_shadow(1 if args.shadow else 0)
 
-    if args.overlap_gate == 2:
+    if args.overlap_gate >= 2:
         local.stream_wait_scan(side_stream)       # (first call: switches the event recording on)
 
     def one_pass():
         if not args.overlap_gate:
             ens.gate(x, 0, 0.0, out=gate_out)
             return index.search(q, args.k)
-        if args.overlap_gate == 2:
+        if args.overlap_gate == 3 and world == 1:
+            # one C call: the gate's prober workgroups in the launch of the search's bound kernel (prag_search_and_gate)
+            out, _ = pra.search_and_gate(local, q, args.k, ens, x, 0, 0.0, gate_out=gate_out)
+            return out
+        if args.overlap_gate >= 2:
             # the search first; the gate (independent work: the decisions of the NEXT batch of generations) starts on
             # the side stream as soon as the search's corpus scan is done and runs beside its low-occupancy tail
             out = index.search(q, args.k)
@@ -936,7 +950,7 @@ def main(argv=None):
                    "docs_total": args.docs, "docs_per_gpu": n_local, "d_emb": d_emb, "queries": args.queries,
                    "k": args.k, "gate_batch": args.gate_batch, "gate_batch_per_gpu": Bg, "d_model": d_model,
                    "parallelism": f"corpus rows sharded x{world}; gate rows split x{world}",
-                   "gate_overlap": {0: "none (one stream)", 1: "beside the scan", 2: "beside the search's tail (second stream waits for the scan only)"}[args.overlap_gate],
+                   "gate_overlap": {0: "none (one stream)", 1: "beside the scan", 2: "beside the search's tail (second stream waits for the scan only)", 3: "in the launch of the search's bound kernel (prag_search_and_gate; N > 1: as 2)"}[args.overlap_gate],
                    "two_level_shadow": scan_kernel == "scan8_kernel"},
         "probe_decisions_per_s": args.gate_batch / (gate_avg_ms * 1e-3) if gate_ms else None,
         "scores_per_s_per_gpu": value / world,

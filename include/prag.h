@@ -334,6 +334,16 @@ int prag_index_set_candidate_depth(prag_index_t* ix, int depth);
  * certified and went through the exact float64 scan.  Synchronises `stream`. */
 int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out);
 
+/* One pass of the hot path as one call: `D, I = index.search(q, k)` (utils.py:379; exp_rag.py:432-436) AND the gate over
+ * the NEXT batch of pooled states (exp_rag.py:406-415) - two independent pieces of work of a loop that keeps batches
+ * in flight.  Arguments = those of prag_index_search (device i/o) followed by those of prag_gate.  When the search is
+ * a two-level search the prober's workgroups are carried by the launch of the search's bound kernel - what follows the
+ * scan leaves 3/4 of the chip idle - otherwise the call equals prag_index_search followed by prag_gate.  Results are
+ * those of the two calls in every case; Bg = 0 skips the gate. */
+int prag_search_and_gate(prag_index_t* ix, const float* q_dev, int B, int k, int64_t id_offset, float* D_dev, int64_t* I_dev,
+                         prag_prober_t* p, const void* x_dev, int x_dtype, int64_t x_layer_stride, int Bg, int ablation,
+                         double theta, float* logits_dev, float* probsum_dev, int32_t* decision_dev, void* stream);
+
 /* Pipelining hook: make `other_stream` wait until the CORPUS SCAN of the most recent search enqueued on this handle
  * has finished - not the whole search.  What follows the scan (the exact bound / rerank of the survivors, the fallback
  * probes) runs on a few dozen workgroups; independent work of the caller - exp_rag.py's gate for the NEXT batch of

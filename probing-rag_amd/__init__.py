@@ -16,7 +16,7 @@ from .sharded import ShardedFlatIndex, partition_rows, search_shards_on_one_gpu 
 from .trainer import HipProberTrainer, method_1_train, method_2_train, method_3_train  # noqa: F401
 from .encoder import MeanPoolEncoder  # noqa: F401
 from .loop import (HiddenStatePool, masked_mean_pool, method_1_eval, method_2_eval, method_3_eval, pool_each_token,  # noqa: F401
-                   pool_last_token, pool_ragged, retrieve_decide, return_evidences)
+                   pool_last_token, pool_ragged, retrieve_decide, return_evidences, search_and_gate)
 
 ImprovedProbe = HipProber  # utils.py:29
 __version__ = "0.1.0"

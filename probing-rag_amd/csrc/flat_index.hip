@@ -30,6 +30,7 @@
 
 #include "exchange.h"
 #include "flat_internal.h"
+#include "tail_gate.h"
 
 namespace prag {
 
@@ -1576,6 +1577,7 @@ struct prag_index {
     // gate of the next batch - can start beside the search's low-occupancy tail on another stream
     hipEvent_t scan_done_ev = nullptr;
     bool scan_done_recorded = false;
+    TailGate* tail = nullptr;   // prag_search_and_gate: the gate launch the running search may carry beside its bound kernel
     int last_flagged = -1;   // flag count of the last host-io search (-1: last search was device-io)
     std::string last_plan;   // plan_describe of the most recent search (prag_index_last_plan)
     EventRing prof;
@@ -3031,6 +3033,7 @@ static int exec_two_level(SearchRun& r) {
     // one more small launch; pays once the candidate lists are long (measured: profiles/r04p_exact_bound_ab.txt)
     ss.quad_min_rows = ix->scan8_quad_rows;
     ss.scan_done = allow_mm8 && !ix->gate.word ? ix->scan_done_ev : nullptr;   // (not the gated inner searches)
+    ss.tail = allow_mm8 && !ix->gate.word ? ix->tail : nullptr;
     if (ss.scan_done) ix->scan_done_recorded = true;
     ss.exact_bound = k <= 32 && (ix->shadow_bound_mode < 0 ? ix->ntotal >= (1ll << 19) : ix->shadow_bound_mode != 0);
     rc = shadow_search(ss, st, prof);
@@ -3456,6 +3459,29 @@ extern "C" int prag_index_set_scan_workgroups(prag_index_t* ix, int n_workgroups
     PRAG_REQUIRE(ix != nullptr && n_workgroups >= 0, PRAG_EINVAL, "prag_index_set_scan_workgroups: bad argument");
     ix->wg_cap = n_workgroups;
     return PRAG_OK;
+}
+
+// One pass of the retrieval-gating hot path as ONE call: the top-k of B queries over this index AND the gate over the
+// next batch of pooled states (exp_rag.py:406-415, 432-436).  The two are independent; when the search is a two-level
+// search the gate's prober workgroups ride in the launch of its bound kernel (bound_gate_kernel, flat_shadow.hip) - the
+// search's tail occupies a quarter of the chip - otherwise (direct scans, tiled scans, gate shapes prober16_kernel does
+// not take) the call is prag_index_search followed by prag_gate.  Same results as the two calls, always.
+extern "C" int prag_search_and_gate(prag_index_t* ix, const float* q_dev, int B, int k, int64_t id_offset, float* D_dev,
+                                    int64_t* I_dev, prag_prober_t* p, const void* x_dev, int x_dtype, int64_t x_layer_stride,
+                                    int Bg, int ablation, double theta, float* logits_dev, float* probsum_dev,
+                                    int32_t* decision_dev, void* stream) {
+    PRAG_REQUIRE(ix != nullptr && p != nullptr, PRAG_EINVAL, "prag_search_and_gate: NULL handle");
+    PRAG_REQUIRE(logits_dev && probsum_dev && decision_dev, PRAG_EINVAL, "prag_search_and_gate: NULL gate output");
+    TailGate tg;
+    const bool have = Bg >= 1 && prober_describe_tail(p, x_dev, x_dtype, x_layer_stride, Bg, logits_dev, &tg);
+    ix->tail = have ? &tg : nullptr;
+    const int rc = index_search_impl(ix, q_dev, B, k, id_offset, D_dev, I_dev, 1, stream, 0);
+    ix->tail = nullptr;
+    if (rc != PRAG_OK) return rc;
+    if (Bg < 1) return PRAG_OK;
+    if (have && tg.taken)       // the logits are on their way: softmax / sum over layers / threshold (exp_rag.py:407-415)
+        return prag_gate_from_logits(logits_dev, tg.pa.n_run, Bg, ablation, theta, probsum_dev, decision_dev, stream);
+    return prag_gate(p, x_dev, x_dtype, x_layer_stride, Bg, ablation, theta, logits_dev, probsum_dev, decision_dev, stream);
 }
 
 extern "C" int prag_index_stream_wait_scan(prag_index_t* ix, void* other_stream) {

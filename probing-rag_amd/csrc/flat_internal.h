@@ -546,6 +546,7 @@ struct ShadowSearch {
     Gate gate;
     const double* kshift = nullptr;   // [Bpad] K_q of every query (prep_queries_kernel) or null
     hipEvent_t scan_done = nullptr;   // recorded behind the scan of the last query tile (prag_index_stream_wait_scan)
+    struct TailGate* tail = nullptr;  // a gate launch to carry beside the bound kernel of the last query tile (tail_gate.h)
     bool exact_bound = false;   // lower g_tau to an exact k-th best before the gather (shadow_bound_kernel)
     int64_t quad_min_rows = (int64_t)8 << 20;   // shards from this size on scan with the quad-test epilogue (flat_shadow.hip)
 };

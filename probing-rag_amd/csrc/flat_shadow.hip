@@ -48,6 +48,7 @@
 #include <vector>
 
 #include "flat_internal.h"
+#include "tail_gate.h"
 
 namespace prag {
 
@@ -1113,8 +1114,13 @@ __device__ __forceinline__ double sh_exact_row(const GatherArgs& a, const float*
 // ---------------------------------------------------------------------------
 constexpr int kShFinish = 256;                 // survivors this kernel scores itself (steps of 32 rows)
 constexpr uint32_t kShDoneTaken = 0x80000000u; // done[b]: the query was finished by shadow_bound_kernel
+// LDS of one bound workgroup: the query (4 KiB), kShFinish keys and ids, four scalars
+constexpr int kShBoundLds = 1024 * 4 + kShFinish * 8 + kShFinish * 4 + 32;
+// The body as a device function of (query index inside the tile, LDS block): shadow_bound_kernel runs it alone;
+// bound_gate_kernel runs it in the first nq workgroups of a launch whose other workgroups are the gate (below).
 template <bool F32>
-__global__ __launch_bounds__(kShThreads) void shadow_bound_kernel(GatherArgs a, uint32_t* __restrict__ g_tau_w) {
+__device__ __forceinline__ void shadow_bound_body(const GatherArgs& a, uint32_t* __restrict__ g_tau_w, const int qi_,
+                                                  char* const lds) {
     if (gate_closed(a.cert.gate)) return;
 #ifdef PRAG_MM_DIAG
     unsigned long long stamp[10];
@@ -1124,15 +1130,16 @@ __global__ __launch_bounds__(kShThreads) void shadow_bound_kernel(GatherArgs a, 
 #define SH_STAMP() do {} while (0)
 #endif
     SH_STAMP();
-    __shared__ __attribute__((aligned(16))) float s_q[1024];
-    __shared__ unsigned long long s_key[kShFinish];
-    __shared__ int s_fid[kShFinish];
-    __shared__ double s_qn2;
-    __shared__ int s_n, s_over;
-    __shared__ float s_taux;
+    float* const s_q = reinterpret_cast<float*>(lds);                                          // [1024]
+    unsigned long long* const s_key = reinterpret_cast<unsigned long long*>(lds + 4096);       // [kShFinish]
+    int* const s_fid = reinterpret_cast<int*>(lds + 4096 + kShFinish * 8);                     // [kShFinish]
+    double& s_qn2 = *reinterpret_cast<double*>(lds + 4096 + kShFinish * 12);
+    int& s_n = *reinterpret_cast<int*>(lds + 4096 + kShFinish * 12 + 8);
+    int& s_over = *reinterpret_cast<int*>(lds + 4096 + kShFinish * 12 + 12);
+    float& s_taux = *reinterpret_cast<float*>(lds + 4096 + kShFinish * 12 + 16);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int sub = lane & 15, slot = lane >> 4;
-    const int qi = blockIdx.x, b = a.q0 + qi, d = a.d;
+    const int qi = qi_, b = a.q0 + qi, d = a.d;
     const uint32_t tau_bits = a.g_tau[qi];
     const float tau_final = unsortable_f32(tau_bits);
     if (tid == 0) {
@@ -1302,6 +1309,36 @@ __global__ __launch_bounds__(kShThreads) void shadow_bound_kernel(GatherArgs a, 
 #endif
 #undef SH_STAMP
 }
+
+
+template <bool F32>
+__global__ __launch_bounds__(kShThreads) void shadow_bound_kernel(GatherArgs a, uint32_t* __restrict__ g_tau_w) {
+    __shared__ __attribute__((aligned(16))) char lds[kShBoundLds];
+    shadow_bound_body<F32>(a, g_tau_w, (int)blockIdx.x, lds);
+}
+
+}  // namespace prag
+
+// The gate BESIDE the bound kernel, in one launch (round 5): the first nq workgroups run shadow_bound_body, the others
+// prober16_body - the fused prober ensemble over the NEXT batch of pooled states (exp_rag.py:406-415), which depends on
+// nothing in the search.  What follows scan8 occupies 64 of 256 CUs for ~30 us; a second stream that waits for the
+// scan's event hides only ~7 us of the gate's 40 behind it (the cross-stream dependency costs the rest), a shared
+// launch all of it.  Both bodies are the ones their own kernels run (prober16.hip, shadow_bound_kernel above).
+#define PSTAMP(i)
+#define P16_ABL(bit) 0
+#include "prober16_body.h"
+#undef PSTAMP
+#undef P16_ABL
+
+namespace prag {
+
+template <bool F32, int CT16>
+__global__ __launch_bounds__(512, 2) void bound_gate_kernel(GatherArgs g, uint32_t* __restrict__ g_tau_w, int nq, ProberArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) char fused_smem[];
+    if ((int)blockIdx.x < nq) shadow_bound_body<F32>(g, g_tau_w, (int)blockIdx.x, fused_smem);
+    else prober16_body<CT16>(pa, fused_smem, (int)blockIdx.x - nq);
+}
+static_assert(kShThreads == 512, "bound_gate_kernel: both bodies are written for 512-thread workgroups");
 
 template <bool F32>
 __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a) {
@@ -1531,6 +1568,25 @@ static int launch_scan8(const Scan8Args& a, int grid, hipStream_t st, EventRing&
 // (profiles/r04t_scan8_quad_ab.txt): 21 M rows 2.68 -> 2.56 ms (0.76 -> 0.795 of 8 TB/s); 2.625 M rows the pass is
 // 0.469 -> 0.481-0.498 ms - short scans spend their time in the early tiles, where most quads hold a candidate and the
 // test is extra work - hence the row threshold.
+template <bool F32, int CT16>
+static int launch_bound_gate_ct(const TailGate& t, const GatherArgs& g, uint32_t* tau, int nq, hipStream_t st) {
+    auto kern = bound_gate_kernel<F32, CT16>;
+    const int lds = std::max(kShBoundLds, t.lds_bytes);
+    static LdsOptIn lds_opt_in;
+    const int rc_ = lds_opt_in.ensure(reinterpret_cast<const void*>(kern), 160 * 1024);
+    if (rc_ != PRAG_OK) return rc_;
+    hipLaunchKernelGGL(kern, dim3(nq + t.n_wg), dim3(kShThreads), lds, st, g, tau, nq, t.pa);
+    PRAG_LAUNCH_CHECK();
+    return PRAG_OK;
+}
+static int launch_bound_gate(bool f32, const TailGate& t, const GatherArgs& g, uint32_t* tau, int nq, hipStream_t st) {
+#define PRAG_BG(CT_) case CT_: return f32 ? launch_bound_gate_ct<true, CT_>(t, g, tau, nq, st) : launch_bound_gate_ct<false, CT_>(t, g, tau, nq, st);
+    switch (t.ct16) { PRAG_BG(2) PRAG_BG(4) PRAG_BG(8) }
+#undef PRAG_BG
+    set_error("internal: bound_gate_kernel has no %d-row tile", 16 * t.ct16);
+    return PRAG_EUNSUPPORTED;
+}
+
 constexpr int kScan8Aln = 3;
 int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
     const int qstride = (s.d + 255) / 256 * 256;
@@ -1665,11 +1721,18 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         g.dbg = a.dbg;
         g.kshift = s.kshift;
         if (s.exact_bound) {     // (k <= 32: the kernel scores 32 rows)
-            if (s.store.store_f32)
-                hipLaunchKernelGGL(shadow_bound_kernel<true>, dim3(nq), dim3(kShThreads), 0, st, g, s.g_tau + p0);
-            else
-                hipLaunchKernelGGL(shadow_bound_kernel<false>, dim3(nq), dim3(kShThreads), 0, st, g, s.g_tau + p0);
-            PRAG_LAUNCH_CHECK();
+            TailGate* tg = s.tail && !s.tail->taken && p0 + QT >= Bpad ? s.tail : nullptr;
+            if (tg) {            // the gate of the next batch in the same launch (bound_gate_kernel)
+                const int rc_t = launch_bound_gate(s.store.store_f32 != 0, *tg, g, s.g_tau + p0, nq, st);
+                if (rc_t != PRAG_OK) return rc_t;
+                tg->taken = true;
+            } else {
+                if (s.store.store_f32)
+                    hipLaunchKernelGGL(shadow_bound_kernel<true>, dim3(nq), dim3(kShThreads), 0, st, g, s.g_tau + p0);
+                else
+                    hipLaunchKernelGGL(shadow_bound_kernel<false>, dim3(nq), dim3(kShThreads), 0, st, g, s.g_tau + p0);
+                PRAG_LAUNCH_CHECK();
+            }
         }
         if (s.store.store_f32)
             hipLaunchKernelGGL(shadow_gather_kernel<true>, dim3(nsplit, nq), dim3(kShThreads), 0, st, g);

@@ -45,6 +45,7 @@
 
 #include "prag_common.h"
 #include "prober_internal.h"
+#include "tail_gate.h"
 #include "prober_small.h"
 
 namespace prag {
@@ -1605,6 +1606,36 @@ static int forward_impl(prag_prober_t* p, const void* x_dev, int x_dtype, int64_
 #undef PRAG_DISPATCH
     set_error("internal: no kernel for na=%d nb=%d ct=%d", p->na, nb, ct);
     return PRAG_EUNSUPPORTED;
+}
+
+// prag_gate's prober launch as data (tail_gate.h): only the throughput shape - fp16 activations, fp16 weights, the
+// 16 x 16 kernel, more rows than the small-batch path takes
+bool prag::prober_describe_tail(prag_prober* p, const void* x_dev, int x_dtype, int64_t x_layer_stride, int B, float* logits_dev,
+                                TailGate* out) {
+    if (!p || !x_dev || !logits_dev || !out || B < 1 || x_dtype != PRAG_F16 || p->na != 1 || !p->shape16) return false;
+    for (int l = 0; l < p->n_layers; ++l)
+        if (!p->loaded[l]) return false;
+    if (p->small_mode && small_supported(B, p->d) && B <= (p->na == 2 ? 4 : 2)) return false;
+    int ct = pick_ct(B, p->n_layers, 4, p->n_cu);
+    if (p->ct_force == 1 || p->ct_force == 2 || p->ct_force == 4) ct = p->ct_force;
+    TailGate t;
+    t.pa = ProberArgs{};
+    t.pa.layers = p->d_layers;
+    t.pa.xh = reinterpret_cast<const _Float16*>(x_dev);
+    t.pa.xl = nullptr;
+    t.pa.x_layer_stride = x_layer_stride;
+    t.pa.layer0 = 0;
+    t.pa.B = B;
+    t.pa.d = p->d;
+    t.pa.logits = logits_dev;
+    t.ct16 = 2 * ct;
+    t.pa.n_tiles = (B + 16 * t.ct16 - 1) / (16 * t.ct16);
+    t.pa.n_run = p->n_layers;
+    t.n_wg = 8 * ((t.pa.n_tiles * p->n_layers + 7) / 8);
+    t.lds_bytes = prober16_lds_bytes(t.ct16);
+    t.taken = false;
+    *out = t;
+    return t.lds_bytes > 0;
 }
 
 extern "C" int prag_prober_forward(prag_prober_t* p, const void* x_dev, int x_dtype,

@@ -107,5 +107,6 @@ constexpr int kLoShift = 13;   // lo is scaled by 2^13 before the fp8 conversion
 
 // prober16.hip: the launch on 16 x 16 tiles (rows_per_tile = 32, 64 or 128)
 int prober16_launch(const ProberArgs& a, int n_run, int rows_per_tile, hipStream_t st, EventRing& prof);
+int prober16_lds_bytes(int ct16);     // dynamic LDS of prober16_body<ct16> (0: no such tile height)
 
 }  // namespace prag

@@ -247,6 +247,40 @@ def masked_mean_pool(hidden, attention_mask):
     return out
 
 
+def search_and_gate(index, q, k: int, ens, x, ablation: int = 0, threshold: float = 0.0, out=None, gate_out=None,
+                    id_offset: int = 0):
+    """One pass of the hot path as one C call (``prag_search_and_gate``): ``index.search(q, k)`` (utils.py:379) AND
+    ``ens.gate(x, ablation, threshold)`` over the NEXT batch of pooled states (exp_rag.py:406-415) - independent work
+    of a loop that keeps batches in flight.  On a two-level search the gate's prober workgroups ride in the launch of the
+    search's bound kernel (the search's tail leaves 3/4 of the chip idle); otherwise it is the two calls in a row.
+    Same results either way.  q [B,d] and x [L,Bg,d_model] are CUDA tensors; returns ((D, I), (logits, probsum,
+    decision))."""
+    import torch
+    _lib.require_gpu()
+    if not (isinstance(q, torch.Tensor) and q.is_cuda):
+        raise RuntimeError("search_and_gate needs device queries (CUDA tensor [B,d])")
+    q = q.contiguous().float()
+    x = ens._check_x(x, 3)
+    L, Bg = x.shape[0], x.shape[1]
+    if L != ens.n_layers:
+        raise RuntimeError(f"expected {ens.n_layers} layers of activations, got {L}")
+    B, k = q.shape[0], int(k)
+    if out is None:
+        out = (torch.empty((B, k), dtype=torch.float32, device=q.device), torch.empty((B, k), dtype=torch.int64, device=q.device))
+    if gate_out is None:
+        gate_out = (torch.empty((L, Bg, 2), dtype=torch.float32, device=x.device),
+                    torch.empty((Bg, 2), dtype=torch.float32, device=x.device),
+                    torch.empty((Bg,), dtype=torch.int32, device=x.device))
+    from .prober import _x_dtype
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.lib().prag_search_and_gate(
+            index._h, ctypes.c_void_p(q.data_ptr()), B, k, int(id_offset), ctypes.c_void_p(out[0].data_ptr()),
+            ctypes.c_void_p(out[1].data_ptr()), ens._h, ctypes.c_void_p(x.data_ptr()), _x_dtype(x), Bg * ens.d_model, Bg,
+            int(ablation), float(threshold), ctypes.c_void_p(gate_out[0].data_ptr()), ctypes.c_void_p(gate_out[1].data_ptr()),
+            ctypes.c_void_p(gate_out[2].data_ptr()), _lib.current_stream_ptr(q.device)))
+    return out, gate_out
+
+
 def return_evidences(retrieved_passages) -> str:
     """exp_rag.py:369-379 (dense branch: passages are plain strings)."""
     return "\n".join(f"passage {n + 1}: {p}" for n, p in enumerate(retrieved_passages))

@@ -433,3 +433,62 @@ def test_flagged_queries_are_retried_32_at_a_time_before_the_exact_scan(monkeypa
         torch.cuda.synchronize()
         assert ix.last_exact_fallbacks() == 0
     ix.close()
+
+
+@pytest.mark.parametrize("store", ["f16", "f32"])
+def test_search_and_gate_equals_the_two_calls(store):
+    """prag_search_and_gate: the top-k of a query batch AND the gate over the next batch of pooled states in one call; on
+    a two-level search the prober's workgroups ride in the launch of the search's bound kernel (bound_gate_kernel: the
+    bodies of shadow_bound_kernel and prober16_kernel side by side).  Whatever path it takes - fused launch at every
+    prober tile height, direct scan, float32 states, the small-batch gate, no gate at all, a captured graph - D, I,
+    logits, sums and decisions are those of index.search and ens.gate."""
+    import torch
+    import probing_rag_amd as pra
+    from tests.golden import cases
+    N, d, k = 300_000, 768, 10
+    ix = pra.HipFlatIndex(d, "cos", store, capacity=N)
+    ix.add_synthetic(42, 0, N)
+    ix.set_shadow(2)
+    ix.prepare()
+    q = torch.from_numpy(onp.synth_rows(7, 0, 64, d)).cuda()
+    case = cases.PROBER_CASES[1]
+    ens = pra.HipProberEnsemble(case["L"], case["d"], 2, weights="f16")
+    for l in range(case["L"]):
+        ens.load_layer(l, cases.synth_state(case["wseed"] + l, case["d"]))
+    D0, I0 = ix.search(q, k)
+    for Bg in (40, 96, 512, 1400, 4096):                 # 32-, 64- and 128-row prober tiles, ragged last tiles
+        x = torch.from_numpy(cases.synth_x(case["xseed"] + Bg, case["L"], Bg, case["d"], 1.0)).cuda().half()
+        want = [t.clone() for t in ens.gate(x, 1, 0.25)]
+        for nq in (64, 1, 33):                           # 64- and 32-query tiles of the scan
+            (D, I), got = pra.search_and_gate(ix, q[:nq], k, ens, x, 1, 0.25)
+            assert ix.last_plan()["family"] == "scan8_kernel"
+            assert torch.equal(I, I0[:nq]) and torch.equal(D, D0[:nq])
+            assert all(torch.equal(a, b) for a, b in zip(got, want)), (Bg, nq)
+    x = torch.from_numpy(cases.synth_x(case["xseed"], case["L"], 96, case["d"], 1.0)).cuda()
+    for xx in (x, x.half()[:, :1].contiguous()):         # float32 states; ONE pooled state (the small-batch gate)
+        want = [t.clone() for t in ens.gate(xx, 0, 0.0)]
+        (D, I), got = pra.search_and_gate(ix, q, k, ens, xx)
+        assert torch.equal(I, I0) and all(torch.equal(a, b) for a, b in zip(got, want))
+    xh = x.half()
+    want = [t.clone() for t in ens.gate(xh, 0, 0.0)]
+    ix.set_shadow(0)                                     # direct scan: search, then the gate
+    (D, I), got = pra.search_and_gate(ix, q, k, ens, xh)
+    assert torch.equal(I, I0) and all(torch.equal(a, b) for a, b in zip(got, want))
+    ix.set_shadow(2)
+    # captured into a graph and replayed
+    out = (torch.empty_like(D0), torch.empty_like(I0))
+    gout = tuple(torch.empty_like(t) for t in want)
+    cs = torch.cuda.Stream()
+    cs.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cs):
+        pra.search_and_gate(ix, q, k, ens, xh, out=out, gate_out=gout)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cs):
+            pra.search_and_gate(ix, q, k, ens, xh, out=out, gate_out=gout)
+    for _ in range(3):
+        for t in (*out, *gout):
+            t.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out[1], I0) and all(torch.equal(a, b) for a, b in zip(gout, want))

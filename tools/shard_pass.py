@@ -29,7 +29,11 @@ side = torch.cuda.Stream()
 TAIL = os.environ.get("SHARD_TAIL") == "1"      # the gate beside the search's tail (prag_index_stream_wait_scan)
 if TAIL:
     ix.stream_wait_scan(side)
+FUSED = os.environ.get("SHARD_FUSED") == "1"    # prag_search_and_gate: the gate in the bound kernel's launch
 def one():
+    if FUSED:
+        pra.search_and_gate(ix, q, 10, ens, x, 0, 0.0, out=out, gate_out=gate_out)
+        return
     if not TAIL:
         ens.gate(x, 0, 0.0, out=gate_out)
         ix.search(q, 10, out=out)
