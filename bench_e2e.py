@@ -43,6 +43,13 @@ class _Clock:
         return out
 
 
+def _clock_overhead_us(torch, n=200):
+    c = _Clock(torch)
+    for _ in range(n):
+        c.run("gate", lambda: None)
+    return c.t["gate"] / n * 1e6
+
+
 class _Lockstep:
     """One retrieval step across all ranks: gather the pending queries, search every shard, merge."""
 
@@ -198,6 +205,10 @@ def run(args, pra, torch, dist, world, rank, dev_index):
                                f"IndexFlatL2 over {args.docs} x 768 {args.store} docs row-sharded x{world}, k=5",
                    "timed_region_s": dt, "queries": args.e2e_queries, "queries_this_rank": len(my_queries)},
         "hip_path": {"wall_s_rank0": sum(clock.t.values()), "seconds": clock.t, "calls": clock.n,
+                     # every timed call is bracketed by two device synchronisations: their own cost, measured on an
+                     # empty call, is in every per-call figure (the gate's ~30 us - bench.py gate_b1_latency - sits under it)
+                     "clock_overhead_us_per_call": _clock_overhead_us(torch),
+                     "us_per_call": {k_: (clock.t[k_] / clock.n[k_] * 1e6 if clock.n[k_] else None) for k_ in clock.t},
                      "share": {k: v / max(1e-12, sum(clock.t.values())) for k, v in clock.t.items()},
                      "retrieval_rounds_per_query": counts},
     }

@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
     // certificate bookkeeping: the flag list starts empty (or holds every query when the search goes
     // straight to the exact scan)
     if (b == 0 && lane == 0) *n_flag = flag_all ? (uint32_t)B : 0u;
+    if (b == 0 && lane == 0 && sp.unfinished) *sp.unfinished = 0u;
     if (flag_all && b < B && lane == 0) flag_list[b] = b;
     if (mm_cnt && lane == 0) {  // MFMA-tiled scan: candidate counts / overflow flags (word Bpad: "any")
         mm_cnt[b] = mm_first_rows;
@@ -1572,6 +1573,16 @@ struct prag_index {
     int retry_mode = -1;                  // PRAG_RETRY_TIER at creation: -1 adaptive, 0 never, 1 always armed
     int exact_group_mode = -1;            // PRAG_EXACT_GROUP at creation: -1 adaptive, 0 never, 1 always (exact_group_kernel)
     bool exact_group_hint = false;        // recent retry tiers left >= 4 queries for the exact scan
+    // the sliced gather behind the exact-bound kernel: the bound kernel finishes every query itself when <= 256 rows stay
+    // under its bound (40-100 in practice), and the gather launch is then ~9 us of nothing on the critical path.  It is
+    // enqueued while "armed": from the start, and again for 64 searches whenever a search left a query unfinished (that
+    // query went through the flag list: retry tier / exact scan); 16 clean searches in a row disarm it.  PRAG_GATHER=1
+    // keeps it always (the round 2-4 launch sequence).
+    bool gather_armed = true;
+    int gather_clean = 0;
+    int gather_mode = -1;                 // PRAG_GATHER at creation: -1 adaptive, 1 always
+    bool r2_has_unfinished = false;       // the pending statistics record carries an `unfinished` count
+    uint32_t* sh_unfin = nullptr;         // device word
     // prag_index_stream_wait_scan: an event recorded right behind the corpus scan of every search (two-level search:
     // after scan8, before the bound kernel / gather / fallback probes), so that independent work of the caller - the
     // gate of the next batch - can start beside the search's low-occupancy tail on another stream
@@ -1796,6 +1807,7 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
     if (const char* e = getenv("PRAG_SHADOW_AFFINE")) ix->shadow_affine_mode = atoi(e);
     if (const char* e = getenv("PRAG_RETRY_TIER")) ix->retry_mode = atoi(e);
     if (const char* e = getenv("PRAG_EXACT_GROUP")) ix->exact_group_mode = atoi(e);
+    if (const char* e = getenv("PRAG_GATHER")) ix->gather_mode = atoi(e);
 #ifdef PRAG_MM_DIAG
     if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e);
     if (const char* e = getenv("PRAG_CERT")) ix->cert_mode = atoi(e);
@@ -2617,6 +2629,15 @@ static void consume_retry_stats(prag_index* ix, bool wait) {
         ix->retry_armed = false;
         ix->exact_group_hint = false;
     }
+    if (ix->r2_has_unfinished) {            // [3] = queries the bound kernel left to the gather in that search
+        ix->r2_has_unfinished = false;
+        if (ix->r2_word_host[3] > 0u) {
+            ix->gather_armed = true;
+            ix->gather_clean = -48;             // (armed for 64 searches)
+        } else if (ix->gather_armed && ++ix->gather_clean >= 16) {
+            ix->gather_armed = false;
+        }
+    }
     if (ix->r2_word_host[2] != 0u) {        // the tier ran in that search: [1] = what its inner searches still flagged
         ix->exact_group_hint = ix->r2_word_host[1] >= 4u;
         ix->r2_word_host[2] = 0u;
@@ -2895,6 +2916,7 @@ static int search_shadow_args(SearchRun& r) {
             const int rc_ws = ws_regrow({{vpp(&ix->sh_q8), (size_t)2 * BpadS * ix->d},
                                          {&ix->sh_sq, (size_t)BpadS * shadow_q_bytes()},
                                          {vpp(&ix->sh_kshift), (size_t)BpadS * sizeof(double)},
+                                         {vpp(&ix->sh_unfin), 4 * sizeof(uint32_t)},
                                          {vpp(&ix->sh_slots), (size_t)BpadS * shadow_slot_words() * sizeof(uint32_t)},
                                          {vpp(&ix->sh_ovf), (size_t)2 * BpadS * sizeof(uint32_t)}});   // + arrival counters
             if (rc_ws != PRAG_OK) return rc_ws;
@@ -2928,6 +2950,7 @@ static int search_shadow_args(SearchRun& r) {
         sprep.bias_max = ix->sh_bias_max;
         sprep.centre_query = use_shadow ? 1 : 0;     // (the int8 tiles keep the query as it is: their rows carry no bias term)
         sprep.kshift = ix->sh_kshift;
+        sprep.unfinished = ix->sh_unfin;
         // sample for the pre-bound: kShadowSampleSlices x kShadowSampleTiles whole tiles spread over the shard
         sprep.rows8 = ix->rows8;
         sprep.sscale = ix->sscale;
@@ -3034,6 +3057,10 @@ static int exec_two_level(SearchRun& r) {
     ss.quad_min_rows = ix->scan8_quad_rows;
     ss.scan_done = allow_mm8 && !ix->gate.word ? ix->scan_done_ev : nullptr;   // (not the gated inner searches)
     ss.tail = allow_mm8 && !ix->gate.word ? ix->tail : nullptr;
+    ss.unfinished = ix->sh_unfin;
+    // (only where the statistics that re-arm it travel: outer 33-128-query searches with device i/o - search_finish)
+    ss.skip_gather = ix->gather_mode != 1 && !ix->gather_armed && allow_mm8 && !ix->gate.word && io_is_device && B > 32 &&
+                     B <= 128 && ix->retry_mode != 0;
     if (ss.scan_done) ix->scan_done_recorded = true;
     ss.exact_bound = k <= 32 && (ix->shadow_bound_mode < 0 ? ix->ntotal >= (1ll << 19) : ix->shadow_bound_mode != 0);
     rc = shadow_search(ss, st, prof);
@@ -3214,6 +3241,10 @@ static int search_finish(SearchRun& r, float* D, int64_t* I) {
                     PRAG_HIP(hipEventCreateWithFlags(&ix->r2_event, hipEventDisableTiming));
                 }
                 PRAG_HIP(hipMemcpyAsync(ix->r2_word_host, flag_word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                if (use_shadow && ix->sh_unfin) {      // ... and how many queries the bound kernel left to the gather
+                    PRAG_HIP(hipMemcpyAsync(ix->r2_word_host + 3, ix->sh_unfin, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                    ix->r2_has_unfinished = true;
+                }
                 PRAG_HIP(hipEventRecord(ix->r2_event, st));
                 ix->r2_pending = true;
             }
@@ -3473,14 +3504,17 @@ extern "C" int prag_search_and_gate(prag_index_t* ix, const float* q_dev, int B,
     PRAG_REQUIRE(ix != nullptr && p != nullptr, PRAG_EINVAL, "prag_search_and_gate: NULL handle");
     PRAG_REQUIRE(logits_dev && probsum_dev && decision_dev, PRAG_EINVAL, "prag_search_and_gate: NULL gate output");
     TailGate tg;
-    const bool have = Bg >= 1 && prober_describe_tail(p, x_dev, x_dtype, x_layer_stride, Bg, logits_dev, &tg);
+    const bool have = Bg >= 1 && prober_describe_tail(p, x_dev, x_dtype, x_layer_stride, Bg, logits_dev, ablation, theta,
+                                                      probsum_dev, decision_dev, &tg);
     ix->tail = have ? &tg : nullptr;
     const int rc = index_search_impl(ix, q_dev, B, k, id_offset, D_dev, I_dev, 1, stream, 0);
     ix->tail = nullptr;
     if (rc != PRAG_OK) return rc;
     if (Bg < 1) return PRAG_OK;
-    if (have && tg.taken)       // the logits are on their way: softmax / sum over layers / threshold (exp_rag.py:407-415)
+    if (have && tg.taken) {     // the logits are on their way: softmax / sum over layers / threshold (exp_rag.py:407-415)
+        if (tg.gate_folded) return PRAG_OK;     // ... done by the last prober workgroup of every row tile
         return prag_gate_from_logits(logits_dev, tg.pa.n_run, Bg, ablation, theta, probsum_dev, decision_dev, stream);
+    }
     return prag_gate(p, x_dev, x_dtype, x_layer_stride, Bg, ablation, theta, logits_dev, probsum_dev, decision_dev, stream);
 }
 
@@ -3571,7 +3605,7 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
                     ix->io_q, ix->io_res, ix->mm_cnt, ix->mm_ovf, ix->mm_kq, ix->mm_ckey, ix->mm_cidx, ix->t2_list, ix->t2_q,
                     ix->t2_D, ix->t2_I, ix->t2_word, ix->xch_send, ix->xch_recv,
                     ix->mm_wcnt, ix->mm_wkey, ix->mm_widx, ix->rows16, ix->qinfo, ix->qn2, ix->flag_list, ix->g_slot,
-                    ix->cert_words, ix->ex_key, ix->ex_id, ix->rows8, ix->sscale, ix->serr, ix->shadow_err_max, ix->sh_aff, ix->sh_aff_sums, ix->sh_yn_max, ix->sh_bias_max, ix->sbias, ix->sh_kshift, ix->sh_q8,
+                    ix->cert_words, ix->ex_key, ix->ex_id, ix->rows8, ix->sscale, ix->serr, ix->shadow_err_max, ix->sh_aff, ix->sh_aff_sums, ix->sh_yn_max, ix->sh_bias_max, ix->sbias, ix->sh_kshift, ix->sh_unfin, ix->sh_q8,
                     ix->sh_sq, ix->sh_slots, ix->sh_ovf, ix->sh_cand, ix->sh_ccnt, ix->sh_pkey, ix->sh_pid, ix->ex_done};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

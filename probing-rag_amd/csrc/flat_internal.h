@@ -287,6 +287,7 @@ struct ShadowPrep {
     int centre_query;        // 1: the int8 terms approximate (q - mu) c (<= 128-query scans, rows carry sbias_i);
                              // 0: q c (int8 tiles of the > 128-query scans)
     double* kshift;          // [Bpad] out: K_q = alpha q.mu
+    uint32_t* unfinished;    // zeroed here: queries the bound kernel leaves to the gather
     // sample for the pre-bound (sample_stride == 0: none, the slots of the pre-epoch stay +inf)
     const signed char* rows8;
     const float* sscale;
@@ -547,6 +548,8 @@ struct ShadowSearch {
     const double* kshift = nullptr;   // [Bpad] K_q of every query (prep_queries_kernel) or null
     hipEvent_t scan_done = nullptr;   // recorded behind the scan of the last query tile (prag_index_stream_wait_scan)
     struct TailGate* tail = nullptr;  // a gate launch to carry beside the bound kernel of the last query tile (tail_gate.h)
+    uint32_t* unfinished = nullptr;   // device word: queries the bound kernel left to the gather (zeroed by the prep kernel)
+    bool skip_gather = false;         // no sliced gather behind the bound kernel (recent searches never needed one)
     bool exact_bound = false;   // lower g_tau to an exact k-th best before the gather (shadow_bound_kernel)
     int64_t quad_min_rows = (int64_t)8 << 20;   // shards from this size on scan with the quad-test epilogue (flat_shadow.hip)
 };

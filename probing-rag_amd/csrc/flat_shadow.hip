@@ -1049,6 +1049,8 @@ struct GatherArgs {
     CertArgs cert;          // flag list for the exact fallback
     int dbg;                // timing experiments only (PRAG_SHADOW_DBG bits 32 / 64 / 128; results are WRONG)
     const double* kshift;   // [B] K_q = alpha q.mu: exact key - K_q is the scan's key space (null: 0)
+    uint32_t* unfinished;   // one word: queries the bound kernel left to the sliced gather (statistics for the host)
+    int no_gather;          // 1: no gather follows this launch - a query the bound kernel cannot finish is flagged
 };
 
 // Exact float64 score of one stored row against the staged query: 16 lanes per row (sub = lane & 15), every lane of
@@ -1265,7 +1267,15 @@ __device__ __forceinline__ void shadow_bound_body(const GatherArgs& a, uint32_t*
     const int n_fin = 32 + s_n;
     // finish here only when it is certain and small: no overflowed region, at most kShFinish survivors (fewer than k
     // is fine: the scan excluded every other row for good - the padding below is what the gather's merge writes)
-    if (s_over || n_fin > kShFinish) return;
+    if (s_over || n_fin > kShFinish) {
+        // left to the sliced gather - or, when the host enqueued none (it does not while recent searches never needed
+        // it: shadow_search), to the retry tier / exact scan through the flag list
+        if (tid == 0) {
+            if (a.unfinished) atomicAdd(a.unfinished, 1u);
+            if (a.no_gather && atomicExch(a.ovf + b, 1u) == 0u) cert_flag(a.cert, b);
+        }
+        return;
+    }
     for (int i0 = 32; i0 < n_fin; i0 += 32) {
         const int ci = i0 + w * 4 + slot;
         const bool have = ci < n_fin;
@@ -1720,6 +1730,9 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         g.cert.gate = s.gate;
         g.dbg = a.dbg;
         g.kshift = s.kshift;
+        g.unfinished = s.unfinished;
+        const bool skip_gather = s.exact_bound && s.skip_gather;
+        g.no_gather = skip_gather ? 1 : 0;
         if (s.exact_bound) {     // (k <= 32: the kernel scores 32 rows)
             TailGate* tg = s.tail && !s.tail->taken && p0 + QT >= Bpad ? s.tail : nullptr;
             if (tg) {            // the gate of the next batch in the same launch (bound_gate_kernel)
@@ -1734,11 +1747,13 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
                 PRAG_LAUNCH_CHECK();
             }
         }
-        if (s.store.store_f32)
-            hipLaunchKernelGGL(shadow_gather_kernel<true>, dim3(nsplit, nq), dim3(kShThreads), 0, st, g);
-        else
-            hipLaunchKernelGGL(shadow_gather_kernel<false>, dim3(nsplit, nq), dim3(kShThreads), 0, st, g);
-        PRAG_LAUNCH_CHECK();
+        if (!skip_gather) {
+            if (s.store.store_f32)
+                hipLaunchKernelGGL(shadow_gather_kernel<true>, dim3(nsplit, nq), dim3(kShThreads), 0, st, g);
+            else
+                hipLaunchKernelGGL(shadow_gather_kernel<false>, dim3(nsplit, nq), dim3(kShThreads), 0, st, g);
+            PRAG_LAUNCH_CHECK();
+        }
     }
     return PRAG_OK;
 }

@@ -1106,6 +1106,10 @@ struct prag_prober {
     char* dec_dev = nullptr;            // device staging for batches beyond kDecideDirect
     int dec_cap = 0;
     int dec_spin = 1;                   // PRAG_DECIDE_SPIN=0 at creation: always hipStreamSynchronize
+    // tickets of the gate folded into prober16_body: one word per row tile, zero between launches
+    uint32_t* tile_cnt = nullptr;
+    int tile_cnt_cap = 0;
+    int gate_fold = 1;                  // PRAG_GATE_FOLD=0 at creation: gate_kernel as a launch of its own (A/B)
 };
 constexpr int kDecideDirect = 256;
 
@@ -1245,6 +1249,7 @@ extern "C" int prag_prober_create(prag_prober_t** out, int n_layers, int d_model
     if (const char* ev = getenv("PRAG_PROBER_CT")) p->ct_force = atoi(ev);
     if (const char* ev = getenv("PRAG_PROBER_SHAPE")) p->shape16 = atoi(ev) != 32;
     if (const char* ev = getenv("PRAG_DECIDE_SPIN")) p->dec_spin = atoi(ev) != 0;
+    if (const char* ev = getenv("PRAG_GATE_FOLD")) p->gate_fold = atoi(ev) != 0;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -1450,9 +1455,15 @@ extern "C" int prag_prober_effective_weights(prag_prober_t* p, int li, float* W1
     return PRAG_OK;
 }
 
+static int ensure_tile_cnt(prag_prober* p, int B);
+
 extern "C" int prag_prober_reserve(prag_prober_t* p, int max_B) {
     PRAG_REQUIRE(p != nullptr, PRAG_EINVAL, "prober handle is NULL");
     PRAG_REQUIRE(max_B >= 1, PRAG_EINVAL, "max_B=%d", max_B);
+    {
+        const int rc_t = ensure_tile_cnt(p, max_B);      // tickets of the folded gate
+        if (rc_t != PRAG_OK) return rc_t;
+    }
     const int64_t rows = (int64_t)p->n_layers * max_B;
     if (rows <= p->ws_rows) return PRAG_OK;
     if (p->ws_h) (void)hipFree(p->ws_h);
@@ -1462,6 +1473,20 @@ extern "C" int prag_prober_reserve(prag_prober_t* p, int max_B) {
     PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&p->ws_h), (size_t)rows * p->d * sizeof(_Float16)));
     PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&p->ws_l), (size_t)rows * p->d * sizeof(_Float16)));
     p->ws_rows = rows;
+    return PRAG_OK;
+}
+
+// tickets for the folded gate: one word per 32-row tile of the largest batch seen (grown outside any capture: a
+// first call of a larger batch allocates, like every workspace of the handle)
+static int ensure_tile_cnt(prag_prober* p, int B) {
+    const int need = (B + 31) / 32 + 8;
+    if (need <= p->tile_cnt_cap) return PRAG_OK;
+    if (p->tile_cnt) (void)hipFree(p->tile_cnt);
+    p->tile_cnt = nullptr;
+    p->tile_cnt_cap = 0;
+    PRAG_HIP(hipMalloc(reinterpret_cast<void**>(&p->tile_cnt), (size_t)need * sizeof(uint32_t)));
+    PRAG_HIP(hipMemset(p->tile_cnt, 0, (size_t)need * sizeof(uint32_t)));
+    p->tile_cnt_cap = need;
     return PRAG_OK;
 }
 
@@ -1597,7 +1622,22 @@ static int forward_impl(prag_prober_t* p, const void* x_dev, int x_dtype, int64_
     // through round 3: slower, and 132 B of scratch per lane; removed)
     // fp16 weights x fp16 activations (the throughput mode): 16 x 16 MFMA tiles (prober16.hip) at every tile height;
     // PRAG_PROBER_SHAPE=32 keeps the 32 x 32 kernel for A/B timing
-    if (p->na == 1 && nb == 1 && p->shape16) return prober16_launch(a, n_run, 32 * ct, st, p->prof);
+    if (p->na == 1 && nb == 1 && p->shape16) {
+        // the gate folded into the launch when the whole ensemble runs (prag_gate): one launch less per decision batch
+        if (gate && gate_done && p->gate_fold && layer0 == 0 && n_run == p->n_layers && gate->decision) {
+            const int rc_t = ensure_tile_cnt(p, B);
+            if (rc_t != PRAG_OK) return rc_t;
+            a.probsum = gate->probsum;
+            a.decision = gate->decision;
+            a.tile_cnt = p->tile_cnt;
+            a.ablation = gate->ablation;
+            a.theta = gate->theta;
+            const int rc_l = prober16_launch(a, n_run, 32 * ct, st, p->prof);
+            if (rc_l == PRAG_OK) *gate_done = true;
+            return rc_l;
+        }
+        return prober16_launch(a, n_run, 32 * ct, st, p->prof);
+    }
     if (p->na == 1 && nb == 1 && ct == 4) return launch_fused<1, 1, 4, 8>(a, n_run, st, p->prof);
     PRAG_DISPATCH(1, 1)
     PRAG_DISPATCH(1, 2)
@@ -1611,8 +1651,9 @@ static int forward_impl(prag_prober_t* p, const void* x_dev, int x_dtype, int64_
 // prag_gate's prober launch as data (tail_gate.h): only the throughput shape - fp16 activations, fp16 weights, the
 // 16 x 16 kernel, more rows than the small-batch path takes
 bool prag::prober_describe_tail(prag_prober* p, const void* x_dev, int x_dtype, int64_t x_layer_stride, int B, float* logits_dev,
-                                TailGate* out) {
+                                int ablation, double theta, float* probsum_dev, int32_t* decision_dev, TailGate* out) {
     if (!p || !x_dev || !logits_dev || !out || B < 1 || x_dtype != PRAG_F16 || p->na != 1 || !p->shape16) return false;
+    if (ablation < 0 || ablation > p->n_layers) return false;
     for (int l = 0; l < p->n_layers; ++l)
         if (!p->loaded[l]) return false;
     if (p->small_mode && small_supported(B, p->d) && B <= (p->na == 2 ? 4 : 2)) return false;
@@ -1634,6 +1675,15 @@ bool prag::prober_describe_tail(prag_prober* p, const void* x_dev, int x_dtype, 
     t.n_wg = 8 * ((t.pa.n_tiles * p->n_layers + 7) / 8);
     t.lds_bytes = prober16_lds_bytes(t.ct16);
     t.taken = false;
+    t.gate_folded = false;
+    if (p->gate_fold && decision_dev && ensure_tile_cnt(p, B) == PRAG_OK) {     // the gate rides along too
+        t.pa.probsum = probsum_dev;
+        t.pa.decision = decision_dev;
+        t.pa.tile_cnt = p->tile_cnt;
+        t.pa.ablation = ablation;
+        t.pa.theta = theta;
+        t.gate_folded = true;
+    }
     *out = t;
     return t.lds_bytes > 0;
 }
@@ -1754,6 +1804,7 @@ extern "C" void prag_prober_destroy(prag_prober_t* p) {
     if (p->small_sync) (void)hipFree(p->small_sync);
     if (p->ws_h) (void)hipFree(p->ws_h);
     if (p->ws_l) (void)hipFree(p->ws_l);
+    if (p->tile_cnt) (void)hipFree(p->tile_cnt);
     if (p->dec_logits) (void)hipFree(p->dec_logits);
     if (p->dec_host) (void)hipHostFree(p->dec_host);
     if (p->dec_dev) (void)hipFree(p->dec_dev);

@@ -43,6 +43,14 @@ struct ProberArgs {
     int n_tiles;    // row tiles per layer (set by the launcher)
     int n_run;      // layers in this launch
     float* logits;  // [n_run][B][2]
+    // gate folded into the launch (prober16_body; decision == nullptr: logits only).  The LAST of the n_run workgroups
+    // of a row tile to publish its logits - a ticket per tile in tile_cnt, which it hands back at zero - runs
+    // exp_rag.py:407-415 for the tile's rows: gate_kernel's arithmetic, in gate_kernel's order.
+    float* probsum = nullptr;       // [B][2] or null
+    int32_t* decision = nullptr;    // [B]
+    uint32_t* tile_cnt = nullptr;   // [n_tiles] zero between launches
+    int ablation = 0;
+    double theta = 0.0;
 #ifdef PRAG_MM_DIAG
     int stamps;     // 1: phase stamps of three workgroups
     int ablate;     // PRAG_PROBER_ABLATE, timing only (WRONG results): bit 0 no epilogue-1 arithmetic, bit 1 no

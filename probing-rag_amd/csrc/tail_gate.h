@@ -16,11 +16,12 @@ struct TailGate {
     int n_wg = 0;        // workgroups of the launch (8 * ceil(n_tiles * n_run / 8))
     int lds_bytes = 0;   // p16_lds_bytes<ct16>()
     bool taken = false;  // set by whoever launched it
+    bool gate_folded = false;   // pa carries the gate's outputs: the launch also does exp_rag.py:407-415
 };
 
 // prober.hip: describe the prober launch of prag_gate(p, x, ...) - false when that call would not run prober16_kernel
 // (small batches, float32 activations or weights, the 32 x 32 shape): the caller then runs prag_gate as usual.
 bool prober_describe_tail(prag_prober* p, const void* x_dev, int x_dtype, int64_t x_layer_stride, int B, float* logits_dev,
-                          TailGate* out);
+                          int ablation, double theta, float* probsum_dev, int32_t* decision_dev, TailGate* out);
 
 }  // namespace prag

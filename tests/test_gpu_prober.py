@@ -474,3 +474,40 @@ def test_decide_returns_the_gate_decisions_in_host_memory(torch_cuda, golden, mo
         d1 = ens.decide(x[:, :1].contiguous(), 0, 0.0)
         assert np.array_equal(d1, ens.gate(x[:, :1].contiguous(), 0, 0.0)[2].cpu().numpy())
         ens.close()
+
+
+@pytest.mark.parametrize("B", [40, 129, 512, 1400])
+def test_gate_folded_into_the_prober_launch_equals_gate_kernel(torch_cuda, monkeypatch, B):
+    """Round 5: the last of the six workgroups of a row tile runs exp_rag.py:407-415 for the tile's rows inside
+    prober16_kernel (a ticket per tile; one launch less per batch of decisions).  Same arithmetic, same order as
+    gate_kernel: logits, sums and decisions are IDENTICAL to the two-launch form (PRAG_GATE_FOLD=0), for every ablation,
+    call after call (the tickets return to zero inside the launch) and replayed from a captured graph."""
+    torch = torch_cuda
+    case = dict(cases.PROBER_CASES[1], B=B)
+    x = torch.from_numpy(cases.synth_x(case["xseed"], case["L"], B, case["d"], 1.0)).cuda().half()
+    monkeypatch.setenv("PRAG_GATE_FOLD", "0")
+    ens0, _ = _ensemble(case, "f16")
+    monkeypatch.delenv("PRAG_GATE_FOLD")
+    ens1, _ = _ensemble(case, "f16")
+    for ab, th in ((0, 0.0), (3, -0.5), (5, 1.0), (6, 0.0)):
+        want = [t.cpu().numpy() for t in ens0.gate(x, ab, th)]
+        for _ in range(3):
+            got = [t.cpu().numpy() for t in ens1.gate(x, ab, th)]
+            for g, w_ in zip(got, want):
+                assert np.array_equal(g, w_), (ab, th)
+    out = tuple(torch.empty_like(t) for t in ens1.gate(x, 1, 0.25))
+    want = [t.clone() for t in ens0.gate(x, 1, 0.25)]
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ens1.gate(x, 1, 0.25, out=out)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            ens1.gate(x, 1, 0.25, out=out)
+    for _ in range(3):
+        for t in out:
+            t.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(out, want))

@@ -492,3 +492,40 @@ def test_search_and_gate_equals_the_two_calls(store):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(out[1], I0) and all(torch.equal(a, b) for a, b in zip(gout, want))
+
+
+def test_gather_launch_is_skipped_only_while_nothing_needs_it(monkeypatch):
+    """Round 5: behind the exact-bound kernel the sliced gather is ~9 us of nothing when the bound kernel finished every
+    query; after 16 such searches the launch is dropped.  A query the bound kernel then cannot finish - here 400 copies of
+    one row tie under its bound, more than the 256 it scores itself - goes through the flag list (retry tier / exact
+    scan) and re-arms the gather: the results are the definition's before, during and after."""
+    import torch
+    import probing_rag_amd as pra
+    monkeypatch.setenv("PRAG_SHADOW_BOUND", "1")
+    N, d, k = 120_000, 768, 10
+    X = onp.synth_rows(42, 0, N, d)
+    rng = np.random.default_rng(3)
+    where = rng.choice(N, 400, replace=False)
+    X[where] = X[where[0]]
+    ix = pra.HipFlatIndex(d, "cos", "f16", capacity=N)
+    ix.set_shadow(2)
+    ix.add(X)
+    stored = ix.reconstruct_n(0, N)
+    q = torch.from_numpy(onp.synth_rows(7, 0, 64, d)).cuda()
+    D0, I0 = oracle_c.flat_search(stored, q.cpu().numpy(), k, onp.METRIC_COS)
+    for _ in range(24):                              # clean searches: the gather is disarmed on the way
+        D, I = ix.search(q, k)
+        torch.cuda.synchronize()
+    _check(D.cpu().numpy(), I.cpu().numpy(), D0, I0, onp.METRIC_COS)
+    assert ix.last_exact_fallbacks() == 0
+    qh = q.clone()
+    qh[5] = torch.from_numpy(X[where[0]]).cuda()      # 400 exact ties at the top of this query
+    Dh0, Ih0 = oracle_c.flat_search(stored, qh.cpu().numpy(), k, onp.METRIC_COS)
+    for _ in range(4):                               # the first one meets a skipped gather, the next ones an armed one
+        D, I = ix.search(qh, k)
+        torch.cuda.synchronize()
+        _check(D.cpu().numpy(), I.cpu().numpy(), Dh0, Ih0, onp.METRIC_COS)
+    assert sorted(I[5].tolist()) == sorted(np.sort(where)[:k].tolist())      # ties -> lowest ids
+    D, I = ix.search(q, k)
+    _check(D.cpu().numpy(), I.cpu().numpy(), D0, I0, onp.METRIC_COS)
+    ix.close()
