@@ -3230,11 +3230,14 @@ static int search_finish(SearchRun& r, float* D, int64_t* I) {
     if (io_is_device) {
         ix->last_flagged = -1;
         const bool retry_now = retry_shape && (ix->retry_armed || ix->retry_mode == 1);
+        bool recorded_now = false;
         if (retry_shape) {      // statistics for the next search's decision; never waited for, nothing while capturing
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
-            ix->r2_pending = false;
-            if (!capturing) {
+            // (a record still on its way is not overwritten: a caller that enqueues passes faster than the device runs
+            //  them would never see one arrive - the next record is made once this one has been looked at)
+            if (!capturing && !ix->r2_pending) {
+                recorded_now = true;
                 if (!ix->r2_word_host) {
                     PRAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->r2_word_host), 4 * sizeof(uint32_t)));
                     memset(ix->r2_word_host, 0, 4 * sizeof(uint32_t));
@@ -3252,7 +3255,7 @@ static int search_finish(SearchRun& r, float* D, int64_t* I) {
         if (retry_now) {
             const int rc = retry_tier(ix, q_dev, B, k, id_offset, D_dev, I_dev, stream, tag_ids, flag_word);
             if (rc != PRAG_OK) return rc;
-            if (ix->r2_pending) {       // (not capturing) the tier's own outcome travels back with the flag count
+            if (recorded_now) {         // (not capturing) the tier's own outcome travels back with the flag count
                 PRAG_HIP(hipMemcpyAsync(ix->r2_word_host + 1, ix->r2_word + 1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                 PRAG_HIP(hipEventRecord(ix->r2_event, st));
             }

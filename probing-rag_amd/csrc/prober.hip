@@ -1109,7 +1109,11 @@ struct prag_prober {
     // tickets of the gate folded into prober16_body: one word per row tile, zero between launches
     uint32_t* tile_cnt = nullptr;
     int tile_cnt_cap = 0;
-    int gate_fold = 1;                  // PRAG_GATE_FOLD=0 at creation: gate_kernel as a launch of its own (A/B)
+    // PRAG_GATE_FOLD=1 at creation: the gate inside the prober launch.  Built, bit-identical, and SLOWER as it stands
+    // (profiles/r05i_shard_ab.txt: the launch that carries the 512-row gate 37.5 -> 57.8 us, pass 0.443 -> 0.460 ms): the
+    // hand-off costs every workgroup a device-scope fence (an L2 write-back on this chip) and the last arriver twelve
+    // dependent loads from beyond its L2 per row, where gate_kernel's launch costs ~9 us.  Off by default.
+    int gate_fold = 0;
 };
 constexpr int kDecideDirect = 256;
 
