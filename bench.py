@@ -74,8 +74,11 @@ def parse(argv=None):
     ap.add_argument("--shadow", type=int, default=1,
                     help="1: two-level exact search through the 8-bit shadow of the rows (prag_index_set_shadow); "
                          "0: scan the stored rows themselves")
-    ap.add_argument("--overlap-gate", type=int, default=2,
-                    help="2 (default): the gate of the NEXT batch on a second stream that waits for the search's corpus "
+    ap.add_argument("--overlap-gate", type=int, default=3,
+                    help="3 (default): one C call per pass and rank (prag_search_and_gate): the gate of the NEXT batch rides "
+                         "in the launch of the local search's bound kernel - what follows the corpus scan occupies a "
+                         "quarter of the chip (8-GPU shard size: 0.437 -> 0.415-0.418 ms per pass, 21 M rows 2.742 -> 2.696, "
+                         "profiles/r05j_*); 2: the gate of the NEXT batch on a second stream that waits for the search's corpus "
                          "scan only (prag_index_stream_wait_scan): it runs beside the search's tail - bound kernel, exact "
                          "rerank, fallback probes - measured 0.459 -> 0.454 ms per pass at the 8-GPU shard size, 0.420 "
                          "with the sampled pre-bound (profiles/r05c_shard_ab.txt); 0: one stream; 1: the gate on a second "
@@ -763,9 +766,10 @@ def main(argv=None):
         if not args.overlap_gate:
             ens.gate(x, 0, 0.0, out=gate_out)
             return index.search(q, args.k)
-        if args.overlap_gate == 3 and world == 1:
-            # one C call: the gate's prober workgroups in the launch of the search's bound kernel (prag_search_and_gate)
-            out, _ = pra.search_and_gate(local, q, args.k, ens, x, 0, 0.0, gate_out=gate_out)
+        if args.overlap_gate == 3:
+            # one C call per rank: the gate's prober workgroups in the launch of the local search's bound kernel
+            # (prag_search_and_gate), then the exchange
+            out, _ = index.search_and_gate(q, args.k, ens, x, 0, 0.0, gate_out=gate_out)
             return out
         if args.overlap_gate >= 2:
             # the search first; the gate (independent work: the decisions of the NEXT batch of generations) starts on
@@ -950,7 +954,7 @@ def main(argv=None):
                    "docs_total": args.docs, "docs_per_gpu": n_local, "d_emb": d_emb, "queries": args.queries,
                    "k": args.k, "gate_batch": args.gate_batch, "gate_batch_per_gpu": Bg, "d_model": d_model,
                    "parallelism": f"corpus rows sharded x{world}; gate rows split x{world}",
-                   "gate_overlap": {0: "none (one stream)", 1: "beside the scan", 2: "beside the search's tail (second stream waits for the scan only)", 3: "in the launch of the search's bound kernel (prag_search_and_gate; N > 1: as 2)"}[args.overlap_gate],
+                   "gate_overlap": {0: "none (one stream)", 1: "beside the scan", 2: "beside the search's tail (second stream waits for the scan only)", 3: "in the launch of the search's bound kernel (prag_search_and_gate)"}[args.overlap_gate],
                    "two_level_shadow": scan_kernel == "scan8_kernel"},
         "probe_decisions_per_s": args.gate_batch / (gate_avg_ms * 1e-3) if gate_ms else None,
         "scores_per_s_per_gpu": value / world,

@@ -339,10 +339,12 @@ int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out);
  * in flight.  Arguments = those of prag_index_search (device i/o) followed by those of prag_gate.  When the search is
  * a two-level search the prober's workgroups are carried by the launch of the search's bound kernel - what follows the
  * scan leaves 3/4 of the chip idle - otherwise the call equals prag_index_search followed by prag_gate.  Results are
- * those of the two calls in every case; Bg = 0 skips the gate. */
+ * those of the two calls in every case; Bg = 0 skips the gate.  flags bit 0: ids in the exchange format of
+ * prag_index_search_tagged (a row shard of a sharded index: the caller all-gathers and merges). */
 int prag_search_and_gate(prag_index_t* ix, const float* q_dev, int B, int k, int64_t id_offset, float* D_dev, int64_t* I_dev,
                          prag_prober_t* p, const void* x_dev, int x_dtype, int64_t x_layer_stride, int Bg, int ablation,
-                         double theta, float* logits_dev, float* probsum_dev, int32_t* decision_dev, void* stream);
+                         double theta, float* logits_dev, float* probsum_dev, int32_t* decision_dev, int flags,
+                         void* stream);
 
 /* Pipelining hook: make `other_stream` wait until the CORPUS SCAN of the most recent search enqueued on this handle
  * has finished - not the whole search.  What follows the scan (the exact bound / rerank of the survivors, the fallback

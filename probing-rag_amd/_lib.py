@@ -96,7 +96,7 @@ SIGNATURES = {
     "prag_plan_search": (_I, [_I, _I, _I, _L, _I, _I, _I, _I, ctypes.c_char_p, _I]),
     "prag_index_last_plan": (_I, [_P, ctypes.c_char_p, _I]),
     "prag_index_last_fallbacks": (_I, [_P, _P, ctypes.POINTER(_I)]),
-    "prag_search_and_gate": (_I, [_P, _P, _I, _I, _L, _P, _P, _P, _P, _I, _L, _I, _I, ctypes.c_double, _P, _P, _P, _P]),
+    "prag_search_and_gate": (_I, [_P, _P, _I, _I, _L, _P, _P, _P, _P, _I, _L, _I, _I, ctypes.c_double, _P, _P, _P, _I, _P]),
     "prag_index_stream_wait_scan": (_I, [_P, _P]),
     "prag_index_last_survivors": (_I, [_P, _P, ctypes.POINTER(_L), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "prag_index_last_tiled8": (_I, [_P, ctypes.POINTER(_I)]),

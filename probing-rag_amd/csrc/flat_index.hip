@@ -3503,14 +3503,17 @@ extern "C" int prag_index_set_scan_workgroups(prag_index_t* ix, int n_workgroups
 extern "C" int prag_search_and_gate(prag_index_t* ix, const float* q_dev, int B, int k, int64_t id_offset, float* D_dev,
                                     int64_t* I_dev, prag_prober_t* p, const void* x_dev, int x_dtype, int64_t x_layer_stride,
                                     int Bg, int ablation, double theta, float* logits_dev, float* probsum_dev,
-                                    int32_t* decision_dev, void* stream) {
+                                    int32_t* decision_dev, int flags, void* stream) {
     PRAG_REQUIRE(ix != nullptr && p != nullptr, PRAG_EINVAL, "prag_search_and_gate: NULL handle");
+    const int tag_ids = flags & 1;
+    PRAG_REQUIRE(!tag_ids || (id_offset >= 0 && id_offset + ix->ntotal < (1ll << kTagShift)), PRAG_EUNSUPPORTED,
+                 "tagged ids hold %d-bit global row ids", kTagShift);
     PRAG_REQUIRE(logits_dev && probsum_dev && decision_dev, PRAG_EINVAL, "prag_search_and_gate: NULL gate output");
     TailGate tg;
     const bool have = Bg >= 1 && prober_describe_tail(p, x_dev, x_dtype, x_layer_stride, Bg, logits_dev, ablation, theta,
                                                       probsum_dev, decision_dev, &tg);
     ix->tail = have ? &tg : nullptr;
-    const int rc = index_search_impl(ix, q_dev, B, k, id_offset, D_dev, I_dev, 1, stream, 0);
+    const int rc = index_search_impl(ix, q_dev, B, k, id_offset, D_dev, I_dev, 1, stream, tag_ids);
     ix->tail = nullptr;
     if (rc != PRAG_OK) return rc;
     if (Bg < 1) return PRAG_OK;

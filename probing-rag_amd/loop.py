@@ -248,13 +248,13 @@ def masked_mean_pool(hidden, attention_mask):
 
 
 def search_and_gate(index, q, k: int, ens, x, ablation: int = 0, threshold: float = 0.0, out=None, gate_out=None,
-                    id_offset: int = 0):
+                    id_offset: int = 0, tagged: bool = False):
     """One pass of the hot path as one C call (``prag_search_and_gate``): ``index.search(q, k)`` (utils.py:379) AND
     ``ens.gate(x, ablation, threshold)`` over the NEXT batch of pooled states (exp_rag.py:406-415) - independent work
     of a loop that keeps batches in flight.  On a two-level search the gate's prober workgroups ride in the launch of the
     search's bound kernel (the search's tail leaves 3/4 of the chip idle); otherwise it is the two calls in a row.
     Same results either way.  q [B,d] and x [L,Bg,d_model] are CUDA tensors; returns ((D, I), (logits, probsum,
-    decision))."""
+    decision)).  ``tagged``: ids in the exchange format of a row-sharded search (``ShardedFlatIndex.search_and_gate``)."""
     import torch
     _lib.require_gpu()
     if not (isinstance(q, torch.Tensor) and q.is_cuda):
@@ -277,7 +277,7 @@ def search_and_gate(index, q, k: int, ens, x, ablation: int = 0, threshold: floa
             index._h, ctypes.c_void_p(q.data_ptr()), B, k, int(id_offset), ctypes.c_void_p(out[0].data_ptr()),
             ctypes.c_void_p(out[1].data_ptr()), ens._h, ctypes.c_void_p(x.data_ptr()), _x_dtype(x), Bg * ens.d_model, Bg,
             int(ablation), float(threshold), ctypes.c_void_p(gate_out[0].data_ptr()), ctypes.c_void_p(gate_out[1].data_ptr()),
-            ctypes.c_void_p(gate_out[2].data_ptr()), _lib.current_stream_ptr(q.device)))
+            ctypes.c_void_p(gate_out[2].data_ptr()), 1 if tagged else 0, _lib.current_stream_ptr(q.device)))
     return out, gate_out
 
 

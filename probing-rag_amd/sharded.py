@@ -69,10 +69,18 @@ class HipEngine:
         """Local search straight into this rank's slot-sized packed buffer (D then I).  The buffers of a
         (B, k, world) shape are allocated once and reused: a search allocates nothing (the caller owns
         the results until the next search of the same shape)."""
-        from .index import packed_result_buffer, packed_views
         q = torch.as_tensor(q)
         if not q.is_cuda:
             q = q.to(self.device)
+        buf, D, I, gathered = self.packed_buffers(q, k, world)
+        # ids tagged with the float32 residual of their float64 score: float32 ties ACROSS shards are then broken
+        # by the float64 values in the merge, as an unsharded search breaks them
+        self.index.search(q, k, id_offset=id_offset, out=(D, I), tagged=True)
+        return buf, D, I, gathered
+
+    def packed_buffers(self, q, k, world: int = 1):
+        """(packed send block, its D / I views, the [world, stride] receive block) of a (B, k, world) shape."""
+        from .index import packed_result_buffer, packed_views
         B = q.shape[0]
         key = (B, k, world, q.device)
         ws = self._ws.get(key)
@@ -84,9 +92,6 @@ class HipEngine:
                 self._ws.clear()
             self._ws[key] = ws
         buf, (D, I), gathered = ws
-        # ids tagged with the float32 residual of their float64 score: float32 ties ACROSS shards are then broken
-        # by the float64 values in the merge, as an unsharded search breaks them
-        self.index.search(q, k, id_offset=id_offset, out=(D, I), tagged=True)
         return buf, D, I, gathered
 
     def merge_packed(self, gathered, B, k, metric):
@@ -256,6 +261,32 @@ class ShardedFlatIndex:
         self.dist.all_gather_into_tensor(D_all, D_loc.contiguous(), group=self.group)
         self.dist.all_gather_into_tensor(I_all, I_loc.contiguous(), group=self.group)
         return self.engine.merge(D_all.view(self.world, B, k), I_all.view(self.world, B, k), k, self.metric)
+
+
+def _sharded_search_and_gate(self, q, k: int, ens, x, ablation: int = 0, threshold: float = 0.0, gate_out=None):
+    """``search(q, k)`` AND ``ens.gate(x, ablation, threshold)`` over this rank's slice of the NEXT batch of pooled states
+    (gate rows are split across ranks, replicas only): the gate's prober workgroups ride in the launch of the LOCAL
+    search's bound kernel (``prag_search_and_gate``), then the usual exchange - one all-gather of the packed local
+    top-k, the (score, residual, id) merge.  Returns ((D, I), (logits, probsum, decision))."""
+    from .loop import search_and_gate
+    if not self._synced:
+        raise RuntimeError("ShardedFlatIndex.sync() must run (on every rank) after adding rows")
+    q = torch.as_tensor(q)
+    if not q.is_cuda:
+        q = q.to(self.engine.device)
+    if self.world == 1:
+        return search_and_gate(self.engine.index, q, k, ens, x, ablation, threshold, gate_out=gate_out, id_offset=self.id_offset)
+    if self._comm is not None:          # the exchange in C has no fused form: the search, then the gate
+        out = self.engine.index.search_sharded(q, k, self.id_offset)
+        return out, ens.gate(x, ablation, threshold, out=gate_out)
+    buf, D_loc, I_loc, gathered = self.engine.packed_buffers(q, k, self.world)
+    _, gate_out = search_and_gate(self.engine.index, q, k, ens, x, ablation, threshold, out=(D_loc, I_loc), gate_out=gate_out,
+                                  id_offset=self.id_offset, tagged=True)
+    self.dist.all_gather_into_tensor(gathered, buf, group=self.group)
+    return self.engine.merge_packed(gathered, D_loc.shape[0], k, self.metric), gate_out
+
+
+ShardedFlatIndex.search_and_gate = _sharded_search_and_gate
 
 
 def search_shards_on_one_gpu(shards, q, k: int, metric, packed: bool = True):

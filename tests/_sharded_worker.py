@@ -37,6 +37,26 @@ def main():
         assert torch.equal(D, D0), (rank, metric)
         if metric == "l2":
             assert I[0, :2].tolist() == [7, 150_000]
+    # the pass as one call per rank: the gate over this rank's slice of the next batch rides in the launch of the local
+    # search's bound kernel (prag_search_and_gate, tagged ids), then the same exchange
+    from tests.golden import cases
+    case = cases.PROBER_CASES[1]
+    ens = pra.HipProberEnsemble(case["L"], case["d"], 2, weights="f16")
+    for l in range(case["L"]):
+        ens.load_layer(l, cases.synth_state(case["wseed"] + l, case["d"]))
+    xg = torch.from_numpy(cases.synth_x(case["xseed"] + rank, case["L"], 96, case["d"], 1.0)).cuda().half()
+    ix = pra.ShardedFlatIndex(d, "cos", "f16")
+    lo, hi = pra.partition_rows(N, world, rank)
+    ix.engine.index.set_shadow(2)
+    ix.add_local(X[lo:hi])
+    ix.sync()
+    q64 = torch.from_numpy(Q[:64]).cuda()
+    D1, I1 = ix.search(q64, k)
+    want = [t.clone() for t in ens.gate(xg, 0, 0.0)]
+    (D2, I2), got = ix.search_and_gate(q64, k, ens, xg)
+    assert ix.engine.index.last_plan()["family"] == "scan8_kernel"
+    assert torch.equal(I1, I2) and torch.equal(D1, D2), rank
+    assert all(torch.equal(a, b) for a, b in zip(got, want)), rank
     dist.barrier()
     if rank == 0:
         print("SHARDED_OK")
