@@ -147,6 +147,27 @@ def current_stream_ptr(device=None):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+class _NoCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_CTX = _NoCtx()
+
+
+def on_device(device):
+    """`with on_device(dev):` = `with torch.cuda.device(dev):` when dev is not the current device, nothing otherwise
+    (the context manager costs ~5 us per call: a third of a one-query gate decision)."""
+    import torch
+    idx = device.index if hasattr(device, "index") else int(device)
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_CTX
+    return torch.cuda.device(device)
+
+
 def require_gpu():
     import torch
     if not torch.cuda.is_available():

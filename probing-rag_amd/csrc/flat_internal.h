@@ -261,6 +261,21 @@ int exact_run(const ExactRun& r, hipStream_t st);
 // ---------------------------------------------------------------------------
 // 8-bit shadow, two-level exact search (flat_shadow.hip)
 // ---------------------------------------------------------------------------
+// The 8-bit rows inside a 4-KiB chunk (32 rows x 128 bytes = 32 x 8 pieces of 16 bytes).  Round 5: the pieces are
+// stored in the operand order of v_mfma_i32_32x32x32_i8 - k-step s of the chunk (bytes [32 s, 32 s + 32) of every row)
+// is ONE KiB in which lane l = 32 hh + r of a wave finds bytes [32 s + 16 hh, + 16) of row r at byte 16 l - so the
+// scan's coalesced 16-byte loads ARE the MFMA's A operand: no staging through LDS, no fragment reads of the rows.
+// (-DPRAG_SHADOW_CHUNK_MAJOR: the row-major chunk of rounds 2-4, staged through LDS - kept for same-box A/B runs.)
+#ifdef PRAG_SHADOW_CHUNK_MAJOR
+constexpr bool kShadowFragMajor = false;
+#else
+constexpr bool kShadowFragMajor = true;
+#endif
+// byte offset of 16-byte piece p (0..7) of row r (0..31) inside its chunk
+__host__ __device__ constexpr int shadow_piece_off(int r, int p) {
+    return kShadowFragMajor ? (((p >> 1) * 64 + (p & 1) * 32 + r) << 4) : r * 128 + p * 16;
+}
+
 // Bound slots of the two-level scan, per query: kShadowEpochs epochs x 32 slots filled inside the scan launch
 // (after tiles 1, 2, 4, ..., 256) and one more "epoch" filled BEFORE it by prep_queries_kernel from a sample of
 // the shard (below).
@@ -412,16 +427,20 @@ __device__ __forceinline__ void shadow_prep_wave(const ShadowPrep& p, int b, int
 // near the 0.4 % quantile instead of +inf - no warm-up tiles to visit twice, no flood of early candidates.
 // q8_lds: 1024 bytes of this wave's LDS.
 constexpr int kShadowSampleRing = 4;
+// Lane -> bytes of a chunk: the 16 bytes at 16 lane + 1024 i, i = 0..3.  Fragment-major chunks: piece 2 i + lane / 32
+// of row lane % 32 (a row is shared by lanes l and l ^ 32, one metadata triple per lane); row-major chunks: piece
+// lane % 8 of row 8 i + lane / 8 (a row is shared by 8 lanes, four triples per lane).
+constexpr int kShadowSampleRows = kShadowFragMajor ? 1 : 4;
 struct ShadowSample {        // what a sampling wave requests before it even looks at its query
     i32x4 ring[kShadowSampleRing][4];
-    float rs[4], re[4], rx[4];     // scale, error bound, ||x||^2 of the tile being scored (4 rows per lane group)
+    float rs[kShadowSampleRows], re[kShadowSampleRows], rx[kShadowSampleRows];     // scale, error bound, bias of the row(s) of the tile being scored
 };
 __device__ __forceinline__ void shadow_sample_meta(const ShadowPrep& p, int slice, int j, int lane, ShadowSample& sm) {
     const int jc = j < p.sample_tiles ? j : p.sample_tiles - 1;
     const int64_t tile = ((int64_t)slice * p.sample_tiles + jc) * p.sample_stride;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t row = tile * 32 + 8 * i + (lane >> 3);       // (whole tiles below N only)
+    for (int i = 0; i < kShadowSampleRows; ++i) {
+        const int64_t row = tile * 32 + (kShadowFragMajor ? (lane & 31) : 8 * i + (lane >> 3));       // (whole tiles below N only)
         sm.rs[i] = p.sscale[row];
         sm.re[i] = p.serr[row];
         sm.rx[i] = p.sbias ? p.sbias[row] : 0.f;
@@ -459,32 +478,45 @@ __device__ __forceinline__ void shadow_prebound_wave(const ShadowPrep& p, int b,
     __builtin_amdgcn_wave_barrier();
     shadow_sample_issue(p, d, slice, lane, sm);
     const int nch = d >> 7;
-    const int piece = lane & 7;
+    [[maybe_unused]] const int piece = lane & 7;
     float best = INFINITY;
     // the slice as one stream of 4-KiB chunks (tile-major, chunk-minor), a ring of them in flight
     constexpr int kRing = kShadowSampleRing;
     const int total = p.sample_tiles * nch;
-    int acc[4] = {0, 0, 0, 0};
+    int acc[kShadowSampleRows] = {};
     int ch = 0, j = 0;
     for (int s0 = 0; s0 < total; s0 += kRing) {
 #pragma unroll
         for (int u = 0; u < kRing; ++u) {
             if (s0 + u < total) {
-                const i32x4 qv = *reinterpret_cast<const i32x4*>(q8_lds + ch * 128 + piece * 16);
+                if constexpr (kShadowFragMajor) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i) {
+                        const i32x4 qv = *reinterpret_cast<const i32x4*>(q8_lds + ch * 128 + (2 * i + (lane >> 5)) * 16);
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) acc[i] = __builtin_amdgcn_sdot4(sm.ring[u][i][w], qv[w], acc[i], false);
+                        for (int w = 0; w < 4; ++w) acc[0] = __builtin_amdgcn_sdot4(sm.ring[u][i][w], qv[w], acc[0], false);
+                    }
+                } else {
+                    const i32x4 qv = *reinterpret_cast<const i32x4*>(q8_lds + ch * 128 + piece * 16);
+#pragma unroll
+                    for (int i = 0; i < kShadowSampleRows; ++i)
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) acc[i] = __builtin_amdgcn_sdot4(sm.ring[u][i][w], qv[w], acc[i], false);
+                }
                 const signed char* src = shadow_sample_chunk(p, d, slice, lane, s0 + u + kRing);   // (clamped: a harmless re-read)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sm.ring[u][i] = *reinterpret_cast<const i32x4*>(src + i * 1024);
-                if (++ch == nch) {       // tile finished: 8 lanes share a row
+                if (++ch == nch) {       // tile finished: the lanes that share a row add their parts (exact integers)
                     ch = 0;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < kShadowSampleRows; ++i) {
                         int a = acc[i];
+                        if constexpr (kShadowFragMajor) {
+                            a += __shfl_xor(a, 32, 64);
+                        } else {
 #pragma unroll
-                        for (int o = 1; o < 8; o <<= 1) a += __shfl_xor(a, o, 64);
+                            for (int o = 1; o < 8; o <<= 1) a += __shfl_xor(a, o, 64);
+                        }
                         acc[i] = 0;
                         const float mid = fmaf(c.kscale * sm.rs[i], (float)a, sm.rx[i]);
                         const float eps = fmaf(c.A1, sm.re[i], c.C1);
@@ -506,7 +538,7 @@ struct ShadowStore {
     const void* rows;        // the stored rows (exact scores come from these)
     int store_f32;
     int d;
-    signed char* rows8;      // [cap/32][d/128][32][128]: 8-bit rows, chunk-major inside 32-row tiles
+    signed char* rows8;      // [cap/32][d/128][4 KiB chunk]: 8-bit rows, chunk-major inside 32-row tiles, pieces at shadow_piece_off
     float* sscale;           // [cap] s_i
     float* serr;             // [cap] e_i = ||x_i - s_i x^_i||, rounded up
     uint32_t* err_max;       // float bits of max_i e_i (diagnostic)

@@ -80,7 +80,8 @@ constexpr int kMmLdsCnt = 131072 + 4096;   // [Bpad] survivor counters of this w
 // MODE 0: the launch over the first segment (no bound yet; every row becomes a candidate);
 // MODE 1: inner product / cosine (key = -score); MODE 2: squared L2 (key = ||x||^2 - 2 score).
 // I8: the same pipeline over the 8-bit shadow of the rows (chunk-major inside 32-row tiles: a 128-byte K tile of
-// 32 consecutive rows is one contiguous 4-KiB block) and the first int8 term of the queries, K tiles of 128
+// 32 consecutive rows is one contiguous 4-KiB block, its 16-byte pieces in the MFMA operand order of the two-level
+// scan - copied to LDS verbatim, one contiguous KiB per DMA instruction) and the first int8 term of the queries, K tiles of 128
 // elements on v_mfma_i32_32x32x32_i8 - twice the fp16 rate, exact integer dot products.  The selection key
 //   key = ||x_i||^2 (L2) + kq_b * (s_i * dot)        (two float roundings, the same expression wherever it is formed)
 // is within A1 e_i + C1 of the exact key (flat_internal.h, ShadowQ): the caller keeps a deeper candidate list and
@@ -121,13 +122,17 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
 
     // ---- fragment read offsets: A row = 128*wr + 32*mt + r, B row = 64*wc + 32*nt + r; the
     //      swizzle term (row>>1)&7 only depends on r, k-step ks flips byte bits 5..6 ---------
+    // FM (I8 over fragment-major shadow chunks, flat_internal.h shadow_piece_off): the A buffer holds the 8 shadow
+    // tiles of the 256 rows verbatim - 4 KiB each, k-step s = one KiB in lane order - so a DMA instruction copies one
+    // contiguous KiB and a 32 x 32 fragment read is 16 lane + 1024 s: conflict-free without a swizzle
+    constexpr bool FM = I8 && kShadowFragMajor;
     const int swz = (r >> 1) & 7;
     int a_off[4], b_off[4];
     if constexpr (!S16) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int piece = ((2 * ks + h) ^ swz) << 4;
-            a_off[ks] = (128 * wr + r) * 128 + piece;
+            a_off[ks] = FM ? 16384 * wr + ((ks * 64 + lane) << 4) : (128 * wr + r) * 128 + piece;
             b_off[ks] = 65536 + (64 * wc + r) * 128 + piece;
         }
     } else {
@@ -137,7 +142,8 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int piece = (((4 * (ks & 1) + q4) ^ swz16) << 4);
-            a_off[ks] = (128 * wr + c16) * 128 + piece;          // (only [0] and [1] are used)
+            a_off[ks] = FM ? 16384 * wr + shadow_piece_off(c16, 4 * (ks & 1) + q4)
+                           : (128 * wr + c16) * 128 + piece;          // (only [0] and [1] are used)
             b_off[ks] = 65536 + (64 * wc + c16) * 128 + piece;
         }
     }
@@ -170,7 +176,9 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
         TilePtr p;
         p.row0 = a.row0 + (int64_t)rt * 256;
         p.q0 = qb * 256;
-        if constexpr (I8)   // (row0 is a multiple of 256: the row's place inside its 32-row tile is a_thr & 31)
+        if constexpr (FM)   // wave w: k-step w & 3 of shadow tile w >> 2 of the 256 rows (SA0: +4 tiles; SA1: +2, +6)
+            p.pa = rows_g + ((p.row0 >> 5) + (w >> 2)) * (32 * RB) + (w & 3) * 1024 + le * 16;
+        else if constexpr (I8)   // (row0 is a multiple of 256: the row's place inside its 32-row tile is a_thr & 31)
             p.pa = rows_g + ((p.row0 + a_thr) >> 5) * (32 * RB) + (a_thr & 31) * 128 + colb;
         else
             p.pa = rows_g + (p.row0 + a_thr) * RB + colb;
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void scan_mm_kernel(MmArgs a) {
     // f = 2 * (tile of 16) + (k-step of 32), kept in the same registers
 #define MM_READ_A(base_)                                                                              \
     _Pragma("unroll") for (int f = 0; f < 8; ++f) {                                                   \
-        if constexpr (S16) A[f >> 2][f & 3] = MM_LDSR(a_off[f & 1] + (f >> 1) * 2048 + (base_));      \
+        if constexpr (S16) A[f >> 2][f & 3] = MM_LDSR(a_off[f & 1] + (FM ? (f >> 2) * 4096 + ((f >> 1) & 1) * 256 : (f >> 1) * 2048) + (base_)); \
         else A[f >> 2][f & 3] = MM_LDSR(a_off[f & 3] + (f >> 2) * 4096 + (base_));                    \
     }
 #define MM_READ_B(BF_, base_)                                                                         \

@@ -71,7 +71,8 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 // 16-byte loads (8 lanes of a row cover 256 contiguous bytes of fp16, 512 of float32; every load of the
 // tile is issued before the first use), the row's max |x| and residual norm are 8-lane butterflies (fixed
 // association: the build is bit-reproducible), and the 16 quantised bytes go out as ONE 16-byte store to
-// rows8[tile][chunk][row][16 piece ...] - the workgroup writes each 4-KiB chunk block contiguously.
+// rows8[tile][chunk] + shadow_piece_off(row, piece) (flat_internal.h: the MFMA operand order) - the workgroup writes
+// each 4-KiB chunk block whole, 128 contiguous bytes per 8 lanes.
 // (Round 2 built one wave per row with 2-byte loads and 1-byte stores: 238 ms for 21 M rows, 0.2 TB/s.)
 // ---------------------------------------------------------------------------
 template <bool F32, int NCH>
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void shadow_build_kernel(const void* __restric
     // is off by < 1024 * 2^-24 relatively - covered by the 1e-4 the bound is rounded up by.  (The float64 version
     // made the build float64-issue-bound: 31.5 ms for 21 M x 768 rows.)
     float err2 = 0.f;
-    signed char* out = rows8 + tile * (32 * (int64_t)d) + tid * 16;
+    signed char* out = rows8 + tile * (32 * (int64_t)d) + shadow_piece_off(row_in, piece);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         u32x4 pk;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void shadow_affine_kernel(const double* __rest
 // ---------------------------------------------------------------------------
 struct Scan8Args {
     int kslots;                 // bound slots in use per epoch = k (<= KC): see the slot comment in scan8_kernel
-    const signed char* rows8;   // [N/32][d/128][32][128]: chunk-major inside 32-row tiles
+    const signed char* rows8;   // [N/32][d/128][4 KiB]: chunk-major inside 32-row tiles, pieces at shadow_piece_off
     const float* sscale;        // [roundup(N,32)]
     const float* serr;
     const float* sbias;         // [roundup(N,32)] per-row additive part of the key: alpha mu.(x_i - mu) [+ ||x_i||^2 for L2]
@@ -358,6 +359,17 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
 #define S8_VALUE(i, v) do {} while (0)
 #endif
     constexpr int NQ = QT / 32;
+    // 128-query tiles, epilogue order.  Rounds 3-4: query column outermost, its three constants read from LDS per
+    // column (the row-major order kept 16 constants + the row metadata live beside the staging loop's registers and
+    // spilled).  Without the LDS staging there is room: -DPRAG_S8_Q128_ROW_EPI=1 takes the 64-query tiles' order
+    // (row quad outermost: the quad's metadata is read once, not once per column).
+#ifndef PRAG_S8_IMAX_TEST
+#define PRAG_S8_IMAX_TEST 1     // (0 in A/B builds: the 64-query quad test on converted keys, as in round 4)
+#endif
+#ifndef PRAG_S8_Q128_ROW_EPI
+#define PRAG_S8_Q128_ROW_EPI 0
+#endif
+    constexpr bool COL_EPI = QT == 128 && !PRAG_S8_Q128_ROW_EPI;
     // 32-query tiles carry the query as two int8 terms (the HBM-bound loop has matrix-pipe slack for the
     // second MFMA); 64-query tiles use the first term only and pay with a wider eps (more candidates)
     constexpr int TERMS = QT == 32 ? 2 : 1;
@@ -407,7 +419,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
         }
         __syncthreads();
     }
-    if constexpr (QT == 128) {
+    if constexpr (COL_EPI) {
         if (tid < QT) {
             const ShadowQ sq_ = a.sq[tid];
             s_sqc[3 * tid] = sq_.kscale;
@@ -468,11 +480,11 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     const int n_my = gw < a.n_tiles ? (a.n_tiles - gw + nW - 1) / nW : 0;
 
     KeyList<LISTS ? KC : 1> top[NQ];    // (LISTS false: k[0] = the lane's best key)
-    float kscale[QT == 128 ? 1 : NQ], cA[QT == 128 ? 1 : NQ], cC[QT == 128 ? 1 : NQ];
+    float kscale[COL_EPI ? 1 : NQ], cA[COL_EPI ? 1 : NQ], cC[COL_EPI ? 1 : NQ];
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
         top[t].init();
-        if constexpr (QT != 128) {
+        if constexpr (!COL_EPI) {
             const ShadowQ s = a.sq[32 * t + r];
             kscale[t] = s.kscale;
             cA[t] = TERMS == 2 ? s.A2 : s.A1;
@@ -569,20 +581,35 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
             issue(ldr, tile_nx, c_nx);
             return;
         }
+        if constexpr (!kShadowFragMajor) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(s_st + st_dst[i]) = ldr[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (staged by some lanes, read as fragments by others)
-        __builtin_amdgcn_wave_barrier();
-        issue(ldr, tile_nx, c_nx);
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(s_st + st_dst[i]) = ldr[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (staged by some lanes, read as fragments by others)
+            __builtin_amdgcn_wave_barrier();
+            issue(ldr, tile_nx, c_nx);
+        }
         // query-fragment slot of k-step piece P = 8 c + 2 s + hh in row qrow = 32 t + r:
         //   (P & ~15) | ((P ^ qrow) & 15)  =  (P & ~15) | (((8 c + 2 s) & 15) ^ xq),  xq = (r ^ hh) & 15
         int xq = xq0;
         // (unrolled chunks: hoisted out of the tile loop these offsets would be 4 NCHS registers)
         if constexpr (NCHS > 0) asm volatile("" : "+v"(xq));
-        if (PRAG_SH_DBG(a.dbg) & 2048) return;     // timing only: stream + staging writes, no fragment reads, no MFMAs
+        if (PRAG_SH_DBG(a.dbg) & 2048) {           // timing only: stream + staging writes, no fragment reads, no MFMAs
+            if constexpr (kShadowFragMajor) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ldr[i]));
+                issue(ldr, tile_nx, c_nx);
+            }
+            return;
+        }
+        // fragment-major chunks: the KiB a lane group loaded IS k-step s's A operand; its registers are refilled with
+        // the same KiB of chunk (tile_nx, c_nx) as soon as the step's MFMAs have been issued (they read their
+        // operands at issue)
+        [[maybe_unused]] const char* nx_base = rows + (int64_t)tile_nx * (32 * row_bytes) + c_nx * 4096;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {               // 4 k-steps of 32 elements per 128-byte chunk
-            const i32x4 av = *reinterpret_cast<const i32x4*>(s_st + a_off + (((2 * s + hh) ^ a_sw) << 4));
+            i32x4 av;
+            if constexpr (kShadowFragMajor) av = __builtin_bit_cast(i32x4, ldr[s]);
+            else av = *reinterpret_cast<const i32x4*>(s_st + a_off + (((2 * s + hh) ^ a_sw) << 4));
             const int P0 = c * 8 + 2 * s;           // (bit 0 = hh lives in xq)
             const int q_sw = ((P0 & ~15) | (((P0 & 15) ^ xq))) << 4;
             // the first k-step of a tile starts from the constant 0 (an inline operand of the MFMA): the epilogue does not
@@ -610,6 +637,13 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                         acc2[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b2, acc2[t], 0, 0, 0);
                     }
                 }
+            }
+            if constexpr (kShadowFragMajor) {
+#ifdef PRAG_SCAN_PLAIN_LOADS
+                ldr[s] = *reinterpret_cast<const u32x4*>(nx_base + lane16 + 1024 * s);
+#else
+                ldr[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(nx_base + lane16 + 1024 * s));
+#endif
             }
         }
     };
@@ -664,34 +698,45 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                 }
             };
             float tau[NQ];
-            if constexpr (QT == 128) {
+            if constexpr (COL_EPI) {
                 // query tile outermost, its constants read from LDS: with four query columns per lane the
                 // row-major order below keeps 16 constants and the row metadata live at once and spills
+                // Quad test on the INTEGER accumulators (round 5): with kscale <= 0 (alpha is -1 or -2) and s_e >= 0,
+                //   key_e - eps_e >= rx_min - |kscale| s_max max(acc_0..3, 0) - (A e_max + C)
+                // - every step is monotone in its operands and rounds once, exactly as the per-pair code does, so no pair
+                // the per-pair code would take is skipped (a few more quads are taken).  The three per-quad extremes are
+                // formed once per tile (not per query column), a quad of a column then costs two v_max3_i32, one convert,
+                // one multiply, two fmas, a subtraction and the compare - it was 4 converts, 4 multiplies, 5 fmas, 6 min /
+                // max.  profiles/r05o_scan8_ablation.txt: the epilogue's issue time adds to the stream's, 0.58 ms of a
+                // 3.06 ms scan at 128 queries.
+                float rs_max[4], rx_min[4], re_max[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 rs = *reinterpret_cast<const f32x4*>(s_meta + 8 * g + 4 * hh);
+                    const f32x4 re = *reinterpret_cast<const f32x4*>(s_meta + 32 + 8 * g + 4 * hh);
+                    const f32x4 rx = *reinterpret_cast<const f32x4*>(s_meta + 64 + 8 * g + 4 * hh);
+                    rs_max[g] = fmaxf(fmaxf(rs[0], rs[1]), fmaxf(rs[2], rs[3]));
+                    re_max[g] = fmaxf(fmaxf(re[0], re[1]), fmaxf(re[2], re[3]));
+                    rx_min[g] = fminf(fminf(rx[0], rx[1]), fminf(rx[2], rx[3]));
+                    // (the last, partial tile of a shard: every quad takes the per-pair code, which masks rows past N)
+                    if (!QUAD || doc0 + 32 > a.N) rx_min[g] = -INFINITY;
+                }
 #pragma unroll
                 for (int t = 0; t < NQ; ++t) {
                     tau[t] = unsortable_f32(s_tau[32 * t + r]);
                     const float ks = s_sqc[3 * (32 * t + r)], cA_t = s_sqc[3 * (32 * t + r) + 1], cC_t = s_sqc[3 * (32 * t + r) + 2];
-                    const bool partial128 = doc0 + 32 > a.N;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const f32x4 rs = *reinterpret_cast<const f32x4*>(s_meta + 8 * g + 4 * hh);
-                        const f32x4 re = *reinterpret_cast<const f32x4*>(s_meta + 32 + 8 * g + 4 * hh);
-                        const f32x4 rx = *reinterpret_cast<const f32x4*>(s_meta + 64 + 8 * g + 4 * hh);
-                        if (QUAD && !partial128) {
-                            // the quad test of the 64-query tiles (below).  List-less: a lane's best key + eps per query
-                            // is only refreshed in quads that hold something under the bound - a skipped value is above
-                            // the bound and could not have lowered any slot below it; the stale one stays valid (larger)
-                            const float re_max = fmaxf(fmaxf(re[0], re[1]), fmaxf(re[2], re[3]));
-                            float mid[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) mid[e] = fmaf(ks * rs[e], (float)acc1[t][4 * g + e], rx[e]);
-                            const float m = fminf(fminf(mid[0], mid[1]), fminf(mid[2], mid[3])) - fmaf(cA_t, re_max, cC_t);
-                            if (m <= tau[t]) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    pair(t, 4 * g + e, doc0 + 8 * g + 4 * hh + e, rs[e], re[e], rx[e], ks, cA_t, cC_t, tau[t]);
-                            }
-                        } else {
+                        // (list-less: a lane's best key + eps per query is only refreshed in quads that hold something
+                        //  under the bound - a skipped value is above the bound and could not have lowered any slot
+                        //  below it; the stale one stays valid (larger))
+                        int am = max(max(acc1[t][4 * g], acc1[t][4 * g + 1]), max(acc1[t][4 * g + 2], acc1[t][4 * g + 3]));
+                        am = max(am, 0);
+                        const float m = fmaf(ks * rs_max[g], (float)am, rx_min[g]) - fmaf(cA_t, re_max[g], cC_t);
+                        if (!(m > tau[t])) {       // (also when a NaN got in: the per-pair code decides)
+                            const f32x4 rs = *reinterpret_cast<const f32x4*>(s_meta + 8 * g + 4 * hh);
+                            const f32x4 re = *reinterpret_cast<const f32x4*>(s_meta + 32 + 8 * g + 4 * hh);
+                            const f32x4 rx = *reinterpret_cast<const f32x4*>(s_meta + 64 + 8 * g + 4 * hh);
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
                                 pair(t, 4 * g + e, doc0 + 8 * g + 4 * hh + e, rs[e], re[e], rx[e], ks, cA_t, cC_t, tau[t]);
@@ -722,17 +767,31 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
                         // key - eps (a few more quads take the exact per-pair code, none is missed), and a pair costs
                         // convert, multiply, fma, min instead of two more fmas and a subtraction
                         const float re_max = fmaxf(fmaxf(re[0], re[1]), fmaxf(re[2], re[3]));
+                        // single-term tiles: the test on the integer accumulators (see the 128-query form above)
+                        [[maybe_unused]] const float rs_max = fmaxf(fmaxf(rs[0], rs[1]), fmaxf(rs[2], rs[3]));
+                        [[maybe_unused]] const float rx_min = fminf(fminf(rx[0], rx[1]), fminf(rx[2], rx[3]));
 #pragma unroll
                         for (int t = 0; t < NQ; ++t) {
                             float mid[4], eps[4];
+                            float m;
+                            if constexpr (TERMS == 1 && PRAG_S8_IMAX_TEST) {
+                                int am = max(max(acc1[t][4 * g], acc1[t][4 * g + 1]), max(acc1[t][4 * g + 2], acc1[t][4 * g + 3]));
+                                am = max(am, 0);
+                                m = fmaf(kscale[t] * rs_max, (float)am, rx_min) - fmaf(cA[t], re_max, cC[t]);
+                            } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float dq = (float)acc1[t][4 * g + e];
-                                if constexpr (TERMS == 2) dq = fmaf((float)acc2[t][4 * g + e], 1.0f / 128.0f, dq);
-                                mid[e] = fmaf(kscale[t] * rs[e], dq, rx[e]);          // (key_eps's arithmetic)
+                                for (int e = 0; e < 4; ++e) {
+                                    float dq = (float)acc1[t][4 * g + e];
+                                    if constexpr (TERMS == 2) dq = fmaf((float)acc2[t][4 * g + e], 1.0f / 128.0f, dq);
+                                    mid[e] = fmaf(kscale[t] * rs[e], dq, rx[e]);          // (key_eps's arithmetic)
+                                }
+                                m = fminf(fminf(mid[0], mid[1]), fminf(mid[2], mid[3])) - fmaf(cA[t], re_max, cC[t]);
                             }
-                            const float m = fminf(fminf(mid[0], mid[1]), fminf(mid[2], mid[3])) - fmaf(cA[t], re_max, cC[t]);
                             if (m <= tau[t]) {
+                                if constexpr (TERMS == 1 && PRAG_S8_IMAX_TEST) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) mid[e] = fmaf(kscale[t] * rs[e], (float)acc1[t][4 * g + e], rx[e]);
+                                }
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) eps[e] = fmaf(cA[t], re[e], cC[t]);
 #pragma unroll
@@ -873,12 +932,23 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
             }
         }
     };
+    // the wave that streams and feeds the matrix pipe is served ahead of its SIMD partner's epilogue (same box, 21 M rows:
+    // 128-query tiles 2.886-2.908 -> 2.864-2.878 ms per search, 64-query tiles 2.560 -> 2.550 ms per launch)
+#ifndef PRAG_S8_NO_SETPRIO
+#define S8_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define S8_PRIO(x) do {} while (0)
+#endif
     auto body = [&](u32x4 (&ldr)[4], bool may_end) __attribute__((always_inline)) {      // may_end: a constant at every call site
         const int tile_cur = vtile(vt_cur);
         if (c_cur == 0) load_meta(tile_cur);
         chunk_step(ldr, c_cur, vtile(vt_nx), c_nx);
         advance(vt_nx, c_nx);
-        if (may_end && c_cur == NCH - 1) epilogue(tile_cur, vt_cur >= n_my);
+        if (may_end && c_cur == NCH - 1) {
+            S8_PRIO(0);
+            epilogue(tile_cur, vt_cur >= n_my);
+            S8_PRIO(1);
+        }
         advance(vt_cur, c_cur);
     };
 
@@ -897,20 +967,26 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
             for (int vt = 0; vt < n_my + redo; ++vt) {
                 const int tile_cur = vtile(vt), tile_next = vtile(vt + 1);
                 load_meta(tile_cur);         // NCHS refills older than its use in the epilogue
+                S8_PRIO(1);
 #pragma unroll
                 for (int c = 0; c < NCHS; ++c) {
                     const int cn = c + NLD;  // the chunk this buffer holds next
                     chunk_step(ld[c % NLD], c, cn < NCHS ? tile_cur : tile_next, cn < NCHS ? cn : cn - NCHS);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                S8_PRIO(0);
                 epilogue(tile_cur, vt >= n_my);
             }
         }
     } else if (n_my > 0) {
+        S8_PRIO(1);
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             issue(ld[u], vtile(vt_nx), c_nx);
             advance(vt_nx, c_nx);
+            // in this order (left alone, the compiler requests the LAST set first and the loop then opens every
+            // round of NLD chunks with s_waitcnt vmcnt(0): the waits are counted from the issue order)
+            if constexpr (kShadowFragMajor) __builtin_amdgcn_sched_barrier(0);
         }
         // (`redo` grows during the first tiles only, long before the loop bound is reached - or, on a
         // shard of a few tiles, up to n_my: every tile is then visited twice)
@@ -943,6 +1019,7 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
             }
         }
     }
+    S8_PRIO(0);
     S8_STAMP(11);
     S8_VALUE(13, redo);
     S8_VALUE(14, n_my);
@@ -1652,9 +1729,16 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
         int rc;
         const bool quad16 = (s.d / 128) % kScan8Aln == 0 && s.N >= s.quad_min_rows;
         const bool quad32 = s.N >= s.quad_min_rows;
+#ifndef PRAG_S8_Q128_NLD
+#define PRAG_S8_Q128_NLD 0      // (0: three staging sets for 768-element rows; A/B builds: 6 = a whole tile in flight)
+#endif
+#ifndef PRAG_S8_Q32_ALN
+#define PRAG_S8_Q32_ALN 0       // (0: four sets, run-time chunk loop; A/B builds: 6 with 768-element rows)
+#endif
+        const bool q32_aln = PRAG_S8_Q32_ALN > 0 && s.d == 128 * (PRAG_S8_Q32_ALN > 0 ? PRAG_S8_Q32_ALN : 1);
         if (QT == 128)
-            rc = s.d == 768 ? (s.kc == 8 ? launch_scan8<128, 8, false, 6, 0, true>(a, grid, st, prof)
-                                         : launch_scan8<128, 16, false, 6, 0, true>(a, grid, st, prof))
+            rc = s.d == 768 ? (s.kc == 8 ? launch_scan8<128, 8, false, 6, PRAG_S8_Q128_NLD, true>(a, grid, st, prof)
+                                         : launch_scan8<128, 16, false, 6, PRAG_S8_Q128_NLD, true>(a, grid, st, prof))
                             : (s.kc == 8 ? launch_scan8<128, 8, false, 4, 0, true>(a, grid, st, prof)
                                          : launch_scan8<128, 16, false, 4, 0, true>(a, grid, st, prof));
         else if (QT == 64)
@@ -1664,7 +1748,8 @@ int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof) {
                               : launch_scan8<64, 32>(a, grid, st, prof);
         else
             rc = quad32 ? (s.kc == 8 ? launch_scan8<32, 8, true, 0, 0, true>(a, grid, st, prof)
-                           : s.kc == 16 ? launch_scan8<32, 16, true, 0, 0, true>(a, grid, st, prof)
+                           : s.kc == 16 ? (q32_aln ? launch_scan8<32, 16, true, 0, PRAG_S8_Q32_ALN, true>(a, grid, st, prof)
+                                                   : launch_scan8<32, 16, true, 0, 0, true>(a, grid, st, prof))
                                         : launch_scan8<32, 32, true, 0, 0, true>(a, grid, st, prof))
                         : (s.kc == 8 ? launch_scan8<32, 8>(a, grid, st, prof)
                            : s.kc == 16 ? launch_scan8<32, 16>(a, grid, st, prof) : launch_scan8<32, 32>(a, grid, st, prof));

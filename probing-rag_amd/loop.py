@@ -16,6 +16,17 @@ import ctypes
 from . import _lib
 
 
+_DT = None
+
+
+def _DTYPES():
+    global _DT
+    if _DT is None:
+        import torch
+        _DT = {torch.float32: _lib.PRAG_F32, torch.float16: _lib.PRAG_F16, torch.bfloat16: _lib.PRAG_BF16}
+    return _DT
+
+
 class HiddenStatePool:
     """acc[l] = sum over all positions of every forward pass after the first.
 
@@ -48,12 +59,12 @@ class HiddenStatePool:
             return
         pend, self._pending = self._pending, {}
         L = len(self.passes)
+        dts = _DTYPES()
         for s_, (a_, _, ver) in pend.items():
             if a_._version != ver:
                 raise RuntimeError(f"HiddenStatePool(defer=True): the activations noted for layer slot {s_} were modified "
                                    "in place before they were pooled; use defer=False with this model")
         items = [(pend[s][0], pend[s][1]) if s in pend else None for s in range(L)]
-        dts = {torch.float32: _lib.PRAG_F32, torch.float16: _lib.PRAG_F16, torch.bfloat16: _lib.PRAG_BF16}
         full = all(it is not None for it in items)
         if full:
             a0, as0 = items[0]
@@ -63,7 +74,7 @@ class HiddenStatePool:
             a0, as0 = items[0]
             n = a0.numel()
             ptrs = (ctypes.c_void_p * L)(*[a.data_ptr() for a, _ in items])
-            with torch.cuda.device(a0.device):
+            with _lib.on_device(a0.device):
                 _lib.check(_lib.lib().prag_pool_accumulate_layers(ctypes.c_void_p(self.acc.data_ptr()), ptrs, L, dts[a0.dtype],
                                                                   n, as0, _lib.current_stream_ptr(a0.device)))
             return

@@ -191,7 +191,7 @@ class HipProberEnsemble:
             buf = self._decide_buf = (np.empty((max(B, 8),), np.int32), np.empty((max(B, 8), 2), np.float32))
         dec, ps = buf
         import torch
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().prag_gate_decide(self._h, x.data_ptr(), _x_dtype(x), B * self.d_model, B, int(ablation),
                                                    float(threshold), dec.ctypes.data,
                                                    ps.ctypes.data if with_probsum else None,

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 5: same-box A/B of up to three builds (libprag.so, libprag_ab.so, libprag_prev.so) on the two-level scan
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
+TAG=${1:-r05q}; export SCAN8_AB_Q=${2:-64,128}
+rm -f $OUT/${TAG}_ab.txt
+for rep in 1 2 3; do
+  for lib in libprag.so libprag_ab.so libprag_prev.so; do
+    [ -f $R/probing-rag_amd/lib/$lib ] || continue
+    PRAG_LIB=$R/probing-rag_amd/lib/$lib timeout 300 python tools/scan8_ab.py 21000000 40 2>&1 | tail -1 >> $OUT/${TAG}_ab.txt
+  done
+done
+cat $OUT/${TAG}_ab.txt
