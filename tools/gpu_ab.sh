@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 5: same-box A/B of up to three builds (libprag.so, libprag_ab.so, libprag_prev.so) on the two-level scan
+# Same-box A/B of up to three builds (libprag.so, libprag_ab.so = `make ab ABFLAGS=...`, libprag_prev.so = a kept copy) on the two-level scan
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
-TAG=${1:-r05q}; export SCAN8_AB_Q=${2:-64,128}
+TAG=${1:-ab}; export SCAN8_AB_Q=${2:-64,128}
 rm -f $OUT/${TAG}_ab.txt
 for rep in 1 2 3; do
   for lib in libprag.so libprag_ab.so libprag_prev.so; do
