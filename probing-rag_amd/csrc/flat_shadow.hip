@@ -480,11 +480,15 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
     const int n_my = gw < a.n_tiles ? (a.n_tiles - gw + nW - 1) / nW : 0;
 
     KeyList<LISTS ? KC : 1> top[NQ];    // (LISTS false: k[0] = the lane's best key)
-    float kscale[COL_EPI ? 1 : NQ], cA[COL_EPI ? 1 : NQ], cC[COL_EPI ? 1 : NQ];
+#ifndef PRAG_S8_Q128_REGCONST
+#define PRAG_S8_Q128_REGCONST 1     // (the 128-query tiles' per-column constants in registers for 768-element rows: 2.98 -> 2.96 ms; 0 in A/B builds)
+#endif
+    constexpr bool REG_CONST = !COL_EPI || (PRAG_S8_Q128_REGCONST && NCHS == 6);
+    float kscale[REG_CONST ? NQ : 1], cA[REG_CONST ? NQ : 1], cC[REG_CONST ? NQ : 1];
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
         top[t].init();
-        if constexpr (!COL_EPI) {
+        if constexpr (REG_CONST) {
             const ShadowQ s = a.sq[32 * t + r];
             kscale[t] = s.kscale;
             cA[t] = TERMS == 2 ? s.A2 : s.A1;
@@ -724,7 +728,12 @@ __global__ __launch_bounds__(512, 1) void scan8_kernel(Scan8Args a) {
 #pragma unroll
                 for (int t = 0; t < NQ; ++t) {
                     tau[t] = unsortable_f32(s_tau[32 * t + r]);
-                    const float ks = s_sqc[3 * (32 * t + r)], cA_t = s_sqc[3 * (32 * t + r) + 1], cC_t = s_sqc[3 * (32 * t + r) + 2];
+                    float ks, cA_t, cC_t;
+                    if constexpr (REG_CONST) {
+                        ks = kscale[t]; cA_t = cA[t]; cC_t = cC[t];
+                    } else {
+                        ks = s_sqc[3 * (32 * t + r)]; cA_t = s_sqc[3 * (32 * t + r) + 1]; cC_t = s_sqc[3 * (32 * t + r) + 2];
+                    }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         // (list-less: a lane's best key + eps per query is only refreshed in quads that hold something
