@@ -74,6 +74,8 @@ def parse(argv=None):
     ap.add_argument("--shadow", type=int, default=1,
                     help="1: two-level exact search through the 8-bit shadow of the rows (prag_index_set_shadow); "
                          "0: scan the stored rows themselves")
+    ap.add_argument("--scan-workgroups", type=int, default=0,
+                    help="workgroups of the corpus scan (0: the library's choice - 7/8 of the CUs for HBM-bound two-level scans)")
     ap.add_argument("--overlap-gate", type=int, default=3,
                     help="3 (default): one C call per pass and rank (prag_search_and_gate): the gate of the NEXT batch rides "
                          "in the launch of the local search's bound kernel - what follows the corpus scan occupies a "
@@ -768,6 +770,8 @@ def main(argv=None):
     n_cu = torch.cuda.get_device_properties(dev_index).multi_processor_count
     if args.overlap_gate == 1:
         local.set_scan_workgroups(n_cu - 16)
+    elif args.scan_workgroups:
+        local.set_scan_workgroups(args.scan_workgroups)
     local.set_shadow(1 if args.shadow else 0)
 
     if args.overlap_gate >= 2:
@@ -897,6 +901,10 @@ def main(argv=None):
     value = scores * passes_total / dt
     # which scan kernel served the pass
     scan_kernel, alg_bytes, launches, tiled = scan_model(local)     # the plan the timed searches executed
+    # --overlap-gate 3: which launch carried the gate's prober workgroups (the scan's own - scan8_gate_kernel - when the
+    # gate fits under the scan on the CUs the scan leaves free, else the bound kernel's)
+    gate_launch = local.last_plan().get("gate_launch")
+    scan_launch_name = "scan8_gate_kernel" if gate_launch == "scan8_gate_kernel" else scan_kernel
     scan_avg_ms = float(np.mean(scan_ms)) if scan_ms else float("nan")
     if per_rank:        # N > 1: the roofline is the SLOWEST rank's launch (every pass waits for it in the all-gather)
         slow = max((r for r in per_rank if r and r["scan_ms"]), key=lambda r: r["scan_ms"], default=None)
@@ -948,7 +956,8 @@ def main(argv=None):
     gate_in_pass = bool(gate_ms)
     gate_avg_ms = float(np.mean(gate_ms)) if gate_ms else (gate_alone_ms if gate_alone_ms else float("nan"))
     gate_timing = ("HIP events around the prober's launches inside the timed region" if gate_in_pass else
-                   "stand-alone launches after the timed region (in the pass the prober shares bound_gate_kernel's launch)")
+                   "stand-alone launches after the timed region (in the pass the prober's workgroups ride in %s's launch)"
+                   % (gate_launch or "bound_gate_kernel"))
     gate_flops = 2.0 * L * (d_model * 512 + 512 * 512 + 512 * 2) * Bg
     out = {
         "metric": "probe-decisions/sec + query*doc scores/sec/GPU (value = query*doc scores/sec, whole job)",
@@ -971,7 +980,7 @@ def main(argv=None):
                    "docs_total": args.docs, "docs_per_gpu": n_local, "d_emb": d_emb, "queries": args.queries,
                    "k": args.k, "gate_batch": args.gate_batch, "gate_batch_per_gpu": Bg, "d_model": d_model,
                    "parallelism": f"corpus rows sharded x{world}; gate rows split x{world}",
-                   "gate_overlap": {0: "none (one stream)", 1: "beside the scan", 2: "beside the search's tail (second stream waits for the scan only)", 3: "in the launch of the search's bound kernel (prag_search_and_gate)"}[args.overlap_gate],
+                   "gate_overlap": {0: "none (one stream)", 1: "beside the scan", 2: "beside the search's tail (second stream waits for the scan only)", 3: "in a launch of the search (prag_search_and_gate): the scan's when the gate fits under it, else the bound kernel's"}[args.overlap_gate],
                    "two_level_shadow": scan_kernel == "scan8_kernel"},
         "probe_decisions_per_s": args.gate_batch / (gate_avg_ms * 1e-3) if gate_avg_ms == gate_avg_ms else None,
         "scores_per_s_per_gpu": value / world,
@@ -985,7 +994,10 @@ def main(argv=None):
                       "frac": mm_tf / (MFMA_I8_PEAK_TOP if i8_tiles else MFMA_F16_PEAK_TF), "traffic": None,
                       "algorithmic_flops_per_launch": mm_flops, "rows_in_launch": rows_last,
                       "avg_launch_ms": scan_avg_ms, "launches_per_pass": launches} if tiled else
-                     {"bound": "hbm", "kernel": scan_kernel,
+                     {"bound": "hbm", "kernel": scan_launch_name,
+                      "launch_carries": ("the scan's workgroups (scan8_kernel's body) on 7/8 of the CUs and, behind them, the "
+                                         "gate's prober workgroups on the rest: the duration is the whole launch's, the bytes "
+                                         "are the scan's" if scan_launch_name == "scan8_gate_kernel" else "the scan alone"),
                       "achieved": achieved, "peak": HBM_PEAK_GBS,
                       "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                       "frac_bytes_moved": achieved / HBM_PEAK_GBS,

@@ -1442,6 +1442,23 @@ struct prag_index {
     int mm_mode = 1;   // 0 = never take the MFMA-tiled path (PRAG_SCAN_MM=0)
     int shadow_bound_mode = -1;   // -1 auto, 0 off, 1 on (PRAG_SHADOW_BOUND)
     int shadow_sample_mode = -1;  // -1 auto, 0 off, 1 on (PRAG_SHADOW_SAMPLE): the sampled pre-bound of the two-level search
+    int scan_gate_mode = -1;      // prag_search_and_gate: the gate's workgroups in the SCAN's launch: -1 auto, 0 never, 1 always (PRAG_SCAN_GATE)
+    // Workgroups of the two-level scan, <= 64 queries: 7/8 of the CUs or all of them - measured on this index's own
+    // searches (shadow_scan_wg_cap in flat_internal.h says why it cannot be a constant).  Eight searches alternate the
+    // two with timing events around the scan launch (never waited for: a sample is read when the NEXT search finds its
+    // event done; nothing while a stream is capturing), the faster minimum wins (all CUs only if >= 1 % faster); a shard
+    // that grows or shrinks by 1/8 measures again.  PRAG_SCAN_WG_TUNE=0 / 1: always 7/8 / always every CU.
+    struct WgTune {
+        int phase = 0;                    // samples taken (8 = decided)
+        float best[2] = {1e30f, 1e30f};   // fastest scan launch seen on [0] 7/8 of the CUs, [1] every CU (ms)
+        int choice = 0;
+        bool pending = false;
+        int pending_arm = 0;
+        int64_t rows = -1;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    };
+    WgTune wg_tune[2];            // [0] <= 32 queries (two-term tiles), [1] 33-64 queries
+    int wg_tune_mode = -1;
     int64_t scan8_quad_rows = (int64_t)8 << 20;   // PRAG_SCAN8_QUAD_ROWS (tests: 0 = the quad-test scans at every size)
     int mm_shape16 = 1;   // tiled scans on 16 x 16 MFMA tiles (PRAG_MM_SHAPE=32: the 32 x 32 form, A/B timing)
     // 8-bit selection for the MFMA-tiled scan (> 128 queries on an index that keeps a shadow): int8 MFMA over the
@@ -1815,6 +1832,8 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
     if (const char* e = getenv("PRAG_MM_SHAPE")) ix->mm_shape16 = atoi(e) != 32;
     if (const char* e = getenv("PRAG_SHADOW_BOUND")) ix->shadow_bound_mode = atoi(e);
     if (const char* e = getenv("PRAG_SHADOW_SAMPLE")) ix->shadow_sample_mode = atoi(e);
+    if (const char* e = getenv("PRAG_SCAN_GATE")) ix->scan_gate_mode = atoi(e);
+    if (const char* e = getenv("PRAG_SCAN_WG_TUNE")) ix->wg_tune_mode = atoi(e);
     if (const char* e = getenv("PRAG_SCAN8_QUAD_ROWS")) ix->scan8_quad_rows = atoll(e);
     if (const char* e = getenv("PRAG_MM8")) ix->mm8_mode = atoi(e) != 0;
     if (const char* e = getenv("PRAG_MM8_MIN_ROWS")) ix->mm8_min_rows = atoll(e);
@@ -2240,6 +2259,8 @@ static SearchPlan plan_search(const PlanEnv& e) {
         if (P.use_shadow) ws += (size_t)e.n_cu * (P.QT == 128 ? 128 : 64) * 512 * 8 + (size_t)e.n_cu * 128 * 4 + BpadS * shadow_split() * k * 12;
     }
     P.ws_bytes = ws;
+    // (what shadow_search launches: the plan's record says the same)
+    if (P.use_shadow) P.grid = std::max(1, std::min(shadow_scan_wg_cap(P.cu_budget, e.wg_cap <= 0, P.QT), (P.n_tiles + 7) / 8));
     return P;
 }
 
@@ -3047,6 +3068,49 @@ static int exec_two_level(SearchRun& r) {
     ss.cap = kShadowCap;
     ss.wg_slots = ix->n_cu;
     ss.max_wg = cu_budget;
+    // 7/8 of the CUs or all of them (<= 64 queries; WgTune above)
+    prag_index::WgTune* tune = nullptr;
+    bool every_cu = ix->wg_tune_mode == 1;
+    if (ix->wg_cap <= 0 && B <= 64 && ix->wg_tune_mode < 0 && allow_mm8 && !ix->gate.word) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        prag_index::WgTune& T = ix->wg_tune[B > 32 ? 1 : 0];
+        if (!capturing) {
+            if (T.pending) {
+                if (hipEventQuery(T.ev1) == hipSuccess) {
+                    float ms = 0.f;
+                    if (hipEventElapsedTime(&ms, T.ev0, T.ev1) == hipSuccess && ms > 0.f) {
+                        T.best[T.pending_arm] = std::min(T.best[T.pending_arm], ms);
+                        if (++T.phase >= 8) T.choice = T.best[1] < 0.99f * T.best[0] ? 1 : 0;
+                    }
+                    T.pending = false;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+            if (T.rows >= 0 && !T.pending && (ix->ntotal > T.rows + T.rows / 8 || ix->ntotal < T.rows - T.rows / 8)) {
+                T.phase = 0;
+                T.best[0] = T.best[1] = 1e30f;
+            }
+            // (shards of under a million rows scan in ~0.1 ms: launch noise, and nothing to gain either way)
+            if (T.phase < 8 && !T.pending && ix->ntotal >= (1ll << 20)) {
+                if (!T.ev0) {
+                    PRAG_HIP(hipEventCreate(&T.ev0));
+                    PRAG_HIP(hipEventCreate(&T.ev1));
+                }
+                if (T.phase == 0) T.rows = ix->ntotal;
+                tune = &T;
+            }
+        }
+        every_cu = tune ? (T.phase & 1) != 0 : T.choice == 1;
+    }
+    ss.auto_wg = ix->wg_cap <= 0 && !every_cu;
+    if (tune) {
+        ss.time_ev0 = tune->ev0;
+        ss.time_ev1 = tune->ev1;
+        tune->pending = true;
+        tune->pending_arm = every_cu ? 1 : 0;
+    }
     ss.part_key = ix->sh_pkey;
     ss.part_id = ix->sh_pid;
     ss.ovf = ix->sh_ovf;
@@ -3057,6 +3121,7 @@ static int exec_two_level(SearchRun& r) {
     ss.quad_min_rows = ix->scan8_quad_rows;
     ss.scan_done = allow_mm8 && !ix->gate.word ? ix->scan_done_ev : nullptr;   // (not the gated inner searches)
     ss.tail = allow_mm8 && !ix->gate.word ? ix->tail : nullptr;
+    ss.scan_gate_mode = ix->scan_gate_mode;
     ss.unfinished = ix->sh_unfin;
     // (only where the statistics that re-arm it travel: outer 33-128-query searches with device i/o - search_finish)
     ss.skip_gather = ix->gather_mode != 1 && !ix->gather_armed && allow_mm8 && !ix->gate.word && io_is_device && B > 32 &&
@@ -3065,6 +3130,13 @@ static int exec_two_level(SearchRun& r) {
     ss.exact_bound = k <= 32 && (ix->shadow_bound_mode < 0 ? ix->ntotal >= (1ll << 19) : ix->shadow_bound_mode != 0);
     rc = shadow_search(ss, st, prof);
     if (rc != PRAG_OK) return rc;
+    if (allow_mm8 && !ix->gate.word) {      // the plan on record says what was launched
+        const size_t at = ix->last_plan.find(" grid=");
+        if (at != std::string::npos) {
+            const size_t end = ix->last_plan.find(' ', at + 1);
+            ix->last_plan.replace(at, (end == std::string::npos ? ix->last_plan.size() : end) - at, " grid=" + std::to_string(ss.grid_used));
+        }
+    }
     reranked = true;
     return PRAG_OK;
 }
@@ -3516,6 +3588,8 @@ extern "C" int prag_search_and_gate(prag_index_t* ix, const float* q_dev, int B,
     const int rc = index_search_impl(ix, q_dev, B, k, id_offset, D_dev, I_dev, 1, stream, tag_ids);
     ix->tail = nullptr;
     if (rc != PRAG_OK) return rc;
+    // (the record of what ran: the scan's launch was scan8_gate_kernel / the bound kernel's was bound_gate_kernel)
+    if (have && tg.taken) ix->last_plan += tg.in_scan ? " gate_launch=scan8_gate_kernel" : " gate_launch=bound_gate_kernel";
     if (Bg < 1) return PRAG_OK;
     if (have && tg.taken) {     // the logits are on their way: softmax / sum over layers / threshold (exp_rag.py:407-415)
         if (tg.gate_folded) return PRAG_OK;     // ... done by the last prober workgroup of every row tile
@@ -3603,6 +3677,9 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
     ix->prof.disable();
     ix->prof_xch.disable();
     if (ix->scan_done_ev) (void)hipEventDestroy(ix->scan_done_ev);
+    for (auto& T : ix->wg_tune)
+        for (hipEvent_t ev : {T.ev0, T.ev1})
+            if (ev) (void)hipEventDestroy(ev);
     if (ix->r2_event) (void)hipEventDestroy(ix->r2_event);
     if (ix->r2_word_host) (void)hipHostFree(ix->r2_word_host);
     for (void* p : {(void*)ix->r2_word, (void*)ix->r2_list, (void*)ix->r2_q, (void*)ix->r2_D, (void*)ix->r2_I})

@@ -276,6 +276,18 @@ __host__ __device__ constexpr int shadow_piece_off(int r, int p) {
     return kShadowFragMajor ? (((p >> 1) * 64 + (p & 1) * 32 + r) << 4) : r * 128 + p * 16;
 }
 
+// Workgroups the two-level scan may use.  Scans of <= 64 queries are HBM-bound and FASTER on fewer workgroups than CUs
+// (profiles/r05u_scan_wg_sweep.txt, 21 M rows, scan8 alone, 256 / 224 / 208 / 192 / 176 workgroups: 64 queries 2.547 /
+// 2.506 / 2.504 / 2.500 / 2.552 ms, 1 query 2.37-2.45 / 2.339 / 2.327 / 2.325 / 2.377; 2.625 M rows, 64 queries: 0.383 /
+// 0.373 / 0.381 / 0.394 / 0.416) - fewer concurrent 4-KiB streams, and CUs left to whatever runs beside the scan.
+// 128-query tiles are bound by their epilogue and want every CU (2.83-2.87 / 2.90 / 2.94 / 3.02 / 3.11).  A caller's
+// own cap (prag_index_set_scan_workgroups) is kept as given.  Which of the two an index uses is MEASURED on its own
+// searches (flat_index.hip, WgTune): on embedding-shaped rows the same 64-query scans lose 5-8 % on 7/8 of the CUs
+// (profiles/r05w_bench.json: 2.604 -> 2.729 ms at 21 M rows, 0.554 -> 0.599 at 4 M) where iid rows gain 1.6-3 %.
+inline int shadow_scan_wg_cap(int max_wg, bool auto_wg, int QT) {
+    return (auto_wg && QT <= 64) ? (max_wg * 7 / 8 > 1 ? max_wg * 7 / 8 : 1) : max_wg;
+}
+
 // Bound slots of the two-level scan, per query: kShadowEpochs epochs x 32 slots filled inside the scan launch
 // (after tiles 1, 2, 4, ..., 256) and one more "epoch" filled BEFORE it by prep_queries_kernel from a sample of
 // the shard (below).
@@ -571,6 +583,7 @@ struct ShadowSearch {
     int* cand;               // [wg_slots][64][cap] x 2 ints (row id, bits of key - a eps)
     uint32_t* ccnt;          // [wg_slots][64]
     int cap, wg_slots, max_wg;
+    bool auto_wg = false;    // max_wg is "every CU", not a caller's choice: HBM-bound tiles take 7/8 of it (shadow_scan_wg_cap)
     unsigned long long* part_key;   // [Bpad][shadow_split()][k]
     int* part_id;
     uint32_t* ovf;           // [Bpad]
@@ -580,6 +593,10 @@ struct ShadowSearch {
     const double* kshift = nullptr;   // [Bpad] K_q of every query (prep_queries_kernel) or null
     hipEvent_t scan_done = nullptr;   // recorded behind the scan of the last query tile (prag_index_stream_wait_scan)
     struct TailGate* tail = nullptr;  // a gate launch to carry beside the bound kernel of the last query tile (tail_gate.h)
+    hipEvent_t time_ev0 = nullptr, time_ev1 = nullptr;   // recorded around the scan launch of the last query tile (workgroup tuning)
+    int grid_used = 0;                // out: workgroups of the scan launches
+    int scan_gate_mode = -1;          // ... or behind the SCAN's workgroups in its launch (flat_scan_gate.hip): -1 when the gate
+                                      // fits under the scan, 0 never, 1 always (PRAG_SCAN_GATE)
     uint32_t* unfinished = nullptr;   // device word: queries the bound kernel left to the gather (zeroed by the prep kernel)
     bool skip_gather = false;         // no sliced gather behind the bound kernel (recent searches never needed one)
     bool exact_bound = false;   // lower g_tau to an exact k-th best before the gather (shadow_bound_kernel)
@@ -593,7 +610,7 @@ size_t shadow_q_bytes();
 int shadow_split();
 int shadow_build(const ShadowStore& s, int64_t row0, int64_t row1, hipStream_t st);
 int shadow_affine_fit(const ShadowStore& s, int64_t n_rows, int identity, double* sums, hipStream_t st);
-int shadow_search(const ShadowSearch& s, hipStream_t st, EventRing& prof);
+int shadow_search(ShadowSearch& s, hipStream_t st, EventRing& prof);
 
 bool mm_supported(int d, int store_dtype, int kc);
 bool mm8_supported(int d, int kc);

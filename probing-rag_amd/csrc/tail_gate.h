@@ -16,6 +16,7 @@ struct TailGate {
     int n_wg = 0;        // workgroups of the launch (8 * ceil(n_tiles * n_run / 8))
     int lds_bytes = 0;   // p16_lds_bytes<ct16>()
     bool taken = false;  // set by whoever launched it
+    bool in_scan = false;   // ... behind the scan's workgroups in the scan's launch (scan8_gate_kernel), not beside the bound kernel
     bool gate_folded = false;   // pa carries the gate's outputs: the launch also does exp_rag.py:407-415
 };
 

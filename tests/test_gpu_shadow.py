@@ -435,16 +435,19 @@ def test_flagged_queries_are_retried_32_at_a_time_before_the_exact_scan(monkeypa
     ix.close()
 
 
-@pytest.mark.parametrize("store", ["f16", "f32"])
-def test_search_and_gate_equals_the_two_calls(store):
+@pytest.mark.parametrize("store,scan_gate", [("f16", "0"), ("f32", "0"), ("f16", "1"), ("f32", "1")])
+def test_search_and_gate_equals_the_two_calls(store, scan_gate, monkeypatch):
     """prag_search_and_gate: the top-k of a query batch AND the gate over the next batch of pooled states in one call; on
     a two-level search the prober's workgroups ride in the launch of the search's bound kernel (bound_gate_kernel: the
-    bodies of shadow_bound_kernel and prober16_kernel side by side).  Whatever path it takes - fused launch at every
-    prober tile height, direct scan, float32 states, the small-batch gate, no gate at all, a captured graph - D, I,
-    logits, sums and decisions are those of index.search and ens.gate."""
+    bodies of shadow_bound_kernel and prober16_kernel side by side; PRAG_SCAN_GATE=0) or behind the scan's workgroups
+    in the SCAN's launch (scan8_gate_kernel: 64-query tiles; forced here with PRAG_SCAN_GATE=1 - by itself the library
+    takes it when the gate fits under the scan).  Whatever path it takes - fused launch at every prober tile height,
+    direct scan, float32 states, the small-batch gate, no gate at all, a captured graph - D, I, logits, sums and
+    decisions are those of index.search and ens.gate."""
     import torch
     import probing_rag_amd as pra
     from tests.golden import cases
+    monkeypatch.setenv("PRAG_SCAN_GATE", scan_gate)
     N, d, k = 300_000, 768, 10
     ix = pra.HipFlatIndex(d, "cos", store, capacity=N)
     ix.add_synthetic(42, 0, N)
@@ -529,3 +532,46 @@ def test_gather_launch_is_skipped_only_while_nothing_needs_it(monkeypatch):
     D, I = ix.search(q, k)
     _check(D.cpu().numpy(), I.cpu().numpy(), D0, I0, onp.METRIC_COS)
     ix.close()
+
+
+def test_scan_workgroups_are_measured_not_assumed(monkeypatch):
+    """Round 5: a two-level scan of <= 64 queries runs on 7/8 of the CUs or on all of them - iid rows are 1.6-3 % faster
+    on 7/8 (fewer concurrent HBM streams), embedding-shaped rows 5-8 % slower - so an index times eight of its own
+    searches (alternating, events never waited for) and keeps the faster.  Results never depend on the grid; the plan on
+    record names the grid that ran; PRAG_SCAN_WG_TUNE pins either choice; a caller's own cap is kept."""
+    import torch
+    import probing_rag_amd as pra
+    N, d, k = 1_200_000, 768, 10
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    q = torch.from_numpy(onp.synth_rows(7, 0, 64, d)).cuda()
+
+    def build():
+        ix = pra.HipFlatIndex(d, "cos", "f16", capacity=N)
+        ix.add_synthetic(42, 0, N)
+        ix.set_shadow(2)
+        ix.prepare()
+        return ix
+
+    ix = build()
+    D0, I0 = ix.search(q, k)
+    grids = []
+    for _ in range(14):
+        D, I = ix.search(q, k)
+        torch.cuda.synchronize()
+        assert torch.equal(I, I0) and torch.equal(D, D0)
+        grids.append(ix.last_plan()["grid"])
+    assert set(grids[:8]) == {n_cu * 7 // 8, n_cu}          # both were tried ...
+    assert len(set(grids[-4:])) == 1 and grids[-1] in (n_cu * 7 // 8, n_cu)   # ... and one was kept
+    D1, I1 = ix.search(q[:1], k)                                # <= 32 queries: measured separately
+    assert ix.last_plan()["grid"] in (n_cu * 7 // 8, n_cu)
+    ix.set_scan_workgroups(100)                                 # the caller's own cap
+    D, I = ix.search(q, k)
+    assert ix.last_plan()["grid"] == 100 and torch.equal(I, I0)
+    ix.close()
+    for mode, want in (("0", n_cu * 7 // 8), ("1", n_cu)):
+        monkeypatch.setenv("PRAG_SCAN_WG_TUNE", mode)
+        ix = build()
+        for _ in range(3):
+            D, I = ix.search(q, k)
+            assert ix.last_plan()["grid"] == want and torch.equal(I, I0)
+        ix.close()

@@ -17,6 +17,8 @@ ix = pra.HipFlatIndex(d, "cos", "f16", capacity=bench.SHARD_ROWS)
 ix.add_synthetic(42, 0, bench.SHARD_ROWS)
 ix.set_shadow(1)
 ix.prepare()
+if os.environ.get("SHARD_SCAN_WG"):
+    ix.set_scan_workgroups(int(os.environ["SHARD_SCAN_WG"]))
 q = torch.from_numpy(synth_rows(7, 0, bench.SHARD_QUERIES, d)).cuda()
 g = torch.Generator(device="cuda").manual_seed(4321)
 Bg = bench.SHARD_GATE_ROWS
