@@ -78,9 +78,11 @@ def parse(argv=None):
                     help="workgroups of the corpus scan (0: the library's choice - 7/8 of the CUs for HBM-bound two-level scans)")
     ap.add_argument("--overlap-gate", type=int, default=3,
                     help="3 (default): one C call per pass and rank (prag_search_and_gate): the gate of the NEXT batch rides "
-                         "in the launch of the local search's bound kernel - what follows the corpus scan occupies a "
-                         "quarter of the chip (8-GPU shard size: 0.437 -> 0.415-0.418 ms per pass, 21 M rows 2.742 -> 2.696, "
-                         "profiles/r05j_*); 2: the gate of the NEXT batch on a second stream that waits for the search's corpus "
+                         "in a launch of the local search - behind the scan's own workgroups when it fits under the scan "
+                         "(the scan runs on 7/8 of the CUs; 21 M rows 2.65-2.68 -> 2.62-2.64 ms per pass, 8-GPU shard size "
+                         "0.418 -> 0.408, profiles/r05u_scan_wg_sweep.txt), else beside the bound kernel - what follows the "
+                         "corpus scan occupies a quarter of the chip (0.437 -> 0.415-0.418 ms per pass, 21 M rows 2.742 -> "
+                         "2.696, profiles/r05j_*); 2: the gate of the NEXT batch on a second stream that waits for the search's corpus "
                          "scan only (prag_index_stream_wait_scan): it runs beside the search's tail - bound kernel, exact "
                          "rerank, fallback probes - measured 0.459 -> 0.454 ms per pass at the 8-GPU shard size, 0.420 "
                          "with the sampled pre-bound (profiles/r05c_shard_ab.txt); 0: one stream; 1: the gate on a second "

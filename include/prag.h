@@ -337,8 +337,11 @@ int prag_index_last_fallbacks(prag_index_t* ix, void* stream, int* n_out);
 /* One pass of the hot path as one call: `D, I = index.search(q, k)` (utils.py:379; exp_rag.py:432-436) AND the gate over
  * the NEXT batch of pooled states (exp_rag.py:406-415) - two independent pieces of work of a loop that keeps batches
  * in flight.  Arguments = those of prag_index_search (device i/o) followed by those of prag_gate.  When the search is
- * a two-level search the prober's workgroups are carried by the launch of the search's bound kernel - what follows the
- * scan leaves 3/4 of the chip idle - otherwise the call equals prag_index_search followed by prag_gate.  Results are
+ * a two-level search the prober's workgroups are carried by a launch of the search: behind the scan's own workgroups
+ * when the gate fits under the scan (an HBM-bound scan runs on 7/8 of the CUs; workgroups of one launch are placed in
+ * index order, so the scan's settle first and the prober's take the CUs left), else beside the bound kernel - what
+ * follows the scan leaves 3/4 of the chip idle; otherwise the call equals prag_index_search followed by prag_gate.
+ * (PRAG_SCAN_GATE=0|1 forces the second / first form; prag_index_last_plan names the launch.)  Results are
  * those of the two calls in every case; Bg = 0 skips the gate.  flags bit 0: ids in the exchange format of
  * prag_index_search_tagged (a row shard of a sharded index: the caller all-gathers and merges). */
 int prag_search_and_gate(prag_index_t* ix, const float* q_dev, int B, int k, int64_t id_offset, float* D_dev, int64_t* I_dev,
