@@ -226,9 +226,9 @@ def cpu_baseline(args, states, q_c1, x_c1):
 # ---------------------------------------------------------------------------------------------
 def _timed_searches(torch, ix, q, k, min_s=0.6, max_reps=200):
     """ms per search (host-timed over back-to-back searches) + the profiled scan-kernel launches."""
-    for _ in range(2):
+    for _ in range(10):             # (waited for: the scan workgroup count of a <= 64-query two-level search settles here)
         ix.search(q, k)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     ix.profile(1024)
     t0 = time.perf_counter()
     reps = 0
@@ -533,6 +533,9 @@ def shard_variant(torch, pra, ens, k, metric, ms_per_pass_full, passes=300):
     ens.reserve(SHARD_GATE_ROWS)
 
     def timed(fn, n):
+        for _ in range(12):         # (waited for one by one: the index settles its scan workgroup count on these)
+            fn()
+            torch.cuda.synchronize()
         for _ in range(20):
             fn()
         torch.cuda.synchronize()
@@ -818,6 +821,11 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # On its first searches an index measures whether its scan runs better on 7/8 of the CUs or on all of them (eight
+    # samples, each read when a later search finds it finished): waited-for passes let that settle before the warm-up
+    for _ in range(12):
+        one_pass()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     n_pass = args.steps * args.inner
@@ -952,6 +960,16 @@ def main(argv=None):
     gate_alone = ens.profile_read()
     ens.profile(0)
     gate_alone_ms = float(np.mean(gate_alone)) if gate_alone else None
+    # ... and the scan launch of a plain search (no gate in it), same index, same queries
+    scan_alone_ms = None
+    if world == 1 and not tiled:
+        local.profile(64)
+        for _ in range(40):
+            local.search(q, args.k)
+        torch.cuda.synchronize()
+        sa = local.profile_read()
+        local.profile(0)
+        scan_alone_ms = float(np.sum(sa)) / 40 if sa else None
     # --overlap-gate 3: the prober's workgroups ride in bound_gate_kernel's launch, so the pass holds no prober launch
     # to put events around; the gate's own figures are then the stand-alone launch's (the fused launch's duration is
     # in the rocprofv3 summary of this command: bound_gate_kernel)
@@ -1009,6 +1027,10 @@ def main(argv=None):
                       "algorithmic_bytes_per_launch": alg_bytes,
                       "stored_row_bytes": stored_row_bytes(args.store, args.metric, n_local),
                       "avg_launch_ms": scan_avg_ms,
+                      "scan_alone": ({"kernel": scan_kernel, "avg_launch_ms": scan_alone_ms,
+                                      "frac": alg_bytes / (scan_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "what": "the scan launch of a plain search (no gate workgroups behind the scan's), "
+                                              "40 searches after the timed region"} if scan_alone_ms else None),
                       "launches_per_pass": launches, "launches_timed": len(scan_ms)}),
         "roofline_gate": {"bound": "mfma", "kernel": GATE_KERNELS[1 if os.environ.get("PRAG_PROBER_SHAPE") == "32" else 0], "achieved": gate_flops / (gate_avg_ms * 1e-3) / 1e12,
                           "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",

@@ -45,6 +45,9 @@ def one():
     with torch.cuda.stream(side):
         ens.gate(x, 0, 0.0, out=gate_out)
     torch.cuda.current_stream().wait_stream(side)
+for _ in range(12):
+    one()
+    torch.cuda.synchronize()
 for _ in range(20):
     one()
 torch.cuda.synchronize()
