@@ -971,6 +971,9 @@ int shadow_search(ShadowSearch& s, hipStream_t st, EventRing& prof) {
             const double gate_us = (double)((s.tail->n_wg + free_cu - 1) / free_cu) * (s.tail->ct16 == 8 ? 95.0 : s.tail->ct16 == 4 ? 60.0 : 40.0);
             const double scan_us = (double)s.N * (s.d + 12) / 6.0e6;
             scan_gate = s.scan_gate_mode > 0 || (grid < s.wg_slots && gate_us <= 0.9 * scan_us);
+            // (a launch that is being timed for the workgroup count carries the scan alone - with the prober's
+            //  workgroups in it the 7/8 arm would be charged the gate: the tail carries it in those eight searches)
+            if (timed && s.scan_gate_mode <= 0) scan_gate = false;
         }
 #ifndef PRAG_S8_Q128_NLD
 #define PRAG_S8_Q128_NLD 0      // (0: three staging sets for 768-element rows; A/B builds: 6 = a whole tile in flight)

@@ -8,11 +8,23 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import probing_rag_amd as pra
 
+from tests.golden import cases as _cases
+
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t0, n_case, n_fb = time.time(), 0, 0
 by = {}
+# prag_search_and_gate sub-cases: one prober ensemble, the gate's launch beside the bound kernel (PRAG_SCAN_GATE=0), behind
+# the scan's workgroups (1, whenever the shape has that form) or where the library puts it (-1)
+_pc = _cases.PROBER_CASES[1]
+_ens = pra.HipProberEnsemble(_pc["L"], _pc["d"], 2, weights="f16")
+for _l in range(_pc["L"]):
+    _ens.load_layer(_l, _cases.synth_state(_pc["wseed"] + _l, _pc["d"]))
+_gate_x = {}
+n_fused = 0
 while time.time() - t0 < budget:
+    os.environ["PRAG_SCAN_GATE"] = str(rng.choice(["0", "1", "-1"]))     # (read when an index is created)
+    os.environ["PRAG_SCAN_WG_TUNE"] = str(rng.choice(["0", "1", "-1"]))
     d = int(rng.choice([128, 256, 384, 512, 640, 768, 1024]))
     N = int(rng.choice([1, 7, 33, 500, 4095, 4096, 4130, 20_000, 65_537, 300_000, 1_200_000], p=[.03, .03, .04, .1, .1, .1, .1, .2, .15, .1, .05]))
     if N * d > 600_000_000:
@@ -76,6 +88,20 @@ while time.time() - t0 < budget:
             sh.close()
         n_sharded = globals().get("n_sharded", 0) + 1
         globals()["n_sharded"] = n_sharded
+    if ok and rng.random() < 0.2:
+        # the search AND the gate of another batch in one call: D / I those of the two-level search, logits / sums /
+        # decisions those of ens.gate, whichever launch carries the prober's workgroups
+        Bg = int(rng.choice([40, 96, 512, 1400]))
+        if Bg not in _gate_x:
+            _gate_x[Bg] = torch.from_numpy(_cases.synth_x(_pc["xseed"] + Bg, _pc["L"], Bg, _pc["d"], 1.0)).cuda().half()
+        abl, theta = int(rng.integers(0, 3)), float(rng.choice([0.0, 0.25]))
+        want = [t.clone() for t in _ens.gate(_gate_x[Bg], abl, theta)]
+        ix.set_shadow(2)
+        (D2, I2), got = pra.search_and_gate(ix, Q, k, _ens, _gate_x[Bg], abl, theta)
+        ok = torch.equal(I2, I1) and torch.equal(D2, D1) and all(torch.equal(a, b) for a, b in zip(got, want))
+        if not ok:
+            print(f"MISMATCH in search_and_gate (PRAG_SCAN_GATE={os.environ['PRAG_SCAN_GATE']}, gate rows {Bg}): plan {ix.last_plan()}", flush=True)
+        n_fused += 1
     n_case += 1
     if 'Is' in dir() and ok:
         del Is
@@ -97,5 +123,5 @@ while time.time() - t0 < budget:
 for key in sorted(by, key=lambda k: -by[k][2] / max(1, by[k][1]))[:25]:
     c = by[key]
     print(key, f"cases {c[0]} queries {c[1]} fallbacks {c[2]} = {c[2] / max(1, c[1]):.3f} per query")
-print(f"sharded sub-cases: {globals().get('n_sharded', 0)}")
+print(f"sharded sub-cases: {globals().get('n_sharded', 0)}; search_and_gate sub-cases: {n_fused}")
 print(f"fuzz ok: {n_case} cases in {time.time() - t0:.0f} s, {n_fb} exact fallbacks in total", flush=True)

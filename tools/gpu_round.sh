@@ -5,6 +5,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 TAG=${1:-r05}; FS=${2:-1}
 timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_gpu_suite.txt 2>&1; tail -4 $OUT/${TAG}_gpu_suite.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; tail -c 300 $OUT/${TAG}_bench.json; tail -3 $OUT/${TAG}_bench.err
 timeout 300 python bench.py --docs 2625000 --gate-batch 512 --no-variants --no-cpu-baseline > $OUT/${TAG}_bench_shard_2625000_gate512.json 2>> $OUT/${TAG}_bench.err
 PRAG_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 5 --warmup 1 --no-variants --no-cpu-baseline > $OUT/${TAG}_bench_2ranks_gloo.json 2> $OUT/${TAG}_bench_2ranks_gloo.err; echo "gloo rc=$?"; tail -2 $OUT/${TAG}_bench_2ranks_gloo.err
