@@ -1446,7 +1446,7 @@ struct prag_index {
     // Workgroups of the two-level scan, <= 64 queries: 7/8 of the CUs or all of them - measured on this index's own
     // searches (shadow_scan_wg_cap in flat_internal.h says why it cannot be a constant).  Eight searches alternate the
     // two with timing events around the scan launch (never waited for: a sample is read when the NEXT search finds its
-    // event done; nothing while a stream is capturing), the faster minimum wins (all CUs only if >= 1 % faster); a shard
+    // event done; nothing while a stream is capturing), the faster minimum wins (all CUs only if >= 2.5 % faster); a shard
     // that grows or shrinks by 1/8 measures again.  PRAG_SCAN_WG_TUNE=0 / 1: always 7/8 / always every CU.
     struct WgTune {
         int phase = 0;                    // samples taken (8 = decided)
@@ -3081,7 +3081,9 @@ static int exec_two_level(SearchRun& r) {
                     float ms = 0.f;
                     if (hipEventElapsedTime(&ms, T.ev0, T.ev1) == hipSuccess && ms > 0.f) {
                         T.best[T.pending_arm] = std::min(T.best[T.pending_arm], ms);
-                        if (++T.phase >= 8) T.choice = T.best[1] < 0.99f * T.best[0] ? 1 : 0;
+                        // (every CU only when clearly faster - 2.5 %: embedding-shaped rows show 5-8 %, the noise of four
+                        //  samples is ~1 % - because 7/8 also leaves CUs to the gate's workgroups in the scan's launch)
+                        if (++T.phase >= 8) T.choice = T.best[1] < 0.975f * T.best[0] ? 1 : 0;
                     }
                     T.pending = false;
                 } else {
@@ -3592,7 +3594,7 @@ extern "C" int prag_search_and_gate(prag_index_t* ix, const float* q_dev, int B,
     if (have && tg.taken) ix->last_plan += tg.in_scan ? " gate_launch=scan8_gate_kernel" : " gate_launch=bound_gate_kernel";
     if (Bg < 1) return PRAG_OK;
     if (have && tg.taken) {     // the logits are on their way: softmax / sum over layers / threshold (exp_rag.py:407-415)
-        if (tg.gate_folded) return PRAG_OK;     // ... done by the last prober workgroup of every row tile
+        if (tg.gate_folded || tg.finished) return PRAG_OK;     // ... done by the last prober workgroup of every row tile / by the bound launch
         return prag_gate_from_logits(logits_dev, tg.pa.n_run, Bg, ablation, theta, probsum_dev, decision_dev, stream);
     }
     return prag_gate(p, x_dev, x_dtype, x_layer_stride, Bg, ablation, theta, logits_dev, probsum_dev, decision_dev, stream);

@@ -657,6 +657,22 @@ __global__ __launch_bounds__(512, 2) void bound_gate_kernel(GatherArgs g, uint32
 }
 static_assert(kShThreads == 512, "bound_gate_kernel: both bodies are written for 512-thread workgroups");
 
+// ... and when the prober already ran behind the scan's workgroups (scan8_gate_kernel), the bound launch finishes the gate:
+// workgroups nq.. run gate_kernel's body over the complete logits (exp_rag.py:407-415) - one launch less in the pass.
+struct GateFinish {
+    const float* logits;
+    int L, B, ablation;
+    double theta;
+    float* probsum;
+    int32_t* decision;
+};
+template <bool F32>
+__global__ __launch_bounds__(kShThreads) void bound_finish_kernel(GatherArgs g, uint32_t* __restrict__ g_tau_w, int nq, GateFinish f) {
+    extern __shared__ __attribute__((aligned(16))) char fused_smem[];
+    if ((int)blockIdx.x < nq) shadow_bound_body<F32>(g, g_tau_w, (int)blockIdx.x, fused_smem);
+    else gate_row(f.logits, f.L, f.B, f.ablation, f.theta, f.probsum, f.decision, ((int)blockIdx.x - nq) * kShThreads + (int)threadIdx.x);
+}
+
 template <bool F32>
 __global__ __launch_bounds__(kShThreads) void shadow_gather_kernel(GatherArgs a) {
     __shared__ ShTopK tk;
@@ -1070,10 +1086,20 @@ int shadow_search(ShadowSearch& s, hipStream_t st, EventRing& prof) {
         g.no_gather = skip_gather ? 1 : 0;
         if (s.exact_bound) {     // (k <= 32: the kernel scores 32 rows)
             TailGate* tg = s.tail && !s.tail->taken && p0 + QT >= Bpad ? s.tail : nullptr;
+            TailGate* tf = s.tail && s.tail->in_scan && !s.tail->finished && !s.tail->gate_folded && p0 + QT >= Bpad ? s.tail : nullptr;
             if (tg) {            // the gate of the next batch in the same launch (bound_gate_kernel)
                 const int rc_t = launch_bound_gate(s.store.store_f32 != 0, *tg, g, s.g_tau + p0, nq, st);
                 if (rc_t != PRAG_OK) return rc_t;
                 tg->taken = true;
+            } else if (tf) {     // the prober ran in the scan's launch: this one finishes the gate (bound_finish_kernel)
+                const GateFinish f{tf->pa.logits, tf->pa.n_run, tf->pa.B, tf->fin_ablation, tf->fin_theta, tf->fin_probsum, tf->fin_decision};
+                const int n_fin = (tf->pa.B + kShThreads - 1) / kShThreads;
+                if (s.store.store_f32)
+                    hipLaunchKernelGGL(bound_finish_kernel<true>, dim3(nq + n_fin), dim3(kShThreads), kShBoundLds, st, g, s.g_tau + p0, nq, f);
+                else
+                    hipLaunchKernelGGL(bound_finish_kernel<false>, dim3(nq + n_fin), dim3(kShThreads), kShBoundLds, st, g, s.g_tau + p0, nq, f);
+                PRAG_LAUNCH_CHECK();
+                tf->finished = true;
             } else {
                 if (s.store.store_f32)
                     hipLaunchKernelGGL(shadow_bound_kernel<true>, dim3(nq), dim3(kShThreads), 0, st, g, s.g_tau + p0);

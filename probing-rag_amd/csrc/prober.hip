@@ -928,24 +928,7 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ log
                                                   int ablation, double theta,
                                                   float* __restrict__ probsum,
                                                   int32_t* __restrict__ decision) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    float s0 = 0.f, s1 = 0.f;
-    for (int n = ablation; n < L; ++n) {
-        const float2 z = *reinterpret_cast<const float2*>(logits + ((size_t)n * B + b) * 2);
-        const float m = fmaxf(z.x, z.y);
-        const float e0 = expf(z.x - m), e1 = expf(z.y - m);
-        const float inv = 1.0f / (e0 + e1);
-        s0 += e0 * inv;
-        s1 += e1 * inv;
-    }
-    if (probsum) {
-        probsum[2 * b] = s0;
-        probsum[2 * b + 1] = s1;
-    }
-    // the reference compares Python floats: `s[0].item() + threshold < s[1].item()` (exp_rag.py:414)
-    // - float32 sums widened to double, theta a double
-    if (decision) decision[b] = ((double)s0 + theta < (double)s1) ? 0 : 1;
+    gate_row(logits, L, B, ablation, theta, probsum, decision, blockIdx.x * blockDim.x + threadIdx.x);   // (prober_internal.h)
 }
 
 // ---------------------------------------------------------------------------
@@ -1680,6 +1663,10 @@ bool prag::prober_describe_tail(prag_prober* p, const void* x_dev, int x_dtype, 
     t.lds_bytes = prober16_lds_bytes(t.ct16);
     t.taken = false;
     t.gate_folded = false;
+    t.fin_probsum = probsum_dev;
+    t.fin_decision = decision_dev;
+    t.fin_ablation = ablation;
+    t.fin_theta = theta;
     if (p->gate_fold && decision_dev && ensure_tile_cnt(p, B) == PRAG_OK) {     // the gate rides along too
         t.pa.probsum = probsum_dev;
         t.pa.decision = decision_dev;

@@ -60,6 +60,29 @@ struct ProberArgs {
 };
 
 
+// exp_rag.py:407-415 for pooled state b, in the reference's own order (float32, layer by layer): gate_kernel's body, also
+// run by the workgroups the two-level search's bound launch adds for it (flat_shadow.hip bound_finish_kernel)
+__device__ __forceinline__ void gate_row(const float* __restrict__ logits, int L, int B, int ablation, double theta,
+                                         float* __restrict__ probsum, int32_t* __restrict__ decision, int b) {
+    if (b >= B) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int n = ablation; n < L; ++n) {
+        const float2 z = *reinterpret_cast<const float2*>(logits + ((size_t)n * B + b) * 2);
+        const float m = fmaxf(z.x, z.y);
+        const float e0 = expf(z.x - m), e1 = expf(z.y - m);
+        const float inv = 1.0f / (e0 + e1);
+        s0 += e0 * inv;
+        s1 += e1 * inv;
+    }
+    if (probsum) {
+        probsum[2 * b] = s0;
+        probsum[2 * b + 1] = s1;
+    }
+    // the reference compares Python floats: `s[0].item() + threshold < s[1].item()` (exp_rag.py:414)
+    // - float32 sums widened to double, theta a double
+    if (decision) decision[b] = ((double)s0 + theta < (double)s1) ? 0 : 1;
+}
+
 __device__ __forceinline__ float silu_f(float h) {
     // h * sigmoid(h) as v_mul + v_exp_f32 + v_add + v_rcp_f32 + v_mul; the two transcendentals
     // are ~1 ulp, far inside the 1e-4 budget.  (__frcp_rn / "1.0f / x" expand to the full IEEE

@@ -17,6 +17,14 @@ struct TailGate {
     int lds_bytes = 0;   // p16_lds_bytes<ct16>()
     bool taken = false;  // set by whoever launched it
     bool in_scan = false;   // ... behind the scan's workgroups in the scan's launch (scan8_gate_kernel), not beside the bound kernel
+    // exp_rag.py:407-415 over the logits (gate_kernel's arithmetic): what whoever finishes the gate needs.  When the
+    // prober ran in the scan's launch the logits are complete before the bound kernel starts, and that launch finishes
+    // the gate on workgroups of its own (bound_finish_kernel) - one launch less in the pass.
+    float* fin_probsum = nullptr;
+    int32_t* fin_decision = nullptr;
+    int fin_ablation = 0;
+    double fin_theta = 0.0;
+    bool finished = false;  // probsum / decision are written (set by the launcher that did it)
     bool gate_folded = false;   // pa carries the gate's outputs: the launch also does exp_rag.py:407-415
 };
 
