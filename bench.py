@@ -1034,6 +1034,9 @@ def main(argv=None):
                       "launches_per_pass": launches, "launches_timed": len(scan_ms)}),
         "roofline_gate": {"bound": "mfma", "kernel": GATE_KERNELS[1 if os.environ.get("PRAG_PROBER_SHAPE") == "32" else 0], "achieved": gate_flops / (gate_avg_ms * 1e-3) / 1e12,
                           "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
+                          # (the rate a bare 16x16x32 MFMA loop sustains on this chip with 256 workgroups issuing - power:
+                          #  profiles/r04a_mfma_shape_clock.txt - for reference beside the nominal dense peak)
+                          "frac_of_sustained_mfma_rate_1940TF": gate_flops / (gate_avg_ms * 1e-3) / 1e12 / 1940.0,
                           "frac": gate_flops / (gate_avg_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF,
                           "avg_launch_ms": gate_avg_ms, "avg_launch_ms_back_to_back_alone": gate_alone_ms,
                           "timing": gate_timing,
