@@ -448,6 +448,8 @@ def test_search_and_gate_equals_the_two_calls(store, scan_gate, monkeypatch):
     import probing_rag_amd as pra
     from tests.golden import cases
     monkeypatch.setenv("PRAG_SCAN_GATE", scan_gate)
+    if scan_gate == "1":        # ... with the exact-bound kernel on at this size: its launch then finishes the gate (bound_finish_kernel)
+        monkeypatch.setenv("PRAG_SHADOW_BOUND", "1")
     N, d, k = 300_000, 768, 10
     ix = pra.HipFlatIndex(d, "cos", store, capacity=N)
     ix.add_synthetic(42, 0, N)
