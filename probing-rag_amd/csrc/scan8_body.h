@@ -17,8 +17,10 @@ namespace prag {
 
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
-// LDS of the scan: query planes (both terms for 32-query tiles), one 4-KiB stage and 384 B of row metadata per
-// wave, bounds / counters
+// LDS of the scan: query planes (both terms for 32-query tiles), 4 KiB + 384 B of row metadata per wave, bounds /
+// counters.  (The 4 KiB per wave were the staging buffers of the row-major chunks; with the shadow in MFMA operand
+// order the rows never pass through LDS and the block only holds the pre-bound's 32 sample slots per query while
+// the kernel starts - and the stages of the -DPRAG_SHADOW_CHUNK_MAJOR A/B build.)
 inline int scan8_lds_bytes(int QT, int qstride) {
     return (QT == 32 ? 2 : 1) * QT * qstride + 8 * 4096 + 8 * 384 + 4 * QT * 4 + 64 + (QT == 128 ? 3 * QT * 4 + 64 : 0);
 }
@@ -262,7 +264,7 @@ __device__ __forceinline__ void scan8_body(const Scan8Args& a, char* const smem,
         }
     }
 
-    // staging geometry: 4 x 16-B loads per lane per 128-byte chunk of 32 rows
+    // staging geometry of the row-major chunks (A/B build only): 4 x 16-B loads per lane per 128-byte chunk of 32 rows
     int st_doc[4], st_dst[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -343,7 +345,8 @@ __device__ __forceinline__ void scan8_body(const Scan8Args& a, char* const smem,
         m_e = a.serr[row];
         m_x = a.sbias[row];
     };
-    // stage one 4-KiB chunk (32 rows x 128 bytes), refill its registers with chunk (tile_nx, c_nx), 4 k-steps
+    // one 4-KiB chunk (32 rows x 128 bytes), 4 k-steps: the registers its loads filled ARE the A operands (row-major
+    // chunks of the A/B build pass through LDS first); they are refilled with chunk (tile_nx, c_nx)
     auto chunk_step = [&](u32x4 (&ldr)[4], int c, int tile_nx, int c_nx) __attribute__((always_inline)) {
         if (PRAG_SH_DBG(a.dbg) & 4096) {      // timing only: the stream alone (loads into registers, nothing else)
 #pragma unroll
