@@ -268,7 +268,9 @@ int prag_index_d(const prag_index_t* ix);
  * captured into a HIP graph and replayed, and every rank of a lockstep retrieval issues the same COLLECTIVES (one
  * all-gather per sharded search).  The kernel sequence itself may differ between ranks and between runs of one input:
  * whether a > 128-query search takes the int8 tiles is per-process host state fed by an asynchronous copy of the
- * previous searches' failed counts (prag_index_last_tiled8) - results are the definition's either way.
+ * previous searches' failed counts (prag_index_last_tiled8), and the workgroup count of a two-level scan of <= 64
+ * queries (7/8 of the CUs or all of them) is timed on each index's own first searches (PRAG_SCAN_WG_TUNE=0|1 pins it;
+ * prag_index_last_plan reports what ran) - results are the definition's either way.
  * With io_is_device == 0 the call copies in/out and synchronises `stream`. */
 int prag_index_search(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset,
                       float* D, int64_t* I, int io_is_device, void* stream);
