@@ -1446,7 +1446,7 @@ struct prag_index {
     // Workgroups of the two-level scan, <= 64 queries: 7/8 of the CUs or all of them - measured on this index's own
     // searches (shadow_scan_wg_cap in flat_internal.h says why it cannot be a constant).  Eight searches alternate the
     // two with timing events around the scan launch (never waited for: a sample is read when the NEXT search finds its
-    // event done; nothing while a stream is capturing), the faster minimum wins (all CUs only if >= 2.5 % faster); a shard
+    // event done; nothing while a stream is capturing), the faster minimum wins (all CUs only if >= 2.5 % faster, 5 % when the call carries a gate); a shard
     // that grows or shrinks by 1/8 measures again.  PRAG_SCAN_WG_TUNE=0 / 1: always 7/8 / always every CU.
     struct WgTune {
         int phase = 0;                    // samples taken (8 = decided)
@@ -3081,9 +3081,7 @@ static int exec_two_level(SearchRun& r) {
                     float ms = 0.f;
                     if (hipEventElapsedTime(&ms, T.ev0, T.ev1) == hipSuccess && ms > 0.f) {
                         T.best[T.pending_arm] = std::min(T.best[T.pending_arm], ms);
-                        // (every CU only when clearly faster - 2.5 %: embedding-shaped rows show 5-8 %, the noise of four
-                        //  samples is ~1 % - because 7/8 also leaves CUs to the gate's workgroups in the scan's launch)
-                        if (++T.phase >= 8) T.choice = T.best[1] < 0.975f * T.best[0] ? 1 : 0;
+                        ++T.phase;
                     }
                     T.pending = false;
                 } else {
@@ -3104,6 +3102,10 @@ static int exec_two_level(SearchRun& r) {
                 tune = &T;
             }
         }
+        // Every CU only when clearly faster - by 2.5 % (embedding-shaped rows show 5-8 %, the noise of four samples is
+        // ~1 %), by 5 % when this call has a gate to carry: on 7/8 of the CUs the gate's workgroups run behind the
+        // scan's in the scan's launch, which is worth 1-2 % of a 21 M-row pass and 3-5 % of a 2.6 M-row one.
+        if (T.phase >= 8) T.choice = T.best[1] < (ix->tail ? 0.95f : 0.975f) * T.best[0] ? 1 : 0;
         every_cu = tune ? (T.phase & 1) != 0 : T.choice == 1;
     }
     ss.auto_wg = ix->wg_cap <= 0 && !every_cu;
