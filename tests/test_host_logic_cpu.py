@@ -265,6 +265,12 @@ def test_search_plan_over_the_shape_grid():
                                     assert shadow and B > 128 and p["kc"] == 256 and k <= 32 and (N >= 2 << 20 or shadow == 2)
                                 if p["shadow"]:
                                     assert shadow and d % 128 == 0 and d <= 1024 and B <= 128 and p["family"] == "scan8_kernel"
+                                    # HBM-bound tiles (<= 64 queries) are planned on 7/8 of the CUs - which of 7/8 and all
+                                    # an index really uses is timed on its own searches and written back into the plan on
+                                    # record (test_gpu_shadow.py) -, the epilogue-bound 128-query tiles on every CU
+                                    assert p["grid"] <= (224 if p["QT"] <= 64 else 256)
+                                    if N >= 1 << 20:
+                                        assert p["grid"] == (224 if p["QT"] <= 64 else 256)
                                 if p["hp"]:
                                     assert p["QT"] == 32
                                 elt = 4 if store == "f32" else 2
@@ -300,3 +306,15 @@ def test_search_plan_over_the_shape_grid():
     assert pra.plan_search(768, "cos", "f16", 1_000_000, 1000, 10, 1)["int8_tiles"] == 0       # below 2 Mi rows
     with __import__("pytest").raises(pra.PragError, match="911"):
         pra.plan_search(768, "cos", "f16", 1000, 1, 912)
+
+
+def test_plan_lines_carry_what_ran():
+    """prag_index_last_plan is a line of key=value fields; execution appends what a plan cannot know (the launch that
+    carried a gate) - the parser keeps every field, ints where they parse."""
+    from probing_rag_amd.index import parse_plan
+    p = parse_plan("family=scan8_kernel QT=64 kc=16 Bpad=64 grid=224 launches=1 bytes_per_launch=16380000000 store=f16 "
+                   "metric=2 rows=21000000 queries=64 k=10 gate_launch=scan8_gate_kernel")
+    assert p["family"] == "scan8_kernel" and p["grid"] == 224 and p["bytes_per_launch"] == 16380000000
+    assert p["gate_launch"] == "scan8_gate_kernel" and p["store"] == "f16"
+    p = parse_plan("family=scan_mm_kernel<int8 tiles over the 8-bit shadow> QT=256 kc=256 tiled=1")
+    assert p["family"] == "scan_mm_kernel<int8 tiles over the 8-bit shadow>" and p["tiled"] == 1
