@@ -18,7 +18,8 @@ gate rows are split across ranks.
   python bench.py --gpus N             # starts its own torch.distributed.run child (one rank per GPU, RCCL)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N     # same thing
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects
+Rank 0's LAST stdout line is the compact JSON record (contract in the task statement, < 6 KB: compact_record); the
+full record goes out one line earlier, prefixed `BENCH_DETAIL `, and into gpurun_out/bench_detail.json.  Extra objects:
   roofline      dominant kernel of the headline step (scan8 - or scan_topk with --shadow 0 -, HBM-bound),
                 measured live with HIP events on the launch stream inside libprag; algorithmic bytes =
                 the rows in the form that is scanned; `traffic` = HBM bytes per launch from two child
@@ -166,6 +167,7 @@ def cpu_baseline(args, states, q_c1, x_c1):
     out["value"] = 128 * N1 * r / dt
     out["sample"] = (f"config 1: torch-cpu flat L2 top-{k1}, 128 queries x {N1} docs x {D_EMB} fp32, {r} reps in "
                      f"{dt:.1f}s (faiss-cpu is not installed in this image)")
+    out["sample_short"] = f"C1: torch-cpu flat L2 top-{k1}, 128 q x {N1} docs x {D_EMB} f32, {r} reps in {dt:.1f}s; no faiss here"
     r, dt = _timed(lambda: torch_cpu.flat_search(docs, dn, q128[:1], k1, True), slice_s, 4000)
     out["flat_b1_scores_per_s"] = N1 * r / dt
     out["flat_b1_ms_per_search"] = dt / r * 1e3
@@ -387,6 +389,133 @@ def measure_gate_mfma(gate_batch):
     if got is None or not got["SQ_BUSY_CU_CYCLES"]:
         return None, note
     return got["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * got["SQ_BUSY_CU_CYCLES"]), note
+
+
+# ---------------------------------------------------------------------------------------------
+# The line the driver reads.  Round 5's single line grew to 20.7 KB and the driver could not parse it: the LAST stdout
+# line is now a compact record (< 6 KB, asserted by tests/test_bench_launch_cpu.py); the full record - variants,
+# thread sweeps, notes - goes out on an EARLIER line prefixed `BENCH_DETAIL ` and into gpurun_out/bench_detail.json.
+# ---------------------------------------------------------------------------------------------
+COMPACT_LIMIT = 6000
+
+
+def _sig(o, sig=5):
+    """Floats to `sig` significant digits (the compact line is a summary; the detail record keeps every digit)."""
+    if isinstance(o, bool) or o is None:
+        return o
+    if isinstance(o, float):
+        if o != o or abs(o) == float("inf"):
+            return None
+        if o == 0.0:
+            return 0.0
+        if abs(o) >= 1e15:
+            return o
+        r = float(f"{o:.{sig}g}")
+        return int(r) if r.is_integer() and abs(r) >= 10 ** sig else r
+    if isinstance(o, dict):
+        return {k: _sig(v, sig) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_sig(v, sig) for v in o]
+    return o
+
+
+def _pick(d, *keys):
+    d = d or {}
+    return {k: d.get(k) for k in keys if d.get(k) is not None}
+
+
+def compact_record(full):
+    """The < 6 KB record printed as the last stdout line: the contract's keys, `config` as scalars only, `roofline`
+    for the dominant kernel (+ the gate's kernel as `roofline.gate`), `cpu_baseline` with a short sample string."""
+    cfg = dict(full.get("config") or {})
+    emb = cfg.pop("embedding_like", None) or {}
+    for name in ("cos_4M", "l2_4M", "cos_21M"):                     # three numbers, not three dicts
+        e = emb.get(name) or {}
+        if e:
+            cfg[f"emb_{name}_two_level_ms"] = (e.get("two_level") or {}).get("ms_per_search")
+            cfg[f"emb_{name}_ids_identical"] = e.get("ids_identical")
+    cfg.pop("shard_pass_ms_by_mode", None)
+    cfg.pop("gate_overlap", None)
+    cfg = {k: v for k, v in cfg.items() if not isinstance(v, (dict, list))}
+    roof = full.get("roofline") or {}
+    r = _pick(roof, "bound", "kernel", "achieved", "peak", "unit", "frac", "frac_stored_rows", "traffic",
+              "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "avg_launch_ms", "launches_per_pass",
+              "launches_timed", "shard_scan8_frac", "shard_scan8_ms")
+    r.setdefault("traffic", None)
+    sa = roof.get("scan_alone") or {}
+    if sa:
+        r["scan_alone_ms"], r["scan_alone_frac"] = sa.get("avg_launch_ms"), sa.get("frac")
+    g = full.get("roofline_gate") or roof.get("gate") or {}
+    if g:
+        r["gate"] = _pick(g, "bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "hbm_GBs")
+        r["gate"]["matrix_pipe_busy"] = g.get("matrix_pipe_busy_frac_of_cu_busy")
+    cb = full.get("cpu_baseline")
+    if cb:
+        c = _pick(cb, "cores", "kind", "unit", "value", "gate_decisions_per_s", "gate_threads", "gate_b1_decisions_per_s",
+                  "flat_b1_scores_per_s")
+        c["sample"] = (cb.get("sample_short") or cb.get("sample") or "")[:100]
+        mw = cb.get("metric_workload_sample") or {}
+        if mw:
+            c["metric_workload_scores_per_s"] = mw.get("value")
+        cb = c
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "backend", "steps", "warmup",
+                                    "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["dtype"] = (full.get("dtype_short") or str(full.get("dtype") or ""))[:24]
+    out["config"] = cfg
+    out["roofline"] = r
+    out["cpu_baseline"] = cb
+    for k in ("probe_decisions_per_s", "scores_per_s_per_gpu", "planted_top1_recall", "result_lists_sorted",
+              "exact_fallbacks_last_search", "recall_at_k_vs_oracle", "topk_ids_bit_exact_vs_oracle", "exchange",
+              "plan", "detail"):
+        if full.get(k) is not None:
+            out[k] = full[k]
+    pr = full.get("per_rank")
+    if pr:                                   # N > 1: one short row per rank
+        out["per_rank"] = [[p.get("rows"), p.get("scan_ms"), p.get("gate_ms"), p.get("allgather_us")] if p else None
+                           for p in pr]
+        out["per_rank_columns"] = "rows, scan_ms, gate_ms, allgather_us"
+    cp = full.get("c_exchange_probe")
+    if cp:
+        out["c_exchange_probe"] = _pick(cp, "ok", "ms_per_pass", "allgather_us", "error")
+    out = _sig(_finite(out))
+    for k in ("value", "ms_per_step"):       # the driver checks these against its own clock: every digit
+        out[k] = _finite(full.get(k))
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > COMPACT_LIMIT:            # never let a long string through: drop optional blocks until it fits
+        for k in ("per_rank", "c_exchange_probe", "plan", "per_rank_columns"):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) <= COMPACT_LIMIT:
+                break
+    return out, line
+
+
+def emit(full, stream=None):
+    """BENCH_DETAIL line + side file first, the compact line LAST (the only line that starts with `{`)."""
+    stream = stream or sys.stdout
+    full = _finite(full)
+    detail_path = None
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        detail_path = os.path.join("gpurun_out", "bench_detail.json")
+        with open(os.path.join(ROOT, detail_path), "w") as f:
+            json.dump(full, f)
+    except OSError:
+        detail_path = None
+    full["detail"] = "BENCH_DETAIL line above" + (f"; {detail_path}" if detail_path else "")
+    _, line = compact_record(full)
+    stream.write("BENCH_DETAIL " + json.dumps(full) + "\n")
+    stream.write(line + "\n")
+    stream.flush()
+
+
+def quiet_stdout():
+    """Library chatter (gloo / RCCL banners, rocm warnings) must not land on stdout next to the record: fd 1 is
+    pointed at stderr for the rest of the process and the record is written to a private copy of the real stdout."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
 
 
 def launch_command(n_gpus, argv, port=None):
@@ -698,6 +827,7 @@ def main(argv=None):
     rc = self_launch(args, argv)
     if rc is not None:
         raise SystemExit(rc)
+    real_stdout = quiet_stdout()        # from here on only emit() reaches the real stdout
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -737,7 +867,8 @@ def main(argv=None):
         if rank == 0:
             out.update({"rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": backend,
                         "rank_devices": rank_devices})
-            print(json.dumps(out), flush=True)
+            real_stdout.write(json.dumps(_finite(out)) + "\n")
+            real_stdout.flush()
         if world > 1:
             dist.destroy_process_group()
         return
@@ -984,6 +1115,7 @@ def main(argv=None):
         "value": value, "unit": "query*doc scores/s",
         "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": backend,
         "rank_devices": rank_devices, "exchange": index.exchange, "exchange_note": index.exchange_note,
+        "dtype_short": "i8" if (scan_kernel == "scan8_kernel" or (tiled and i8_tiles)) else "f16",
         "per_rank": per_rank, "c_exchange_probe": c_probe,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -1169,7 +1301,6 @@ def main(argv=None):
         out["variants"] = None
     out["config"]["probe_decisions_per_s"] = out["probe_decisions_per_s"]
     out["config"]["exchange"] = index.exchange
-    out["roofline"]["gate"] = out["roofline_gate"]
 
     if world == 1 and not args.no_cpu_baseline:
         q_c1 = synth_rows(7, 0, 128, d_emb)
@@ -1177,7 +1308,7 @@ def main(argv=None):
         out["cpu_baseline"] = cpu_baseline(args, states, q_c1, x_c1)
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(_finite(out)), flush=True)
+    emit(out, real_stdout)
     if world > 1:
         index.close()
         dist.destroy_process_group()

@@ -57,6 +57,21 @@ class HipFlatIndex:
             raise ValueError(f"expected [n,{self.d}], got {x.shape}")
         return ctypes.c_void_p(x.ctypes.data), x.shape[0], 0, x
 
+    def _out_arg(self, out, B: int, k: int, device):
+        """(D float32 [B,k], I int64 [B,k]) on `device`: fresh tensors, or the caller's after a check - the C entry
+        points take bare pointers and write B*k elements of each."""
+        import torch
+        if out is None:
+            return (torch.empty((B, k), dtype=torch.float32, device=device),
+                    torch.empty((B, k), dtype=torch.int64, device=device))
+        D, I = out
+        for t, dt, name in ((D, torch.float32, "D"), (I, torch.int64, "I")):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.device == torch.device(device)):
+                raise ValueError(f"out {name}: expected a CUDA tensor on {device}")
+            if t.dtype != dt or tuple(t.shape) != (B, k) or not t.is_contiguous():
+                raise ValueError(f"out {name}: expected contiguous {dt} [{B},{k}], got {t.dtype} {tuple(t.shape)}")
+        return D, I
+
     def add(self, x):
         import torch
         if isinstance(x, torch.Tensor) and x.is_cuda and x.device != self.device:
@@ -84,12 +99,10 @@ class HipFlatIndex:
         k = int(k)
         fn = _lib.lib().prag_index_search_tagged if tagged else _lib.lib().prag_index_search
         if isinstance(x, torch.Tensor) and x.is_cuda:
+            if x.device != self.device:
+                raise ValueError(f"queries on {x.device}, index on {self.device}")
             ptr, B, _, keep = self._rows_arg(x)
-            if out is None:
-                D = torch.empty((B, k), dtype=torch.float32, device=x.device)
-                I = torch.empty((B, k), dtype=torch.int64, device=x.device)
-            else:
-                D, I = out
+            D, I = self._out_arg(out, B, k, x.device)
             with torch.cuda.device(self.device):
                 _lib.check(fn(self._h, ptr, B, k, int(id_offset), ctypes.c_void_p(D.data_ptr()),
                               ctypes.c_void_p(I.data_ptr()), 1, _lib.current_stream_ptr(x.device)))
@@ -116,12 +129,10 @@ class HipFlatIndex:
         k = int(k)
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
             x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).to(self.device)
+        if x.device != self.device:
+            raise ValueError(f"queries on {x.device}, index on {self.device}")
         ptr, B, _, keep = self._rows_arg(x)
-        if out is None:
-            D = torch.empty((B, k), dtype=torch.float32, device=x.device)
-            I = torch.empty((B, k), dtype=torch.int64, device=x.device)
-        else:
-            D, I = out
+        D, I = self._out_arg(out, B, k, x.device)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().prag_index_search_sharded(self._h, ptr, B, k, int(id_offset), ctypes.c_void_p(D.data_ptr()),
                                                             ctypes.c_void_p(I.data_ptr()), _lib.current_stream_ptr(x.device)))

@@ -155,11 +155,14 @@ def pool_ragged(acts, pred_lens, mean: bool = True):
     return out
 
 
-def pool_each_token(acts, pred_lens, labels=None):
+def pool_each_token(acts, pred_lens, labels=None, strict: bool = False):
     """`_input_tensor_method1` (train.py:153-162, utils.py:134-143) on device: the last pred_lens[b] positions of every
     sample of acts [B,T,d], concatenated -> float32 [sum(pred_lens), d], and (if `labels` is given)
     ``torch.repeat_interleave(labels, pred_lens)`` as an int64 tensor.  `pred_lens` comes from the data loader (host):
-    the row offsets are a host prefix sum, like the reference's Python loop over samples."""
+    the row offsets are a host prefix sum, like the reference's Python loop over samples.
+    ``strict`` (what method_1_train / method_1_eval pass): a pred_len of 0 or above T raises - in the reference `-0:` takes
+    ALL T positions and an over-long pred_len takes T, rows and repeated labels then differ in count and the loss
+    raises; without it such lengths are clipped to [0, T] (a ragged gather in its own right)."""
     import numpy as np
     import torch
     _lib.require_gpu()
@@ -167,9 +170,14 @@ def pool_each_token(acts, pred_lens, labels=None):
     if acts.dtype not in (torch.float32, torch.float16, torch.bfloat16):
         acts = acts.float()
     B, T, d = acts.shape
-    lens = np.clip(np.asarray(torch.as_tensor(pred_lens).cpu(), dtype=np.int64).reshape(-1), 0, T)
+    lens = np.asarray(torch.as_tensor(pred_lens).cpu(), dtype=np.int64).reshape(-1)
     if lens.shape[0] != B:
         raise ValueError(f"expected {B} pred_lens, got {lens.shape[0]}")
+    if strict and ((lens <= 0) | (lens > T)).any():
+        bad = int(np.flatnonzero((lens <= 0) | (lens > T))[0])
+        raise ValueError(f"pred_lens[{bad}] = {int(lens[bad])} outside [1, {T}]: rows and repeated labels would differ in "
+                         "count (utils.py:134-143)")
+    lens = np.clip(lens, 0, T)
     off = np.zeros(B + 1, np.int64)
     np.cumsum(lens, out=off[1:])
     n_rows = int(off[-1])
@@ -207,35 +215,31 @@ def _eval_forward(prober, x, labels):
     return round(correct / labels.size(0), 4), loss, probs
 
 
-def method_1_eval(prober, activations, labels, pred_lens):
+def method_1_eval(prober, activations, labels, pred_lens, args=None, return_probs: bool = False):
     """train.py:193-197 / utils.py:175-179 (`each_token`): every one of the last pred_len tokens is a sample with its
-    sequence's label.  Returns (accuracy over the TOKEN rows rounded to 4 places, len(labels) - the number of
-    sequences, as the reference returns it -, loss, probs)."""
-    x, new_labels = pool_each_token(activations, pred_lens, labels)
+    sequence's label.  Returns the reference's 3-tuple (accuracy over the TOKEN rows rounded to 4 places, len(labels) -
+    the number of sequences, as the reference returns it -, loss); ``return_probs=True`` appends the probabilities.
+    `args` (the reference's fifth positional: only `.device` is read there) is accepted and unused."""
+    x, new_labels = pool_each_token(activations, pred_lens, labels, strict=True)
     acc, loss, probs = _eval_forward(prober, x, new_labels)
-    return acc, len(labels), loss, probs
+    return (acc, len(labels), loss, probs) if return_probs else (acc, len(labels), loss)
 
 
-def method_3_eval(prober, activations, labels, pred_lens=None):
-    """train.py:245-249 / utils.py:222-226 (`last_token`): the prober on the last position only."""
+def method_3_eval(prober, activations, labels, pred_lens=None, args=None, return_probs: bool = False):
+    """train.py:245-249 / utils.py:222-226 (`last_token`): the prober on the last position only.  Same returns."""
     acc, loss, probs = _eval_forward(prober, pool_last_token(activations), labels)
-    return acc, len(labels), loss, probs
+    return (acc, len(labels), loss, probs) if return_probs else (acc, len(labels), loss)
 
 
-def method_2_eval(prober, activations, labels, pred_lens):
+def method_2_eval(prober, activations, labels, pred_lens, args=None, return_probs: bool = False):
     """train.py:199-208, 222-225 / utils.py:181-203 (`_method_2_util` + `return_acc`), forward
     only: ragged last-`pred_len` MEAN pool (HIP) -> prober (HIP) -> softmax(-1) ->
     CrossEntropyLoss applied to the probabilities (the reference's double softmax,
     train.py:149-150) -> argmax accuracy.  activations [B,T,d] on the GPU.
-    Returns (accuracy rounded to 4 places, n, loss, probs) - the reference returns the first
-    three."""
-    import torch
+    Returns (accuracy rounded to 4 places, n, loss) as the reference does; ``return_probs=True`` appends probs."""
     pooled = pool_ragged(activations, pred_lens, mean=True)
-    probs = torch.softmax(prober(pooled), dim=-1)
-    labels = torch.as_tensor(labels, device=probs.device).long()
-    loss = torch.nn.functional.cross_entropy(probs, labels)
-    correct = (torch.argmax(probs, dim=-1) == labels).sum().item()
-    return round(correct / labels.size(0), 4), len(labels), loss, probs
+    acc, loss, probs = _eval_forward(prober, pooled, labels)
+    return (acc, len(labels), loss, probs) if return_probs else (acc, len(labels), loss)
 
 
 def masked_mean_pool(hidden, attention_mask):
@@ -270,25 +274,36 @@ def search_and_gate(index, q, k: int, ens, x, ablation: int = 0, threshold: floa
     _lib.require_gpu()
     if not (isinstance(q, torch.Tensor) and q.is_cuda):
         raise RuntimeError("search_and_gate needs device queries (CUDA tensor [B,d])")
-    q = q.contiguous().float()
+    if q.device != index.device:
+        raise ValueError(f"queries on {q.device}, index on {index.device}")
+    q_ptr, B, _, keep = index._rows_arg(q)        # [B, index.d] float32 contiguous, or ValueError (the C entry has no d)
     x = ens._check_x(x, 3)
+    if x.device != index.device:
+        raise ValueError(f"pooled states on {x.device}, index on {index.device}")
     L, Bg = x.shape[0], x.shape[1]
     if L != ens.n_layers:
         raise RuntimeError(f"expected {ens.n_layers} layers of activations, got {L}")
-    B, k = q.shape[0], int(k)
-    if out is None:
-        out = (torch.empty((B, k), dtype=torch.float32, device=q.device), torch.empty((B, k), dtype=torch.int64, device=q.device))
+    k = int(k)
+    out = index._out_arg(out, B, k, index.device)
     if gate_out is None:
         gate_out = (torch.empty((L, Bg, 2), dtype=torch.float32, device=x.device),
                     torch.empty((Bg, 2), dtype=torch.float32, device=x.device),
                     torch.empty((Bg,), dtype=torch.int32, device=x.device))
+    else:
+        for t, shape, dt, name in ((gate_out[0], (L, Bg, 2), torch.float32, "logits"),
+                                   (gate_out[1], (Bg, 2), torch.float32, "probsum"),
+                                   (gate_out[2], (Bg,), torch.int32, "decision")):
+            if not (isinstance(t, torch.Tensor) and t.device == x.device and t.dtype == dt and tuple(t.shape) == shape
+                    and t.is_contiguous()):
+                raise ValueError(f"gate_out {name}: expected contiguous {dt} {list(shape)} on {x.device}")
     from .prober import _x_dtype
-    with torch.cuda.device(q.device):
+    with torch.cuda.device(index.device):
         _lib.check(_lib.lib().prag_search_and_gate(
-            index._h, ctypes.c_void_p(q.data_ptr()), B, k, int(id_offset), ctypes.c_void_p(out[0].data_ptr()),
+            index._h, q_ptr, B, k, int(id_offset), ctypes.c_void_p(out[0].data_ptr()),
             ctypes.c_void_p(out[1].data_ptr()), ens._h, ctypes.c_void_p(x.data_ptr()), _x_dtype(x), Bg * ens.d_model, Bg,
             int(ablation), float(threshold), ctypes.c_void_p(gate_out[0].data_ptr()), ctypes.c_void_p(gate_out[1].data_ptr()),
-            ctypes.c_void_p(gate_out[2].data_ptr()), 1 if tagged else 0, _lib.current_stream_ptr(q.device)))
+            ctypes.c_void_p(gate_out[2].data_ptr()), 1 if tagged else 0, _lib.current_stream_ptr(index.device)))
+    del keep
     return out, gate_out
 
 

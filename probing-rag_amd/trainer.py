@@ -141,7 +141,7 @@ def method_1_train(model: HipProberTrainer, optim, scheduler, activations, label
     """utils.py:164-173 / train.py:182-191 (`--method each_token`, train.py:354's default): every one of the last
     pred_lens[b] tokens is a training row carrying its sequence's label (`_input_tensor_method1`)."""
     from .loop import pool_each_token
-    x, new_labels = pool_each_token(activations, pred_lens, labels)
+    x, new_labels = pool_each_token(activations, pred_lens, labels, strict=True)
     loss, _ = model.step(x, new_labels)
     return round(loss.item(), 4), model.lr
 

@@ -131,3 +131,82 @@ def test_traffic_is_never_measured_from_inside_a_profiled_run(monkeypatch):
     monkeypatch.setenv("PATH", "/nonexistent")
     val, note = bench.measure_traffic(1000, "f16", "cos", 64, 1, "scan8_kernel")
     assert val is None and "rocprofv3" in note and not started
+
+
+# ---- the line the driver parses (a 20.7 KB line left BENCH_r05.parsed = null) -----------------------
+def _strict_loads(line):
+    import json
+
+    def _no_constants(name):
+        raise AssertionError(f"{name} is not JSON")
+    return json.loads(line, parse_constant=_no_constants)
+
+
+def _full_record(n_ranks=1):
+    """Round 5's full single-GPU record (profiles/r05f_bench.json, 20.7 KB), optionally dressed up as an N-rank run with
+    every optional block present and over-long strings - the worst case the compact line has to survive."""
+    import json
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05f_bench.json")))
+    if n_ranks > 1:
+        full["n_gpus"] = full["rccl_ranks"] = n_ranks
+        full["per_rank"] = [{"rank": r, "device": r, "rows": 2_625_000, "gate_rows": 512, "scan_ms": 0.38689423620700836,
+                             "gate_ms": None, "allgather_us": 31.41592653589793, "timed_region_s": 1.0512253229971975,
+                             "exact_fallbacks_last_search": 0} for r in range(n_ranks)]
+        full["c_exchange_probe"] = {"ok": True, "ms_per_pass": 0.4512345678, "allgather_us": 27.123456789, "passes": 100}
+        full["exchange_note"] = "x" * 900
+        full["cpu_baseline"]["sample"] = "y" * 900
+        full["roofline"]["nan_field"] = float("nan")
+        full["config"]["ms_per_pass"] = float("inf")
+    return full
+
+
+def test_the_last_line_is_compact_strict_json_with_the_contract_keys():
+    import bench
+    for n in (1, 8):
+        full = _full_record(n)
+        rec, line = bench.compact_record(full)
+        assert len(line) < bench.COMPACT_LIMIT == 6000 and "\n" not in line
+        got = _strict_loads(line)
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert key in got, key
+        assert got["value"] == full["value"] and got["ms_per_step"] == full["ms_per_step"]
+        assert "workload" in got["config"] and "model" not in got["config"]
+        assert not any(isinstance(v, (dict, list)) for v in got["config"].values())      # scalars only
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms"):
+            assert key in got["roofline"], key
+        assert got["roofline"]["gate"]["kernel"] and "roofline_gate" not in got            # one copy of the gate block
+        assert "definition" not in got["roofline"] and "variants" not in got
+        for key in ("value", "unit", "cores", "kind", "sample"):
+            assert key in got["cpu_baseline"], key
+        assert len(got["cpu_baseline"]["sample"]) <= 100 and len(got["dtype"]) <= 24
+        if n > 1:
+            assert len(got["per_rank"]) == n and got["per_rank"][0][0] == 2_625_000
+
+
+def test_emit_prints_the_detail_first_and_the_compact_line_last(tmp_path, monkeypatch):
+    import io
+    import json
+    import bench
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    buf = io.StringIO()
+    bench.emit(_full_record(8), buf)
+    lines = buf.getvalue().splitlines()
+    assert len(lines) == 2 and lines[0].startswith("BENCH_DETAIL {")
+    assert lines[-1].startswith("{") and len(lines[-1]) < bench.COMPACT_LIMIT
+    last = _strict_loads(lines[-1])
+    detail = _strict_loads(lines[0][len("BENCH_DETAIL "):])
+    assert "variants" in detail and detail["value"] == last["value"]
+    assert json.load(open(tmp_path / "gpurun_out" / "bench_detail.json"))["value"] == last["value"]
+
+
+def test_library_chatter_cannot_reach_stdout():
+    """After quiet_stdout() anything a library writes to fd 1 lands on stderr; only the saved stream is stdout."""
+    code = ("import os, sys; sys.path.insert(0, %r); import bench\n"
+            "real = bench.quiet_stdout()\n"
+            "os.write(1, b'[Gloo] Rank 0 is connected\\n'); print('python chatter')\n"
+            "real.write('{\"ok\": true}\\n'); real.flush()\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout == '{"ok": true}\n'
+    assert "[Gloo]" in out.stderr and "python chatter" in out.stderr

@@ -282,7 +282,7 @@ def test_method_2_eval_matches_reference_golden(torch_cuda, golden):
     acts, pred_lens, labels = cases.synth_pool_inputs(case)
     p = pra.HipProber(case["d"], 2)
     p.load_state_dict(cases.synth_state(case["wseed"], case["d"]))
-    acc, n, loss, probs = pra.method_2_eval(p, torch.from_numpy(acts).cuda(), labels, pred_lens)
+    acc, n, loss, probs = pra.method_2_eval(p, torch.from_numpy(acts).cuda(), labels, pred_lens, return_probs=True)
     np.testing.assert_allclose(probs.cpu().numpy(), golden[f"{case['name']}/probs"], atol=TOL, rtol=0)
     assert abs(float(loss) - float(golden[f"{case['name']}/loss"])) < 1e-4
     assert acc == round(float(golden[f"{case['name']}/acc"]), 4) and n == case["B"]

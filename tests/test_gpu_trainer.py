@@ -182,7 +182,8 @@ def test_each_token_and_last_token_methods_keep_the_reference_signatures(golden)
     prober.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
     a = torch.from_numpy(acts).cuda()
     for tag, fn in (("m1", pra.method_1_eval), ("m3", pra.method_3_eval)):
-        acc, n, loss, probs = fn(prober, a, torch.from_numpy(labels), torch.from_numpy(pred_lens))
+        acc, n, loss, probs = fn(prober, a, torch.from_numpy(labels), torch.from_numpy(pred_lens), None, return_probs=True)
+        assert len(fn(prober, a, torch.from_numpy(labels), torch.from_numpy(pred_lens), None)) == 3   # the reference's call
         np.testing.assert_allclose(probs.cpu().numpy(), golden[f"{name}/{tag}_probs"], atol=1e-4, rtol=0)
         assert abs(loss.item() - float(golden[f"{name}/{tag}_loss"])) < 1e-4
         assert acc == float(golden[f"{name}/{tag}_acc"]) and n == int(golden[f"{name}/{tag}_n"])
@@ -198,6 +199,10 @@ def test_each_token_and_last_token_methods_keep_the_reference_signatures(golden)
     rows, lab = pra.pool_each_token(a, lens, labels)
     want, wl = onp.pool_each_token(acts, lens, labels)
     assert rows.shape[0] == int(lens.sum()) and np.array_equal(rows.cpu().numpy(), want) and np.array_equal(lab.cpu().numpy(), wl)
+    # ... which the reference's method_1_* cannot digest (`-0:` takes every position, labels repeat 0 times): they raise
+    for bad in (lens, np.full_like(lens, case["T"] + 1)):
+        with pytest.raises(ValueError):
+            pra.method_1_eval(prober, a, torch.from_numpy(labels), torch.from_numpy(bad), None)
     # the training wrappers
     for train_fn, pool in ((pra.method_1_train, lambda: pra.pool_each_token(a, pred_lens, labels)),
                            (pra.method_3_train, lambda: (pra.pool_last_token(a), torch.from_numpy(labels)))):
