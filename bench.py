@@ -115,6 +115,10 @@ def parse(argv=None):
     ap.add_argument("--e2e-new-tokens", type=int, default=16)
     ap.add_argument("--e2e-prompt-len", type=int, default=64)
     ap.add_argument("--e2e-theta", type=float, default=0.0)
+    ap.add_argument("--e2e-step-gate", type=int, default=1,
+                    help="1 (default): the pool's one launch per decode step also runs the gate on the sums so far "
+                         "(HiddenStatePool.attach_gate / prag_pool_step_gate), the loop's gate call reads the decision from "
+                         "host memory; 0: round 5's loop - prag_gate_decide after `generate` has returned")
     ap.add_argument("--e2e-cpu-docs", type=int, default=200_000,
                     help="rows of the sub-corpus the reference-style path scans on the CPU")
     return ap.parse_args(argv)

@@ -102,10 +102,17 @@ def _run_path(kind, torch, pra, lm, states, lock, my_queries, args, dev, cpu_sub
             handles.append(lm.model.layers[l].register_forward_hook(
                 lambda mod, inp, out, slot=slot: pool.observe(slot, out[0] if isinstance(out, tuple) else out)))
         reset = pool.reset
+        if getattr(args, "e2e_step_gate", 1):
+            # round 6: every decode step's pooling launch also runs the gate on the sums so far (prag_pool_step_gate);
+            # the decision of the last step is in host memory when `generate` returns
+            pool.attach_gate(ens, 0, args.e2e_theta)
 
-        def gate():
-            # one C call: gate kernels, the decision in host memory, the wait (prag_gate_decide)
-            return int(ens.decide(pool.pooled(), ablation=0, threshold=args.e2e_theta)[0])
+            def gate():
+                return int(pool.decide()[0])
+        else:
+            def gate():
+                # one C call: gate kernels, the decision in host memory, the wait (prag_gate_decide)
+                return int(ens.decide(pool.pooled(), ablation=0, threshold=args.e2e_theta)[0])
     else:
         from oracle import torch_cpu                     # baseline leg: the reference-shaped eager modules
         probers = [m.to(dev) for m in torch_cpu.make_probers(states, D_MODEL)]

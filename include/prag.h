@@ -154,6 +154,31 @@ int prag_pool_accumulate(float* acc_dev, const void* h_dev, int h_dtype, int64_t
 int prag_pool_accumulate_layers(float* acc_dev, const void* const* h_dev_ptrs, int n_layers, int h_dtype,
                                 int64_t n_elems, int assign, void* stream);
 
+/* One decode step of the hooked layers AND the gate on the sums so far, in ONE launch (round 6).  The reference's hooks
+ * copy each probed layer's activations to the host on every forward pass (exp_rag.py:317-329) and the gate - cat / sum,
+ * six probers, softmax / sum / threshold, exp_rag.py:381-389, 406-415 - only starts after `generate` has returned.
+ * Here the launch that adds a decode step's activations to the running sums (prag_pool_accumulate_layers' one launch
+ * per token) also runs the B <= 4 gate on the sums it has just formed and leaves decision, sums and a tag in pinned host
+ * memory: the decision of the last decode step is on the host by the time `generate` returns, computed in the shadow of
+ * the LM's remaining layers; the loop's `if` (exp_rag.py:414) reads it with prag_gate_step_result.  The decision is
+ * bit-identical to prag_gate_decide on acc_out (same kernels' arithmetic, same order).
+ *   acc_in_dev / acc_out_dev  float32 [L][B][d_model]: sums before / after this step - two DIFFERENT buffers (the
+ *                             caller alternates them); acc_in is not read when assign != 0 (first step after a reset)
+ *   h_dev_ptrs                HOST array of L device pointers: each layer's [B][d_model] activations, type h_dtype
+ *   *tag_out                  names this step for prag_gate_step_result
+ * Work on `stream`; the handle's workspaces are shared with prag_gate*, so use one stream per handle.
+ * PRAG_EUNSUPPORTED when prag_gate would not take the small-batch kernels for this B (B > 4, or > 2 with PRAG_W_F16),
+ * d_model > 4096 or L > 16: the caller uses prag_pool_accumulate_layers + prag_gate_decide. */
+int prag_pool_step_gate(prag_prober_t* p, const float* acc_in_dev, float* acc_out_dev, const void* const* h_dev_ptrs,
+                        int h_dtype, int B, int assign, int ablation, double theta, uint64_t* tag_out, void* stream);
+
+/* exp_rag.py:393, 406-415's host branch for the step `tag` (the handle's most recent prag_pool_step_gate; anything
+ * else: PRAG_ESTATE): decision_host int32 [B] (1 = retrieve), probsum_host float32 [B,2] or NULL.  Polls the tag word
+ * the launch writes last (~200 us), then waits for `stream`.  PRAG_ESTATE also when a hand-off inside the launch gave
+ * up after ~50 ms (another kernel held the chip): the sums are intact, decide on them with prag_gate_decide. */
+int prag_gate_step_result(prag_prober_t* p, uint64_t tag, int B, int32_t* decision_host, float* probsum_host,
+                          void* stream);
+
 /* Replaces input_tensor_method1 + per-sample mean (train.py:153-162, 202-205;
  * utils.py:134-143, 184-186): out[b,:] = mean over the last pred_lens[b]
  * positions of acts[b] ([B,T,d], element type dtype: PRAG_F32 / PRAG_F16 / PRAG_BF16).  out float32 [B,d];

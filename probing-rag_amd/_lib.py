@@ -64,6 +64,8 @@ SIGNATURES = {
     "prag_prober_destroy": (None, [_P]),
     "prag_pool_accumulate": (_I, [_P, _P, _I, _L, _I, _P]),
     "prag_pool_accumulate_layers": (_I, [_P, _P, _I, _I, _L, _I, _P]),
+    "prag_pool_step_gate": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_double, ctypes.POINTER(ctypes.c_uint64), _P]),
+    "prag_gate_step_result": (_I, [_P, ctypes.c_uint64, _I, _P, _P, _P]),
     "prag_pool_ragged": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "prag_pool_masked_mean": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
     "prag_pool_each_token": (_I, [_P, _I, _I, _I, _I, _P, _L, _P, _P, _P, _P]),

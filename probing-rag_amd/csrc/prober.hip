@@ -1070,8 +1070,9 @@ struct prag_prober {
     // PRAG_PROBER_SMALL=0: always the MFMA-tiled kernel; 1 (default): three short launches; 3: the same stages in
     // ONE launch with in-launch hand-offs (round 4: built, bit-identical, and SLOWER - 30.2 against 25.2 us per gate
     // at one pooled state, profiles/r04c_latency.txt: a hand-off costs a write-through drain, an atomic, a poll and
-    // a load from beyond L2, ~5 us, where a kernel boundary costs ~2 us and leaves the data in L2; since round 5 the
-    // kernel exists in the `make diag` build only - in libprag.so mode 3 runs the three launches)
+    // a load from beyond L2, ~5 us, where a kernel boundary costs ~2 us and leaves the data in L2).  Round 6: the
+    // one-launch form is what a decode step of the LM ends with (prag_pool_step_gate below) - there the launch count
+    // per token is what the host pays for)
     int small_mode = 1;
     int ct_force = 0;            // PRAG_PROBER_CT at creation: row-tile height override (tuning runs)
     _Float16* ws_h = nullptr;  // [L][maxB][d] hi / lo workspace for fp32 activations
@@ -1089,6 +1090,11 @@ struct prag_prober {
     char* dec_dev = nullptr;            // device staging for batches beyond kDecideDirect
     int dec_cap = 0;
     int dec_spin = 1;                   // PRAG_DECIDE_SPIN=0 at creation: always hipStreamSynchronize
+    // prag_pool_step_gate: the result block of the most recent step (mapped pinned memory the kernel writes):
+    // uint64 tag | int32 decision[8] | float probsum[8][2]
+    uint64_t* step_host = nullptr;
+    uint64_t* step_host_dev = nullptr;
+    uint64_t step_tag = 0;              // tag of the most recent step enqueued on this handle
     // tickets of the gate folded into prober16_body: one word per row tile, zero between launches
     uint32_t* tile_cnt = nullptr;
     int tile_cnt_cap = 0;
@@ -1770,6 +1776,112 @@ extern "C" int prag_gate_decide(prag_prober_t* p, const void* x_dev, int x_dtype
     return PRAG_OK;
 }
 
+// One decode step of the hooked layers AND the gate on the sums so far, in ONE launch.  The reference's hooks copy every
+// layer's activations to the host on every forward pass (exp_rag.py:317-329) and the gate - cat / sum / six probers /
+// softmax / threshold, exp_rag.py:381-389, 406-415 - starts when `generate` has returned, on a host whose caches the LM's
+// 140 ms of Python have emptied: measured 87-135 us per prag_gate_decide call inside the loop against 30 back to back
+// (profiles/r06b_gate_in_loop.txt; the kernels themselves take 25 us there, the rest is the cold host path of three
+// launches and a poll).  Here the launch that adds a decode step's activations to the running sums (the pool's one
+// launch per token since round 4) also runs the gate on the sums it has just formed and leaves the decision in pinned
+// host memory: when `generate` returns, the decision of its last step is already on the host.
+//   acc_in / acc_out  float32 [L][B][d_model], DIFFERENT buffers (ping-pong; acc_in is not read when assign != 0)
+//   h_dev_ptrs        host array of L device pointers, [B][d_model] of h_dtype each
+//   *tag_out          identifies this step for prag_gate_step_result
+// PRAG_EUNSUPPORTED outside the small-batch envelope (B rows the small path serves, d_model <= 4096, L <= 16): the
+// caller then adds with prag_pool_accumulate_layers and decides with prag_gate_decide.
+extern "C" int prag_pool_step_gate(prag_prober_t* p, const float* acc_in_dev, float* acc_out_dev,
+                                   const void* const* h_dev_ptrs, int h_dtype, int B, int assign, int ablation,
+                                   double theta, uint64_t* tag_out, void* stream) {
+    PRAG_REQUIRE(p != nullptr, PRAG_EINVAL, "prober handle is NULL");
+    PRAG_REQUIRE(acc_out_dev && h_dev_ptrs && tag_out && (assign || acc_in_dev), PRAG_EINVAL,
+                 "prag_pool_step_gate: NULL pointer");
+    PRAG_REQUIRE(acc_in_dev != acc_out_dev, PRAG_EINVAL, "prag_pool_step_gate: acc_in and acc_out must be different buffers");
+    PRAG_REQUIRE(h_dtype == PRAG_F32 || h_dtype == PRAG_F16 || h_dtype == PRAG_BF16, PRAG_EINVAL, "h_dtype=%d", h_dtype);
+    PRAG_REQUIRE(ablation >= 0 && ablation <= p->n_layers, PRAG_EINVAL, "ablation=%d outside [0,%d]", ablation, p->n_layers);
+    PRAG_REQUIRE(B >= 1, PRAG_EINVAL, "B=%d must be >= 1", B);
+    for (int l = 0; l < p->n_layers; ++l) {
+        PRAG_REQUIRE(p->loaded[l], PRAG_ESTATE, "layer %d has no weights loaded", l);
+        PRAG_REQUIRE(h_dev_ptrs[l] != nullptr, PRAG_EINVAL, "prag_pool_step_gate: layer %d pointer is NULL", l);
+    }
+    // the rows prag_gate would hand to the small-batch kernels, so that the step's decision IS prag_gate_decide's
+    PRAG_REQUIRE(p->small_mode && small_supported(B, p->d) && B <= (p->na == 2 ? 4 : 2) && p->d <= 4096 &&
+                     p->n_layers <= kSmallStepMaxLayers && p->small_sync != nullptr,
+                 PRAG_EUNSUPPORTED, "prag_pool_step_gate: B=%d d_model=%d layers=%d is outside the small-batch gate", B, p->d,
+                 p->n_layers);
+    int rc = decide_reserve(p, B);
+    if (rc != PRAG_OK) return rc;
+    if (!p->step_host) {
+        PRAG_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->step_host), 128, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(p->step_host, 0, 128);
+        PRAG_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->step_host_dev), p->step_host, 0));
+    }
+    SmallRun r;
+    r.layers = p->d_small;
+    r.x = nullptr;
+    r.x_dtype = h_dtype;
+    r.x_layer_stride = 0;
+    r.layer0 = 0;
+    r.n_run = p->n_layers;
+    r.B = B;
+    r.d = p->d;
+    r.h1 = p->small_ws;
+    r.h2 = p->small_ws + (size_t)p->n_layers * kSmallMaxB * kHidden;
+    r.logits = p->dec_logits;
+    r.ablation = ablation;
+    r.theta = theta;
+    r.probsum = nullptr;
+    r.decision = nullptr;
+    r.sync = p->small_sync;
+    r.fused = 1;
+    SmallStep sp;
+    sp.h = h_dev_ptrs;
+    sp.acc_in = acc_in_dev;
+    sp.acc_out = acc_out_dev;
+    sp.assign = assign;
+    sp.tag = ++p->step_tag;
+    sp.host_dev = p->step_host_dev;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    p->prof.begin(st);
+    rc = small_step_run(r, sp, st);
+    p->prof.end(st);
+    if (rc != PRAG_OK) return rc;
+    *tag_out = sp.tag;
+    return PRAG_OK;
+}
+
+// The decision the step tagged `tag` left on the host (exp_rag.py:393, 406-415's `if`): decision_host int32 [B],
+// probsum_host float32 [B,2] or NULL.  Only the MOST RECENT step of a handle can be asked for (PRAG_ESTATE otherwise:
+// a later step has overwritten the block).  Polls the tag word for ~200 us, then waits for `stream` (the stream the
+// step was enqueued on).  PRAG_ESTATE as well when a hand-off inside that launch timed out (another kernel held the
+// chip for ~50 ms): the sums are fine - the caller falls back to prag_gate_decide on them.
+extern "C" int prag_gate_step_result(prag_prober_t* p, uint64_t tag, int B, int32_t* decision_host, float* probsum_host,
+                                     void* stream) {
+    PRAG_REQUIRE(p != nullptr && decision_host != nullptr, PRAG_EINVAL, "prag_gate_step_result: NULL pointer");
+    PRAG_REQUIRE(B >= 1 && B <= kSmallMaxB, PRAG_EINVAL, "B=%d outside [1,%d]", B, kSmallMaxB);
+    PRAG_REQUIRE(p->step_host != nullptr && tag != 0 && tag == p->step_tag, PRAG_ESTATE,
+                 "prag_gate_step_result: tag %llu is not the handle's most recent step (%llu)", (unsigned long long)tag,
+                 (unsigned long long)p->step_tag);
+    volatile uint64_t* tw = p->step_host;
+    constexpr uint64_t kVoid = 1ull << 63;
+    bool done = false;
+    for (int it = 0; it < 200000 && !done; ++it) {
+        done = (__atomic_load_n(tw, __ATOMIC_ACQUIRE) & ~kVoid) == tag;
+        if (!done) __builtin_ia32_pause();
+    }
+    if (!done) {
+        PRAG_HIP(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+        done = (__atomic_load_n(tw, __ATOMIC_ACQUIRE) & ~kVoid) == tag;
+    }
+    PRAG_REQUIRE(done, PRAG_ESTATE, "prag_gate_step_result: the step's launch finished without publishing tag %llu",
+                 (unsigned long long)tag);
+    PRAG_REQUIRE((*tw & kVoid) == 0, PRAG_ESTATE, "prag_gate_step_result: a hand-off inside the step's launch timed out");
+    const int32_t* hd = reinterpret_cast<const int32_t*>(p->step_host + 1);
+    const float* hp = reinterpret_cast<const float*>(hd + kSmallMaxB);
+    for (int b = 0; b < B; ++b) decision_host[b] = hd[b];
+    if (probsum_host) memcpy(probsum_host, hp, (size_t)B * 2 * sizeof(float));
+    return PRAG_OK;
+}
+
 extern "C" int prag_prober_profile(prag_prober_t* p, int slots) {
     PRAG_REQUIRE(p != nullptr && slots >= 0 && slots <= 4096, PRAG_EINVAL, "prag_prober_profile: bad argument");
     if (slots == 0) {
@@ -1799,6 +1911,7 @@ extern "C" void prag_prober_destroy(prag_prober_t* p) {
     if (p->dec_logits) (void)hipFree(p->dec_logits);
     if (p->dec_host) (void)hipHostFree(p->dec_host);
     if (p->dec_dev) (void)hipFree(p->dec_dev);
+    if (p->step_host) (void)hipHostFree(p->step_host);
     delete p;
 }
 

@@ -37,6 +37,18 @@ struct SmallRun {
 };
 
 constexpr int kSmallMaxB = 8;
+constexpr int kSmallStepMaxLayers = 16;   // layers of one prag_pool_step_gate launch (pointer table passed by value)
+
+// One decode step of the hooked layers + the gate on the sums so far (prag_pool_step_gate)
+struct SmallStep {
+    const void* const* h;       // host array [n_run] of device pointers: each layer's activations of this step, [B][d]
+    const float* acc_in;        // device [n_run][B][d]: sums before this step (not read when assign)
+    float* acc_out;             // device [n_run][B][d]: sums after it; a different buffer
+    int assign;
+    uint64_t tag;               // > 0, < 2^63
+    uint64_t* host_dev;         // device view of the mapped pinned block: tag | int32 decision[8] | float probsum[8][2]
+};
+int small_step_run(const SmallRun& r, const SmallStep& sp, hipStream_t st);
 constexpr int kSmallMaxElems = 16384;   // B * d staged in LDS as f32 (64 KiB)
 inline bool small_supported(int B, int d) { return B >= 1 && B <= kSmallMaxB && (int64_t)B * d <= kSmallMaxElems; }
 // Enqueue the gate on `st`: one launch (r.sync given), or the three launches of rounds 2-3.

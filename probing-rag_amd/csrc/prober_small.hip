@@ -57,6 +57,33 @@ __device__ __forceinline__ float sm_silu(float h) { return h / (1.0f + __expf(-h
 // (K <= 4096: 16 x 16 B per lane) - round 3 read it three times, three dependent memory round trips in front of
 // the first weight - mean, centred second moment and the normalised values come from the registers, in the
 // order of the three-pass form (same sums, same results).
+// (the K <= 4096 form: the row sits in registers, 16 x 16 B per lane)
+__device__ __forceinline__ void small_ln_regs(const f32x4 (&v)[16], int K, int lane, float* dst) {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        if (lane * 4 + u * 256 < K) s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+    const float mean = wave_sum(s) / (float)K;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        if (lane * 4 + u * 256 < K) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dv = v[u][e] - mean;
+                q = fmaf(dv, dv, q);
+            }
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + kSmEps);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int i = lane * 4 + u * 256;
+        if (i < K)
+            *reinterpret_cast<f32x4*>(dst + i) =
+                f32x4{(v[u][0] - mean) * rstd, (v[u][1] - mean) * rstd, (v[u][2] - mean) * rstd, (v[u][3] - mean) * rstd};
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void small_ln_rows(const T* __restrict__ in_rows, int B, int K, float* s_xn, int w, int lane) {
     for (int b = w; b < B; b += 4) {
@@ -68,29 +95,7 @@ __device__ __forceinline__ void small_ln_rows(const T* __restrict__ in_rows, int
                 const int i = lane * 4 + u * 256;
                 v[u] = i < K ? sm_load4(src + i) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            float s = 0.f;
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (lane * 4 + u * 256 < K) s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
-            const float mean = wave_sum(s) / (float)K;
-            float q = 0.f;
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (lane * 4 + u * 256 < K) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float dv = v[u][e] - mean;
-                        q = fmaf(dv, dv, q);
-                    }
-                }
-            const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + kSmEps);
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int i = lane * 4 + u * 256;
-                if (i < K)
-                    *reinterpret_cast<f32x4*>(s_xn + b * K + i) =
-                        f32x4{(v[u][0] - mean) * rstd, (v[u][1] - mean) * rstd, (v[u][2] - mean) * rstd, (v[u][3] - mean) * rstd};
-            }
+            small_ln_regs(v, K, lane, s_xn + b * K);
         } else {
             float s = 0.f;
             for (int i = lane * 4; i < K; i += 256) {
@@ -114,6 +119,30 @@ __device__ __forceinline__ void small_ln_rows(const T* __restrict__ in_rows, int
                     f32x4{(v[0] - mean) * rstd, (v[1] - mean) * rstd, (v[2] - mean) * rstd, (v[3] - mean) * rstd};
             }
         }
+    }
+}
+
+// The decode-step form (round 6, K <= 4096): the input row of the gate is the running sum of the hooked activations,
+// acc_out = (assign ? 0 : acc_in) + h - pool_accumulate_layers_kernel's arithmetic, element by element - formed in
+// registers on the way into the LayerNorm; `acc_out` != null (one workgroup per layer) also stores it.
+template <typename T>
+__device__ __forceinline__ void small_ln_rows_step(const float* __restrict__ acc_in, const T* __restrict__ h,
+                                                   float* __restrict__ acc_out, int assign, int B, int K, float* s_xn, int w,
+                                                   int lane) {
+    for (int b = w; b < B; b += 4) {
+        f32x4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = lane * 4 + u * 256;
+            if (i < K) {
+                const f32x4 hv = sm_load4(h + (int64_t)b * K + i);
+                v[u] = assign ? hv : (*reinterpret_cast<const f32x4*>(acc_in + (int64_t)b * K + i) + hv);
+                if (acc_out) *reinterpret_cast<f32x4*>(acc_out + (int64_t)b * K + i) = v[u];
+            } else {
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        small_ln_regs(v, K, lane, s_xn + b * K);
     }
 }
 
@@ -304,7 +333,6 @@ struct SmallSync {          // device words of one prober handle, zero between l
     uint32_t pad[2];
 };
 
-#ifdef PRAG_MM_DIAG   // measured slower than three launches (profiles/r04c_latency.txt): kept for A/B in libprag_diag.so only
 // One launch for the whole small-batch gate.
 // Hand-offs follow cdna_hip_programming.md Guideline 16 in its counter form, with write-through payloads:
 //   producer: every value another workgroup will read is stored `sc1` (relaxed agent-scope atomic store = one
@@ -321,12 +349,30 @@ struct SmallSync {          // device words of one prober handle, zero between l
 // of this launch has happened), so a replayed graph node starts from clean state; they are zeroed once at creation.
 // ---------------------------------------------------------------------------------------------------------------
 
-template <typename T, int B_MAX>
+//
+// Round 6 - STEP: the launch a decode step of the LM ends with (prag_pool_step_gate).  Stage 1's input rows are the
+// running sums of the hooked activations, formed on the way in (acc_out = acc_in + h, stored by the first workgroup of
+// each layer; acc_in and acc_out are DIFFERENT buffers - the layer's other workgroups still read acc_in), and the last
+// stage leaves decision, sums and the step's tag in pinned host memory: the decision is on the host before
+// `generate` returns, computed in the shadow of the LM's last layers.  Standing alone the one-launch form is ~5 us
+// slower on the GPU than three launches (profiles/r04c_latency.txt); inside the loop the launch count per token is
+// what the host pays for, and it stays ONE (it replaces pool_accumulate_layers_kernel's).
+struct SmallStepArgs {
+    const void* h[kSmallStepMaxLayers];   // where the model left each layer's activations of this step ([B][K], type T)
+    const float* acc_in;                  // [n_run][B][K] sums before this step (not read when assign)
+    float* acc_out;                       // [n_run][B][K] sums after it
+    int assign;
+    uint64_t tag;                         // written to host[0] last (bit 63 set: a hand-off timed out, outputs void)
+    uint64_t* host;                       // mapped pinned block: tag | int32 decision[8] | float probsum[8][2]
+};
+
+template <typename T, int B_MAX, bool STEP>
 __global__ __launch_bounds__(256) void small_fused_kernel(const SmallLayer* __restrict__ layers, int layer0, int n_run,
                                                          const T* __restrict__ in, int64_t in_layer_stride, int B, int K,
                                                          float* h1, float* h2, SmallSync* sync,
                                                          float* __restrict__ logits, int ablation, double theta,
-                                                         float* __restrict__ probsum, int32_t* __restrict__ decision) {
+                                                         float* __restrict__ probsum, int32_t* __restrict__ decision,
+                                                         SmallStepArgs step) {
     extern __shared__ __attribute__((aligned(16))) float s_xn[];   // [B][max(K, 512)] normalised rows | head scratch
     // (the flag word sits BEHIND the rows in the dynamic region: a static __shared__ object in front would move
     // the region's base off its 16-byte alignment - cdna_hip_programming.md Guideline 17)
@@ -338,7 +384,13 @@ __global__ __launch_bounds__(256) void small_fused_kernel(const SmallLayer* __re
     // ---- stage 1: LayerNorm of the caller's rows -> LDS, fc1 + SiLU -> h1 (write-through) ----------------------
     SmallWPre pre;
     small_w_preload(pre, L.W1, K, n0, lane);
-    small_ln_rows<T>(in + (int64_t)lrun * in_layer_stride, B, K, s_xn, w, lane);
+    if constexpr (STEP) {
+        const int64_t lo = (int64_t)lrun * B * K;
+        small_ln_rows_step<T>(step.acc_in + lo, reinterpret_cast<const T*>(step.h[lrun]),
+                              blockIdx.x == 0 ? step.acc_out + lo : nullptr, step.assign, B, K, s_xn, w, lane);
+    } else {
+        small_ln_rows<T>(in + (int64_t)lrun * in_layer_stride, B, K, s_xn, w, lane);
+    }
     __syncthreads();
     small_fc_tile<B_MAX, true>(L.W1, L.b1, s_xn, B, K, n0, lane, h1 + (int64_t)lrun * B * kSmH, pre);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
@@ -426,7 +478,9 @@ __global__ __launch_bounds__(256) void small_fused_kernel(const SmallLayer* __re
             s_logit[pr * 2 + 1] = d1;
         }
     }
-    if (!decision && !probsum) return;
+    if constexpr (!STEP) {
+        if (!decision && !probsum) return;
+    }
     __syncthreads();
     if (tid < B) {   // the gate: same arithmetic and order as gate_kernel (prober.hip)
         float s0 = 0.f, s1 = 0.f;
@@ -438,24 +492,40 @@ __global__ __launch_bounds__(256) void small_fused_kernel(const SmallLayer* __re
             s0 += e0 * inv;
             s1 += e1 * inv;
         }
+        const int32_t dec = ((double)s0 + theta < (double)s1) ? 0 : 1;
         if (probsum) {
             probsum[2 * tid] = s0;
             probsum[2 * tid + 1] = s1;
         }
-        if (decision) decision[tid] = ((double)s0 + theta < (double)s1) ? 0 : 1;
+        if (decision) decision[tid] = dec;
+        if constexpr (STEP) {
+            int32_t* hd = reinterpret_cast<int32_t*>(step.host + 1);
+            float* hp = reinterpret_cast<float*>(hd + kSmallMaxB);
+            hd[tid] = dec;
+            hp[2 * tid] = s0;
+            hp[2 * tid + 1] = s1;
+            __threadfence_system();           // the results are on their way to the host before the tag
+        }
+    }
+    if constexpr (STEP) {
+        __syncthreads();
+        if (tid == 0) {
+            // a hand-off of this launch that timed out voids the outputs: the tag says so and the word is handed back
+            const uint32_t gave_up = __hip_atomic_load(&sync->giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gave_up) __hip_atomic_store(&sync->giveup, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(step.host, step.tag | (gave_up ? (1ull << 63) : 0ull), __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
-#endif  // PRAG_MM_DIAG
-
 size_t small_sync_bytes() { return sizeof(SmallSync); }
 
-#ifdef PRAG_MM_DIAG
-template <typename T, int BM>
-static int launch_fused_small_bm(const SmallRun& r, hipStream_t st) {
+template <typename T, int BM, bool STEP>
+static int launch_fused_small_bm(const SmallRun& r, const SmallStepArgs& step, hipStream_t st) {
     const dim3 grid(kSmH / 16, r.n_run), block(256);
     const size_t lds = (size_t)r.B * (r.d > kSmH ? r.d : kSmH) * sizeof(float) + 16;   // + the flag word
-    auto kern = small_fused_kernel<T, BM>;
+    auto kern = small_fused_kernel<T, BM, STEP>;
     static LdsOptIn lds_opt_in;     // 8 rows x 2048 (or 4 x 4096) floats + the flag word is just over 64 KiB
     {
         const int rc_ = lds_opt_in.ensure(reinterpret_cast<const void*>(kern), kSmallMaxElems * (int)sizeof(float) + 16);
@@ -463,20 +533,35 @@ static int launch_fused_small_bm(const SmallRun& r, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, grid, block, lds, st, r.layers, r.layer0, r.n_run, reinterpret_cast<const T*>(r.x),
                        r.x_layer_stride, r.B, r.d, r.h1, r.h2, reinterpret_cast<SmallSync*>(r.sync), r.logits, r.ablation,
-                       r.theta, r.probsum, r.decision);
+                       r.theta, r.probsum, r.decision, step);
     PRAG_LAUNCH_CHECK();
     return PRAG_OK;
 }
 
-template <typename T>
-static int launch_fused_small(const SmallRun& r, hipStream_t st) {
-    if (r.B <= 1) return launch_fused_small_bm<T, 1>(r, st);
-    if (r.B <= 2) return launch_fused_small_bm<T, 2>(r, st);
-    if (r.B <= 4) return launch_fused_small_bm<T, 4>(r, st);
-    return launch_fused_small_bm<T, 8>(r, st);
+template <typename T, bool STEP>
+static int launch_fused_small(const SmallRun& r, const SmallStepArgs& step, hipStream_t st) {
+    if (r.B <= 1) return launch_fused_small_bm<T, 1, STEP>(r, step, st);
+    if (r.B <= 2) return launch_fused_small_bm<T, 2, STEP>(r, step, st);
+    if (r.B <= 4) return launch_fused_small_bm<T, 4, STEP>(r, step, st);
+    return launch_fused_small_bm<T, 8, STEP>(r, step, st);
 }
 
-#endif  // PRAG_MM_DIAG
+// One decode step + the gate on the sums so far, one launch (prag_pool_step_gate).  r.x is not read.
+int small_step_run(const SmallRun& r, const SmallStep& sp, hipStream_t st) {
+    PRAG_REQUIRE(small_supported(r.B, r.d) && r.d <= 4096 && r.d % 4 == 0 && r.layer0 == 0 && r.n_run >= 1 &&
+                     r.n_run <= kSmallStepMaxLayers && r.sync != nullptr,
+                 PRAG_EUNSUPPORTED, "internal: step gate called outside its envelope (B=%d d=%d layers=%d)", r.B, r.d, r.n_run);
+    SmallStepArgs a{};
+    for (int l = 0; l < r.n_run; ++l) a.h[l] = sp.h[l];
+    a.acc_in = sp.acc_in;
+    a.acc_out = sp.acc_out;
+    a.assign = sp.assign;
+    a.tag = sp.tag;
+    a.host = sp.host_dev;
+    if (r.x_dtype == PRAG_F32) return launch_fused_small<float, true>(r, a, st);
+    if (r.x_dtype == PRAG_F16) return launch_fused_small<_Float16, true>(r, a, st);
+    return launch_fused_small<unsigned short, true>(r, a, st);
+}
 
 template <typename T>
 static void launch_fc1(const SmallRun& r, hipStream_t st) {
@@ -495,13 +580,12 @@ static void launch_fc1(const SmallRun& r, hipStream_t st) {
 int small_run(const SmallRun& r, hipStream_t st) {
     PRAG_REQUIRE(small_supported(r.B, r.d) && r.n_run >= 1 && r.n_run <= 64 && r.d % 4 == 0, PRAG_EUNSUPPORTED,
                  "internal: small-batch prober called outside its envelope (B=%d d=%d)", r.B, r.d);
-#ifdef PRAG_MM_DIAG
-    if (r.sync && r.fused) {        // one launch (PRAG_PROBER_SMALL=3: A/B timing; three launches are faster, prober.hip)
-        if (r.x_dtype == PRAG_F32) return launch_fused_small<float>(r, st);
-        if (r.x_dtype == PRAG_F16) return launch_fused_small<_Float16>(r, st);
-        return launch_fused_small<unsigned short>(r, st);
+    if (r.sync && r.fused) {        // one launch (PRAG_PROBER_SMALL=3: A/B timing; standing alone three launches are faster)
+        const SmallStepArgs none{};
+        if (r.x_dtype == PRAG_F32) return launch_fused_small<float, false>(r, none, st);
+        if (r.x_dtype == PRAG_F16) return launch_fused_small<_Float16, false>(r, none, st);
+        return launch_fused_small<unsigned short, false>(r, none, st);
     }
-#endif
     if (r.x_dtype == PRAG_F32) launch_fc1<float>(r, st);
     else if (r.x_dtype == PRAG_F16) launch_fc1<_Float16>(r, st);
     else launch_fc1<unsigned short>(r, st);

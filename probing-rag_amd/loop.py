@@ -37,20 +37,49 @@ class HiddenStatePool:
     layer's hook - or ``pooled()`` - flushes the set.  The noted tensors are kept alive until then and must not be
     overwritten in place meanwhile: TransformerLens hook points and HF decoder-layer outputs are fresh tensors (the
     call sites that opt in: bench_e2e.py, tests), static / compiled output buffers or an in-place residual add are
-    not - a tensor whose version counter moved between the note and the flush raises instead of being summed wrong."""
+    not - a tensor whose version counter moved between the note and the flush raises instead of being summed wrong.
+
+    ``attach_gate(ens, ablation, threshold)`` (round 6, with ``defer=True``): the launch that adds a decode step also runs
+    the gate on the sums it has just formed (``prag_pool_step_gate``) and leaves the decision in pinned host memory, so
+    ``pool.decide()`` - exp_rag.py:393, 406-415's host branch - finds the decision of the last step already there when
+    `generate` returns instead of starting three launches on a host the LM has left cold (5 us against 90-120 in
+    the loop).  Same arithmetic as ``ens.decide(pool.pooled())``: bit-identical sums and decisions; shapes outside the
+    small-batch gate (batch > 4) fall back to exactly that call."""
 
     def __init__(self, n_layers: int, d_model: int, batch: int = 1, device=None, defer: bool = False):
         _lib.require_gpu()
         import torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.acc = torch.zeros((n_layers, batch, d_model), dtype=torch.float32, device=self.device)
+        # two buffers: the step launch reads the sums of one while it writes the other (a layer's workgroups all read
+        # the old sums); every other path works in place on the current one
+        self._acc2 = torch.zeros((2, n_layers, batch, d_model), dtype=torch.float32, device=self.device)
+        self._cur = 0
         self.passes = [0] * n_layers
         self.defer = bool(defer) and n_layers <= 64
         self._pending = {}      # slot -> (tensor [B,1,d], assign, tensor._version when noted)
+        self._gate = None       # (ens, ablation, threshold) of attach_gate
+        self._step_tag = None   # tag of the step launch whose decision describes the CURRENT sums, else None
+        self._step_ok = True    # False once the library has said the shape is outside the step launch
+
+    @property
+    def acc(self):
+        """float32 [L, B, d_model]: the running sums (a view of the current one of the two buffers)."""
+        return self._acc2[self._cur]
+
+    def attach_gate(self, ens, ablation: int = 0, threshold: float = 0.0):
+        """From now on a decode step's launch also decides (see the class docstring); ``ens`` is a
+        ``HipProberEnsemble`` with every layer loaded, on this pool's device.  ``attach_gate(None)`` detaches."""
+        if ens is not None and (ens.n_layers != len(self.passes) or ens.d_model != self._acc2.shape[-1]):
+            raise ValueError(f"the pool holds {len(self.passes)} layers x {self._acc2.shape[-1]}, the ensemble "
+                             f"{ens.n_layers} x {ens.d_model}")
+        self._gate = None if ens is None else (ens, int(ablation), float(threshold))
+        self._step_tag, self._step_ok = None, True
+        return self
 
     def reset(self):            # `cache = {}` exp_rag.py:397, 423: noted-but-unflushed activations are DROPPED with it
         self._pending = {}
         self.passes = [0] * len(self.passes)
+        self._step_tag = None
 
     def _flush(self):
         """Add the noted decode-step activations: one launch when every layer noted one of the same kind."""
@@ -70,11 +99,26 @@ class HiddenStatePool:
             a0, as0 = items[0]
             full = all(a.dtype == a0.dtype and a.shape == a0.shape and a.device == a0.device and asg == as0
                        for a, asg in items) and tuple(a0.shape[:1]) == tuple(self.acc.shape[1:2])
+        self._step_tag = None                   # the sums are about to change
         if full:
             a0, as0 = items[0]
             n = a0.numel()
             ptrs = (ctypes.c_void_p * L)(*[a.data_ptr() for a, _ in items])
             with _lib.on_device(a0.device):
+                if self._gate is not None and self._step_ok and a0.device == self.device:
+                    ens, abl, thr = self._gate
+                    tag = ctypes.c_uint64(0)
+                    nxt = self._cur ^ 1
+                    rc = _lib.lib().prag_pool_step_gate(ens._h, ctypes.c_void_p(self._acc2[self._cur].data_ptr()),
+                                                        ctypes.c_void_p(self._acc2[nxt].data_ptr()), ptrs, dts[a0.dtype],
+                                                        a0.shape[0], as0, abl, thr, ctypes.byref(tag),
+                                                        _lib.current_stream_ptr(a0.device))
+                    if rc == _lib.PRAG_OK:
+                        self._cur, self._step_tag = nxt, tag.value
+                        return
+                    if rc != -4:                 # PRAG_EUNSUPPORTED: this shape never takes the step launch
+                        _lib.check(rc)
+                    self._step_ok = False
                 _lib.check(_lib.lib().prag_pool_accumulate_layers(ctypes.c_void_p(self.acc.data_ptr()), ptrs, L, dts[a0.dtype],
                                                                   n, as0, _lib.current_stream_ptr(a0.device)))
             return
@@ -115,6 +159,7 @@ class HiddenStatePool:
                 self._flush()
             return
         self._flush()                        # keep the order of additions per layer
+        self._step_tag = None
         with torch.cuda.device(a.device):
             if T == 1:
                 _lib.check(_lib.lib().prag_pool_accumulate(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(a.data_ptr()),
@@ -133,6 +178,29 @@ class HiddenStatePool:
         if min(self.passes) < 2:   # torch.concat([]) raises in the reference
             raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
         return self.acc
+
+    def decide(self, with_probsum: bool = False):
+        """exp_rag.py:393, 406-415 on the pooled sums, as a host int32 array [B] (1 = retrieve) - what
+        ``ens.decide(pool.pooled(), ablation, threshold)`` returns, for the ensemble given to ``attach_gate``.  When the
+        last decode step's launch already decided (nothing was added since) this only reads that result from host
+        memory; otherwise it is that call."""
+        import numpy as np
+        if self._gate is None:
+            raise RuntimeError("HiddenStatePool.decide() needs attach_gate(ens, ablation, threshold) first")
+        ens, abl, thr = self._gate
+        x = self.pooled()
+        if self._step_tag is not None:
+            B = x.shape[1]
+            dec = np.empty((8,), np.int32)
+            ps = np.empty((8, 2), np.float32) if with_probsum else None
+            rc = _lib.lib().prag_gate_step_result(ens._h, ctypes.c_uint64(self._step_tag), B, dec.ctypes.data,
+                                                  ps.ctypes.data if with_probsum else None,
+                                                  _lib.current_stream_ptr(self.device))
+            if rc == _lib.PRAG_OK:
+                return (dec[:B].copy(), ps[:B].copy()) if with_probsum else dec[:B].copy()
+            if rc != -5:                         # PRAG_ESTATE: overwritten / voided - the sums are intact, decide on them
+                _lib.check(rc)
+        return ens.decide(x, abl, thr, with_probsum=with_probsum)
 
 
 def pool_ragged(acts, pred_lens, mean: bool = True):

@@ -512,3 +512,54 @@ def test_gate_folded_into_the_prober_launch_equals_gate_kernel(torch_cuda, monke
         g.replay()
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(out, want))
+
+
+@pytest.mark.parametrize("weights,Bt,dtype", [("f32", 1, "float32"), ("f32", 1, "float16"), ("f32", 4, "bfloat16"),
+                                              ("f16", 2, "float16"), ("f32", 5, "float32"), ("f16", 3, "float32")])
+def test_decode_step_launch_also_decides(torch_cuda, weights, Bt, dtype):
+    """Round 6: with `attach_gate` the launch that adds a decode step of all hooked layers (exp_rag.py:317-329) also runs
+    the gate on the sums it has just formed (prag_pool_step_gate), and `pool.decide()` - exp_rag.py:393, 406-415's host
+    branch - reads that result.  Sums, decisions and the two softmax sums must be bit-identical to a plain pool
+    followed by `ens.decide(pool.pooled())`: after every step, across a reset, when a multi-position pass (no KV
+    cache) invalidates the step's decision, and for a batch the small-batch gate does not serve (falls back to exactly
+    that call)."""
+    torch = torch_cuda
+    import probing_rag_amd as pra
+    case = cases.PROBER_CASES[1]
+    L, d = case["L"], case["d"]
+    ens, _ = _ensemble(case, weights)
+    dt = getattr(torch, dtype)
+    rng = np.random.default_rng(11)
+    a = pra.HiddenStatePool(L, d, batch=Bt, defer=True).attach_gate(ens, 1, -0.25)
+    b = pra.HiddenStatePool(L, d, batch=Bt, defer=True)
+    stepped = weights == "f32" and Bt <= 4 or weights == "f16" and Bt <= 2
+    for episode in range(3):
+        a.reset()
+        b.reset()
+        n_steps = 6 if episode < 2 else 3
+        for t in range(n_steps):
+            T = 7 if t == 0 or (episode == 1 and t == 3) else 1          # prompt pass; one pass without KV cache
+            st = torch.from_numpy(rng.standard_normal((L, Bt, T, d)).astype(np.float32) * 3.0).cuda().to(dt)
+            for l in range(L):
+                a.observe(l, st[l])
+                b.observe(l, st[l])
+            if t == 0:
+                continue
+            assert (a._step_tag is not None) == (stepped and T == 1)
+            if t % 2 == 1 or t == n_steps - 1:
+                want_dec, want_ps = ens.decide(b.pooled(), 1, -0.25, with_probsum=True)
+                got_dec, got_ps = a.decide(with_probsum=True)
+                assert torch.equal(a.pooled(), b.pooled())
+                assert np.array_equal(got_dec, want_dec) and np.array_equal(got_ps, want_ps)
+                assert np.array_equal(a.decide(), want_dec)              # asking twice is fine
+    # an older step's tag is refused by the library (the block holds the most recent step only) ...
+    if stepped:
+        import ctypes
+        from probing_rag_amd import _lib
+        dec = np.empty((8,), np.int32)
+        rc = _lib.lib().prag_gate_step_result(ens._h, ctypes.c_uint64(a._step_tag - 1), Bt, dec.ctypes.data, None, None)
+        assert rc == -5
+    # ... and the pool never asks for one: a detached pool decides with the plain call
+    with pytest.raises(RuntimeError, match="attach_gate"):
+        b.decide()
+    ens.close()
