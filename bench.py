@@ -89,10 +89,16 @@ def parse(argv=None):
                          "with the sampled pre-bound (profiles/r05c_shard_ab.txt); 0: one stream; 1: the gate on a second "
                          "stream beside the scan itself (scan capped at n_cu-16 workgroups; measured slower in rounds 3 "
                          "and 5: scan8 holds all of a CU's LDS)")
+    ap.add_argument("--adaptive", type=int, default=0,
+                    help="0 (default): the deterministic plan (prag_index_set_adaptive(ix, 0)) - every rank and every run "
+                         "issues the same launches (scan on 7/8 of the CUs, nothing armed by history), the plan is in the "
+                         "line; 1: the index times its scan grid on its first searches and arms tiers by history")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("PRAG_BENCH_LAUNCH_TIMEOUT", "1800")),
                     help="`--gpus N` without a launcher: seconds after which the torch.distributed.run child (its whole "
                          "process group) is killed and this process exits 124")
+    ap.add_argument("--no-gate-in-loop", action="store_true",
+                    help="skip the in-loop gate latency variant (builds a Gemma-2B-shaped random-weight decoder, ~15 s)")
     ap.add_argument("--no-shard-variant", action="store_true",
                     help="skip the 8-GPU shard shape (2 625 000 rows, 64 queries, 512 gate rows) in `variants`")
     ap.add_argument("--c-exchange-probe", type=int, default=int(os.environ.get("PRAG_BENCH_C_PROBE", "0")),
@@ -261,6 +267,12 @@ def scan_model(ix):
     return plan["family"], plan["bytes_per_launch"], plan["launches"], bool(plan["tiled"])
 
 
+def plan_summary(plan):
+    """The launch-determining fields of a plan on record, as one short string (compared across ranks at N > 1)."""
+    keys = ("family", "QT", "kc", "grid", "launches", "shadow", "tiled", "int8_tiles", "gate_launch", "adaptive")
+    return " ".join(f"{k_}={plan[k_]}" for k_ in keys if k_ in plan)
+
+
 def stored_row_bytes(store, metric, n_local):
     """N*d*s of the rows AS STORED (+4 B of ||x||^2 per row for L2)."""
     return n_local * D_EMB * (2 if store == "f16" else 4) + (n_local * 4 if metric == "l2" else 0)
@@ -384,6 +396,19 @@ def measure_traffic(n_local, store, metric, queries, shadow, kernel, k=10):
         "(reads doubled per the gfx950 correction of MI355X_MICROARCH.md)"
 
 
+def measure_gate_f32_pmc(gate_batch):
+    """The reference-precision gate (fp32 states, hi+lo fp16 weight terms): HBM bytes and matrix-pipe utilisation of
+    prober_fused_kernel from four child `rocprofv3 --pmc` passes.  Returns (dict or None, note)."""
+    got, note = _pmc_passes(("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES"), "prober_fused_kernel",
+                            ["--skip-scan", "--gate-batch", str(gate_batch), "--iters", "5", "--weights", "f32",
+                             "--x-dtype", "f32"])
+    if got is None:
+        return None, note
+    return {"hbm_bytes_per_launch": 2.0 * got["FETCH_SIZE"] * 1024 + got["WRITE_SIZE"] * 1024,
+            "matrix_pipe_busy_frac_of_cu_busy": (got["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * got["SQ_BUSY_CU_CYCLES"])
+                                                 if got["SQ_BUSY_CU_CYCLES"] else None)}, note
+
+
 def measure_gate_mfma(gate_batch):
     """Matrix-pipe utilisation of the fused prober kernel (prober16_kernel: 16x16x32 MFMA tiles, the default;
     prober_fused_kernel: the 32x32x16 form behind PRAG_PROBER_SHAPE=32): SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x
@@ -470,7 +495,7 @@ def compact_record(full):
     out["cpu_baseline"] = cb
     for k in ("probe_decisions_per_s", "scores_per_s_per_gpu", "planted_top1_recall", "result_lists_sorted",
               "exact_fallbacks_last_search", "recall_at_k_vs_oracle", "topk_ids_bit_exact_vs_oracle", "exchange",
-              "plan", "detail"):
+              "plan", "plans_identical_across_ranks", "detail"):
         if full.get(k) is not None:
             out[k] = full[k]
     pr = full.get("per_rank")
@@ -629,7 +654,7 @@ def embedding_variant(torch, pra, d_emb, k, n_rows, metric="cos", store="f16", B
 SHARD_ROWS, SHARD_QUERIES, SHARD_GATE_ROWS = 2_625_000, 64, 512     # one rank's share of the headline at 8 GPUs
 
 
-def shard_variant(torch, pra, ens, k, metric, ms_per_pass_full, passes=300):
+def shard_variant(torch, pra, ens, k, metric, ms_per_pass_full, passes=300, adaptive=False):
     """The 8-GPU shard shape on this one GPU: what ONE rank of the 8-rank job runs per pass - the gate over 512 of
     the 4096 pooled states, then the top-k of the 64 replicated queries over its 2 625 000 rows (the all-gather of
     8 x 64 x 10 x 12 bytes and the merge are not in it).  Timed four ways (same inputs, same outputs checked):
@@ -653,6 +678,7 @@ def shard_variant(torch, pra, ens, k, metric, ms_per_pass_full, passes=300):
     ix = pra.HipFlatIndex(d_emb, metric, "f16", capacity=SHARD_ROWS)
     ix.add_synthetic(42, 0, SHARD_ROWS)
     ix.set_shadow(1)
+    ix.set_adaptive(adaptive)
     ix.prepare()
     q = torch.from_numpy(synth_rows(7, 0, SHARD_QUERIES, d_emb)).cuda()
     g = torch.Generator(device="cuda").manual_seed(4321)
@@ -913,6 +939,7 @@ def main(argv=None):
     elif args.scan_workgroups:
         local.set_scan_workgroups(args.scan_workgroups)
     local.set_shadow(1 if args.shadow else 0)
+    local.set_adaptive(bool(args.adaptive))
 
     if args.overlap_gate >= 2:
         local.stream_wait_scan(side_stream)       # (first call: switches the event recording on)
@@ -956,9 +983,10 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
-    # On its first searches an index measures whether its scan runs better on 7/8 of the CUs or on all of them (eight
-    # samples, each read when a later search finds it finished): waited-for passes let that settle before the warm-up
-    for _ in range(12):
+    # --adaptive 1: on its first searches an index measures whether its scan runs better on 7/8 of the CUs or on all of
+    # them (eight samples, each read when a later search finds it finished): waited-for passes let that settle before
+    # the warm-up.  The deterministic plan (default) has nothing to settle
+    for _ in range(12 if args.adaptive else 2):
         one_pass()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -1002,7 +1030,7 @@ def main(argv=None):
                 b_.record()
             fence()
             allgather_us = float(np.median([a_.elapsed_time(b_) for a_, b_ in ev])) * 1e3
-        mine = {"rank": rank, "device": dev_index, "rows": n_local, "gate_rows": Bg,
+        mine = {"rank": rank, "device": dev_index, "rows": n_local, "gate_rows": Bg, "plan": plan_summary(local.last_plan()),
                 "scan_ms": float(np.mean(scan_ms)) if scan_ms else None,
                 "gate_ms": float(np.mean(gate_ms)) if gate_ms else None,
                 "allgather_us": allgather_us, "timed_region_s": dt_rank,
@@ -1119,6 +1147,8 @@ def main(argv=None):
         "value": value, "unit": "query*doc scores/s",
         "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": backend,
         "rank_devices": rank_devices, "exchange": index.exchange, "exchange_note": index.exchange_note,
+        "plan": plan_summary(local.last_plan()),
+        "plans_identical_across_ranks": (len({r_["plan"] for r_ in per_rank if r_}) == 1) if per_rank else None,
         "dtype_short": "i8" if (scan_kernel == "scan8_kernel" or (tiled and i8_tiles)) else "f16",
         "per_rank": per_rank, "c_exchange_probe": c_probe,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -1187,7 +1217,7 @@ def main(argv=None):
         if not args.no_shard_variant and args.docs > SHARD_ROWS:
             try:
                 variants[f"shard_{SHARD_ROWS}_q{SHARD_QUERIES}_gate{SHARD_GATE_ROWS}"] = \
-                    shard_variant(torch, pra, ens, args.k, args.metric, ms_per_step / args.inner)
+                    shard_variant(torch, pra, ens, args.k, args.metric, ms_per_step / args.inner, adaptive=bool(args.adaptive))
             except Exception as e:
                 variants[f"shard_{SHARD_ROWS}_q{SHARD_QUERIES}_gate{SHARD_GATE_ROWS}"] = {"error": f"{type(e).__name__}: {e}"}
         try:
@@ -1216,6 +1246,43 @@ def main(argv=None):
             e32 = pra.HipProberEnsemble(L, d_model, 2, weights="f32")
             for l, st in enumerate(states):
                 e32.load_layer(l, st)
+            # the reference-precision gate at the config-2 batch: float32 pooled states - what
+            # exp_rag.py:385-387 hands the prober - through weights kept to ~22 bits (hi + lo fp16 terms, logits within
+            # ~2e-6 of the fp32 module): a normalise-and-split pre-pass, then 3 MFMAs per product term
+            try:
+                x32 = torch.randn((L, args.gate_batch, d_model), device="cuda")
+                e32.reserve(args.gate_batch)
+                for _ in range(5):
+                    e32.gate(x32, 0, 0.0)
+                torch.cuda.synchronize()
+                e32.profile(64)
+                t1 = time.perf_counter()
+                for _ in range(40):
+                    e32.gate(x32, 0, 0.0)
+                torch.cuda.synchronize()
+                us32 = (time.perf_counter() - t1) / 40 * 1e6
+                k32 = e32.profile_read()
+                e32.profile(0)
+                k32_us = float(np.mean(k32)) * 1e3 if k32 else None
+                alg32 = L * args.gate_batch * d_model * 4 + L * 1318914 * 4 + L * args.gate_batch * 8
+                rec32 = {"what": "HipProberEnsemble(weights='f32').gate on float32 states [6, %d, 2048]: prenorm_split_kernel "
+                                 "(LayerNorm-0 in fp32, hi + lo fp16 split) + prober_fused_kernel (3 MFMAs per product) + "
+                                 "gate_kernel, host-timed back to back" % args.gate_batch,
+                         "us_per_call": us32, "decisions_per_s": args.gate_batch / us32 * 1e6,
+                         "prober_fused_kernel_us": k32_us,
+                         "algorithmic_bytes": alg32, "frac_of_8TBs_on_algorithmic_bytes": alg32 / us32 / 1e3 / HBM_PEAK_GBS,
+                         "flops_reference": gate_flops, "mfma_flops_issued": 3.0 * gate_flops,
+                         "frac_of_2.5PF_on_reference_flops": gate_flops / us32 / 1e6 / MFMA_F16_PEAK_TF,
+                         "frac_of_2.5PF_on_issued_mfma_flops": 3.0 * gate_flops / us32 / 1e6 / MFMA_F16_PEAK_TF,
+                         "over_f16_mode": us32 / (gate_alone_ms * 1e3) if gate_alone_ms else None}
+                if args.measure_traffic:
+                    pmc32, note32 = measure_gate_f32_pmc(args.gate_batch)
+                    rec32["pmc"] = pmc32
+                    rec32["pmc_source"] = note32
+                variants["gate_f32w_f32x_b%d (reference precision at the config-2 batch)" % args.gate_batch] = rec32
+                del x32
+            except Exception as e:      # noqa: BLE001
+                variants["gate_f32w_f32x (reference precision at the config-2 batch)"] = {"error": f"{type(e).__name__}: {e}"}
             x1 = torch.randn((L, 1, d_model), device="cuda")
             for _ in range(10):
                 e32.gate(x1, 0, 0.0)
@@ -1248,6 +1315,19 @@ def main(argv=None):
                 "kernel_us_back_to_back": us,
                 "what": "ens.decide(x [6,1,2048] f32): gate kernels + decision written to pinned host memory + wait, per "
                         "call, host-timed with every call waited for; second figure: ens.gate(...) then int(decision[0])"}
+            # ... and where the loop really calls it: after a Gemma-2B-shaped `generate` has emptied the caches, on the
+            # device AND on the host.  `step`: the decode steps' pooling launches decide as they go
+            # (round 6); `decide`: round 5's call after `generate` has returned
+            if not args.no_gate_in_loop:
+                try:
+                    import bench_e2e
+                    g_rec = bench_e2e.gate_in_loop(torch, pra, states, torch.device("cuda", dev_index))
+                    g_rec["cold_us (512 MB read between calls, host warm)"] = bench_e2e.gate_cold(
+                        torch, pra, states, torch.device("cuda", dev_index))
+                    variants["gate_b1_in_loop (Gemma-2B-shaped generate between calls)"] = g_rec
+                except Exception as e:      # noqa: BLE001 - e.g. no transformers on the box
+                    variants["gate_b1_in_loop (Gemma-2B-shaped generate between calls)"] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
             # the reference's retrieval call as the loop sees it: index.search(np.float32 [1,768], k=5) -> numpy
             # (utils.py:378-380, exp_rag.py:432-436), host buffers in and out, every call waited for
             lat_ix = ref_ix
@@ -1289,6 +1369,8 @@ def main(argv=None):
         b1l = variants.get("gate_b1_latency (reference call, decision on the host)") or {}
         s1l = variants.get("search_b1_latency_host_io (reference call)") or {}
         q128 = variants.get(f"f16_cos_k{args.k}_q128_shadow") or {}
+        gil = variants.get("gate_b1_in_loop (Gemma-2B-shaped generate between calls)") or {}
+        g32 = variants.get("gate_f32w_f32x_b%d (reference precision at the config-2 batch)" % args.gate_batch) or {}
         emb = variants.get("embedding_like_f16_k10_q64") or {}
         out["config"].update({
             "shard_pass_ms": sv.get("pass_ms"), "shard_pass_mode": sv.get("pass_mode"),
@@ -1297,6 +1379,12 @@ def main(argv=None):
             "predicted_strong_scaling_eff": sv.get("predicted_strong_scaling_eff"),
             "c3_ms": c3v.get("ms_per_search"), "c3_frac_of_2.5PF": c3v.get("frac"),
             "gate_b1_us": b1.get("us_per_decision"), "gate_b1_latency_us": b1l.get("us_per_decision"),
+            "gate_f32w_f32x_b4096_us": g32.get("us_per_call"), "gate_f32w_f32x_decisions_per_s": g32.get("decisions_per_s"),
+            "gate_f32w_f32x_frac_hbm": g32.get("frac_of_8TBs_on_algorithmic_bytes"),
+            "gate_f32w_f32x_frac_mfma_issued": g32.get("frac_of_2.5PF_on_issued_mfma_flops"),
+            "gate_f32w_f32x_over_f16": g32.get("over_f16_mode"),
+            "gate_b1_cold_us": gil.get("cold_us (512 MB read between calls, host warm)"),
+            "gate_b1_in_loop_us": gil.get("step_gate_us"), "gate_b1_in_loop_r5_call_us": gil.get("decide_gate_us"),
             "search_b1_latency_us": s1l.get("two_level_us"), "q128_shadow_ms": q128.get("ms_per_search"),
             "embedding_like": {k_: emb.get(k_) for k_ in ("cos_4M", "l2_4M", "cos_21M")} if emb else None})
         out["roofline"]["shard_scan8_frac"] = sv.get("scan8_frac_of_8TBs")

@@ -240,6 +240,71 @@ def run(args, pra, torch, dist, world, rank, dev_index):
     return out
 
 
+def gate_in_loop(torch, pra, states, dev, gens=24, new_tokens=16, prompt_len=64, lm=None, modes=("step", "decide")):
+    """The loop's gate call by itself (the back-to-back figure is not what the loop sees): a
+    Gemma-2B-shaped decoder generates `new_tokens` tokens (hooks -> HiddenStatePool), then the gate is timed exactly as
+    the loop's clock does - device drained on both sides - once with the decode steps' launches deciding as they go
+    (`step`: HiddenStatePool.attach_gate, prag_pool_step_gate) and once with round 5's call after `generate` has
+    returned (`decide`: prag_gate_decide).  Median us per gate call and ms per generate call, per mode."""
+    lm = lm or _make_lm(torch, dev)
+    out = {"generations_per_mode": gens, "new_tokens": new_tokens}
+    rng = np.random.default_rng(0)
+    for mode in modes:
+        pool = pra.HiddenStatePool(len(LAYERS), D_MODEL, defer=True)
+        ens = pra.HipProberEnsemble(len(LAYERS), D_MODEL, 2, weights="f32")
+        for slot, st in enumerate(states):
+            ens.load_layer(slot, st)
+        if mode == "step":
+            pool.attach_gate(ens, 0, 0.0)
+        handles = [lm.model.layers[l].register_forward_hook(
+            lambda mod, inp, o, slot=slot: pool.observe(slot, o[0] if isinstance(o, tuple) else o))
+            for slot, l in enumerate(LAYERS)]
+        t_gen, t_gate = [], []
+        for g in range(gens + 3):
+            pool.reset()
+            prompt = torch.from_numpy(rng.integers(5, 250000, size=(1, prompt_len))).to(dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lm.generate(prompt, max_new_tokens=new_tokens, do_sample=False, use_cache=True, pad_token_id=0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            d = int(pool.decide()[0]) if mode == "step" else int(ens.decide(pool.pooled(), 0, 0.0)[0])
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if g >= 3:
+                t_gen.append(t1 - t0)
+                t_gate.append(t2 - t1)
+        for h in handles:
+            h.remove()
+        ens.close()
+        out[mode + "_gate_us"] = float(np.median(t_gate)) * 1e6
+        out[mode + "_gate_us_p90"] = float(np.percentile(t_gate, 90)) * 1e6
+        out[mode + "_generate_ms"] = float(np.median(t_gen)) * 1e3
+    return out
+
+
+def gate_cold(torch, pra, states, dev, reps=60, flush_bytes=512 << 20):
+    """ens.decide at B = 1 with a 512 MB read between calls (weights, kernel code and workspaces out of L2 / MALL; the
+    host stays warm - that part only the loop shows, gate_in_loop above): median us per call, every call waited for."""
+    ens = pra.HipProberEnsemble(len(LAYERS), D_MODEL, 2, weights="f32")
+    for slot, st in enumerate(states):
+        ens.load_layer(slot, st)
+    x = torch.randn((len(LAYERS), 1, D_MODEL), device=dev)
+    flush = torch.empty(flush_bytes, dtype=torch.uint8, device=dev)
+    ts = []
+    for i in range(reps + 5):
+        flush.view(torch.int32).sum()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ens.decide(x, 0, 0.0)
+        t1 = time.perf_counter()
+        if i >= 5:
+            ts.append(t1 - t0)
+    ens.close()
+    del flush
+    return float(np.median(ts)) * 1e6
+
+
 def argparse_copy(args, **kw):
     import copy
     a = copy.copy(args)

@@ -442,6 +442,17 @@ int prag_index_prepare(prag_index_t* ix, void* stream);
  * allocates per call.) */
 int prag_index_reserve(prag_index_t* ix, int B, int k, void* stream);
 
+/* The deterministic plan (round 6).  By default a handle adapts to its own history: the workgroup count of a two-level
+ * scan of <= 64 queries is timed on the index's first searches, the retry tier and the sliced gather are armed by what
+ * earlier searches flagged, the int8 tiles switch themselves off after two whole-batch repeats - all result-safe, but the
+ * launch sequence then differs from run to run and from rank to rank.  on = 0 (or PRAG_ADAPTIVE=0 in the environment
+ * when the handle is created) freezes all of it: 7/8 of the CUs for an HBM-bound two-level scan, flagged queries of a
+ * device-io search go straight to the float64 scan (a host-io search still runs the retry tier on its OWN flag count),
+ * the gather is always enqueued, the int8 tiles stay on.  A search then issues the same launches on every rank and in
+ * every run of one input (prag_index_last_plan says `adaptive=0`).  Results are the definition's either way.
+ * (No reference counterpart: faiss.IndexFlat has one code path, make_indexer.py:449-450.) */
+int prag_index_set_adaptive(prag_index_t* ix, int on);
+
 /* Cap the number of workgroups (= CUs) the scan kernels occupy; 0 = all CUs.  The scan is
  * HBM-bound, so leaving a few CUs free lets an independent kernel on another stream (e.g. the
  * prober gate of the next batch) run concurrently instead of queueing behind it. */

@@ -106,6 +106,7 @@ SIGNATURES = {
     "prag_index_prepare": (_I, [_P, _P]),
     "prag_index_reserve": (_I, [_P, ctypes.c_int, ctypes.c_int, _P]),
     "prag_index_set_scan_workgroups": (_I, [_P, _I]),
+    "prag_index_set_adaptive": (_I, [_P, _I]),
     "prag_index_profile": (_I, [_P, _I]),
     "prag_index_profile_read": (_I, [_P, _FP, _I, ctypes.POINTER(_I)]),
     "prag_index_profile_read_exchange": (_I, [_P, _FP, _I, ctypes.POINTER(_I)]),

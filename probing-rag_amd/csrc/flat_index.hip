@@ -1459,6 +1459,14 @@ struct prag_index {
     };
     WgTune wg_tune[2];            // [0] <= 32 queries (two-term tiles), [1] 33-64 queries
     int wg_tune_mode = -1;
+    // prag_index_set_adaptive / PRAG_ADAPTIVE at creation.  0 = the deterministic plan: nothing a search launches depends
+    // on how earlier searches on the handle went or how long they took - the scan grid stays at its default (7/8 of the
+    // CUs for an HBM-bound two-level scan; PRAG_SCAN_WG_TUNE=1 / prag_index_set_scan_workgroups still pin another one),
+    // the retry tier is never armed by history (host-io searches still use it on their OWN flag count, which they
+    // hold; device-io searches send flagged queries straight to the float64 scan), the sliced gather is always
+    // enqueued, the grouped float64 scan is chosen by shape only, the int8 tiles are never switched off.  Every rank
+    // and every run of one input then issues the same launches.  Results are the definition's either way.
+    int adaptive = 1;
     int64_t scan8_quad_rows = (int64_t)8 << 20;   // PRAG_SCAN8_QUAD_ROWS (tests: 0 = the quad-test scans at every size)
     int mm_shape16 = 1;   // tiled scans on 16 x 16 MFMA tiles (PRAG_MM_SHAPE=32: the 32 x 32 form, A/B timing)
     // 8-bit selection for the MFMA-tiled scan (> 128 queries on an index that keeps a shadow): int8 MFMA over the
@@ -1834,6 +1842,7 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
     if (const char* e = getenv("PRAG_SHADOW_SAMPLE")) ix->shadow_sample_mode = atoi(e);
     if (const char* e = getenv("PRAG_SCAN_GATE")) ix->scan_gate_mode = atoi(e);
     if (const char* e = getenv("PRAG_SCAN_WG_TUNE")) ix->wg_tune_mode = atoi(e);
+    if (const char* e = getenv("PRAG_ADAPTIVE")) ix->adaptive = atoi(e) != 0;
     if (const char* e = getenv("PRAG_SCAN8_QUAD_ROWS")) ix->scan8_quad_rows = atoll(e);
     if (const char* e = getenv("PRAG_MM8")) ix->mm8_mode = atoi(e) != 0;
     if (const char* e = getenv("PRAG_MM8_MIN_ROWS")) ix->mm8_min_rows = atoll(e);
@@ -3071,7 +3080,7 @@ static int exec_two_level(SearchRun& r) {
     // 7/8 of the CUs or all of them (<= 64 queries; WgTune above)
     prag_index::WgTune* tune = nullptr;
     bool every_cu = ix->wg_tune_mode == 1;
-    if (ix->wg_cap <= 0 && B <= 64 && ix->wg_tune_mode < 0 && allow_mm8 && !ix->gate.word) {
+    if (ix->wg_cap <= 0 && B <= 64 && ix->wg_tune_mode < 0 && ix->adaptive && allow_mm8 && !ix->gate.word) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
         prag_index::WgTune& T = ix->wg_tune[B > 32 ? 1 : 0];
@@ -3128,11 +3137,12 @@ static int exec_two_level(SearchRun& r) {
     ss.scan_gate_mode = ix->scan_gate_mode;
     ss.unfinished = ix->sh_unfin;
     // (only where the statistics that re-arm it travel: outer 33-128-query searches with device i/o - search_finish)
-    ss.skip_gather = ix->gather_mode != 1 && !ix->gather_armed && allow_mm8 && !ix->gate.word && io_is_device && B > 32 &&
+    ss.skip_gather = ix->adaptive && ix->gather_mode != 1 && !ix->gather_armed && allow_mm8 && !ix->gate.word && io_is_device && B > 32 &&
                      B <= 128 && ix->retry_mode != 0;
     if (ss.scan_done) ix->scan_done_recorded = true;
     ss.exact_bound = k <= 32 && (ix->shadow_bound_mode < 0 ? ix->ntotal >= (1ll << 19) : ix->shadow_bound_mode != 0);
     rc = shadow_search(ss, st, prof);
+    if (tune && (rc != PRAG_OK || !ss.timed_recorded)) tune->pending = false;   // no event pair was recorded: nothing to read later
     if (rc != PRAG_OK) return rc;
     if (allow_mm8 && !ix->gate.word) {      // the plan on record says what was launched
         const size_t at = ix->last_plan.find(" grid=");
@@ -3283,7 +3293,8 @@ static int search_finish(SearchRun& r, float* D, int64_t* I) {
     // (one flagged query is the common case and the single-query kernel is 3.7x faster for it - profiles/
     //  r05f_exact_group_bench.txt -, so "several" means: by construction, or the retry tier's inner searches have been
     //  leaving >= 4 queries flagged lately)
-    er.grouped = ix->exact_group_mode != 0 && (ix->exact_group_mode == 1 || (exact_only && B >= 2) || ix->exact_group_hint);
+    er.grouped = ix->exact_group_mode != 0 &&
+                 (ix->exact_group_mode == 1 || (exact_only && B >= 2) || (ix->adaptive && ix->exact_group_hint));
     const bool may_flag = certify && ix->ntotal > 0;
     if (use_mm8) {
         // second tier, decided on the device (mm8_second_tier): no read-back, no host branch
@@ -3305,9 +3316,9 @@ static int search_finish(SearchRun& r, float* D, int64_t* I) {
                              ix->retry_mode != 0;
     if (io_is_device) {
         ix->last_flagged = -1;
-        const bool retry_now = retry_shape && (ix->retry_armed || ix->retry_mode == 1);
+        const bool retry_now = retry_shape && ((ix->adaptive && ix->retry_armed) || ix->retry_mode == 1);
         bool recorded_now = false;
-        if (retry_shape) {      // statistics for the next search's decision; never waited for, nothing while capturing
+        if (retry_shape && ix->adaptive) {      // statistics for the next search's decision; never waited for, nothing while capturing
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
             // (a record still on its way is not overwritten: a caller that enqueues passes faster than the device runs
@@ -3354,7 +3365,7 @@ static int search_finish(SearchRun& r, float* D, int64_t* I) {
     ix->last_flagged = (int)n_flag;
     if (may_flag && n_flag > 0) {
         if (retry_shape) {
-            ix->retry_armed = true;        // (device-io searches on this handle start armed too)
+            ix->retry_armed = ix->adaptive != 0;   // (device-io searches on this handle start armed too)
             ix->retry_clean = 0;
             const int rc = retry_tier(ix, q_dev, B, k, id_offset, D_dev, I_dev, stream, tag_ids, flag_word);
             if (rc != PRAG_OK) return rc;
@@ -3399,6 +3410,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
             consume_retry_stats(ix, false);    // ... and the flag count of the previous <= 128-query search
         }
     }
+    if (!ix->adaptive) ix->mm8_auto_off = false;
     env.mm8_auto_off = ix->mm8_auto_off;
     SearchPlan P = plan_search(env);
     PRAG_REQUIRE(P.kc != 0, PRAG_EUNSUPPORTED, "k=%d: at most 911 results per query", k);
@@ -3415,6 +3427,7 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
         char buf[640];
         plan_describe(env, P, buf, (int)sizeof(buf));
         ix->last_plan = buf;
+        ix->last_plan += ix->adaptive ? " adaptive=1" : " adaptive=0";
         if (!P.use_mm8) {
             ix->tier_pending = false;
             ix->mm8_last_failed = P.mm8_eligible ? -2 : -1;
@@ -3562,6 +3575,23 @@ extern "C" int prag_index_set_shadow(prag_index_t* ix, int mode) {
     ix->mm8_auto_off = false;
     ix->mm8_off_count = 0;
     ix->mm8_off_period = 64;
+    return PRAG_OK;
+}
+
+extern "C" int prag_index_set_adaptive(prag_index_t* ix, int on) {
+    PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
+    ix->adaptive = on != 0;
+    if (!ix->adaptive) {        // history is dropped with the switch: the next search plans as a fresh handle would
+        ix->retry_armed = false;
+        ix->retry_clean = 0;
+        ix->exact_group_hint = false;
+        ix->gather_armed = true;
+        ix->gather_clean = 0;
+        ix->mm8_auto_off = false;
+        ix->mm8_off_count = 0;
+        ix->mm8_off_period = 64;
+        ix->mm8_whole_batch_streak = 0;
+    }
     return PRAG_OK;
 }
 

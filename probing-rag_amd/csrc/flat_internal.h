@@ -594,6 +594,7 @@ struct ShadowSearch {
     hipEvent_t scan_done = nullptr;   // recorded behind the scan of the last query tile (prag_index_stream_wait_scan)
     struct TailGate* tail = nullptr;  // a gate launch to carry beside the bound kernel of the last query tile (tail_gate.h)
     hipEvent_t time_ev0 = nullptr, time_ev1 = nullptr;   // recorded around the scan launch of the last query tile (workgroup tuning)
+    bool timed_recorded = false;   // out: both events were recorded by this call
     int grid_used = 0;                // out: workgroups of the scan launches
     int scan_gate_mode = -1;          // ... or behind the SCAN's workgroups in its launch (flat_scan_gate.hip): -1 when the gate
                                       // fits under the scan, 0 never, 1 always (PRAG_SCAN_GATE)

@@ -46,14 +46,18 @@ static int launch_ct(const Scan8Args& a, int grid, const TailGate& t, hipStream_
     return PRAG_OK;
 }
 
-bool scan8_gate_supported(int kc, int ct16) { return (kc == 8 || kc == 16) && (ct16 == 2 || ct16 == 4 || ct16 == 8); }
+// Round 6: four forms instead of twelve.  Measured under the deterministic plan (profiles/r06d_shard_fused_ab.txt), one
+// rank's pass of the 8-GPU job: gate behind the scan's workgroups 0.403-0.428 ms, gate beside the bound kernel 0.417-0.436,
+// the two calls 0.443-0.461 - carrying the gate in a launch of the search is worth 6-8 %, WHICH launch carries it ~1 %
+// (1.4 % at 21 M rows).  The forms kept are the ones the BASELINE shapes take: 16-deep lists (5 < k <= 12), the 128-row
+// prober tile of a >= 2731-row gate and the 32-row tile of a <= 682-row one; every other shape rides beside the bound
+// kernel (bound_gate_kernel covers all tile heights).
+bool scan8_gate_supported(int kc, int ct16) { return kc == 16 && (ct16 == 2 || ct16 == 8); }
 
 int launch_scan8_gate(const Scan8Args& a, int grid, int kc, bool quad, const TailGate& t, hipStream_t st, EventRing& prof) {
 #define PRAG_SG(KC_, Q_, CT_) if (kc == KC_ && quad == Q_ && t.ct16 == CT_) return launch_ct<KC_, Q_, CT_>(a, grid, t, st, prof);
-    PRAG_SG(16, true, 8) PRAG_SG(16, true, 4) PRAG_SG(16, true, 2)
-    PRAG_SG(16, false, 8) PRAG_SG(16, false, 4) PRAG_SG(16, false, 2)
-    PRAG_SG(8, true, 8) PRAG_SG(8, true, 4) PRAG_SG(8, true, 2)
-    PRAG_SG(8, false, 8) PRAG_SG(8, false, 4) PRAG_SG(8, false, 2)
+    PRAG_SG(16, true, 8) PRAG_SG(16, true, 2)
+    PRAG_SG(16, false, 8) PRAG_SG(16, false, 2)
 #undef PRAG_SG
     set_error("internal: scan8_gate_kernel has no (kc %d, %d-row tile) form", kc, 16 * t.ct16);
     return PRAG_EUNSUPPORTED;

@@ -1018,7 +1018,10 @@ int shadow_search(ShadowSearch& s, hipStream_t st, EventRing& prof) {
                         : (s.kc == 8 ? launch_scan8<32, 8>(a, grid, st, prof)
                            : s.kc == 16 ? launch_scan8<32, 16>(a, grid, st, prof) : launch_scan8<32, 32>(a, grid, st, prof));
         if (rc != PRAG_OK) return rc;
-        if (timed) PRAG_HIP(hipEventRecord(s.time_ev1, st));
+        if (timed) {
+            PRAG_HIP(hipEventRecord(s.time_ev1, st));
+            s.timed_recorded = true;
+        }
         if (scan_gate) s.tail->taken = s.tail->in_scan = true;
         if (s.scan_done && p0 + QT >= Bpad) PRAG_HIP(hipEventRecord(s.scan_done, st));
 #ifdef PRAG_MM_DIAG

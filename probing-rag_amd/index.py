@@ -403,6 +403,14 @@ def _ix_reserve(self, B: int, k: int):
         _lib.check(_lib.lib().prag_index_reserve(self._h, int(B), int(k), _lib.current_stream_ptr(self.device)))
 
 
+def _ix_set_adaptive(self, on: bool = True):
+    """``set_adaptive(False)``: the deterministic plan (prag_index_set_adaptive) - nothing a search launches depends on
+    how earlier searches on this handle went or how long they took, so every rank and every run of one input issues
+    the same launches; ``last_plan()["adaptive"]`` says which mode ran.  Same results either way."""
+    _lib.check(_lib.lib().prag_index_set_adaptive(self._h, 1 if on else 0))
+
+
+HipFlatIndex.set_adaptive = _ix_set_adaptive
 HipFlatIndex.set_shadow = _ix_set_shadow
 HipFlatIndex.prepare = _ix_prepare
 HipFlatIndex.reserve = _ix_reserve

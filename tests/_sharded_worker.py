@@ -57,6 +57,27 @@ def main():
     assert ix.engine.index.last_plan()["family"] == "scan8_kernel"
     assert torch.equal(I1, I2) and torch.equal(D1, D2), rank
     assert all(torch.equal(a, b) for a, b in zip(got, want)), rank
+    # the deterministic plan (prag_index_set_adaptive(ix, 0)): every rank issues the same launches, run after run -
+    # plans on record identical across ranks (the ragged split differs by one row: `rows` / `bytes` aside) and across
+    # repeated passes, whatever the handle's history (a detour through the adaptive mode in between)
+    local = ix.engine.index
+    local.set_adaptive(False)
+    plans = []
+    for it in range(12):
+        if it == 6:
+            local.set_adaptive(True)
+            for _ in range(3):
+                ix.search_and_gate(q64, k, ens, xg)
+            local.set_adaptive(False)
+        (D3, I3), _ = ix.search_and_gate(q64, k, ens, xg)
+        pl = local.last_plan()
+        assert pl["adaptive"] == 0
+        plans.append({k_: v for k_, v in pl.items() if k_ not in ("rows", "bytes_per_launch", "ws_bytes", "last_seg_rows")})
+        assert torch.equal(I3, I1) and torch.equal(D3, D1), rank
+    assert all(p_ == plans[0] for p_ in plans), (rank, plans[0], [p_ for p_ in plans if p_ != plans[0]][:1])
+    gathered = [None] * world
+    dist.all_gather_object(gathered, plans[0])
+    assert all(g == gathered[0] for g in gathered), gathered
     dist.barrier()
     if rank == 0:
         print("SHARDED_OK")

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--shadow", type=int, default=1)
     ap.add_argument("--skip-scan", action="store_true")
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--weights", default="f16", choices=["f16", "f32"], help="prober weight mode of the gate launches")
+    ap.add_argument("--x-dtype", default="f16", choices=["f16", "f32"], help="element type of the pooled states")
     args = ap.parse_args()
     import torch
     import probing_rag_amd as pra
@@ -38,10 +40,12 @@ def main():
         for _ in range(args.iters):
             ix.search(q, args.k)
     if not args.skip_gate:
-        ens = pra.HipProberEnsemble(6, 2048, 2, weights="f16")
+        ens = pra.HipProberEnsemble(6, 2048, 2, weights=args.weights)
         for l in range(6):
             ens.load_layer(l, random_prober_state(100 + l, 2048))
-        x = torch.randn((6, args.gate_batch, 2048), device="cuda").half()
+        x = torch.randn((6, args.gate_batch, 2048), device="cuda")
+        if args.x_dtype == "f16":
+            x = x.half()
         for _ in range(args.iters):
             ens.gate(x, 0, 0.0)
     torch.cuda.synchronize()
