@@ -594,7 +594,7 @@ def self_launch(args, argv):
         return 124
 
 
-def clustered_variant(torch, pra, d_emb, k, n_rows=4_194_304, n_centres=4096, sigma=0.0175, B=64):
+def clustered_variant(torch, pra, d_emb, k, n_rows=4_194_304, n_centres=4096, sigma=0.0175, B=64, interleaved=False):
     g = torch.Generator(device="cuda").manual_seed(11)
     centres = torch.nn.functional.normalize(torch.randn((n_centres, d_emb), generator=g, device="cuda"), dim=1)
     ix = pra.HipFlatIndex(d_emb, "cos", "f16", capacity=n_rows)
@@ -602,12 +602,17 @@ def clustered_variant(torch, pra, d_emb, k, n_rows=4_194_304, n_centres=4096, si
         m = min(1 << 20, n_rows - lo)
         # rows of a centre are CONTIGUOUS (a corpus in article order: consecutive passages resemble each other),
         # so a centre's ~1000 rows fall into a handful of scan workgroups - the layout that fills a region
-        idx = (torch.arange(lo, lo + m, device="cuda") * n_centres) // n_rows
+        # interleaved: row i belongs to centre i mod n_centres - a centre's rows are spread over every scan workgroup (a
+        # corpus in random order), the layout the fuzzer draws and the one on which candidate regions overflow and
+        # certificates fail (0.165 exact fallbacks per query where the contiguous layout shows 0)
+        idx = (torch.arange(lo, lo + m, device="cuda") % n_centres) if interleaved else \
+            (torch.arange(lo, lo + m, device="cuda") * n_centres) // n_rows
         ix.add(centres[idx] + sigma * torch.randn((m, d_emb), generator=g, device="cuda"))   # ||noise|| ~ 0.48
     q = centres[torch.randint(0, n_centres, (B,), generator=g, device="cuda")] + \
         0.5 * sigma * torch.randn((B, d_emb), generator=g, device="cuda")
     rec = {"rows": n_rows, "centres": n_centres, "queries": B, "k": k,
-           "what": "rows = unit centre + N(0, sigma^2 I), sigma = %.4f: 1024 CONTIGUOUS rows per centre at cosine ~0.9 to it" % sigma}
+           "what": "rows = unit centre + N(0, sigma^2 I), sigma = %.4f: 1024 %s rows per centre at cosine ~0.9 to it"
+                   % (sigma, "INTERLEAVED (row i -> centre i mod 4096)" if interleaved else "CONTIGUOUS")}
     res = {}
     for shadow in (0, 2):
         ix.set_shadow(shadow)
@@ -1350,6 +1355,7 @@ def main(argv=None):
             # near centres - thousands of rows sit inside the shadow's error band of the k-th score, the case
             # where candidate regions can overflow into the exact scan; fallbacks are part of the record
             variants["clustered_f16_cos_k10_q64_x_4M"] = clustered_variant(torch, pra, d_emb, args.k)
+            variants["clustered_interleaved_f16_cos_k10_q64_x_4M"] = clustered_variant(torch, pra, d_emb, args.k, interleaved=True)
             # embedding-shaped corpora (common mean, power-law spectrum, outlier coordinates), next to their iid
             # counterparts above: 4 M rows cosine / L2, and the headline size
             emb = {"what": "rows = mu + U diag(lambda) z, ||mu|| = 0.8 ||x||, lambda_j ~ j^-0.5, 6 outlier coordinates at "
@@ -1383,6 +1389,8 @@ def main(argv=None):
             "gate_f32w_f32x_frac_hbm": g32.get("frac_of_8TBs_on_algorithmic_bytes"),
             "gate_f32w_f32x_frac_mfma_issued": g32.get("frac_of_2.5PF_on_issued_mfma_flops"),
             "gate_f32w_f32x_over_f16": g32.get("over_f16_mode"),
+            "clustered_interleaved_two_level_ms": ((variants.get("clustered_interleaved_f16_cos_k10_q64_x_4M") or {}).get("two_level") or {}).get("ms_per_search"),
+            "clustered_interleaved_fallbacks": ((variants.get("clustered_interleaved_f16_cos_k10_q64_x_4M") or {}).get("two_level") or {}).get("exact_fallbacks_last_search"),
             "gate_b1_cold_us": gil.get("cold_us (512 MB read between calls, host warm)"),
             "gate_b1_in_loop_us": gil.get("step_gate_us"), "gate_b1_in_loop_r5_call_us": gil.get("decide_gate_us"),
             "search_b1_latency_us": s1l.get("two_level_us"), "q128_shadow_ms": q128.get("ms_per_search"),

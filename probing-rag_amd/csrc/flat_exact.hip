@@ -100,6 +100,7 @@ struct ExactArgs {
     float* D;
     int64_t* I;
     uint32_t* done;   // [f_cap] workgroups that have written their list of flag slot f (zero between searches)
+    unsigned long long* gpool;    // [f_cap][n_lists] exact_mfma_kernel: every workgroup's best key of flag slot f (~0 between searches)
     int tag_ids;
     Gate gate;
 };
@@ -475,6 +476,487 @@ __global__ __launch_bounds__(kExThreads) void exact_group_kernel(ExactArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Matrix-core form (round 6): sixteen flagged queries per pass over the rows on v_mfma_f64_16x16x4_f64.
+// The grouped kernel above is bound by its LDS query reads (every v_fma_f64 wants a fresh query operand: 512 B of LDS
+// per wave instruction against 128 B per clock and CU - 5.8 ms per eight-query pass over 4 M x 640 rows where the
+// arithmetic is 0.8 ms).  An MFMA reuses its operands sixteen-fold: a wave owns 16 rows x 16 queries, lane (r, p) holds
+// the A operand x[row r][k] and the B operand q[k][query r] for the k of its 16-byte piece p of every 64-byte row
+// segment (the dot product does not care in which order k runs, so the coalesced load IS the operand: no transpose), one
+// ds_read_b64 and two conversions per MFMA.  The chip sustains 34.7 TFLOP/s on this instruction
+// (profiles/r04z_mfma_f64_probe.txt): 16 queries x 4 M x 640 = 84 GFLOP in ~2.4 ms, 0.15 ms per flagged query
+// against 0.73 (grouped) and 1.4 (one by one).
+//   inner product / cosine: the float64 MFMA sum IS the score (another summation order than the one-query kernel's -
+//     the last bit of a float64 may differ, D and I do not unless two float64 scores tie within that bit);
+//   squared L2: ||x||^2 - 2 q.x + ||q||^2 in float64 only SELECTS (error <= 2 d 2^-53 (||x||^2 + ||q||^2), a margin of
+//     1e-12 (||x||^2 + ||q||^2) is kept); every pair that may enter a list is scored again as the direct sum of
+//     (q - x)^2 by 16 lanes in the one-query kernel's own order - bit-identical scores, no cancellation in what is
+//     returned (identical rows give exactly 0).
+// Queries sit in LDS transposed and padded ([k][16 queries] doubles, 64 B more per 8 k: a wave's ds_read_b64 touches
+// every bank twice, the minimum); 16 threshold lists of 256 slots (k <= 64) alias the merge's big list.  d = 32 NS,
+// NS in {4, 8, 12, 16, 20, 24}; H row segments are in flight per lane (a register is refilled right behind its use,
+// from the next tile when the row is exhausted).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kExMG = 16;
+constexpr int kExMCap = 256;
+constexpr int kExMRows = 128;     // rows per workgroup step: 8 waves x 16
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int exm_q_off(int e, int col) { return (e * 16 + col) * 8 + (e >> 3) * 64; }
+constexpr int exm_q_off_step = 32 * 128 + 4 * 64;     // exm_q_off(e + 32, col) - exm_q_off(e, col)
+size_t exact_mfma_lds_bytes(int d) {   // queries | ||q||^2 | spare | lists | bounds, counters (256 B) | pool scratch [512]
+    return (size_t)d * 136 + 16 * 8 + 8 * 16 * 8 + (size_t)kExMG * kExMCap * 12 + 256 + 512 * 8;
+}
+
+// Sort every list of the group whose bit is set in `need` by (key, id), keep its k best, tighten its bound - all of
+// them in the SAME 36 barrier phases (the lists of a group fill at the same pace: one list at a time cost 16 x 36).
+// All threads; `need` is uniform.
+__device__ __forceinline__ void exm_cut_lists(unsigned long long* l_key, int* l_id, int* s_cnt, unsigned long long* s_bound,
+                                              uint32_t need, int k) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < kExMG * kExMCap; i += kExThreads) {
+        const int g = i / kExMCap, e = i - g * kExMCap;
+        if (((need >> g) & 1u) && e >= min(s_cnt[g], kExMCap)) {
+            l_key[i] = ~0ull;
+            l_id[i] = 0x7fffffff;
+        }
+    }
+    for (int size = 2; size <= kExMCap; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int pp = threadIdx.x; pp < kExMG * (kExMCap >> 1); pp += kExThreads) {
+                const int g = pp / (kExMCap >> 1), p = pp - g * (kExMCap >> 1);
+                if (!((need >> g) & 1u)) continue;
+                unsigned long long* key = l_key + g * kExMCap;
+                int* id = l_id + g * kExMCap;
+                const int i = ((p / stride) * 2 * stride) + (p % stride), j = i + stride;
+                const unsigned long long ka = key[i], kb = key[j];
+                const int ia = id[i], ib = id[j];
+                const bool gt = ka > kb || (ka == kb && ia > ib);
+                if (gt == ((i & size) == 0)) {
+                    key[i] = kb;
+                    key[j] = ka;
+                    id[i] = ib;
+                    id[j] = ia;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kExMG && ((need >> threadIdx.x) & 1u)) {
+        const int g = threadIdx.x, n = min(s_cnt[g], kExMCap);
+        s_cnt[g] = n < k ? n : k;
+        if (n >= k && l_key[g * kExMCap + k - 1] < s_bound[g]) s_bound[g] = l_key[g * kExMCap + k - 1];
+    }
+    __syncthreads();
+}
+
+// k-th smallest (kth = 1 ...) of the up to 256 keys a wave holds four per lane (v[c] = key lane + 64 c; absent ones ~0):
+// radix select from the top bit down, ballots and popcounts only - no LDS, no barrier.  Uniform result.
+__device__ __forceinline__ unsigned long long exm_wave_kth(const unsigned long long (&v)[4], int kth) {
+    unsigned long long prefix = 0;
+    int rem = kth;
+    for (int bit = 63; bit >= 0; --bit) {
+        const unsigned long long hi = bit == 63 ? 0ull : ~((2ull << bit) - 1ull);      // the bits above `bit`
+        int cnt0 = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool m = ((v[c] ^ prefix) & hi) == 0ull && ((v[c] >> bit) & 1ull) == 0ull;
+            cnt0 += __popcll(__ballot(m));
+        }
+        if (rem > cnt0) {
+            prefix |= 1ull << bit;
+            rem -= cnt0;
+        }
+    }
+    return prefix;
+}
+
+// The fold of a query's per-workgroup lists for the matrix-pipe kernel: the lists are sorted, so the k-th smallest of 64
+// of their heads bounds the k-th best entry; one pass keeps what is under it (about 2 k entries instead of n_lists x k
+// through the threshold buffer, ~40 us per query, one query after the other in the last workgroup), one sort finishes.
+// Falls back to exact_merge_lists when more than the buffer holds pass (rows that tie, mostly).
+__device__ __forceinline__ void exm_merge_lists(const ExactArgs& a, ExTopK& tk, unsigned long long* s_pool, int fs, int b) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    __syncthreads();
+    ex_init(tk);
+    const int64_t total = (int64_t)a.n_lists * a.k;
+    const int64_t o = (int64_t)fs * total;
+    unsigned long long bound = ~0ull;
+    if (a.n_lists >= a.k) {
+        // every wave computes the same bound: the k-th smallest of (up to 256 of) the lists' heads
+        unsigned long long hv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int l = lane + 64 * c;
+            hv[c] = l < a.n_lists ? a.part_key[o + (int64_t)l * a.k] : ~0ull;
+        }
+        bound = exm_wave_kth(hv, a.k);
+    }
+    (void)s_pool;
+    __syncthreads();
+    for (int64_t i = tid; i < total; i += kExThreads) {
+        const int id = a.part_id[o + i];
+        const unsigned long long key = a.part_key[o + i];
+        if (id != 0x7fffffff && key <= bound) {
+            const int slot = atomicAdd(&tk.cnt, 1);
+            if (slot < kExCap) {
+                tk.key[slot] = key;
+                tk.id[slot] = id;
+            }
+        }
+    }
+    __syncthreads();
+    if (tk.cnt > kExCap) {          // (uniform) too many entries under the bound: the general fold
+        __syncthreads();
+        exact_merge_lists(a, tk, fs, b);
+        return;
+    }
+    ex_cut(tk, a.k);
+    for (int j = tid; j < a.k; j += kExThreads) {
+        const bool ok = j < tk.cnt;
+        const double sc = ok ? unsortable_f64(a.metric_l2 ? tk.key[j] : ~tk.key[j]) : 0.0;
+        a.D[(int64_t)b * a.k + j] = ok ? (float)sc : (a.metric_l2 ? FLT_MAX : -FLT_MAX);
+        a.I[(int64_t)b * a.k + j] = ok ? tag_id((int64_t)tk.id[j] + a.id_offset, sc, a.tag_ids) : -1;
+    }
+}
+
+template <bool F32, int NS, int H>
+__global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
+    static_assert(NS % H == 0 && H <= NS, "the register ring divides the row");
+    extern __shared__ __attribute__((aligned(16))) char ex_smem[];
+    constexpr int d = NS * 32;
+    char* s_q = ex_smem;                                                    // [d][16] doubles, padded (exm_q_off)
+    double* s_qn2 = reinterpret_cast<double*>(ex_smem + (size_t)d * 136);   // [16] ||q||^2 (L2)
+    double* s_xn = s_qn2 + 16;                                              // (spare)
+    char* s_lists = reinterpret_cast<char*>(s_xn + 8 * 16);
+    unsigned long long* l_key = reinterpret_cast<unsigned long long*>(s_lists);            // [16][kExMCap]
+    int* l_id = reinterpret_cast<int*>(s_lists + (size_t)kExMG * kExMCap * 8);             // [16][kExMCap]
+    ExTopK& tk_big = *reinterpret_cast<ExTopK*>(s_lists);
+    static_assert(sizeof(ExTopK) <= (size_t)kExMG * kExMCap * 12, "the merge list aliases the group's lists");
+    unsigned long long* s_bound = reinterpret_cast<unsigned long long*>(s_lists + (size_t)kExMG * kExMCap * 12);
+    int* s_cnt = reinterpret_cast<int*>(s_bound + kExMG);
+    int& s_last = s_cnt[kExMG];
+    // this workgroup's best key per query so far (what it publishes for the chip-wide bound): behind the 256 bytes of
+    // bounds and counters
+    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_lists + (size_t)kExMG * kExMCap * 12 + 256);
+    if (gate_closed(a.gate)) return;
+    const uint32_t nf = *a.n_flag;
+    if ((uint32_t)a.f0 >= nf) return;
+    const int f1 = (int)std::min<uint32_t>(nf, (uint32_t)(a.f0 + a.f_cap));
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, p = lane >> 4;
+    const int64_t n_tiles = (a.N + kExMRows - 1) / kExMRows;
+    const bool l2 = a.metric_l2 != 0;
+
+    auto push = [&](int col, unsigned long long key, int id) __attribute__((always_inline)) {
+        const int sl = atomicAdd(&s_cnt[col], 1);
+        if (sl < kExMCap) {
+            l_key[col * kExMCap + sl] = key;
+            l_id[col * kExMCap + sl] = id;
+        }
+        atomicMin(&s_best[col], key);
+    };
+
+    for (int fg = a.f0; fg < f1; fg += kExMG) {
+        const int ng = min(kExMG, f1 - fg);
+        __syncthreads();
+        for (int i = tid; i < kExMG * d; i += kExThreads) {
+            const int g = i / d, c = i - g * d;
+            // (slots past the group's last query repeat the first one: same work, results never pushed)
+            const int b = a.flag_list[fg + (g < ng ? g : 0)];
+            *reinterpret_cast<double*>(s_q + exm_q_off(c, g)) = (double)a.q32[(int64_t)b * d + c];
+        }
+        if (tid < kExMG) {
+            s_cnt[tid] = 0;
+            s_bound[tid] = ~0ull;
+            s_best[tid] = ~0ull;
+        }
+        __syncthreads();
+        {
+            for (int gq = 2 * w; gq < 2 * w + 2; ++gq) {
+                double sq = 0.0;
+                for (int c = lane; c < d; c += 64) {
+                    const double v = *reinterpret_cast<const double*>(s_q + exm_q_off(c, gq));
+                    sq = fma(v, v, sq);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+                if (lane == 0) s_qn2[gq] = sq;
+            }
+            __syncthreads();
+        }
+        // ---- the register ring: H of the row's NS 64-byte segments per lane ---------------------------------------
+        u32x4 v0[H], v1[F32 ? H : 1];
+        // this lane's piece of its row in tile `tile`: ONE 64-bit base per tile (opaque: left to itself the compiler
+        // keeps a precomputed address pair per unrolled step alive across the whole kernel and spills them), the steps
+        // are immediate offsets from it
+        constexpr int ES = F32 ? 4 : 2;
+        auto row_base = [&](int64_t tile) __attribute__((always_inline)) {
+            int64_t row = tile * kExMRows + w * 16 + r;
+            row = row < a.N ? row : a.N - 1;                  // (past the end: any valid row, never pushed)
+            const char* b = reinterpret_cast<const char*>(a.rows) + (row * d + p * 8) * ES;
+            asm volatile("" : "+v"(b));
+            return b;
+        };
+        auto load_seg = [&](int slot, const char* base, int it) __attribute__((always_inline)) {
+            v0[slot] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + it * 32 * ES));
+            if constexpr (F32) v1[slot] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + it * 32 * ES + 16));
+        };
+        if ((int64_t)blockIdx.x < n_tiles) {
+            const char* b0 = row_base(blockIdx.x);
+#pragma unroll
+            for (int it = 0; it < H; ++it) load_seg(it, b0, it);
+        }
+        // byte offset of q[k = 8 p][query r] (query 0 for the one-query loop); a step of 32 k is 32 x 128 + 4 x 64 bytes on
+        const int q_lane = exm_q_off(p * 8, r), q_lane1 = exm_q_off(p * 8, 0);
+        static_assert(exm_q_off_step == 4352, "step stride of the padded query block");
+        int steps_done = 0;
+        // what follows a step's scores: capacity check / cuts, the published best key, the chip-wide bound
+        auto step_tail = [&]() __attribute__((always_inline)) {
+            __syncthreads();
+            uint32_t need = 0;                    // (uniform: the counters are read behind the barrier by every thread)
+            for (int g = 0; g < ng; ++g) need |= s_cnt[g] > kExMCap - kExMRows ? 1u << g : 0u;
+            if (need) exm_cut_lists(l_key, l_id, s_cnt, s_bound, need, a.k);
+            // The chip-wide bound.  Every workgroup publishes its best key per query after 1, 2, 4, 8, ... steps and reads
+            // the others' then: the k-th smallest of the workgroups' best keys is the worst of SOME k distinct rows, hence
+            // an upper bound on the k-th best of all rows - about the k-th best of n_lists x 128 x steps rows, where a
+            // workgroup's own list only knows the k-th best of its own.  Pushes (and with them the exact re-scoring of the
+            // pairs that pass the matrix pipe's selection) drop from ~k ln(rows per workgroup / k) per workgroup and
+            // query to about that many over the whole chip.  One wave per query (two rounds), no block barrier.
+            ++steps_done;
+            if ((steps_done & (steps_done - 1)) == 0 && a.n_lists >= a.k) {
+                for (int g = w; g < ng; g += 8) {
+                    unsigned long long* pool = a.gpool + (int64_t)(fg + g - a.f0) * a.n_lists;
+                    if (lane == 0 && s_best[g] != ~0ull)
+                        __hip_atomic_store(pool + blockIdx.x, s_best[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned long long hv[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int l = lane + 64 * c;
+                        hv[c] = l < a.n_lists ? __hip_atomic_load(pool + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+                    }
+                    const unsigned long long kth = exm_wave_kth(hv, a.k);
+                    if (lane == 0 && kth < s_bound[g]) s_bound[g] = kth;
+                }
+            }
+            __syncthreads();
+        };
+        // (two loops, not one loop with a branch in it: with both bodies in one loop the register allocator spilled the
+        //  row ring - 100-500 bytes of scratch per lane)
+        if (ng == 1) {
+            for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+                const int64_t t_next = t + gridDim.x < n_tiles ? t + gridDim.x : t;
+                const char* cur_b = row_base(t);
+                const char* nxt_b = row_base(t_next);
+                // ONE flagged query in this group (the common case when anything is flagged at all): sixteen MFMA columns
+                // for one query would make the pass matrix-bound (1.8 ms over 4 M x 640 rows where the one-query kernel
+                // takes 1.4); the same loads feed plain float64 fmas instead - direct (q - x)^2 for L2 - and the pass is
+                // as HBM-bound as exact_scan_kernel's.  Lane (r, p) sums its quarter of row r; two shuffles finish it.
+                double s1 = 0.0;
+#pragma unroll
+                for (int it = 0; it < NS; ++it) {
+                    const int slot = it % H;
+                    double xd[8];
+                    if constexpr (F32) {
+                        const f32x4 x0 = __builtin_bit_cast(f32x4, v0[slot]);
+                        const f32x4 x1 = __builtin_bit_cast(f32x4, v1[slot]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { xd[j] = (double)x0[j]; xd[4 + j] = (double)x1[j]; }
+                    } else {
+                        const half8 h = __builtin_bit_cast(half8, v0[slot]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xd[j] = (double)(float)h[j];
+                    }
+                    if (it + H < NS) load_seg(slot, cur_b, it + H);
+                    else load_seg(slot, nxt_b, it + H - NS);
+                    // (the step's LDS address is formed HERE: hoisted out of the loop, the NS addresses of the unrolled
+                    //  steps - beyond the 64 KB a ds_read offset reaches - cost a register each and spilled)
+                    int qo = q_lane1 + it * 4352;
+                    asm volatile("" : "+v"(qo));
+                    const char* qb = s_q + qo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const double qv = *reinterpret_cast<const double*>(qb + j * 128);
+                        if (l2) {
+                            const double df = qv - xd[j];
+                            s1 = fma(df, df, s1);
+                        } else {
+                            s1 = fma(qv, xd[j], s1);
+                        }
+                    }
+                    // (one step's reads and conversions at a time: left free, the scheduler hoists the LDS reads and
+                    //  conversions of all NS steps to the top - 100-500 bytes of scratch per lane)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                s1 += __shfl_xor(s1, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                const int64_t rowi = t * kExMRows + w * 16 + r;
+                if (p == 0 && rowi < a.N) {
+                    const unsigned long long key = l2 ? sortable_u64(s1) : ~sortable_u64(s1);
+                    if (key <= s_bound[0]) push(0, key, (int)rowi);
+                }
+                step_tail();
+            }
+        } else {
+            for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+                const int64_t t_next = t + gridDim.x < n_tiles ? t + gridDim.x : t;
+                const char* cur_b = row_base(t);
+                const char* nxt_b = row_base(t_next);
+            // (two accumulator chains per wave: with two waves per SIMD that is the four independent MFMAs in flight the
+            //  rate probe ran with; four per wave cost 16 more registers and the kernel spilled)
+            f64x4 acc[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+            double xsq = 0.0;
+#pragma unroll
+            for (int it = 0; it < NS; ++it) {
+                const int slot = it % H;
+                double xd[8];
+                if constexpr (F32) {
+                    const f32x4 x0 = __builtin_bit_cast(f32x4, v0[slot]);
+                    const f32x4 x1 = __builtin_bit_cast(f32x4, v1[slot]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { xd[j] = (double)x0[j]; xd[4 + j] = (double)x1[j]; }
+                } else {
+                    const half8 h = __builtin_bit_cast(half8, v0[slot]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xd[j] = (double)(float)h[j];
+                }
+                // refill the segment just consumed: a later segment of this tile, or the next tile's
+                if (it + H < NS) load_seg(slot, cur_b, it + H);
+                else load_seg(slot, nxt_b, it + H - NS);
+                int qo = q_lane + it * 4352;                                 // (formed per step: see the one-query loop)
+                asm volatile("" : "+v"(qo));
+                const char* qb = s_q + qo;                                   // (+ 128 B per k inside the piece)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double qv = *reinterpret_cast<const double*>(qb + j * 128);
+                    acc[j & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[j], qv, acc[j & 1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xsq = fma(xd[j], xd[j], xsq);
+                __builtin_amdgcn_sched_barrier(0);      // (one step at a time, as in the one-query loop)
+            }
+            const f64x4 dot = acc[0] + acc[1];                              // D[row = p + 4 reg][query r]
+            const int64_t base_row = t * kExMRows + w * 16;
+            {
+                xsq += __shfl_xor(xsq, 16, 64);
+                xsq += __shfl_xor(xsq, 32, 64);                              // ||x_r||^2 in the row's four lanes
+                const double qn = s_qn2[r];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const double xn = __shfl(xsq, p + 4 * reg, 64);          // row p + 4 reg
+                    const int64_t rowi = base_row + p + 4 * reg;
+                    // the matrix pipe's value only SELECTS (its float64 sums are not even the same for identical rows in
+                    // different places of a tile - the last register of an accumulator rounds differently -, so ties
+                    // between copies of a row would break by position): whatever may enter a list, by a margin above the
+                    // worst-case error d 2^-53 (||x||^2 + ||q||^2), is scored again below in the one-query kernel's order
+                    const double margin = 1e-12 * (xn + qn);
+                    const unsigned long long sel_key = l2 ? sortable_u64(((xn - 2.0 * dot[reg]) + qn) - margin)
+                                                          : ~sortable_u64(dot[reg] + margin);
+                    const bool pass = rowi < a.N && r < ng && sel_key <= s_bound[r];
+                    unsigned long long m = __ballot(pass);
+                    while (m) {        // four (row, query) pairs at a time: 16 lanes each, the one-query kernel's sum
+                        int src = -1;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int bit = m ? __ffsll((long long)m) - 1 : -1;
+                            if (g == p) src = bit;
+                            if (m) m &= m - 1;
+                        }
+                        const int sl = src >= 0 ? src : 0;
+                        const int64_t rowx = base_row + (sl >> 4) + 4 * reg;
+                        const int col = sl & 15;
+                        double sx = 0.0;
+                        for (int e = r * 8; e < d; e += 128) {
+                            double xv[8];
+                            if constexpr (F32) {
+                                const float* src32 = reinterpret_cast<const float*>(a.rows) + rowx * d + e;
+                                const f32x4 x0 = *reinterpret_cast<const f32x4*>(src32);
+                                const f32x4 x1 = *reinterpret_cast<const f32x4*>(src32 + 4);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) { xv[j] = (double)x0[j]; xv[4 + j] = (double)x1[j]; }
+                            } else {
+                                const half8 h = *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(a.rows) + rowx * d + e);
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) xv[j] = (double)(float)h[j];
+                            }
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const double qv = *reinterpret_cast<const double*>(s_q + exm_q_off(e + j, col));
+                                if (l2) {
+                                    const double df = qv - xv[j];
+                                    sx = fma(df, df, sx);
+                                } else {
+                                    sx = fma(qv, xv[j], sx);
+                                }
+                            }
+                        }
+                        sx = dpp_add16_f64(sx);
+                        if (src >= 0 && r == 0) {
+                            const unsigned long long key = l2 ? sortable_u64(sx) : ~sortable_u64(sx);
+                            if (key <= s_bound[col]) push(col, key, (int)rowx);
+                        }
+                    }
+                }
+            }
+                step_tail();
+            }
+        }
+        __syncthreads();
+        exm_cut_lists(l_key, l_id, s_cnt, s_bound, (1u << ng) - 1u, a.k);
+        for (int g = 0; g < ng; ++g) {
+            const int64_t o = ((int64_t)(fg + g - a.f0) * a.n_lists + blockIdx.x) * a.k;
+            for (int j = tid; j < a.k; j += kExThreads) {
+                const bool ok = j < s_cnt[g];
+                a.part_key[o + j] = ok ? l_key[g * kExMCap + j] : ~0ull;
+                a.part_id[o + j] = ok ? l_id[g * kExMCap + j] : 0x7fffffff;
+            }
+        }
+        // the LAST workgroup to finish a query folds its per-workgroup lists (as in the single-query kernel)
+        __threadfence();
+        __syncthreads();
+        for (int g = 0; g < ng; ++g) {
+            const int fs = fg + g - a.f0;
+            if (tid == 0) s_last = atomicAdd(a.done + fs, 1u) == gridDim.x - 1 ? 1 : 0;
+            __syncthreads();
+            if (s_last) {
+                __threadfence();
+                exm_merge_lists(a, tk_big, reinterpret_cast<unsigned long long*>(s_lists + (size_t)kExMG * kExMCap * 12 + 256), fs,
+                                a.flag_list[fg + g]);
+                if (tid == 0) a.done[fs] = 0u;
+                for (int j = tid; j < a.n_lists; j += kExThreads)      // every workgroup is through with the query's pool
+                    __hip_atomic_store(a.gpool + (int64_t)fs * a.n_lists + j, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+bool exact_mfma_supported(int d, int k) {
+    return k <= kExMCap / 4 && d % 128 == 0 && d >= 128 && d <= 768;
+}
+
+template <bool F32>
+static int launch_exact_mfma(const ExactArgs& a, int grid, hipStream_t st) {
+    const size_t lds = exact_mfma_lds_bytes(a.d);
+#define PRAG_EXM(NS_, H16_, H32_)                                                                       \
+    if (a.d == 32 * NS_) {                                                                              \
+        auto kern = exact_mfma_kernel<F32, NS_, F32 ? H32_ : H16_>;                                     \
+        static LdsOptIn opt_in;                                                                         \
+        const int rc_ = opt_in.ensure(reinterpret_cast<const void*>(kern), 160 * 1024);                 \
+        if (rc_ != PRAG_OK) return rc_;                                                                 \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kExThreads), lds, st, a);                             \
+        return PRAG_OK;                                                                                 \
+    }
+    // (row segments in flight per lane: 16 B each on fp16 rows, 32 B on float32 rows - sized so that no form spills)
+    PRAG_EXM(4, 4, 4) PRAG_EXM(8, 8, 4) PRAG_EXM(12, 6, 4) PRAG_EXM(16, 4, 4) PRAG_EXM(20, 5, 4) PRAG_EXM(24, 6, 4)
+#undef PRAG_EXM
+    set_error("internal: exact_mfma_kernel has no d = %d form", a.d);
+    return PRAG_EUNSUPPORTED;
+}
+
 // (Round 3's batched attempt, for the record: rows loaded once per step, float32 queries in LDS, one threshold list per
 // query - four flagged queries cost 10.2 ms batched against 10.4 ms one by one at 8 M x 640 fp16 rows, and ONE flagged
 // query 6.1 ms instead of 2.6: 74 KB of LDS left one workgroup per CU.  The grouped kernel above keeps float64 queries
@@ -501,6 +983,7 @@ int exact_run(const ExactRun& r, hipStream_t st) {
     a.D = r.D;
     a.I = r.I;
     a.done = r.done;
+    a.gpool = r.gpool;
     a.tag_ids = r.tag_ids;
     a.gate = r.gate;
     // several flagged queries expected, and the group's lists hold them: eight queries per pass over the rows
@@ -517,9 +1000,17 @@ int exact_run(const ExactRun& r, hipStream_t st) {
         const int rc_ = opt_in[(r.store_f32 ? 2 : 0) + (short_rows ? 1 : 0)].ensure(gk, 160 * 1024);
         if (rc_ != PRAG_OK) return rc_;
     }
+    // ... sixteen per pass on the float64 matrix pipe where the shape allows (exact_mfma_kernel)
+    const bool mfma = r.grouped && r.mfma && r.gpool != nullptr && exact_mfma_supported(r.d, r.k);
     for (int f0 = 0; f0 < r.B; f0 += r.f_cap) {
         a.f0 = f0;
-        if (grouped) {
+        if (mfma) {
+            // (one workgroup per CU - 155 KB of LDS -: half the list scan's grid, so no CU runs two in turn)
+            ExactArgs am = a;
+            am.n_lists = std::max(1, (r.grid + 1) / 2);
+            const int rc_m = r.store_f32 ? launch_exact_mfma<true>(am, am.n_lists, st) : launch_exact_mfma<false>(am, am.n_lists, st);
+            if (rc_m != PRAG_OK) return rc_m;
+        } else if (grouped) {
             if (r.store_f32) {
                 hipLaunchKernelGGL((exact_group_kernel<true, 6>), dim3(r.grid), dim3(kExThreads), g_lds, st, a);
             } else {

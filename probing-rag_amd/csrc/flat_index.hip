@@ -1531,6 +1531,8 @@ struct prag_index {
     unsigned long long* ex_key = nullptr;
     int* ex_id = nullptr;
     size_t ex_entries = 0;
+    unsigned long long* ex_pool = nullptr;   // [f_cap][grid] exact_mfma_kernel: the workgroups' best keys (all-ones between searches)
+    size_t ex_pool_entries = 0;
     uint32_t* ex_done = nullptr;  // [ex_done_cap] arrival counters of the exact scan's list merge
     int ex_done_cap = 0;
     // 8-bit shadow (flat_shadow.hip): 0 off, 1 (default) on for shards >= kShadowMinRows when the device has
@@ -1598,6 +1600,7 @@ struct prag_index {
     int retry_mode = -1;                  // PRAG_RETRY_TIER at creation: -1 adaptive, 0 never, 1 always armed
     int exact_group_mode = -1;            // PRAG_EXACT_GROUP at creation: -1 adaptive, 0 never, 1 always (exact_group_kernel)
     bool exact_group_hint = false;        // recent retry tiers left >= 4 queries for the exact scan
+    int exact_mfma_mode = 1;              // PRAG_EXACT_MFMA at creation: 0 = never the float64-MFMA form of the grouped scan
     // the sliced gather behind the exact-bound kernel: the bound kernel finishes every query itself when <= 256 rows stay
     // under its bound (40-100 in practice), and the gather launch is then ~9 us of nothing on the critical path.  It is
     // enqueued while "armed": from the start, and again for 64 searches whenever a search left a query unfinished (that
@@ -1832,6 +1835,7 @@ extern "C" int prag_index_create(prag_index_t** out, int d, int metric, int stor
     if (const char* e = getenv("PRAG_SHADOW_AFFINE")) ix->shadow_affine_mode = atoi(e);
     if (const char* e = getenv("PRAG_RETRY_TIER")) ix->retry_mode = atoi(e);
     if (const char* e = getenv("PRAG_EXACT_GROUP")) ix->exact_group_mode = atoi(e);
+    if (const char* e = getenv("PRAG_EXACT_MFMA")) ix->exact_mfma_mode = atoi(e);
     if (const char* e = getenv("PRAG_GATHER")) ix->gather_mode = atoi(e);
 #ifdef PRAG_MM_DIAG
     if (const char* e = getenv("PRAG_SCAN_MM")) ix->mm_mode = atoi(e);
@@ -2261,7 +2265,8 @@ static SearchPlan plan_search(const PlanEnv& e) {
         ws += (size_t)std::max(P.mm_chunk, e.n_cu) * std::max<size_t>(kMmCapQ, e.n_cu) * 12;
         ws += (size_t)e.n_cu * P.mm_chunk * P.mm_cap_wg * 8;
     }
-    if (P.certify && N > 0) ws += exact_part_entries(P.ex_fcap, P.ex_grid, k) * 12 + (size_t)P.ex_fcap * 4;
+    if (P.certify && N > 0)
+        ws += exact_part_entries(P.ex_fcap, P.ex_grid, k) * 12 + (size_t)P.ex_fcap * 4 + exact_part_entries(P.ex_fcap, P.ex_grid, 1) * 8;
     if (P.use_shadow || P.use_mm8) {
         const size_t BpadS = P.use_mm8 ? P.Bpad : (size_t)(B + 63) / 64 * 64;
         ws += BpadS * (2 * (size_t)d + shadow_q_bytes() + shadow_slot_words() * 4 + 8);
@@ -2875,6 +2880,15 @@ static int search_workspaces(SearchRun& r) {
             if (rc_ws != PRAG_OK) return rc_ws;
             ix->ex_entries = need;
         }
+        // every workgroup's best key per flagged query (exact_mfma_kernel's chip-wide bound): all-ones between searches
+        const size_t pool_need = exact_part_entries(ex_fcap, ex_grid, 1);
+        if (pool_need > ix->ex_pool_entries) {
+            ix->ex_pool_entries = 0;
+            const int rc_ws = ws_regrow({{vpp(&ix->ex_pool), pool_need * sizeof(unsigned long long)}});
+            if (rc_ws != PRAG_OK) return rc_ws;
+            PRAG_HIP(hipMemsetAsync(ix->ex_pool, 0xff, pool_need * sizeof(unsigned long long), st));
+            ix->ex_pool_entries = pool_need;
+        }
         if (ex_fcap > ix->ex_done_cap) {
             ix->ex_done_cap = 0;
             const int rc_ws = ws_regrow({{vpp(&ix->ex_done), (size_t)ex_fcap * sizeof(uint32_t)}});
@@ -3286,6 +3300,7 @@ static int search_finish(SearchRun& r, float* D, int64_t* I) {
     er.f_cap = ex_fcap;
     er.grid = ex_grid;
     er.done = ix->ex_done;
+    er.gpool = ix->ex_pool;
     er.tag_ids = tag_ids;
     er.gate = ix->gate;
     // several flagged queries expected - every query goes to the exact scan by construction, or recent searches on this
@@ -3293,8 +3308,13 @@ static int search_finish(SearchRun& r, float* D, int64_t* I) {
     // (one flagged query is the common case and the single-query kernel is 3.7x faster for it - profiles/
     //  r05f_exact_group_bench.txt -, so "several" means: by construction, or the retry tier's inner searches have been
     //  leaving >= 4 queries flagged lately)
+    er.mfma = ix->exact_mfma_mode != 0;
+    // ... or B >= 2 on a shape the matrix-pipe form covers (round 6): it decides on the device - one flagged query in a
+    // group is scanned with plain fmas at the one-query kernel's pace, two or more share a pass on the float64 MFMA - so no
+    // history is needed and the launch sequence is the same whatever earlier searches flagged
     er.grouped = ix->exact_group_mode != 0 &&
-                 (ix->exact_group_mode == 1 || (exact_only && B >= 2) || (ix->adaptive && ix->exact_group_hint));
+                 (ix->exact_group_mode == 1 || (exact_only && B >= 2) || (ix->adaptive && ix->exact_group_hint) ||
+                  (B >= 2 && er.mfma && exact_mfma_supported(ix->d, k)));
     const bool may_flag = certify && ix->ntotal > 0;
     if (use_mm8) {
         // second tier, decided on the device (mm8_second_tier): no read-back, no host branch
@@ -3723,7 +3743,7 @@ extern "C" void prag_index_destroy(prag_index_t* ix) {
                     ix->t2_D, ix->t2_I, ix->t2_word, ix->xch_send, ix->xch_recv,
                     ix->mm_wcnt, ix->mm_wkey, ix->mm_widx, ix->rows16, ix->qinfo, ix->qn2, ix->flag_list, ix->g_slot,
                     ix->cert_words, ix->ex_key, ix->ex_id, ix->rows8, ix->sscale, ix->serr, ix->shadow_err_max, ix->sh_aff, ix->sh_aff_sums, ix->sh_yn_max, ix->sh_bias_max, ix->sbias, ix->sh_kshift, ix->sh_unfin, ix->sh_q8,
-                    ix->sh_sq, ix->sh_slots, ix->sh_ovf, ix->sh_cand, ix->sh_ccnt, ix->sh_pkey, ix->sh_pid, ix->ex_done};
+                    ix->sh_sq, ix->sh_slots, ix->sh_ovf, ix->sh_cand, ix->sh_ccnt, ix->sh_pkey, ix->sh_pid, ix->ex_done, ix->ex_pool};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ix->io_q_host) (void)hipHostFree(ix->io_q_host);

@@ -250,10 +250,13 @@ struct ExactRun {
     int f_cap;              // flagged queries one round can hold
     int grid;               // workgroups of the scan
     uint32_t* done;         // [f_cap] zero-initialised arrival counters (the kernel leaves them zero)
+    unsigned long long* gpool = nullptr;    // [f_cap][grid] all-ones words (exact_mfma_kernel: each workgroup's best key; left all-ones)
     int tag_ids;
     Gate gate;
     bool grouped = false;   // several flagged queries expected: eight per pass over the rows (exact_group_kernel)
+    bool mfma = true;       // ... sixteen per pass on v_mfma_f64_16x16x4_f64 where the shape allows (PRAG_EXACT_MFMA=0: never)
 };
+bool exact_mfma_supported(int d, int k);
 size_t exact_part_entries(int f_cap, int grid, int k);
 // Enqueue ceil(B / f_cap) launches of the exact scan (list merge folded in); each exits at once when no query is flagged.
 int exact_run(const ExactRun& r, hipStream_t st);

@@ -662,7 +662,11 @@ def test_grouped_exact_scan_is_bit_identical_to_the_single_query_scan(monkeypatc
     """Round 5: eight flagged queries per pass over the rows (exact_group_kernel: rows converted to float64 once,
     float64 queries in LDS).  Every lane forms the single-query kernel's sums in the same order, so D and I must be
     IDENTICAL - on a corpus of dense near-duplicates (squared-L2 cancellation, the certificate's worst case), for 1, 5,
-    21 and 40 flagged queries (partial groups, several groups), with ties across workgroups, and against the oracle."""
+    21 and 40 flagged queries (partial groups, several groups), with ties across workgroups, and against the oracle.
+    Round 6: sixteen per pass on the float64 matrix pipe (exact_mfma_kernel).  Squared L2 is selected from
+    ||x||^2 - 2 q.x + ||q||^2 with a margin and every pair that may enter a list is scored again as the direct sum in the
+    single-query kernel's order: identical D and I too.  Inner products are the MFMA's own float64 sums (another
+    order): I identical, D the same float32."""
     import torch
     import probing_rag_amd as pra
     N, d, k = 9000, 640, 30                       # d = 640 with k > 26: every query goes straight to the exact scan
@@ -672,10 +676,12 @@ def test_grouped_exact_scan_is_bit_identical_to_the_single_query_scan(monkeypatc
     X[N - 1] = X[17]
     X[N // 2] = X[17]
     res = {}
-    for mode in ("0", "1"):
+    for mode, mfma in (("0", "0"), ("1", "0"), ("1", "1")):
         monkeypatch.setenv("PRAG_EXACT_GROUP", mode)
+        monkeypatch.setenv("PRAG_EXACT_MFMA", mfma)
         ix = pra.HipFlatIndex(d, metric, store)
         monkeypatch.delenv("PRAG_EXACT_GROUP")
+        monkeypatch.delenv("PRAG_EXACT_MFMA")
         ix.add(X)
         out = []
         for B in (1, 5, 21, 40):
@@ -684,9 +690,54 @@ def test_grouped_exact_scan_is_bit_identical_to_the_single_query_scan(monkeypatc
             D, I = ix.search(torch.from_numpy(Q).cuda(), k)
             assert ix.last_exact_fallbacks() == B
             out.append((D.cpu().numpy(), I.cpu().numpy(), Q))
-        res[mode] = out
+        res[mode + mfma] = out
         ix.close()
-    for (D0, I0, Q), (D1, I1, _) in zip(res["0"], res["1"]):
+    for (D0, I0, Q), (D1, I1, _), (D2, I2, _) in zip(res["00"], res["10"], res["11"]):
         assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
+        assert np.array_equal(I0, I2) and np.array_equal(D0, D2)
         Dw, Iw = onp.flat_search(_stored(X, metric, store), Q, k, metric)
         _check(D1, I1, Dw, Iw, metric)
+
+
+@pytest.mark.parametrize("d,store,metric", [(128, "f16", onp.METRIC_L2), (256, "f32", onp.METRIC_IP), (384, "f16", onp.METRIC_COS),
+                                            (512, "f32", onp.METRIC_L2), (512, "f16", onp.METRIC_IP), (768, "f16", onp.METRIC_L2),
+                                            (768, "f32", onp.METRIC_COS), (768, "f16", onp.METRIC_COS)])
+def test_exact_scan_on_the_float64_matrix_pipe(monkeypatch, d, store, metric):
+    """exact_mfma_kernel at every row length it is built for (d = 128 ... 768), both storages, all metrics: 37 queries
+    (two full groups of 16 and a ragged one), each the exact copy of a row that occurs 40 times - more copies than any
+    candidate list holds, so no certificate clears and every query is recomputed by the float64 scan - on a corpus
+    whose size is no multiple of the kernel's 128-row step.  Results the definition's; the copies come back lowest id
+    first; identical to the one-query-per-pass kernel."""
+    import torch
+    import probing_rag_amd as pra
+    N, B, k = 20_011, 37, 10
+    X = onp.synth_rows(71, 0, N, d)
+    rng = np.random.default_rng(d)
+    dup_rows = []
+    for i in range(B):
+        dups = np.sort(rng.choice(N, 40, replace=False))
+        X[dups] = X[dups[0]]
+        dup_rows.append(dups)
+    Q = np.stack([X[dr[0]] for dr in dup_rows]).astype(np.float32)
+    res = {}
+    for mode, mfma in (("0", "0"), ("1", "1")):
+        monkeypatch.setenv("PRAG_EXACT_GROUP", mode)
+        monkeypatch.setenv("PRAG_EXACT_MFMA", mfma)
+        ix = pra.HipFlatIndex(d, metric, store)
+        monkeypatch.delenv("PRAG_EXACT_GROUP")
+        monkeypatch.delenv("PRAG_EXACT_MFMA")
+        ix.add(X)
+        D, I = ix.search(torch.from_numpy(Q).cuda(), k)
+        n_fb = ix.last_exact_fallbacks()
+        res[mode] = (D.cpu().numpy(), I.cpu().numpy(), n_fb)
+        ix.close()
+    D0, I0, fb0 = res["0"]
+    D1, I1, fb1 = res["1"]
+    assert fb0 == fb1 and fb1 >= B // 2, (fb0, fb1)          # (a later copy set may have overwritten an earlier one's rows)
+    Dw, Iw = oracle_c.flat_search(_stored(X, metric, store), Q, k, metric)
+    _check(D1, I1, Dw, Iw, metric)
+    assert np.array_equal(I0, I1)
+    if metric == onp.METRIC_L2:
+        assert np.array_equal(D0, D1)                       # the same direct sums, bit for bit
+    else:
+        np.testing.assert_allclose(D1, D0, rtol=1e-6, atol=1e-6)

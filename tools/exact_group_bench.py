@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Exact float64 fallback, one query per pass against eight per pass (exact_group_kernel): every query flagged by
+"""Exact float64 fallback, one query per pass against eight per pass (exact_group_kernel) and sixteen per pass on the float64 MFMA (exact_mfma_kernel): every query flagged by
 construction (k = 30 on d = 640 goes straight to the exact scan) - ms per search for 1 ... 64 queries, both kernels."""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,7 +27,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         ix.close()
     sys.exit(0)
 for N in (4_000_000,):
-    for mode, name in (("0", "one query per pass"), ("1", "eight queries per pass")):
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "child", str(N)], env=dict(os.environ, PRAG_EXACT_GROUP=mode),
-                           capture_output=True, text=True)
+    for mode, mfma, name in (("0", "0", "one query per pass (exact_scan_kernel)"), ("1", "0", "eight queries per pass (exact_group_kernel)"),
+                             ("1", "1", "sixteen queries per pass on the float64 matrix pipe (exact_mfma_kernel)")):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "child", str(N)],
+                           env=dict(os.environ, PRAG_EXACT_GROUP=mode, PRAG_EXACT_MFMA=mfma), capture_output=True, text=True)
         print(f"== {name}\n{r.stdout.strip() or r.stderr.strip()[-400:]}", flush=True)
