@@ -572,53 +572,74 @@ __device__ __forceinline__ unsigned long long exm_wave_kth(const unsigned long l
     return prefix;
 }
 
-// The fold of a query's per-workgroup lists for the matrix-pipe kernel: the lists are sorted, so the k-th smallest of 64
-// of their heads bounds the k-th best entry; one pass keeps what is under it (about 2 k entries instead of n_lists x k
-// through the threshold buffer, ~40 us per query, one query after the other in the last workgroup), one sort finishes.
-// Falls back to exact_merge_lists when more than the buffer holds pass (rows that tie, mostly).
-__device__ __forceinline__ void exm_merge_lists(const ExactArgs& a, ExTopK& tk, unsigned long long* s_pool, int fs, int b) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    __syncthreads();
-    ex_init(tk);
+// The fold of the per-workgroup lists of a whole GROUP of queries, by the last workgroup to arrive: one wave per query,
+// eight queries at a time.  The lists are sorted, so the k-th smallest of their heads bounds the k-th best entry; a wave
+// keeps what is under it (about 2 k of its query's n_lists x k entries) in one of the group's list buffers, ONE batched sort
+// (exm_cut_lists) finishes all eight, the outputs follow.  (Query after query through the threshold buffer -
+// exact_merge_lists - this cost ~40 us per query, all in that one workgroup.)  A query with more than a buffer holds under
+// its bound - rows that tie, mostly - takes the general fold afterwards.
+__device__ __forceinline__ void exm_merge_group(const ExactArgs& a, ExTopK& tk_big, unsigned long long* l_key, int* l_id, int* s_cnt,
+                                                unsigned long long* s_bound, int fg, int ng) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t total = (int64_t)a.n_lists * a.k;
-    const int64_t o = (int64_t)fs * total;
-    unsigned long long bound = ~0ull;
-    if (a.n_lists >= a.k) {
-        // every wave computes the same bound: the k-th smallest of (up to 256 of) the lists' heads
-        unsigned long long hv[4];
+    for (int g0 = 0; g0 < ng; g0 += 8) {
+        __syncthreads();
+        const int g = g0 + w;
+        int cnt = 0;
+        if (g < ng) {
+            const int64_t o = (int64_t)(fg + g - a.f0) * total;
+            unsigned long long bound = ~0ull;
+            if (a.n_lists >= a.k) {
+                unsigned long long hv[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int l = lane + 64 * c;
-            hv[c] = l < a.n_lists ? a.part_key[o + (int64_t)l * a.k] : ~0ull;
-        }
-        bound = exm_wave_kth(hv, a.k);
-    }
-    (void)s_pool;
-    __syncthreads();
-    for (int64_t i = tid; i < total; i += kExThreads) {
-        const int id = a.part_id[o + i];
-        const unsigned long long key = a.part_key[o + i];
-        if (id != 0x7fffffff && key <= bound) {
-            const int slot = atomicAdd(&tk.cnt, 1);
-            if (slot < kExCap) {
-                tk.key[slot] = key;
-                tk.id[slot] = id;
+                for (int c = 0; c < 4; ++c) {
+                    const int l = lane + 64 * c;
+                    hv[c] = l < a.n_lists ? a.part_key[o + (int64_t)l * a.k] : ~0ull;
+                }
+                bound = exm_wave_kth(hv, a.k);
+            }
+            for (int64_t i0 = 0; i0 < total; i0 += 64) {
+                const int64_t i = i0 + lane;
+                const unsigned long long key = i < total ? a.part_key[o + i] : ~0ull;
+                const int id = i < total ? a.part_id[o + i] : 0x7fffffff;
+                const bool keep = id != 0x7fffffff && key <= bound;
+                const unsigned long long m = __ballot(keep);
+                const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                if (keep && pos < kExMCap) {
+                    l_key[w * kExMCap + pos] = key;
+                    l_id[w * kExMCap + pos] = id;
+                }
+                cnt += __popcll(m);
             }
         }
+        if (lane == 0) {
+            s_cnt[w] = cnt;
+            s_bound[w] = ~0ull;
+        }
+        __syncthreads();
+        uint32_t ok = 0, over = 0;                    // (uniform: read behind the barrier)
+        for (int q = 0; q < 8; ++q) {
+            if (g0 + q < ng) {
+                if (s_cnt[q] > kExMCap) over |= 1u << q;
+                else ok |= 1u << q;
+            }
+        }
+        if (ok) exm_cut_lists(l_key, l_id, s_cnt, s_bound, ok, a.k);
+        for (int idx = tid; idx < 8 * a.k; idx += kExThreads) {
+            const int q = idx / a.k, j = idx - q * a.k;
+            if (!((ok >> q) & 1u)) continue;
+            const int b = a.flag_list[fg + g0 + q];
+            const bool have = j < s_cnt[q];
+            const unsigned long long key = l_key[q * kExMCap + j];
+            const double sc = have ? unsortable_f64(a.metric_l2 ? key : ~key) : 0.0;
+            a.D[(int64_t)b * a.k + j] = have ? (float)sc : (a.metric_l2 ? FLT_MAX : -FLT_MAX);
+            a.I[(int64_t)b * a.k + j] = have ? tag_id((int64_t)l_id[q * kExMCap + j] + a.id_offset, sc, a.tag_ids) : -1;
+        }
+        __syncthreads();
+        for (int q = 0; q < 8; ++q)                    // (the general fold's buffer aliases the lists: outputs are out)
+            if ((over >> q) & 1u) exact_merge_lists(a, tk_big, fg + g0 + q - a.f0, a.flag_list[fg + g0 + q]);
     }
     __syncthreads();
-    if (tk.cnt > kExCap) {          // (uniform) too many entries under the bound: the general fold
-        __syncthreads();
-        exact_merge_lists(a, tk, fs, b);
-        return;
-    }
-    ex_cut(tk, a.k);
-    for (int j = tid; j < a.k; j += kExThreads) {
-        const bool ok = j < tk.cnt;
-        const double sc = ok ? unsortable_f64(a.metric_l2 ? tk.key[j] : ~tk.key[j]) : 0.0;
-        a.D[(int64_t)b * a.k + j] = ok ? (float)sc : (a.metric_l2 ? FLT_MAX : -FLT_MAX);
-        a.I[(int64_t)b * a.k + j] = ok ? tag_id((int64_t)tk.id[j] + a.id_offset, sc, a.tag_ids) : -1;
-    }
 }
 
 template <bool F32, int NS, int H>
@@ -914,23 +935,20 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
                 a.part_id[o + j] = ok ? l_id[g * kExMCap + j] : 0x7fffffff;
             }
         }
-        // the LAST workgroup to finish a query folds its per-workgroup lists (as in the single-query kernel)
+        // the LAST workgroup to have written its lists of this group folds them for every query of the group (one
+        // arrival counter per group - the slot of its first query; the other slots stay zero)
         __threadfence();
         __syncthreads();
-        for (int g = 0; g < ng; ++g) {
-            const int fs = fg + g - a.f0;
-            if (tid == 0) s_last = atomicAdd(a.done + fs, 1u) == gridDim.x - 1 ? 1 : 0;
-            __syncthreads();
-            if (s_last) {
-                __threadfence();
-                exm_merge_lists(a, tk_big, reinterpret_cast<unsigned long long*>(s_lists + (size_t)kExMG * kExMCap * 12 + 256), fs,
-                                a.flag_list[fg + g]);
-                if (tid == 0) a.done[fs] = 0u;
-                for (int j = tid; j < a.n_lists; j += kExThreads)      // every workgroup is through with the query's pool
-                    __hip_atomic_store(a.gpool + (int64_t)fs * a.n_lists + j, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
+        if (tid == 0) s_last = atomicAdd(a.done + (fg - a.f0), 1u) == gridDim.x - 1 ? 1 : 0;
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            exm_merge_group(a, tk_big, l_key, l_id, s_cnt, s_bound, fg, ng);
+            if (tid == 0) a.done[fg - a.f0] = 0u;
+            for (int j = tid; j < ng * a.n_lists; j += kExThreads)      // every workgroup is through with the group's pools
+                __hip_atomic_store(a.gpool + (int64_t)(fg - a.f0) * a.n_lists + j, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        __syncthreads();
     }
 }
 
