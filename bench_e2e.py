@@ -217,7 +217,7 @@ def run(args, pra, torch, dist, world, rank, dev_index):
                      "clock_overhead_us_per_call": _clock_overhead_us(torch),
                      "us_per_call": {k_: (clock.t[k_] / clock.n[k_] * 1e6 if clock.n[k_] else None) for k_ in clock.t},
                      "share": {k: v / max(1e-12, sum(clock.t.values())) for k, v in clock.t.items()},
-                     "retrieval_rounds_per_query": counts},
+                     "retrieval_rounds_histogram": {str(c): counts.count(c) for c in sorted(set(counts))}},
     }
     if rank == 0 and not args.no_cpu_baseline:
         # the reference's data path on the same queries (this rank's), same LM, same decisions up to rounding
@@ -232,7 +232,8 @@ def run(args, pra, torch, dist, world, rank, dev_index):
         out["reference_style_path"] = {
             "queries_per_s_this_rank": len(my_queries) / rdt, "wall_s": rdt, "seconds": rclock.t, "calls": rclock.n,
             "share": {k: v / max(1e-12, sum(rclock.t.values())) for k, v in rclock.t.items()},
-            "retrieval_rounds_per_query": rcounts,
+            "retrieval_rounds_histogram": {str(c): rcounts.count(c) for c in sorted(set(rcounts))},
+            "same_rounds_as_the_hip_path": rcounts == counts,
             "what": "hooks with activations.detach().cpu() per token and layer, cat/sum + six eager prober calls with "
                     ".to('cpu'), Python gate; retrieval = torch-cpu flat L2 over a "
                     f"{n_sub}-row sub-corpus (lower bound: faiss-cpu absent, the full {args.docs}-row host scan is not run)",
