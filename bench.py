@@ -602,17 +602,20 @@ def clustered_variant(torch, pra, d_emb, k, n_rows=4_194_304, n_centres=4096, si
         m = min(1 << 20, n_rows - lo)
         # rows of a centre are CONTIGUOUS (a corpus in article order: consecutive passages resemble each other),
         # so a centre's ~1000 rows fall into a handful of scan workgroups - the layout that fills a region
-        # interleaved: row i belongs to centre i mod n_centres - a centre's rows are spread over every scan workgroup (a
-        # corpus in random order), the layout the fuzzer draws and the one on which candidate regions overflow and
-        # certificates fail (0.165 exact fallbacks per query where the contiguous layout shows 0)
-        idx = (torch.arange(lo, lo + m, device="cuda") % n_centres) if interleaved else \
+        # interleaved: every row draws its centre at random - a clustered corpus in random order, a centre's rows spread
+        # over every scan workgroup.  (Not `i mod n_centres`: a period of 4096 rows = 128 scan tiles
+        # resonates with a 256-workgroup grid - all 1024 rows of a centre land in TWO workgroups, overflow their 512-entry
+        # candidate regions and 62 of 64 queries go through the retry tier or the exact scan, 2.2 / 14 ms per search; on
+        # 224 workgroups the same corpus takes 0.75 ms - profiles/r06i_clustered_interleaved.txt.  An artefact of a
+        # power-of-two period, not of clustering.)
+        idx = torch.randint(0, n_centres, (m,), generator=g, device="cuda") if interleaved else \
             (torch.arange(lo, lo + m, device="cuda") * n_centres) // n_rows
         ix.add(centres[idx] + sigma * torch.randn((m, d_emb), generator=g, device="cuda"))   # ||noise|| ~ 0.48
     q = centres[torch.randint(0, n_centres, (B,), generator=g, device="cuda")] + \
         0.5 * sigma * torch.randn((B, d_emb), generator=g, device="cuda")
     rec = {"rows": n_rows, "centres": n_centres, "queries": B, "k": k,
            "what": "rows = unit centre + N(0, sigma^2 I), sigma = %.4f: 1024 %s rows per centre at cosine ~0.9 to it"
-                   % (sigma, "INTERLEAVED (row i -> centre i mod 4096)" if interleaved else "CONTIGUOUS")}
+                   % (sigma, "INTERLEAVED (every row draws its centre at random)" if interleaved else "CONTIGUOUS")}
     res = {}
     for shadow in (0, 2):
         ix.set_shadow(shadow)
