@@ -1014,6 +1014,7 @@ def main(argv=None):
     local.profile(0)
     ens.profile(0)
     fallbacks = local.last_exact_fallbacks()
+    plan_timed = plan_summary(local.last_plan())        # the plan of the timed passes (later searches overwrite the record)
     xch_ms = local.profile_read_exchange() if index.exchange == "prag_rccl" else []
     dt_rank = dt
     if world > 1:
@@ -1038,7 +1039,7 @@ def main(argv=None):
                 b_.record()
             fence()
             allgather_us = float(np.median([a_.elapsed_time(b_) for a_, b_ in ev])) * 1e3
-        mine = {"rank": rank, "device": dev_index, "rows": n_local, "gate_rows": Bg, "plan": plan_summary(local.last_plan()),
+        mine = {"rank": rank, "device": dev_index, "rows": n_local, "gate_rows": Bg, "plan": plan_timed,
                 "scan_ms": float(np.mean(scan_ms)) if scan_ms else None,
                 "gate_ms": float(np.mean(gate_ms)) if gate_ms else None,
                 "allgather_us": allgather_us, "timed_region_s": dt_rank,
@@ -1155,7 +1156,7 @@ def main(argv=None):
         "value": value, "unit": "query*doc scores/s",
         "n_gpus": world, "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": backend,
         "rank_devices": rank_devices, "exchange": index.exchange, "exchange_note": index.exchange_note,
-        "plan": plan_summary(local.last_plan()),
+        "plan": plan_timed,
         "plans_identical_across_ranks": (len({r_["plan"] for r_ in per_rank if r_}) == 1) if per_rank else None,
         "dtype_short": "i8" if (scan_kernel == "scan8_kernel" or (tiled and i8_tiles)) else "f16",
         "per_rank": per_rank, "c_exchange_probe": c_probe,
