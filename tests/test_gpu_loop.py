@@ -72,6 +72,9 @@ def test_loop_matches_reference_style_path():
 
     # ---- HIP path: hooks accumulate on device -----------------------------------
     pool = pra.HiddenStatePool(N_LAYERS, D_MODEL, batch=1)
+    # ... and a second pool whose decode-step launches decide as they go (round 6: prag_pool_step_gate): the decision it
+    # hands the loop must be the one the gate computes on the first pool's sums, generation after generation
+    pool2 = pra.HiddenStatePool(N_LAYERS, D_MODEL, batch=1, defer=True).attach_gate(ens, 1, 0.25)
     cache = {}                                      # reference-style cache, filled by the same hooks
 
     def make_hook(slot):
@@ -80,6 +83,7 @@ def test_loop_matches_reference_style_path():
         def fn(mod, inp, out):
             cache.setdefault(slot, []).append(out.detach().cpu())   # exp_rag.py:317-321
             dev_hook(out)
+            pool2.observe(slot, out)
         return fn
 
     for slot, blk in enumerate(lm.blocks):
@@ -95,6 +99,9 @@ def test_loop_matches_reference_style_path():
     def gate_hip():
         _, ps, dec = ens.gate(pool.pooled(), ablation=1, threshold=theta)
         d = int(dec[0])
+        assert pool2._step_tag is not None                       # the last decode step's launch carried the gate
+        d2, ps2 = pool2.decide(with_probsum=True)
+        assert int(d2[0]) == d and np.array_equal(ps2, ps.cpu().numpy()) and torch.equal(pool2.pooled(), pool.pooled())
         # reference-style: cat(cache[1:]) -> sum -> oracle prober -> oracle gate
         x = np.stack([onp.pool_sum_decode_steps([t.numpy() for t in cache[s]]) for s in range(N_LAYERS)])
         np.testing.assert_allclose(pool.pooled().cpu().numpy(), x, rtol=2e-5, atol=2e-4)
@@ -116,6 +123,7 @@ def test_loop_matches_reference_style_path():
 
     def reset():
         pool.reset()
+        pool2.reset()
         cache.clear()
 
     tok = lambda s: torch.tensor([[(ord(c) * 7) % VOCAB for c in s[:24]]], device="cuda")
