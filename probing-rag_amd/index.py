@@ -232,8 +232,10 @@ _HDR = "<iqqqBi"          # d, ntotal, dummy, dummy, is_trained, metric_type
 
 
 def write_index(index: HipFlatIndex, path: str, chunk_rows: int = 1 << 16):
-    """``faiss.write_index(index, path)`` (make_indexer.py:457).  The rows are streamed out in
-    bounded chunks (device -> host -> file): no second copy of the corpus in HBM or host RAM."""
+    """The call site of ``faiss.write_index(index, path)`` (make_indexer.py:457): the IndexFlat on-disk layout AS DOCUMENTED
+    (fourcc, d, ntotal, two reserved words, is_trained, metric, element count, float32 rows) - faiss is not in this image,
+    so the format is unpinned against a file faiss itself wrote (tests use a hand-assembled byte fixture).  The rows are
+    streamed out in bounded chunks (device -> host -> file): no second copy of the corpus in HBM or host RAM."""
     l2 = index.metric == METRIC_L2
     n, d = index.ntotal, index.d
     with open(path, "wb") as f:
@@ -268,7 +270,8 @@ def read_index_header(f):
 
 
 def read_index(path: str, store: str = "f32", chunk_rows: int = 1 << 18) -> HipFlatIndex:
-    """``faiss.read_index(path)`` (exp_rag.py:248) for IndexFlatL2 / IndexFlatIP files."""
+    """The call site of ``faiss.read_index(path)`` (exp_rag.py:248) for files in the documented IndexFlatL2 / IndexFlatIP
+    layout (see ``write_index``: unpinned against faiss's own output)."""
     with open(path, "rb") as f:
         try:
             d, ntotal, metric = read_index_header(f)
