@@ -74,6 +74,14 @@ class HiddenStatePool:
                              f"{ens.n_layers} x {ens.d_model}")
         self._gate = None if ens is None else (ens, int(ablation), float(threshold))
         self._step_tag, self._step_ok = None, True
+        # decide() runs on a host the LM has left cold: everything it needs is made here, once
+        import numpy as np
+        self._dec_buf = np.empty((8,), np.int32)
+        self._ps_buf = np.empty((8, 2), np.float32)
+        self._dec_ptr = ctypes.c_void_p(self._dec_buf.ctypes.data)
+        self._ps_ptr = ctypes.c_void_p(self._ps_buf.ctypes.data)
+        self._step_result_fn = _lib.lib().prag_gate_step_result
+        self._step_stream = None
         return self
 
     def reset(self):            # `cache = {}` exp_rag.py:397, 423: noted-but-unflushed activations are DROPPED with it
@@ -114,7 +122,8 @@ class HiddenStatePool:
                                                         a0.shape[0], as0, abl, thr, ctypes.byref(tag),
                                                         _lib.current_stream_ptr(a0.device))
                     if rc == _lib.PRAG_OK:
-                        self._cur, self._step_tag = nxt, tag.value
+                        self._cur, self._step_tag = nxt, ctypes.c_uint64(tag.value)
+                        self._step_stream = _lib.current_stream_ptr(a0.device)     # (what decide() waits on if it has to)
                         return
                     if rc != -4:                 # PRAG_EUNSUPPORTED: this shape never takes the step launch
                         _lib.check(rc)
@@ -184,22 +193,22 @@ class HiddenStatePool:
         ``ens.decide(pool.pooled(), ablation, threshold)`` returns, for the ensemble given to ``attach_gate``.  When the
         last decode step's launch already decided (nothing was added since) this only reads that result from host
         memory; otherwise it is that call."""
-        import numpy as np
-        if self._gate is None:
+        gate = self._gate
+        if gate is None:
             raise RuntimeError("HiddenStatePool.decide() needs attach_gate(ens, ablation, threshold) first")
-        ens, abl, thr = self._gate
-        x = self.pooled()
-        if self._step_tag is not None:
-            B = x.shape[1]
-            dec = np.empty((8,), np.int32)
-            ps = np.empty((8, 2), np.float32) if with_probsum else None
-            rc = _lib.lib().prag_gate_step_result(ens._h, ctypes.c_uint64(self._step_tag), B, dec.ctypes.data,
-                                                  ps.ctypes.data if with_probsum else None,
-                                                  _lib.current_stream_ptr(self.device))
+        ens, abl, thr = gate
+        if self._pending:
+            self._flush()
+        tag = self._step_tag
+        if tag is not None:          # (a tag implies every layer has seen a decode step: pooled()'s check is not needed)
+            B = self._acc2.shape[2]
+            rc = self._step_result_fn(ens._h, tag, B, self._dec_ptr, self._ps_ptr if with_probsum else None, self._step_stream)
             if rc == _lib.PRAG_OK:
-                return (dec[:B].copy(), ps[:B].copy()) if with_probsum else dec[:B].copy()
+                dec = self._dec_buf[:B].copy()
+                return (dec, self._ps_buf[:B].copy()) if with_probsum else dec
             if rc != -5:                         # PRAG_ESTATE: overwritten / voided - the sums are intact, decide on them
                 _lib.check(rc)
+        x = self.pooled()
         return ens.decide(x, abl, thr, with_probsum=with_probsum)
 
 

@@ -733,7 +733,9 @@ def test_exact_scan_on_the_float64_matrix_pipe(monkeypatch, d, store, metric):
         ix.close()
     D0, I0, fb0 = res["0"]
     D1, I1, fb1 = res["1"]
-    assert fb0 == fb1 and fb1 >= B // 2, (fb0, fb1)          # (a later copy set may have overwritten an earlier one's rows)
+    assert fb0 == fb1
+    if os.environ.get("PRAG_SHADOW") != "2":   # (forced onto the two-level search the copies are survivors of its filter, not flags)
+        assert fb1 >= B // 2, (fb0, fb1)       # (a later copy set may have overwritten an earlier one's rows)
     Dw, Iw = oracle_c.flat_search(_stored(X, metric, store), Q, k, metric)
     _check(D1, I1, Dw, Iw, metric)
     assert np.array_equal(I0, I1)

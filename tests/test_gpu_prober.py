@@ -557,7 +557,7 @@ def test_decode_step_launch_also_decides(torch_cuda, weights, Bt, dtype):
         import ctypes
         from probing_rag_amd import _lib
         dec = np.empty((8,), np.int32)
-        rc = _lib.lib().prag_gate_step_result(ens._h, ctypes.c_uint64(a._step_tag - 1), Bt, dec.ctypes.data, None, None)
+        rc = _lib.lib().prag_gate_step_result(ens._h, ctypes.c_uint64(a._step_tag.value - 1), Bt, dec.ctypes.data, None, None)
         assert rc == -5
     # ... and the pool never asks for one: a detached pool decides with the plain call
     with pytest.raises(RuntimeError, match="attach_gate"):
