@@ -30,6 +30,8 @@
 
 #include "exchange.h"
 #include "flat_internal.h"
+#include "flat_index_state.h"
+#include "flat_plan.h"
 #include "tail_gate.h"
 
 namespace prag {
@@ -104,7 +106,6 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__
     if (lane == 0) xnorm[dst_row0 + i] = (float)q;
 }
 
-constexpr int kSlotWordsFwd = 64;
 // ---------------------------------------------------------------------------
 // queries: q32[b] = (cosine ? q/||q|| : q) in f32 ; q16 = fp16(q32), rows padded
 // with zeros up to a multiple of the tile height.
@@ -289,7 +290,6 @@ struct ScanArgs {
 // atomic instruction per workgroup and epoch; with 240 workgroups a slot is the best of ~4 k rows after
 // one tile (~16 k after four), the max over 16 slots the ~0.09 % (0.02 %) quantile: tighter than the
 // 0.2 % the round-1 pre-pass bought with two extra launches.  The waves take turns polling the slots.
-constexpr int kSlotWords = kSlotWordsFwd;   // per query: 2 epochs x 32 slots (KC <= 32)
 
 template <int KC>
 struct TopList {
@@ -1227,71 +1227,6 @@ __global__ __launch_bounds__(1024) void merge_rerank_kernel(const float* __restr
                       s_out[KC - 1] == ~0ull ? INFINITY : unsortable_f32((uint32_t)(s_out[KC - 1] >> 32)));
 }
 
-// ---------------------------------------------------------------------------
-// cross-shard merge: one wave per query, lane p walks the sorted list of part p
-// ---------------------------------------------------------------------------
-// k rounds of a 64-lane lexicographic minimum over (score, residual tag, id); the winning lane pops its head and
-// prefetches the next entry.  (Round 3 ran one THREAD per query with a head pointer per part in a runtime-indexed
-// array: 272 B of scratch per lane and a serial k x n_parts loop - the exchange step of every sharded search.)
-__global__ __launch_bounds__(64) void merge_shards_kernel(const float* __restrict__ Dp,
-                                                         const int64_t* __restrict__ Ip, int64_t d_stride,
-                                                         int64_t i_stride, int n_parts, int B,
-                                                         int k, int metric_l2, int tagged, float* __restrict__ D,
-                                                         int64_t* __restrict__ I) {
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int64_t id_mask = tagged ? (int64_t)((1ull << kTagShift) - 1) : ~0ll;
-    const bool part = lane < n_parts;
-    const float* dp = Dp + (int64_t)lane * d_stride + (int64_t)b * k;
-    const int64_t* ip = Ip + (int64_t)lane * i_stride + (int64_t)b * k;
-    int head = 0;
-    float dv = 0.f;
-    int64_t raw = -1;
-    if (part) {
-        dv = dp[0];
-        raw = ip[0];
-    }
-    for (int j = 0; j < k; ++j) {
-        // this lane's candidate as (hi, lo): hi = score key (ascending = better) . residual key, lo = id
-        const bool valid = part && head < k && raw >= 0;              // padding (-1) sorts last
-        const float dz = dv + 0.0f;                                   // -0 and +0 compare equal, as floats do
-        const uint32_t kd = metric_l2 ? sortable_u32(dz) : ~sortable_u32(dz);
-        const uint32_t rk = tagged ? (uint32_t)((unsigned long long)raw >> kTagShift) : 0u;
-        unsigned long long hi = valid ? (((unsigned long long)kd << 32) | (metric_l2 ? rk : 0xFFFFFFu - rk)) : ~0ull;
-        unsigned long long lo = valid ? (unsigned long long)(raw & id_mask) : ~0ull;
-        const unsigned long long my_hi = hi, my_lo = lo;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long ohi = __shfl_xor(hi, off, 64), olo = __shfl_xor(lo, off, 64);
-            if (ohi < hi || (ohi == hi && olo < lo)) {
-                hi = ohi;
-                lo = olo;
-            }
-        }
-        const unsigned long long won = __ballot(valid && my_hi == hi && my_lo == lo);
-        if (won == 0ull) {   // every part exhausted: faiss padding
-            if (lane == 0) {
-                D[(int64_t)b * k + j] = metric_l2 ? FLT_MAX : -FLT_MAX;
-                I[(int64_t)b * k + j] = -1;
-            }
-            continue;
-        }
-        const int wl = __ffsll((long long)won) - 1;                   // equal entries in two parts: the lower part first
-        const float out_d = __shfl(dv, wl, 64);
-        if (lane == 0) {
-            D[(int64_t)b * k + j] = out_d;
-            I[(int64_t)b * k + j] = (int64_t)lo;
-        }
-        if (lane == wl) {
-            ++head;
-            if (head < k) {
-                dv = dp[head];
-                raw = ip[head];
-            }
-        }
-    }
-}
-
 template <bool F32>
 __global__ __launch_bounds__(256) void reconstruct_kernel(const void* __restrict__ rows, int64_t n_elems,
                                                          float* __restrict__ out) {
@@ -1409,218 +1344,6 @@ __global__ void retry_finish_kernel(uint32_t* __restrict__ r2_word, uint32_t* __
 // ===========================================================================
 using namespace prag;
 
-struct prag_index {
-    int d, metric, store;
-    int64_t ntotal = 0, cap = 0;
-    void* rows = nullptr;
-    float* xnorm = nullptr;
-    // search workspace
-    float* q32 = nullptr;
-    _Float16* q16 = nullptr;
-    _Float16* q16lo = nullptr;
-    int q_cap = 0;
-    int hp_mode = 1;   // high-precision selection for <= 32 queries (0 = off)
-    float* part_key = nullptr;
-    int* part_idx = nullptr;
-    size_t part_cap = 0;  // entries
-    int* cand = nullptr;
-    size_t cand_cap = 0;
-    uint32_t* g_tau = nullptr;  // [q_cap]
-    uint32_t* g_slot = nullptr; // [q_cap][kSlotWords]
-    int prepass_mode = -1;      // PRAG_PREPASS: 1 = always the pre-pass launches, 0 = always the bound slots, unset = by shard size
-    // MFMA-tiled scan (> 128 queries): per-query candidate buffers
-    uint32_t* mm_cnt = nullptr;
-    uint32_t* mm_ovf = nullptr;
-    float* mm_ckey = nullptr;
-    int* mm_cidx = nullptr;
-    uint32_t* mm_wcnt = nullptr;
-    float* mm_wkey = nullptr;
-    int* mm_widx = nullptr;
-    int mm_q_cap = 0;             // queries the per-query arrays hold
-    size_t mm_w_entries = 0;      // entries of mm_wkey / mm_widx
-    size_t mm_c_entries = 0;      // entries of mm_ckey / mm_cidx, mm_wcnt words
-    int mm_mode = 1;   // 0 = never take the MFMA-tiled path (PRAG_SCAN_MM=0)
-    int shadow_bound_mode = -1;   // -1 auto, 0 off, 1 on (PRAG_SHADOW_BOUND)
-    int shadow_sample_mode = -1;  // -1 auto, 0 off, 1 on (PRAG_SHADOW_SAMPLE): the sampled pre-bound of the two-level search
-    int scan_gate_mode = -1;      // prag_search_and_gate: the gate's workgroups in the SCAN's launch: -1 auto, 0 never, 1 always (PRAG_SCAN_GATE)
-    // Workgroups of the two-level scan, <= 64 queries: 7/8 of the CUs or all of them - measured on this index's own
-    // searches (shadow_scan_wg_cap in flat_internal.h says why it cannot be a constant).  Eight searches alternate the
-    // two with timing events around the scan launch (never waited for: a sample is read when the NEXT search finds its
-    // event done; nothing while a stream is capturing), the faster minimum wins (all CUs only if >= 2.5 % faster, 5 % when the call carries a gate); a shard
-    // that grows or shrinks by 1/8 measures again.  PRAG_SCAN_WG_TUNE=0 / 1: always 7/8 / always every CU.
-    struct WgTune {
-        int phase = 0;                    // samples taken (8 = decided)
-        float best[2] = {1e30f, 1e30f};   // fastest scan launch seen on [0] 7/8 of the CUs, [1] every CU (ms)
-        int choice = 0;
-        bool pending = false;
-        int pending_arm = 0;
-        int64_t rows = -1;
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    };
-    WgTune wg_tune[2];            // [0] <= 32 queries (two-term tiles), [1] 33-64 queries
-    int wg_tune_mode = -1;
-    // prag_index_set_adaptive / PRAG_ADAPTIVE at creation.  0 = the deterministic plan: nothing a search launches depends
-    // on how earlier searches on the handle went or how long they took - the scan grid stays at its default (7/8 of the
-    // CUs for an HBM-bound two-level scan; PRAG_SCAN_WG_TUNE=1 / prag_index_set_scan_workgroups still pin another one),
-    // the retry tier is never armed by history (host-io searches still use it on their OWN flag count, which they
-    // hold; device-io searches send flagged queries straight to the float64 scan), the sliced gather is always
-    // enqueued, the grouped float64 scan is chosen by shape only, the int8 tiles are never switched off.  Every rank
-    // and every run of one input then issues the same launches.  Results are the definition's either way.
-    int adaptive = 1;
-    int64_t scan8_quad_rows = (int64_t)8 << 20;   // PRAG_SCAN8_QUAD_ROWS (tests: 0 = the quad-test scans at every size)
-    int mm_shape16 = 1;   // tiled scans on 16 x 16 MFMA tiles (PRAG_MM_SHAPE=32: the 32 x 32 form, A/B timing)
-    // 8-bit selection for the MFMA-tiled scan (> 128 queries on an index that keeps a shadow): int8 MFMA over the
-    // shadow, kMm8Kc candidates per query, the shadow's error bound in the certificate; the queries that fail that
-    // certificate go through a second tier (mm8_second_tier; PRAG_MM8=0: fp16 tiles only)
-    int mm8_mode = 1;
-    // ... on shards of at least this many rows (shadow mode 2 = "any size": no minimum).  Measured, 1000 queries x
-    // 768, int8 tiles against fp16 tiles: 1 M rows 2.04 ms / 1.73 - the 256-deep lists cost sort compactions and
-    // 0.14 ms of rerank, and with the bound of a segment coming from <= 166 k rows one score in 650 survives the
-    // filter, so the int8 scan itself gains only 7 % -; 2.625 M rows (an 8-GPU shard of 21 M) 3.59 / 3.82;
-    // 4 Mi rows 5.27 / 5.92 (before the balanced gather of the compaction); 8 M 8.60 / 11.09; 21 M 19.4 / 28.7
-    // (0.76 ns per row and 1000 queries in the last segment against 1.34)
-    // (those with segment growth 9; with growth 3: 1 M rows 1.90 / 1.73, 2.625 M 3.36 / 3.90, 21 M 17.8)
-    int64_t mm8_min_rows = 2ll << 20;
-    float* mm_kq = nullptr;            // [mm_q_cap] key scale of every query
-    // The tier decision is taken on the device (mm8_second_tier): every kernel of the second tier is enqueued with a
-    // Gate on t2_word[0] = queries that failed the 8-bit certificate.  The count travels to the host asynchronously
-    // (pinned word + event) for prag_index_last_tiled8 and the auto-off heuristic: no search waits for it.
-    Gate gate;                            // gate of the search being enqueued (second-tier inner searches), else open
-    uint32_t* t2_word = nullptr;          // device: [0] failed count of the last 8-bit tiled search
-    uint32_t* tier_word_host = nullptr;   // pinned copy
-    hipEvent_t tier_event = nullptr;
-    bool tier_pending = false;            // a copy is in flight (tier_event)
-    int tier_hi_sub = 0;                  // largest failed count the compact-batch tier takes in that search
-    int mm8_last_failed = -1;             // queries of the last 8-bit tiled search that failed its certificate
-                                          // (-1: it did not take the 8-bit tiles; -2: skipped, see mm8_auto_off; -3: unknown - captured)
-    // few failed queries: searched again as a compact batch (mm8_second_tier)
-    int* t2_list = nullptr;
-    float* t2_q = nullptr;
-    float* t2_D = nullptr;
-    int64_t* t2_I = nullptr;
-    int t2_cap = 0, t2_k = 0;
-    // two searches in a row whose whole batch had to be repeated on the fp16 tiles (a corpus the 8-bit bound cannot
-    // separate: a few rows of huge norm, look-alikes everywhere): the int8 tiles are skipped from then on, until rows
-    // are added or prag_index_set_shadow is called
-    int mm8_whole_batch_streak = 0;
-    bool mm8_auto_off = false;
-    // ... but not for good: after mm8_off_period eligible searches the tiles get ONE probe (a single whole-batch
-    // repeat switches them off again and doubles the period, up to 4096 searches)
-    int mm8_off_count = 0, mm8_off_period = 64;
-    // fp32 indexes: fp16 copy of the rows for the tiled scan's candidate selection (built on the
-    // first search with > 128 queries, dropped by add; the rerank always reads the fp32 rows)
-    _Float16* rows16 = nullptr;
-    int64_t rows16_n = -1, rows16_cap = 0;
-    // host-io staging
-    // one device block [I int64 | D float | flag count] and its pinned host mirror, plus a pinned/device
-    // pair for the queries: a host-io search is one H2D and one D2H transfer
-    float* io_q = nullptr;
-    char* io_res = nullptr;
-    float* io_q_host = nullptr;
-    char* io_res_host = nullptr;
-    int io_B = 0, io_k = 0;
-    int n_cu = 256;
-    int wg_cap = 0;  // 0 = use every CU
-    int kc_min = 0;  // 0 = default candidate depth for k
-    // exactness certificate + exact fallback (flat_internal.h)
-    float* qinfo = nullptr;       // [q_cap][4]
-    double* qn2 = nullptr;        // [q_cap]
-    int* flag_list = nullptr;     // [q_cap]
-    uint32_t* cert_words = nullptr;  // [0] = n_flag of the last search, [1] = bits of max ||x||^2
-    int64_t xn_max_rows = 0;      // rows already folded into cert_words[1]
-    unsigned long long* ex_key = nullptr;
-    int* ex_id = nullptr;
-    size_t ex_entries = 0;
-    unsigned long long* ex_pool = nullptr;   // [f_cap][grid] exact_mfma_kernel: the workgroups' best keys (all-ones between searches)
-    size_t ex_pool_entries = 0;
-    uint32_t* ex_done = nullptr;  // [ex_done_cap] arrival counters of the exact scan's list merge
-    int ex_done_cap = 0;
-    // 8-bit shadow (flat_shadow.hip): 0 off, 1 (default) on for shards >= kShadowMinRows when the device has
-    // room for it, 2 on at any size
-    int shadow_mode = 1;
-    bool shadow_failed = false;    // the shadow could not be extended at the end of an add (rows are committed; they are
-                                   // scanned directly until prag_index_set_shadow is called again); the message stays
-                                   // in prag_last_error
-    bool shadow_no_room = false;   // mode 1: the allocation did not fit next to the rows; rows are scanned directly
-    signed char* rows8 = nullptr;
-    float* sscale = nullptr;
-    float* serr = nullptr;
-    int64_t shadow_cap = 0, shadow_rows = 0;
-    uint32_t* shadow_err_max = nullptr;
-    // the shadow's affine map y = (x - mu) / c (flat_shadow.hip): [mu | c | 1/c] d floats each, a [2][d] float64
-    // scratch for the column sums behind it, the word max ||y||^2; fitted whenever the shadow is (re)built from row 0
-    float* sh_aff = nullptr;
-    double* sh_aff_sums = nullptr;
-    uint32_t* sh_yn_max = nullptr;
-    float* sbias = nullptr;            // [shadow_cap] per-row additive part of the two-level scan's key
-    uint32_t* sh_bias_max = nullptr;   // float bits of max |sbias_i|
-    // PRAG_SHADOW_AFFINE at creation: 0 identity map (the round 2-4 shadow), 1 (default) rows and queries centred on the
-    // column means, c = 1; 2 centred + power-of-two column scales c_j ~ the column's standard deviation.  Measured on
-    // embedding-shaped rows, 64 queries x 1 M rows, survivors per query mean / max (profiles/r05c_*, r05d_*):
-    // mode 0: 180 000 - 870 000 (every query in the exact scan); mode 2: 1 450 / 2 700 (cosine), 11 200 / 113 000 (L2,
-    // one region overflow); mode 1: 2 400 / 3 800 and 4 100 / 10 100.  Why scales lose with ONE int8 query term: queries
-    // live in the rows' space, so c_j = sigma_j evens out the rows' grid and squares the disparity on the query's
-    // (p_j = q'_j c_j ~ sigma_j^2); with both sides on one grid each, eps ~ ||p|| max|y| + max|p| ||y|| is symmetric
-    // under c <-> 1/c and c = 1 is its minimum.  (The 32-query tiles - two query terms - would prefer mode 2 by ~25 %.)
-    int shadow_affine_mode = 1;
-    double* sh_kshift = nullptr;       // [sh_q_cap] K_q = alpha q.mu of the queries of the running search
-    signed char* sh_q8 = nullptr;      // [2][q_cap][d]
-    void* sh_sq = nullptr;
-    uint32_t* sh_slots = nullptr;
-    uint32_t* sh_ovf = nullptr;
-    int sh_q_cap = 0;
-    int* sh_cand = nullptr;
-    int sh_cand_qt = 0;          // query-tile height the candidate store is sized for (64 or 128)
-    uint32_t* sh_ccnt = nullptr;
-    unsigned long long* sh_pkey = nullptr;
-    int* sh_pid = nullptr;
-    size_t sh_part_entries = 0;
-    int cert_mode = 1;   // 0 = certificate off (PRAG_CERT=0: timing experiments only)
-    // row-sharded search in C (prag_index_set_comm / prag_index_search_sharded): the caller's RCCL communicator
-    // (borrowed), this rank and the world size; packed exchange buffers [D float32 [B,k] | I int64 [B,k]]
-    void* comm = nullptr;
-    int comm_rank = 0, comm_world = 1;
-    char* xch_send = nullptr;
-    char* xch_recv = nullptr;
-    size_t xch_send_cap = 0, xch_recv_cap = 0;
-    EventRing prof_xch;          // HIP events around the all-gather of prag_index_search_sharded (prag_index_profile)
-    // retry tier (retry_tier below): armed by what recent searches flagged - the count travels to the host
-    // asynchronously and is looked at when the NEXT search is planned, never waited for
-    uint32_t* r2_word = nullptr;          // device [4]
-    int* r2_list = nullptr;               // [128]
-    float* r2_q = nullptr;                // [32][d]
-    float* r2_D = nullptr;
-    int64_t* r2_I = nullptr;
-    int r2_k = 0;
-    uint32_t* r2_word_host = nullptr;     // pinned
-    hipEvent_t r2_event = nullptr;
-    bool r2_pending = false;
-    bool retry_armed = false;
-    int retry_clean = 0;                  // armed searches in a row that flagged nothing
-    int retry_mode = -1;                  // PRAG_RETRY_TIER at creation: -1 adaptive, 0 never, 1 always armed
-    int exact_group_mode = -1;            // PRAG_EXACT_GROUP at creation: -1 adaptive, 0 never, 1 always (exact_group_kernel)
-    bool exact_group_hint = false;        // recent retry tiers left >= 4 queries for the exact scan
-    int exact_mfma_mode = 1;              // PRAG_EXACT_MFMA at creation: 0 = never the float64-MFMA form of the grouped scan
-    // the sliced gather behind the exact-bound kernel: the bound kernel finishes every query itself when <= 256 rows stay
-    // under its bound (40-100 in practice), and the gather launch is then ~9 us of nothing on the critical path.  It is
-    // enqueued while "armed": from the start, and again for 64 searches whenever a search left a query unfinished (that
-    // query went through the flag list: retry tier / exact scan); 16 clean searches in a row disarm it.  PRAG_GATHER=1
-    // keeps it always (the round 2-4 launch sequence).
-    bool gather_armed = true;
-    int gather_clean = 0;
-    int gather_mode = -1;                 // PRAG_GATHER at creation: -1 adaptive, 1 always
-    bool r2_has_unfinished = false;       // the pending statistics record carries an `unfinished` count
-    uint32_t* sh_unfin = nullptr;         // device word
-    // prag_index_stream_wait_scan: an event recorded right behind the corpus scan of every search (two-level search:
-    // after scan8, before the bound kernel / gather / fallback probes), so that independent work of the caller - the
-    // gate of the next batch - can start beside the search's low-occupancy tail on another stream
-    hipEvent_t scan_done_ev = nullptr;
-    bool scan_done_recorded = false;
-    TailGate* tail = nullptr;   // prag_search_and_gate: the gate launch the running search may carry beside its bound kernel
-    int last_flagged = -1;   // flag count of the last host-io search (-1: last search was device-io)
-    std::string last_plan;   // plan_describe of the most recent search (prag_index_last_plan)
-    EventRing prof;
-};
 
 static size_t elt(const prag_index* ix) { return ix->store == PRAG_F32 ? 4 : 2; }
 
@@ -1652,37 +1375,6 @@ static int ensure_capacity(prag_index* ix, int64_t want) {
     ix->cap = ncap;
     return PRAG_OK;
 }
-
-// Grow-only device workspaces.  Every buffer of a group is released and nulled, then all are allocated; if an
-// allocation fails the ones already made are released again.  The caller zeroes the group's capacity before
-// the call and sets it after success, so a failed search never leaves a freed pointer behind a non-zero
-// capacity, nor a half-allocated group.  (hipFree synchronises the device: growth is rare by design.)
-struct WsItem {
-    void** ptr;
-    size_t bytes;
-};
-static int ws_regrow(std::initializer_list<WsItem> items) {
-    for (const WsItem& it : items) {
-        if (*it.ptr) (void)hipFree(*it.ptr);
-        *it.ptr = nullptr;
-    }
-    for (const WsItem& it : items) {
-        const hipError_t e = hipMalloc(it.ptr, it.bytes);
-        if (e != hipSuccess) {
-            *it.ptr = nullptr;
-            for (const WsItem& j : items) {
-                if (*j.ptr) (void)hipFree(*j.ptr);
-                *j.ptr = nullptr;
-            }
-            (void)hipGetLastError();
-            set_error("prag_index: workspace of %zu bytes: %s", it.bytes, hipGetErrorString(e));
-            return e == hipErrorOutOfMemory ? PRAG_ENOMEM : PRAG_EHIP;
-        }
-    }
-    return PRAG_OK;
-}
-template <typename T>
-static void** vpp(T** p) { return reinterpret_cast<void**>(p); }
 
 // ---- 8-bit shadow maintenance ---------------------------------------------------------------------
 constexpr int64_t kShadowMinRows = 1 << 20;
@@ -1951,16 +1643,6 @@ extern "C" int prag_index_add_synthetic(prag_index_t* ix, uint32_t seed, int64_t
 extern "C" int64_t prag_index_ntotal(const prag_index_t* ix) { return ix ? ix->ntotal : -1; }
 extern "C" int prag_index_d(const prag_index_t* ix) { return ix ? ix->d : -1; }
 
-static int pick_kc(int k) {
-    if (k <= 5) return 8;
-    if (k <= 12) return 16;
-    if (k <= 26) return 32;
-    // deeper than a per-lane list can hold in registers: the MFMA-tiled scan keeps KC candidates per
-    // query in memory (k plus a margin of near-ties, a multiple of 32, at most kMmMaxKc)
-    const int kc = (k + std::max(16, k / 8) + 31) / 32 * 32;
-    return kc <= kMmMaxKc ? kc : 0;
-}
-
 template <int QT, int KC, bool F32, bool HP = false>
 static int launch_scan(const ScanArgs& a, int grid, hipStream_t st, EventRing& prof) {
     const int lds_loop = (HP ? 2 : 1) * QT * a.qstride + 8 * 4096 + QT * 12;   // queries + stages + thresholds + best keys
@@ -2041,12 +1723,6 @@ static int launch_qs(const ScanArgs& a, int grid, hipStream_t st, EventRing& pro
 }
 
 // query-stationary kernel: fp16 rows, d in {256,512,768,1024}, lists up to 16 deep
-static bool qs_supported(int d, int store, int kc) {
-    // (d = 1024 with 16-deep lists: 128 VGPRs of query fragments + the lists spill - those batches take two
-    // passes of the 64-query list kernel, or the 128-query shadow tiles when the index keeps a shadow)
-    return store == PRAG_F16 && kc <= 16 && (d == 256 || d == 512 || d == 768 || (d == 1024 && kc <= 8));
-}
-
 static int dispatch_qs(int d, int kc, const ScanArgs& a, int grid, hipStream_t st, EventRing& prof) {
 #define PRAG_QS(D_)                                                          \
     if (d == D_) {                                                           \
@@ -2106,203 +1782,6 @@ static int launch_merge_rerank(int kc, bool f32, const float* pk, const int* pi,
 // k-th exact key by the shadow's error bound (~0.55 sigma of the score distribution on 768 Gaussian elements with
 // the worst row's residual): rank ~110 at 1 M and at 21 M rows for k = 10; 256 leaves 0.2 sigma of margin
 // (kMm8Kc = 256, kMm8CapWg, kMm8Chunk, kMm8Growth: with the search plan below)
-
-// ---------------------------------------------------------------------------------------------------------------
-// Search plan: every dispatch decision of a search as a PURE function of the request shape and the index state
-// (no pointers, no HIP calls): which kernel family makes the corpus pass, the tile height, the candidate depth,
-// the grid, the bound strategy, the workspace it needs.  index_search_impl executes a plan; prag_plan_search
-// describes one on a host without a GPU (tests/test_host_logic_cpu.py walks the shape grid); prag_index_last_plan
-// is what bench.py prices its roofline with (round 3 re-derived the dispatch in Python).
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kMm8Kc = 256;       // candidates per query of the 8-bit tiled selection (see search_tiled)
-constexpr int kMm8CapWg = 128;    // survivors one workgroup can hold per query and segment
-constexpr int kMm8Chunk = 1024;   // queries per mm_run call
-constexpr int kMm8Growth = 3;     // segment i+1 ends at 3 x the end of segment i (search_tiled)
-
-// Segment growth of the tiled scans (ONE place: plan_search prices the schedule, search_tiled runs it): keep the
-// expected survivors of a segment (~(growth-1) * KC per query) inside the per-workgroup regions (64 per query) and the
-// compaction's staging buffer (4096).  int8 tiles: a segment yields ~(growth - 1) * 256 survivors per query, each an
-// LDS atomic and two stores in the filter while the other wave group waits; short segments keep the bound fresh.
-// Measured, 1000 queries, growth 9 / 6 / 4 / 3 / 2: 2.625 M rows 3.81 / 3.66 / 3.57 / 3.39 / 3.96 ms, 21 M rows 19.1 /
-// 18.5 / 18.2 / 17.9 / 17.9, 1 M rows 2.13 / 1.95 / 1.97 / 1.90 / 1.94 (same box).
-static inline int mm_segment_growth(int Bpad, int chunk, int cap_wg, int cu_budget, int kc, bool i8) {
-    const int n_qb = std::max(1, std::min(Bpad, chunk) / 256);
-    const int g_wg = 1 + (cap_wg / 4) * cu_budget / std::max(1, kc * n_qb);
-    const int g_lds = 1 + 3000 / kc;
-    int g = std::max(2, std::min(16, std::min(g_wg, g_lds)));
-    if (i8) g = std::min(g, kMm8Growth);
-    return g;
-}
-
-struct PlanEnv {
-    int d = 0, metric = PRAG_METRIC_L2, store = PRAG_F16;
-    int64_t ntotal = 0;
-    int B = 0, k = 0;
-    int kc_min = 0, hp_mode = 1, mm_mode = 1, mm8_mode = 1, cert_mode = 1, prepass_mode = -1, wg_cap = 0, n_cu = 256;
-    int shadow_mode = 1;
-    int64_t mm8_min_rows = 2ll << 20;
-    bool shadow_ready = false;    // the index keeps an up-to-date shadow and wants one at this size
-    bool mm8_auto_off = false;
-    bool allow_mm8 = true;
-};
-
-struct SearchPlan {
-    int kc = 0;                   // 0: k is beyond the deepest list (PRAG_EUNSUPPORTED)
-    bool exact_only = false, mm8_eligible = false, use_mm8 = false, use_mm = false, shadow128 = false, use_qs = false,
-         use_shadow = false, use_hp = false, certify = true, use_slots = false, prepass = false;
-    int qstride = 0, QT = 32, Bpad = 0, n_tiles = 0, cu_budget = 0, grid = 1, mm_chunk = 0, mm_cap_wg = 0, ex_grid = 1,
-        ex_fcap = 1;
-    size_t part_need = 0, cand_need = 0;
-    const char* family = "";      // kernel of the corpus pass
-    int launches = 0;             // corpus passes per search (tiled scans: segments)
-    int mm_growth = 0;            // tiled scans: segment growth (first step; later steps: mm_growth_step)
-    int64_t last_seg_rows = 0;    // tiled scans: rows of the last (largest) corpus segment - the profiled launch
-    int64_t bytes_per_launch = 0; // algorithmic bytes one pass over the shard reads, in the form that is scanned
-    size_t ws_bytes = 0;          // device workspace of the groups this plan touches
-};
-
-static SearchPlan plan_search(const PlanEnv& e) {
-    SearchPlan P;
-    const int B = e.B, k = e.k, d = e.d;
-    int kc = std::max(pick_kc(k), pick_kc(k) ? e.kc_min : 0);
-    if (kc == 0) return P;
-    // float32 rows with 33..64 queries are rounded to fp16 inside the scan (no high-precision terms at
-    // that tile height): the certificate's error bound is ~5e-4 ||q|| ||x||, which an 8-deep list clears
-    // only ~99 % of the time at 21 M rows - and a miss costs a 64 GB exact pass.  A 16-deep list does.
-    if (e.store == PRAG_F32 && kc == 8 && B > 32) kc = 16;
-    // k > 26 on a dimension the MFMA-tiled scan does not cover: straight to the exact float64 scan
-    P.exact_only = kc > 32 && !mm_supported(d, PRAG_F16, kc);
-    if (P.exact_only) kc = 32;  // (sizes the unused candidate workspace)
-    // > 128 queries on an index that keeps an up-to-date shadow: first tier = int8 tiles over the shadow with a
-    // deep candidate list; the queries that fail the (much wider) certificate are searched again (mm8_second_tier)
-    P.mm8_eligible = e.allow_mm8 && e.mm8_mode && e.mm_mode && !P.exact_only && kc <= 32 && B > 128 && e.ntotal > 0 &&
-                     (e.shadow_mode >= 2 || e.ntotal >= e.mm8_min_rows) && e.cert_mode != 0 && e.shadow_ready &&
-                     mm8_supported(d, kMm8Kc) && mm_supported(d, PRAG_F16, kMm8Kc) && k <= kMm8Kc / 8;
-    P.use_mm8 = P.mm8_eligible && !e.mm8_auto_off;
-    if (P.use_mm8) kc = kMm8Kc;
-    P.kc = kc;
-    P.qstride = (d * 2 + 255) / 256 * 256;
-    // 64-query tiles when they fit LDS
-    // (64 queries x 32-deep lists = 128 list registers per lane: scratch on either row type - two 32-query tiles)
-    const bool wide_ok = 64 * P.qstride + 8 * 4096 + 64 * 12 <= 160 * 1024 && kc < 32;
-    // > 128 queries: the contraction bounds the search -> MFMA-tiled scan, 256 queries per tile
-    P.use_mm = !P.exact_only && e.ntotal > 0 && mm_supported(d, PRAG_F16, kc) && ((B > 128 && e.mm_mode) || kc > 32);
-    // 65..128 queries: one pass over the 8-bit shadow with 128-query tiles when the index keeps one ...
-    P.shadow128 = !P.exact_only && !P.use_mm && B > 64 && B <= 128 && e.cert_mode != 0 && e.ntotal > 0 && e.shadow_ready &&
-                  shadow_supported(d, kc, k, B) && shadow_tile128_ok(d, kc);
-    // ... else the query-stationary kernel over the fp16 rows (128 queries per corpus pass)
-    P.use_qs = !P.exact_only && !P.use_mm && !P.shadow128 && B > 64 && qs_supported(d, e.store, kc);
-    P.QT = P.use_mm ? 256 : (P.use_qs || P.shadow128) ? 128 : ((B > 32 && wide_ok) ? 64 : 32);
-    // <= 32 queries (the reference's call shape): high-precision selection, if two query tiles fit LDS
-    P.use_hp = e.hp_mode && P.QT == 32 && 2 * 32 * P.qstride + 8 * 4096 + 32 * 12 <= 160 * 1024;
-    P.Bpad = (B + P.QT - 1) / P.QT * P.QT;
-    P.n_tiles = (int)((e.ntotal + 31) / 32);
-    P.cu_budget = e.wg_cap > 0 ? std::min(e.wg_cap, e.n_cu) : e.n_cu;
-    P.grid = P.use_qs ? std::max(1, std::min(P.cu_budget, (P.n_tiles + 3) / 4))
-                      : std::max(1, std::min(P.cu_budget, (P.n_tiles + 7) / 8));
-    // (the pre-pass may use up to 64 workgroups; the tiled scan sizes its own fallback lists)
-    P.part_need = P.use_mm ? 0 : (size_t)std::max(P.grid, 64) * P.QT * kc;
-    P.cand_need = (size_t)P.Bpad * kc;
-    // queries per mm_run call and survivors one workgroup can hold per query and segment.  Deep lists
-    // (k > 26) yield up to KC/8 survivors per 256-row tile right after the first segment: they get
-    // 512 slots and 256-query chunks.
-    P.mm_chunk = P.use_mm8 ? std::min(P.Bpad, kMm8Chunk) : kc > 32 ? 256 : std::min(P.Bpad, kMmMaxQueries);
-    P.mm_cap_wg = P.use_mm8 ? kMm8CapWg : kc > 32 ? 512 : kMmCapWg;
-    P.certify = e.cert_mode != 0 || P.exact_only;
-    P.ex_grid = (int)std::max<int64_t>(1, std::min<int64_t>(2 * (int64_t)P.cu_budget, (e.ntotal + 31) / 32));
-    // flagged queries one round of the exact scan can hold: <= 64 MB of per-workgroup lists
-    P.ex_fcap = (int)std::max<int64_t>(1, std::min<int64_t>(B, (64ll << 20) / ((int64_t)P.ex_grid * k * 12)));
-    // (the shadow's eps constants read max ||x||^2 and its overflow path needs the exact scan: both exist
-    // only with the certificate on - a diag build with PRAG_CERT=0 scans the rows directly)
-    P.use_shadow = P.certify && !P.exact_only && !P.use_mm && !P.use_qs && e.ntotal > 0 && e.shadow_ready &&
-                   shadow_supported(d, kc, k, B);
-    // Bound for the list scan: slots filled inside the launch (no extra launches: best on shards
-    // of a few million rows, where two launches are ~6 % of the search) or the pre-pass (its bound
-    // is there from the first tile: measured 1.5 % faster at 21 M rows).  Crossover ~8 M rows.
-    constexpr int64_t kSample = 8192;
-    const bool want_slots = e.prepass_mode < 0 ? e.ntotal <= (8ll << 20) : e.prepass_mode == 0;
-    P.use_slots = !P.use_qs && want_slots && !(P.QT == 64 && kc == 32);
-    P.prepass = e.ntotal >= 16 * kSample && !P.use_slots;
-    // ---- what the corpus pass is and what it has to read ----------------------------------------------------------
-    const int64_t N = e.ntotal, l2 = e.metric == PRAG_METRIC_L2 ? 4 * N : 0;
-    const int64_t elt_b = e.store == PRAG_F32 ? 4 : 2;
-    if (N == 0) { P.family = "none (empty index)"; P.launches = 0; }
-    else if (P.exact_only) { P.family = "exact_scan_kernel"; P.launches = B; P.bytes_per_launch = N * d * elt_b; }
-    else if (P.use_mm) {
-        P.family = P.use_mm8 ? "scan_mm_kernel<int8 tiles over the 8-bit shadow>" : "scan_mm_kernel";
-        const int growth = mm_segment_growth(P.Bpad, P.mm_chunk, P.mm_cap_wg, P.cu_budget, kc, P.use_mm8);
-        P.mm_growth = growth;
-        // the schedule of mm_run (flat_mm.hip): [0, kMmFirstSeg), then every segment ends at g_step x its start
-        int segs = 1;
-        int64_t lo = 0, hi = std::min<int64_t>(N, kMmFirstSeg);
-        while (hi < N) {
-            lo = hi;
-            const int g_step = mm_growth_step(growth, segs - 1, P.use_mm8);
-            hi = std::min<int64_t>(N, hi * (int64_t)std::max(2, std::min(16, g_step)));
-            ++segs;
-        }
-        P.last_seg_rows = hi - lo;
-        P.launches = segs * ((P.Bpad + P.mm_chunk - 1) / P.mm_chunk);
-        P.bytes_per_launch = P.use_mm8 ? N * (d + 4) + l2 : N * d * 2 + l2;
-    } else if (P.use_shadow) {
-        P.family = "scan8_kernel";
-        P.launches = P.Bpad / P.QT;
-        P.bytes_per_launch = N * (d + 12);     // 8-bit row + scale, error bound and the additive part of the key
-    } else if (P.use_qs) {
-        P.family = "scan_qs_kernel";
-        P.launches = P.Bpad / 128;
-        P.bytes_per_launch = N * d * 2 + l2;
-    } else {
-        P.family = "scan_topk_kernel";
-        P.launches = P.Bpad / P.QT;
-        P.bytes_per_launch = N * d * elt_b + l2;
-    }
-    // ---- workspace (the groups index_search_impl grows; bytes) ------------------------------------------------------
-    size_t ws = (size_t)P.Bpad * (4 * 4 + 8 + 4 + (size_t)d * 4 + (size_t)d * 2 * 2 + 4 + kSlotWords * 4);   // per-query block
-    ws += P.part_need * 8 + P.cand_need * 4;
-    if (P.use_mm) {
-        ws += (size_t)P.Bpad * 12 + 4;
-        ws += (size_t)std::max(P.mm_chunk, e.n_cu) * std::max<size_t>(kMmCapQ, e.n_cu) * 12;
-        ws += (size_t)e.n_cu * P.mm_chunk * P.mm_cap_wg * 8;
-    }
-    if (P.certify && N > 0)
-        ws += exact_part_entries(P.ex_fcap, P.ex_grid, k) * 12 + (size_t)P.ex_fcap * 4 + exact_part_entries(P.ex_fcap, P.ex_grid, 1) * 8;
-    if (P.use_shadow || P.use_mm8) {
-        const size_t BpadS = P.use_mm8 ? P.Bpad : (size_t)(B + 63) / 64 * 64;
-        ws += BpadS * (2 * (size_t)d + shadow_q_bytes() + shadow_slot_words() * 4 + 8);
-        if (P.use_shadow) ws += (size_t)e.n_cu * (P.QT == 128 ? 128 : 64) * 512 * 8 + (size_t)e.n_cu * 128 * 4 + BpadS * shadow_split() * k * 12;
-    }
-    P.ws_bytes = ws;
-    // (what shadow_search launches: the plan's record says the same)
-    if (P.use_shadow) P.grid = std::max(1, std::min(shadow_scan_wg_cap(P.cu_budget, e.wg_cap <= 0, P.QT), (P.n_tiles + 7) / 8));
-    return P;
-}
-
-static int plan_describe(const PlanEnv& e, const SearchPlan& P, char* out, int cap) {
-    return snprintf(out, cap,
-                    "family=%s QT=%d kc=%d Bpad=%d grid=%d launches=%d bytes_per_launch=%lld ws_bytes=%zu hp=%d slots=%d "
-                    "prepass=%d shadow=%d tiled=%d int8_tiles=%d exact_only=%d store=%s metric=%d d=%d rows=%lld queries=%d k=%d "
-                    "mm_growth=%d last_seg_rows=%lld",
-                    P.family, P.QT, P.kc, P.Bpad, P.grid, P.launches, (long long)P.bytes_per_launch, P.ws_bytes, (int)P.use_hp,
-                    (int)P.use_slots, (int)P.prepass, (int)P.use_shadow, (int)P.use_mm, (int)P.use_mm8, (int)P.exact_only,
-                    e.store == PRAG_F32 ? "f32" : "f16", e.metric, e.d, (long long)e.ntotal, e.B, e.k, P.mm_growth,
-                    (long long)P.last_seg_rows);
-}
-
-extern "C" int prag_plan_search(int d, int metric, int store_dtype, int64_t ntotal, int B, int k, int shadow_ready, int n_cu,
-                                char* out, int cap) {
-    PRAG_REQUIRE(out != nullptr && cap > 0, PRAG_EINVAL, "prag_plan_search: NULL buffer");
-    PRAG_REQUIRE(d >= 16 && d % 16 == 0 && B >= 1 && k >= 1 && ntotal >= 0 && n_cu >= 1, PRAG_EINVAL,
-                 "prag_plan_search: d=%d B=%d k=%d ntotal=%lld n_cu=%d", d, B, k, (long long)ntotal, n_cu);
-    PlanEnv e;
-    e.d = d; e.metric = metric; e.store = store_dtype; e.ntotal = ntotal; e.B = B; e.k = k; e.n_cu = n_cu;
-    e.shadow_ready = shadow_ready != 0 && shadow_store_supported(d);
-    e.shadow_mode = shadow_ready >= 2 ? 2 : 1;
-    const SearchPlan P = plan_search(e);
-    PRAG_REQUIRE(P.kc != 0, PRAG_EUNSUPPORTED, "k=%d: at most 911 results per query", k);
-    plan_describe(e, P, out, cap);
-    return PRAG_OK;
-}
 
 // > 128 queries on fp16 rows: MFMA-tiled scan (flat_mm.hip) in chunks of kMmMaxQueries, then the
 // device-flagged fallback through the per-lane-list kernel for queries whose candidate store
@@ -2412,8 +1891,6 @@ static int search_tiled(prag_index* ix, int B, int Bpad, int kc, int qstride, in
 }
 
 static void consume_tier_stats(prag_index* ix, bool wait);
-static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D, int64_t* I,
-                             int io_is_device, void* stream, int tag_ids, bool allow_mm8 = true);
 
 
 extern "C" int prag_index_search(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D,
@@ -2498,57 +1975,6 @@ extern "C" int prag_index_reserve(prag_index_t* ix, int B, int k, void* stream) 
     for (void* p : {(void*)q, (void*)D, (void*)I})
         if (p) (void)hipFree(p);
     return rc;
-}
-
-extern "C" int prag_index_set_comm(prag_index_t* ix, void* nccl_comm, int rank, int world) {
-    PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
-    PRAG_REQUIRE(world >= 1 && rank >= 0 && rank < world, PRAG_EINVAL, "rank %d of %d", rank, world);
-    PRAG_REQUIRE(nccl_comm != nullptr || world == 1, PRAG_EINVAL, "world=%d needs a communicator", world);
-    ix->comm = nccl_comm;
-    ix->comm_rank = rank;
-    ix->comm_world = world;
-    return PRAG_OK;
-}
-
-// The sharded search as ONE call: local search with tagged ids straight into this rank's slot of the packed exchange
-// format, ONE all-gather on the caller's stream, the (score, residual, id) merge - what ShardedFlatIndex.search did
-// with torch.distributed in between (sharded.py, rounds 1-3).  Device pointers; nothing waits for the stream.
-extern "C" int prag_index_search_sharded(prag_index_t* ix, const float* q_dev, int B, int k, int64_t id_offset,
-                                         float* D_dev, int64_t* I_dev, void* stream) {
-    PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
-    PRAG_REQUIRE(B >= 0 && k >= 1, PRAG_EINVAL, "B=%d k=%d", B, k);
-    if (B == 0) return PRAG_OK;
-    PRAG_REQUIRE(q_dev && D_dev && I_dev, PRAG_EINVAL, "prag_index_search_sharded: NULL pointer");
-    PRAG_REQUIRE(id_offset >= 0 && id_offset + ix->ntotal < (1ll << kTagShift), PRAG_EUNSUPPORTED,
-                 "tagged ids hold %d-bit global row ids", kTagShift);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int world = ix->comm ? ix->comm_world : 1;
-    const size_t i_off = ((size_t)B * k * 4 + 7) / 8 * 8;           // the I block starts 8-byte aligned behind the D block
-    const size_t stride = (i_off + (size_t)B * k * 8 + 15) / 16 * 16;
-    if (stride > ix->xch_send_cap) {
-        ix->xch_send_cap = 0;
-        const int rc_ws = ws_regrow({{vpp(&ix->xch_send), stride}});
-        if (rc_ws != PRAG_OK) return rc_ws;
-        ix->xch_send_cap = stride;
-    }
-    if (ix->comm && stride * world > ix->xch_recv_cap) {
-        ix->xch_recv_cap = 0;
-        const int rc_ws = ws_regrow({{vpp(&ix->xch_recv), stride * world}});
-        if (rc_ws != PRAG_OK) return rc_ws;
-        ix->xch_recv_cap = stride * world;
-    }
-    int rc = index_search_impl(ix, q_dev, B, k, id_offset, reinterpret_cast<float*>(ix->xch_send),
-                               reinterpret_cast<int64_t*>(ix->xch_send + i_off), 1, stream, 1);
-    if (rc != PRAG_OK) return rc;
-    const char* parts = ix->xch_send;
-    if (ix->comm) {      // also with one rank: the collective the multi-rank path issues, in its dtype and shape
-        ix->prof_xch.begin(st);
-        rc = rccl_all_gather_bytes(ix->comm, ix->xch_send, ix->xch_recv, stride, st);
-        ix->prof_xch.end(st);
-        if (rc != PRAG_OK) return rc;
-        parts = ix->xch_recv;
-    }
-    return prag_merge_topk_packed_tagged(parts, (int64_t)stride, world, B, k, ix->metric, D_dev, I_dev, stream);
 }
 
 // Second tier of the 8-bit tiled selection.  The queries that failed its certificate are on the device (flag count
@@ -3406,7 +2832,7 @@ static int search_finish(SearchRun& r, float* D, int64_t* I) {
     return PRAG_OK;
 }
 
-static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D, int64_t* I,
+int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int64_t id_offset, float* D, int64_t* I,
                              int io_is_device, void* stream, int tag_ids, bool allow_mm8) {
     PRAG_REQUIRE(ix != nullptr, PRAG_EINVAL, "index handle is NULL");
     PRAG_REQUIRE(B >= 0 && k >= 1, PRAG_EINVAL, "B=%d k=%d", B, k);
@@ -3481,48 +2907,6 @@ static int index_search_impl(prag_index_t* ix, const float* q, int B, int k, int
     if (rc == PRAG_OK) rc = exec_rerank(r);
     if (rc != PRAG_OK) return rc;
     return search_finish(r, D, I);
-}
-
-static int merge_topk_impl(const float* Dp, const int64_t* Ip, int64_t d_stride, int64_t i_stride, int n_parts,
-                           int B, int k, int metric, float* D_dev, int64_t* I_dev, void* stream, int tagged = 0) {
-    PRAG_REQUIRE(Dp && Ip && D_dev && I_dev, PRAG_EINVAL, "prag_merge_topk: NULL pointer");
-    PRAG_REQUIRE(n_parts >= 1 && n_parts <= 64, PRAG_EINVAL, "n_parts=%d outside [1,64]", n_parts);
-    PRAG_REQUIRE(B >= 0 && k >= 1, PRAG_EINVAL, "B=%d k=%d", B, k);
-    if (B == 0) return PRAG_OK;
-    hipLaunchKernelGGL(merge_shards_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
-                       Dp, Ip, d_stride, i_stride, n_parts, B, k, metric == PRAG_METRIC_L2 ? 1 : 0, tagged, D_dev, I_dev);
-    PRAG_LAUNCH_CHECK();
-    return PRAG_OK;
-}
-
-extern "C" int prag_merge_topk(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts, int B, int k,
-                               int metric, float* D_dev, int64_t* I_dev, void* stream) {
-    return merge_topk_impl(D_parts_dev, I_parts_dev, (int64_t)B * k, (int64_t)B * k, n_parts, B, k, metric, D_dev,
-                           I_dev, stream);
-}
-
-static int merge_packed_impl(const void* parts_dev, int64_t part_stride_bytes, int n_parts, int B, int k, int metric,
-                             float* D_dev, int64_t* I_dev, void* stream, int tagged);
-
-extern "C" int prag_merge_topk_packed(const void* parts_dev, int64_t part_stride_bytes, int n_parts, int B, int k,
-                                      int metric, float* D_dev, int64_t* I_dev, void* stream) {
-    return merge_packed_impl(parts_dev, part_stride_bytes, n_parts, B, k, metric, D_dev, I_dev, stream, 0);
-}
-
-extern "C" int prag_merge_topk_packed_tagged(const void* parts_dev, int64_t part_stride_bytes, int n_parts, int B, int k,
-                                             int metric, float* D_dev, int64_t* I_dev, void* stream) {
-    return merge_packed_impl(parts_dev, part_stride_bytes, n_parts, B, k, metric, D_dev, I_dev, stream, 1);
-}
-
-static int merge_packed_impl(const void* parts_dev, int64_t part_stride_bytes, int n_parts, int B, int k, int metric,
-                             float* D_dev, int64_t* I_dev, void* stream, int tagged) {
-    PRAG_REQUIRE(parts_dev != nullptr, PRAG_EINVAL, "prag_merge_topk_packed: NULL pointer");
-    const int64_t i_off = ((int64_t)B * k * 4 + 7) / 8 * 8;  // I block starts 8-byte aligned after the D block
-    PRAG_REQUIRE(part_stride_bytes >= i_off + (int64_t)B * k * 8 && part_stride_bytes % 8 == 0, PRAG_EINVAL,
-                 "part_stride_bytes=%lld too small or not a multiple of 8", (long long)part_stride_bytes);
-    const char* base = reinterpret_cast<const char*>(parts_dev);
-    return merge_topk_impl(reinterpret_cast<const float*>(base), reinterpret_cast<const int64_t*>(base + i_off),
-                           part_stride_bytes / 4, part_stride_bytes / 8, n_parts, B, k, metric, D_dev, I_dev, stream, tagged);
 }
 
 extern "C" int prag_index_reconstruct(prag_index_t* ix, int64_t row0, int64_t n, float* out_host) {
@@ -3714,11 +3098,6 @@ extern "C" int prag_index_profile(prag_index_t* ix, int slots) {
         if (rc != PRAG_OK) return rc;
     }
     return ix->prof.enable(slots);
-}
-
-extern "C" int prag_index_profile_read_exchange(prag_index_t* ix, float* ms, int cap, int* n_out) {
-    PRAG_REQUIRE(ix != nullptr && ms != nullptr && cap >= 0, PRAG_EINVAL, "prag_index_profile_read_exchange: bad argument");
-    return ix->prof_xch.read(ms, cap, n_out);
 }
 
 extern "C" int prag_index_profile_read(prag_index_t* ix, float* ms, int cap, int* n_out) {
