@@ -101,6 +101,7 @@ struct ExactArgs {
     int64_t* I;
     uint32_t* done;   // [f_cap] workgroups that have written their list of flag slot f (zero between searches)
     unsigned long long* gpool;    // [f_cap][n_lists] exact_mfma_kernel: every workgroup's best key of flag slot f (~0 between searches)
+    const uint32_t* xn_max;       // float bits of max_i ||x_i||^2 (exact_mfma_kernel's inner-product margin; null: per-row norms)
     int tag_ids;
     Gate gate;
 };
@@ -500,6 +501,10 @@ __global__ __launch_bounds__(kExThreads) void exact_group_kernel(ExactArgs a) {
 constexpr int kExMG = 16;
 constexpr int kExMCap = 256;
 constexpr int kExMRows = 128;     // rows per workgroup step: 8 waves x 16
+#ifndef PRAG_EXM_CHAINS
+#define PRAG_EXM_CHAINS 4
+#endif
+constexpr int kExMChains = PRAG_EXM_CHAINS;   // independent accumulator chains per wave
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int exm_q_off(int e, int col) { return (e * 16 + col) * 8 + (e >> 3) * 64; }
@@ -729,6 +734,10 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
 #pragma unroll
             for (int it = 0; it < H; ++it) load_seg(it, b0, it);
         }
+        // inner products: the margin of the selection only needs SOME bound on ||x||^2 - the shard's largest (one word) saves
+        // eight float64 fmas per step and lane; squared L2 needs each row's own norm for the selection value itself
+        const bool need_xsq = l2 || a.xn_max == nullptr;
+        const double xn_shard = need_xsq ? 0.0 : (double)__uint_as_float(*a.xn_max) * (1.0 + 1e-6);
         // byte offset of q[k = 8 p][query r] (query 0 for the one-query loop); a step of 32 k is 32 x 128 + 4 x 64 bytes on
         const int q_lane = exm_q_off(p * 8, r), q_lane1 = exm_q_off(p * 8, 0);
         static_assert(exm_q_off_step == 4352, "step stride of the padded query block");
@@ -826,9 +835,9 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
                 const char* nxt_b = row_base(t_next);
             // (two accumulator chains per wave: with two waves per SIMD that is the four independent MFMAs in flight the
             //  rate probe ran with; four per wave cost 16 more registers and the kernel spilled)
-            f64x4 acc[2];
+            f64x4 acc[kExMChains];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) acc[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+            for (int c = 0; c < kExMChains; ++c) acc[c] = f64x4{0.0, 0.0, 0.0, 0.0};
             double xsq = 0.0;
 #pragma unroll
             for (int it = 0; it < NS; ++it) {
@@ -853,21 +862,27 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const double qv = *reinterpret_cast<const double*>(qb + j * 128);
-                    acc[j & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[j], qv, acc[j & 1], 0, 0, 0);
+                    acc[j % kExMChains] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[j], qv, acc[j % kExMChains], 0, 0, 0);
                 }
+                if (need_xsq) {      // (uniform; inner products take the shard's largest norm for their margin instead)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xsq = fma(xd[j], xd[j], xsq);
+                    for (int j = 0; j < 8; ++j) xsq = fma(xd[j], xd[j], xsq);
+                }
                 __builtin_amdgcn_sched_barrier(0);      // (one step at a time, as in the one-query loop)
             }
-            const f64x4 dot = acc[0] + acc[1];                              // D[row = p + 4 reg][query r]
+            f64x4 dot = acc[0];                                             // D[row = p + 4 reg][query r]
+#pragma unroll
+            for (int c = 1; c < kExMChains; ++c) dot += acc[c];
             const int64_t base_row = t * kExMRows + w * 16;
             {
-                xsq += __shfl_xor(xsq, 16, 64);
-                xsq += __shfl_xor(xsq, 32, 64);                              // ||x_r||^2 in the row's four lanes
+                if (need_xsq) {
+                    xsq += __shfl_xor(xsq, 16, 64);
+                    xsq += __shfl_xor(xsq, 32, 64);                          // ||x_r||^2 in the row's four lanes
+                }
                 const double qn = s_qn2[r];
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const double xn = __shfl(xsq, p + 4 * reg, 64);          // row p + 4 reg
+                    const double xn = need_xsq ? __shfl(xsq, p + 4 * reg, 64) : xn_shard;     // row p + 4 reg
                     const int64_t rowi = base_row + p + 4 * reg;
                     // the matrix pipe's value only SELECTS (its float64 sums are not even the same for identical rows in
                     // different places of a tile - the last register of an accumulator rounds differently -, so ties
@@ -969,7 +984,7 @@ static int launch_exact_mfma(const ExactArgs& a, int grid, hipStream_t st) {
         return PRAG_OK;                                                                                 \
     }
     // (row segments in flight per lane: 16 B each on fp16 rows, 32 B on float32 rows - sized so that no form spills)
-    PRAG_EXM(4, 4, 4) PRAG_EXM(8, 8, 4) PRAG_EXM(12, 6, 4) PRAG_EXM(16, 4, 4) PRAG_EXM(20, 5, 4) PRAG_EXM(24, 6, 4)
+    PRAG_EXM(4, 4, 4) PRAG_EXM(8, 4, 2) PRAG_EXM(12, 6, 4) PRAG_EXM(16, 4, 2) PRAG_EXM(20, 5, 4) PRAG_EXM(24, 4, 4)
 #undef PRAG_EXM
     set_error("internal: exact_mfma_kernel has no d = %d form", a.d);
     return PRAG_EUNSUPPORTED;
@@ -1002,6 +1017,7 @@ int exact_run(const ExactRun& r, hipStream_t st) {
     a.I = r.I;
     a.done = r.done;
     a.gpool = r.gpool;
+    a.xn_max = r.xn_max;
     a.tag_ids = r.tag_ids;
     a.gate = r.gate;
     // several flagged queries expected, and the group's lists hold them: eight queries per pass over the rows

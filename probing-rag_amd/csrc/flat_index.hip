@@ -2727,6 +2727,7 @@ static int search_finish(SearchRun& r, float* D, int64_t* I) {
     er.grid = ex_grid;
     er.done = ix->ex_done;
     er.gpool = ix->ex_pool;
+    er.xn_max = ix->cert_words + 1;
     er.tag_ids = tag_ids;
     er.gate = ix->gate;
     // several flagged queries expected - every query goes to the exact scan by construction, or recent searches on this

@@ -250,6 +250,7 @@ struct ExactRun {
     int f_cap;              // flagged queries one round can hold
     int grid;               // workgroups of the scan
     uint32_t* done;         // [f_cap] zero-initialised arrival counters (the kernel leaves them zero)
+    const uint32_t* xn_max = nullptr;       // float bits of max_i ||x_i||^2 over the shard (the inner-product margin of exact_mfma_kernel)
     unsigned long long* gpool = nullptr;    // [f_cap][grid] all-ones words (exact_mfma_kernel: each workgroup's best key; left all-ones)
     int tag_ids;
     Gate gate;
