@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Diagnostic behind exact_mfma_kernel's design (round 6): 37 queries, each the exact copy of a row that occurs 40 times, k = 40,
+tagged ids (23 bits of the float32 residual of every float64 score).  With the float64 MFMA's sum taken AS the score, the copies
+of a row came back in two groups - rows 12-15 of a 16-row tile (the accumulator's fourth register) carry a sum that differs in
+the last bit - so ties broke by position, not by id.  The kernel therefore only selects with the MFMA value and re-scores what
+may enter a list in the one-query kernel's order; this script now shows every copy in id order."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
