@@ -563,3 +563,35 @@ def test_decode_step_launch_also_decides(torch_cuda, weights, Bt, dtype):
     with pytest.raises(RuntimeError, match="attach_gate"):
         b.decide()
     ens.close()
+
+
+def test_decode_step_launch_under_contention(torch_cuda):
+    """The step launch hands data between its workgroups inside the launch (arrival counters, bounded waits).  With another
+    stream keeping every CU busy - large matrix products back to back - the waits are longer; the decision must still be
+    `ens.decide`'s on the same sums (a hand-off that gives up voids the step and `pool.decide()` falls back to that call)."""
+    torch = torch_cuda
+    import probing_rag_amd as pra
+    case = cases.PROBER_CASES[1]
+    L, d = case["L"], case["d"]
+    ens, _ = _ensemble(case, "f32")
+    a = pra.HiddenStatePool(L, d, batch=1, defer=True).attach_gate(ens, 0, 0.0)
+    b = pra.HiddenStatePool(L, d, batch=1, defer=True)
+    side = torch.cuda.Stream()
+    A = torch.randn((4096, 4096), device="cuda", dtype=torch.float16)
+    rng = np.random.default_rng(5)
+    for episode in range(6):
+        a.reset()
+        b.reset()
+        with torch.cuda.stream(side):
+            for _ in range(12):                      # ~1 ms of chip-filling work per episode on the other stream
+                A = (A @ A).clamp_(-1, 1)
+        for t in range(5):
+            st = torch.from_numpy(rng.standard_normal((L, 1, 7 if t == 0 else 1, d)).astype(np.float32)).cuda()
+            for l in range(L):
+                a.observe(l, st[l])
+                b.observe(l, st[l])
+        got, got_ps = a.decide(with_probsum=True)
+        want, want_ps = ens.decide(b.pooled(), 0, 0.0, with_probsum=True)
+        assert np.array_equal(got, want) and np.array_equal(got_ps, want_ps) and torch.equal(a.pooled(), b.pooled())
+    torch.cuda.synchronize()
+    ens.close()
