@@ -603,11 +603,10 @@ def clustered_variant(torch, pra, d_emb, k, n_rows=4_194_304, n_centres=4096, si
         # rows of a centre are CONTIGUOUS (a corpus in article order: consecutive passages resemble each other),
         # so a centre's ~1000 rows fall into a handful of scan workgroups - the layout that fills a region
         # interleaved: every row draws its centre at random - a clustered corpus in random order, a centre's rows spread
-        # over every scan workgroup.  (Not `i mod n_centres`: a period of 4096 rows = 128 scan tiles
-        # resonates with a 256-workgroup grid - all 1024 rows of a centre land in TWO workgroups, overflow their 512-entry
-        # candidate regions and 62 of 64 queries go through the retry tier or the exact scan, 2.2 / 14 ms per search; on
-        # 224 workgroups the same corpus takes 0.75 ms - profiles/r06i_clustered_interleaved.txt.  An artefact of a
-        # power-of-two period, not of clustering.)
+        # over every scan workgroup.  (`i mod n_centres` was the first layout tried: a period of 4096
+        # rows = 128 scan tiles resonated with a 256-workgroup grid - all 1024 rows of a centre in TWO workgroups' candidate
+        # regions, 62 of 64 queries flagged, 2.2 ms per search - profiles/r06i_clustered_interleaved.txt; the library's own
+        # grids are prime counts since, 0.69 ms on that layout - profiles/r06r_prime_grid_ab.txt.)
         idx = torch.randint(0, n_centres, (m,), generator=g, device="cuda") if interleaved else \
             (torch.arange(lo, lo + m, device="cuda") * n_centres) // n_rows
         ix.add(centres[idx] + sigma * torch.randn((m, d_emb), generator=g, device="cuda"))   # ||noise|| ~ 0.48

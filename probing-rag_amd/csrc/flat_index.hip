@@ -2557,7 +2557,8 @@ static int exec_two_level(SearchRun& r) {
         if (T.phase >= 8) T.choice = T.best[1] < (ix->tail ? 0.95f : 0.975f) * T.best[0] ? 1 : 0;
         every_cu = tune ? (T.phase & 1) != 0 : T.choice == 1;
     }
-    ss.auto_wg = ix->wg_cap <= 0 && !every_cu;
+    ss.auto_wg = ix->wg_cap <= 0;
+    ss.every_cu = every_cu;
     if (tune) {
         ss.time_ev0 = tune->ev0;
         ss.time_ev1 = tune->ev1;

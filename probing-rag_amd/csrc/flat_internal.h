@@ -288,8 +288,29 @@ __host__ __device__ constexpr int shadow_piece_off(int r, int p) {
 // own cap (prag_index_set_scan_workgroups) is kept as given.  Which of the two an index uses is MEASURED on its own
 // searches (flat_index.hip, WgTune): on embedding-shaped rows the same 64-query scans lose 5-8 % on 7/8 of the CUs
 // (profiles/r05w_bench.json: 2.604 -> 2.729 ms at 21 M rows, 0.554 -> 0.599 at 4 M) where iid rows gain 1.6-3 %.
-inline int shadow_scan_wg_cap(int max_wg, bool auto_wg, int QT) {
-    return (auto_wg && QT <= 64) ? (max_wg * 7 / 8 > 1 ? max_wg * 7 / 8 : 1) : max_wg;
+// Round 6: when the library picks the grid it takes the largest PRIME not above that count (256 CUs: 223 for 7/8, 251
+// for "all").  Tiles are dealt to workgroups round-robin (tile t -> workgroup t mod grid: consecutive tiles to different
+// workgroups, which is what keeps a run of similar rows out of one candidate region), so rows that repeat with a period
+// of P tiles land in grid / gcd(grid, P) workgroups: with 256 workgroups and a period of 4096 rows (128 tiles) in TWO -
+// their 512-entry regions overflow and 62 of 64 queries go to the retry tier or the float64 scan (2.2 / 14 ms per
+// search against 0.75, profiles/r06i_clustered_interleaved.txt).  A prime grid spreads every period except its own
+// multiples (7 136 rows for 223) over all workgroups.
+inline int largest_prime_le(int n) {
+    for (int c = n; c > 3; --c) {
+        bool prime = (c & 1) != 0;
+        for (int f = 3; prime && f * f <= c; f += 2) prime = c % f != 0;
+        if (prime) return c;
+    }
+    return n > 1 ? n : 1;
+}
+inline int shadow_scan_wg_cap(int max_wg, bool auto_wg, int QT, bool every_cu = false) {
+    if (!auto_wg) return max_wg;                        // the caller's own cap: kept as given
+    const int want = (QT <= 64 && !every_cu) ? (max_wg * 7 / 8 > 1 ? max_wg * 7 / 8 : 1) : max_wg;
+#ifdef PRAG_NO_PRIME_GRID       // (A/B builds: `make ab ABFLAGS=-DPRAG_NO_PRIME_GRID`)
+    return want;
+#else
+    return want >= 16 ? largest_prime_le(want) : want;
+#endif
 }
 
 // Bound slots of the two-level scan, per query: kShadowEpochs epochs x 32 slots filled inside the scan launch
@@ -588,6 +609,7 @@ struct ShadowSearch {
     uint32_t* ccnt;          // [wg_slots][64]
     int cap, wg_slots, max_wg;
     bool auto_wg = false;    // max_wg is "every CU", not a caller's choice: HBM-bound tiles take 7/8 of it (shadow_scan_wg_cap)
+    bool every_cu = false;   // ... unless the index measured that its scans want every CU (WgTune) or PRAG_SCAN_WG_TUNE=1 says so
     unsigned long long* part_key;   // [Bpad][shadow_split()][k]
     int* part_id;
     uint32_t* ovf;           // [Bpad]

@@ -931,7 +931,7 @@ int shadow_search(ShadowSearch& s, hipStream_t st, EventRing& prof) {
     const int Bpad = (s.B + QT - 1) / QT * QT;
     PRAG_REQUIRE(Bpad <= s.Bpad_ws, PRAG_EUNSUPPORTED, "internal: shadow workspace too small");
     const int n_tiles = (int)((s.N + 31) / 32);
-    const int wg_cap = shadow_scan_wg_cap(s.max_wg, s.auto_wg, QT);   // (7/8 of the CUs for HBM-bound tiles: flat_internal.h)
+    const int wg_cap = shadow_scan_wg_cap(s.max_wg, s.auto_wg, QT, s.every_cu);   // (7/8 of the CUs for HBM-bound tiles, a prime count: flat_internal.h)
     const int grid = std::max(1, std::min(wg_cap, (n_tiles + 7) / 8));
     PRAG_REQUIRE(grid <= s.wg_slots, PRAG_EUNSUPPORTED, "internal: shadow candidate regions too few");
     s.grid_used = grid;

@@ -545,6 +545,10 @@ def test_scan_workgroups_are_measured_not_assumed(monkeypatch):
     import probing_rag_amd as pra
     N, d, k = 1_200_000, 768, 10
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+
+    def prime_le(n):              # the library's own grids are the largest primes not above 7/8 of the CUs / all of them
+        return next(c for c in range(n, 1, -1) if all(c % f for f in range(2, int(c ** 0.5) + 1)))
+    g78, gall = prime_le(n_cu * 7 // 8), prime_le(n_cu)
     q = torch.from_numpy(onp.synth_rows(7, 0, 64, d)).cuda()
 
     def build():
@@ -562,15 +566,15 @@ def test_scan_workgroups_are_measured_not_assumed(monkeypatch):
         torch.cuda.synchronize()
         assert torch.equal(I, I0) and torch.equal(D, D0)
         grids.append(ix.last_plan()["grid"])
-    assert set(grids[:8]) == {n_cu * 7 // 8, n_cu}          # both were tried ...
-    assert len(set(grids[-4:])) == 1 and grids[-1] in (n_cu * 7 // 8, n_cu)   # ... and one was kept
+    assert set(grids[:8]) == {g78, gall}                    # both were tried ...
+    assert len(set(grids[-4:])) == 1 and grids[-1] in (g78, gall)   # ... and one was kept
     D1, I1 = ix.search(q[:1], k)                                # <= 32 queries: measured separately
-    assert ix.last_plan()["grid"] in (n_cu * 7 // 8, n_cu)
+    assert ix.last_plan()["grid"] in (g78, gall)
     ix.set_scan_workgroups(100)                                 # the caller's own cap
     D, I = ix.search(q, k)
     assert ix.last_plan()["grid"] == 100 and torch.equal(I, I0)
     ix.close()
-    for mode, want in (("0", n_cu * 7 // 8), ("1", n_cu)):
+    for mode, want in (("0", g78), ("1", gall)):
         monkeypatch.setenv("PRAG_SCAN_WG_TUNE", mode)
         ix = build()
         for _ in range(3):

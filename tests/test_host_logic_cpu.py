@@ -268,9 +268,11 @@ def test_search_plan_over_the_shape_grid():
                                     # HBM-bound tiles (<= 64 queries) are planned on 7/8 of the CUs - which of 7/8 and all
                                     # an index really uses is timed on its own searches and written back into the plan on
                                     # record (test_gpu_shadow.py) -, the epilogue-bound 128-query tiles on every CU
-                                    assert p["grid"] <= (224 if p["QT"] <= 64 else 256)
+                                    # (round 6: the largest PRIME not above that count - 223 / 251 of 256 - so that rows repeating
+                                    #  with a power-of-two period do not all land in two workgroups' candidate regions)
+                                    assert p["grid"] <= (223 if p["QT"] <= 64 else 251)
                                     if N >= 1 << 20:
-                                        assert p["grid"] == (224 if p["QT"] <= 64 else 256)
+                                        assert p["grid"] == (223 if p["QT"] <= 64 else 251)
                                 if p["hp"]:
                                     assert p["QT"] == 32
                                 elt = 4 if store == "f32" else 2
