@@ -398,6 +398,7 @@ def test_flagged_queries_are_retried_32_at_a_time_before_the_exact_scan(monkeypa
         else:
             monkeypatch.setenv("PRAG_RETRY_TIER", mode)
         ix = pra.HipFlatIndex(d, "l2", "f16", capacity=N)
+        ix.set_adaptive(True)       # (arming by history is the adaptive plan's: also under PRAG_ADAPTIVE=0)
         ix.set_shadow(2)
         ix.add(X)
         if mode == "0":
@@ -553,6 +554,7 @@ def test_scan_workgroups_are_measured_not_assumed(monkeypatch):
 
     def build():
         ix = pra.HipFlatIndex(d, "cos", "f16", capacity=N)
+        ix.set_adaptive(True)       # (the measurement is the adaptive plan's: also under PRAG_ADAPTIVE=0)
         ix.add_synthetic(42, 0, N)
         ix.set_shadow(2)
         ix.prepare()

@@ -120,6 +120,7 @@ def test_second_tier_on_a_corpus_of_look_alikes(metric, store, monkeypatch):
     monkeypatch.setenv("PRAG_SHADOW_AFFINE", "0")     # read when the index is created
     ix = pra.HipFlatIndex(d, metric, store)
     monkeypatch.delenv("PRAG_SHADOW_AFFINE")
+    ix.set_adaptive(True)        # (the auto-off of the int8 tiles is the adaptive plan's: also under PRAG_ADAPTIVE=0)
     ix.set_shadow(2)
     ix.add(X)
     D, I = ix.search(Q, k)
