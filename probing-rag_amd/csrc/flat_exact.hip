@@ -747,6 +747,10 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
             __syncthreads();
             uint32_t need = 0;                    // (uniform: the counters are read behind the barrier by every thread)
             for (int g = 0; g < ng; ++g) need |= s_cnt[g] > kExMCap - kExMRows ? 1u << g : 0u;
+            // after the FIRST step every list is cut at once: its k-th best of 128 rows lets one pair in four through in
+            // the second step, where an empty bound re-scores all 128 x ng of them again (~45 us at 16 queries)
+            if (steps_done == 0)
+                for (int g = 0; g < ng; ++g) need |= s_cnt[g] > a.k ? 1u << g : 0u;
             if (need) exm_cut_lists(l_key, l_id, s_cnt, s_bound, need, a.k);
             // The chip-wide bound.  Every workgroup publishes its best key per query after 1, 2, 4, 8, ... steps and reads
             // the others' then: the k-th smallest of the workgroups' best keys is the worst of SOME k distinct rows, hence
