@@ -738,8 +738,8 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
         // eight float64 fmas per step and lane; squared L2 needs each row's own norm for the selection value itself
         const bool need_xsq = l2 || a.xn_max == nullptr;
         const double xn_shard = need_xsq ? 0.0 : (double)__uint_as_float(*a.xn_max) * (1.0 + 1e-6);
-        // byte offset of q[k = 8 p][query r] (query 0 for the one-query loop); a step of 32 k is 32 x 128 + 4 x 64 bytes on
-        const int q_lane = exm_q_off(p * 8, r), q_lane1 = exm_q_off(p * 8, 0);
+        // byte offset of q[k = 8 p][query r]; a step of 32 k is 32 x 128 + 4 x 64 bytes on
+        const int q_lane = exm_q_off(p * 8, r);
         static_assert(exm_q_off_step == 4352, "step stride of the padded query block");
         int steps_done = 0;
         // what follows a step's scores: capacity check / cuts, the published best key, the chip-wide bound
@@ -776,72 +776,31 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
             }
             __syncthreads();
         };
-        // (two loops, not one loop with a branch in it: with both bodies in one loop the register allocator spilled the
-        //  row ring - 100-500 bytes of scratch per lane)
-        if (ng == 1) {
+        {
+            // (Round 6 had a plain float64 fma loop for ONE flagged query - 1.49 ms over 4 M x 640 fp16 rows; the four-block
+            //  shape below does one query in 1.4, so it went.)
+            // One to sixteen flagged queries on the float64 matrix pipe, in one of two shapes (uniform per group):
+            //   9..16 queries: one 16 x 16 x 4 tile per k-quad - D[row = p + 4 reg][query r], four registers a lane;
+            //   1..8 queries: four 4 x 4 x 4 blocks per instruction (v_mfma_f64_4x4x4_4b) - block b multiplies rows 4 b ..
+            //   4 b + 3 by FOUR queries, so a group of <= 4 costs a 3.5th of the tile's time on the pipe and a group of <= 8
+            //   (a second instruction for queries 4..7) 1.75 times less (tools/micro/mfma_f64_4x4_probe.hip: the operand
+            //   layout - A is the tile's A operand unchanged, B holds q[k = p][query lane & 3], D[i][j] of block b sits in
+            //   lane 16 i + 4 b + j - and the rate, 69.6 TFLOP/s against the tile's 78).
+            auto mfma_pass = [&](auto small_tag) __attribute__((always_inline)) {
+            constexpr bool S = decltype(small_tag)::value;
+            const bool hi = ng > 4;                                          // (S: queries 4..7 in use)
+            const int q_lane_s = exm_q_off(p * 8, lane & 3);
             for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
                 const int64_t t_next = t + gridDim.x < n_tiles ? t + gridDim.x : t;
                 const char* cur_b = row_base(t);
                 const char* nxt_b = row_base(t_next);
-                // ONE flagged query in this group (the common case when anything is flagged at all): sixteen MFMA columns
-                // for one query would make the pass matrix-bound (1.8 ms over 4 M x 640 rows where the one-query kernel
-                // takes 1.4); the same loads feed plain float64 fmas instead - direct (q - x)^2 for L2 - and the pass is
-                // as HBM-bound as exact_scan_kernel's.  Lane (r, p) sums its quarter of row r; two shuffles finish it.
-                double s1 = 0.0;
+            // (independent accumulator chains per wave: with two waves per SIMD the MFMAs in flight the rate probe ran with)
+            f64x4 acc[S ? 1 : kExMChains];
+            double a0[4], a1[4];
 #pragma unroll
-                for (int it = 0; it < NS; ++it) {
-                    const int slot = it % H;
-                    double xd[8];
-                    if constexpr (F32) {
-                        const f32x4 x0 = __builtin_bit_cast(f32x4, v0[slot]);
-                        const f32x4 x1 = __builtin_bit_cast(f32x4, v1[slot]);
+            for (int c = 0; c < (S ? 1 : kExMChains); ++c) acc[c] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { xd[j] = (double)x0[j]; xd[4 + j] = (double)x1[j]; }
-                    } else {
-                        const half8 h = __builtin_bit_cast(half8, v0[slot]);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) xd[j] = (double)(float)h[j];
-                    }
-                    if (it + H < NS) load_seg(slot, cur_b, it + H);
-                    else load_seg(slot, nxt_b, it + H - NS);
-                    // (the step's LDS address is formed HERE: hoisted out of the loop, the NS addresses of the unrolled
-                    //  steps - beyond the 64 KB a ds_read offset reaches - cost a register each and spilled)
-                    int qo = q_lane1 + it * 4352;
-                    asm volatile("" : "+v"(qo));
-                    const char* qb = s_q + qo;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const double qv = *reinterpret_cast<const double*>(qb + j * 128);
-                        if (l2) {
-                            const double df = qv - xd[j];
-                            s1 = fma(df, df, s1);
-                        } else {
-                            s1 = fma(qv, xd[j], s1);
-                        }
-                    }
-                    // (one step's reads and conversions at a time: left free, the scheduler hoists the LDS reads and
-                    //  conversions of all NS steps to the top - 100-500 bytes of scratch per lane)
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                s1 += __shfl_xor(s1, 16, 64);
-                s1 += __shfl_xor(s1, 32, 64);
-                const int64_t rowi = t * kExMRows + w * 16 + r;
-                if (p == 0 && rowi < a.N) {
-                    const unsigned long long key = l2 ? sortable_u64(s1) : ~sortable_u64(s1);
-                    if (key <= s_bound[0]) push(0, key, (int)rowi);
-                }
-                step_tail();
-            }
-        } else {
-            for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-                const int64_t t_next = t + gridDim.x < n_tiles ? t + gridDim.x : t;
-                const char* cur_b = row_base(t);
-                const char* nxt_b = row_base(t_next);
-            // (two accumulator chains per wave: with two waves per SIMD that is the four independent MFMAs in flight the
-            //  rate probe ran with; four per wave cost 16 more registers and the kernel spilled)
-            f64x4 acc[kExMChains];
-#pragma unroll
-            for (int c = 0; c < kExMChains; ++c) acc[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+            for (int c = 0; c < 4; ++c) a0[c] = a1[c] = 0.0;
             double xsq = 0.0;
 #pragma unroll
             for (int it = 0; it < NS; ++it) {
@@ -860,89 +819,117 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
                 // refill the segment just consumed: a later segment of this tile, or the next tile's
                 if (it + H < NS) load_seg(slot, cur_b, it + H);
                 else load_seg(slot, nxt_b, it + H - NS);
-                int qo = q_lane + it * 4352;                                 // (formed per step: see the one-query loop)
+                // (the step's LDS address is formed HERE: hoisted out of the loop, the NS addresses of the unrolled steps -
+                //  beyond the 64 KB a ds_read offset reaches - cost a register each and spilled)
+                int qo = (S ? q_lane_s : q_lane) + it * 4352;
                 asm volatile("" : "+v"(qo));
                 const char* qb = s_q + qo;                                   // (+ 128 B per k inside the piece)
+                if constexpr (S) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const double qv = *reinterpret_cast<const double*>(qb + j * 128);
-                    acc[j % kExMChains] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[j], qv, acc[j % kExMChains], 0, 0, 0);
+                    for (int j = 0; j < 8; ++j) {
+                        const double qv = *reinterpret_cast<const double*>(qb + j * 128);
+                        a0[j % 4] = __builtin_amdgcn_mfma_f64_4x4x4f64(xd[j], qv, a0[j % 4], 0, 0, 0);
+                    }
+                    if (hi) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const double qv = *reinterpret_cast<const double*>(qb + j * 128 + 32);     // query + 4
+                            a1[j % 4] = __builtin_amdgcn_mfma_f64_4x4x4f64(xd[j], qv, a1[j % 4], 0, 0, 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const double qv = *reinterpret_cast<const double*>(qb + j * 128);
+                        acc[j % kExMChains] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[j], qv, acc[j % kExMChains], 0, 0, 0);
+                    }
                 }
                 if (need_xsq) {      // (uniform; inner products take the shard's largest norm for their margin instead)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) xsq = fma(xd[j], xd[j], xsq);
                 }
-                __builtin_amdgcn_sched_barrier(0);      // (one step at a time, as in the one-query loop)
+                // (one step's reads and conversions at a time: left free, the scheduler hoists the LDS reads and conversions
+                //  of all NS steps to the top - 100-500 bytes of scratch per lane)
+                __builtin_amdgcn_sched_barrier(0);
             }
-            f64x4 dot = acc[0];                                             // D[row = p + 4 reg][query r]
-#pragma unroll
-            for (int c = 1; c < kExMChains; ++c) dot += acc[c];
             const int64_t base_row = t * kExMRows + w * 16;
-            {
-                if (need_xsq) {
-                    xsq += __shfl_xor(xsq, 16, 64);
-                    xsq += __shfl_xor(xsq, 32, 64);                          // ||x_r||^2 in the row's four lanes
-                }
-                const double qn = s_qn2[r];
+            if (need_xsq) {
+                xsq += __shfl_xor(xsq, 16, 64);
+                xsq += __shfl_xor(xsq, 32, 64);                              // ||x_r||^2 in the row's four lanes
+            }
+            // One value of the matrix pipe per call: row `row16` of the wave's sixteen, query `col` of the group.  The
+            // pipe's value only SELECTS (its float64 sums are not even the same for identical rows in different places of a
+            // tile - the last register of an accumulator rounds differently -, so ties between copies of a row would break
+            // by position): whatever may enter a list, by a margin above the worst-case error d 2^-53 (||x||^2 + ||q||^2),
+            // is scored again here in the one-query kernel's order.
+            auto consume = [&](double dotv, int row16, int col) __attribute__((always_inline)) {
+                const double xn = need_xsq ? __shfl(xsq, row16, 64) : xn_shard;
+                const double qn = s_qn2[col];
+                const double margin = 1e-12 * (xn + qn);
+                const unsigned long long sel_key = l2 ? sortable_u64(((xn - 2.0 * dotv) + qn) - margin)
+                                                      : ~sortable_u64(dotv + margin);
+                const bool pass = base_row + row16 < a.N && col < ng && sel_key <= s_bound[col];
+                const int mine = row16 | (col << 8);
+                unsigned long long m = __ballot(pass);
+                while (m) {            // four (row, query) pairs at a time: 16 lanes each, the one-query kernel's sum
+                    int src = -1;
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const double xn = need_xsq ? __shfl(xsq, p + 4 * reg, 64) : xn_shard;     // row p + 4 reg
-                    const int64_t rowi = base_row + p + 4 * reg;
-                    // the matrix pipe's value only SELECTS (its float64 sums are not even the same for identical rows in
-                    // different places of a tile - the last register of an accumulator rounds differently -, so ties
-                    // between copies of a row would break by position): whatever may enter a list, by a margin above the
-                    // worst-case error d 2^-53 (||x||^2 + ||q||^2), is scored again below in the one-query kernel's order
-                    const double margin = 1e-12 * (xn + qn);
-                    const unsigned long long sel_key = l2 ? sortable_u64(((xn - 2.0 * dot[reg]) + qn) - margin)
-                                                          : ~sortable_u64(dot[reg] + margin);
-                    const bool pass = rowi < a.N && r < ng && sel_key <= s_bound[r];
-                    unsigned long long m = __ballot(pass);
-                    while (m) {        // four (row, query) pairs at a time: 16 lanes each, the one-query kernel's sum
-                        int src = -1;
+                    for (int g = 0; g < 4; ++g) {
+                        const int bit = m ? __ffsll((long long)m) - 1 : -1;
+                        if (g == p) src = bit;
+                        if (m) m &= m - 1;
+                    }
+                    const int rc = __shfl(mine, src >= 0 ? src : 0, 64);
+                    const int64_t rowx = base_row + (rc & 255);
+                    const int colx = rc >> 8;
+                    double sx = 0.0;
+                    for (int e = r * 8; e < d; e += 128) {
+                        double xv[8];
+                        if constexpr (F32) {
+                            const float* src32 = reinterpret_cast<const float*>(a.rows) + rowx * d + e;
+                            const f32x4 x0 = *reinterpret_cast<const f32x4*>(src32);
+                            const f32x4 x1 = *reinterpret_cast<const f32x4*>(src32 + 4);
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int bit = m ? __ffsll((long long)m) - 1 : -1;
-                            if (g == p) src = bit;
-                            if (m) m &= m - 1;
+                            for (int j = 0; j < 4; ++j) { xv[j] = (double)x0[j]; xv[4 + j] = (double)x1[j]; }
+                        } else {
+                            const half8 h = *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(a.rows) + rowx * d + e);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) xv[j] = (double)(float)h[j];
                         }
-                        const int sl = src >= 0 ? src : 0;
-                        const int64_t rowx = base_row + (sl >> 4) + 4 * reg;
-                        const int col = sl & 15;
-                        double sx = 0.0;
-                        for (int e = r * 8; e < d; e += 128) {
-                            double xv[8];
-                            if constexpr (F32) {
-                                const float* src32 = reinterpret_cast<const float*>(a.rows) + rowx * d + e;
-                                const f32x4 x0 = *reinterpret_cast<const f32x4*>(src32);
-                                const f32x4 x1 = *reinterpret_cast<const f32x4*>(src32 + 4);
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) { xv[j] = (double)x0[j]; xv[4 + j] = (double)x1[j]; }
+                        for (int j = 0; j < 8; ++j) {
+                            const double qv = *reinterpret_cast<const double*>(s_q + exm_q_off(e + j, colx));
+                            if (l2) {
+                                const double df = qv - xv[j];
+                                sx = fma(df, df, sx);
                             } else {
-                                const half8 h = *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(a.rows) + rowx * d + e);
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) xv[j] = (double)(float)h[j];
+                                sx = fma(qv, xv[j], sx);
                             }
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const double qv = *reinterpret_cast<const double*>(s_q + exm_q_off(e + j, col));
-                                if (l2) {
-                                    const double df = qv - xv[j];
-                                    sx = fma(df, df, sx);
-                                } else {
-                                    sx = fma(qv, xv[j], sx);
-                                }
-                            }
-                        }
-                        sx = dpp_add16_f64(sx);
-                        if (src >= 0 && r == 0) {
-                            const unsigned long long key = l2 ? sortable_u64(sx) : ~sortable_u64(sx);
-                            if (key <= s_bound[col]) push(col, key, (int)rowx);
                         }
                     }
+                    sx = dpp_add16_f64(sx);
+                    if (src >= 0 && r == 0) {
+                        const unsigned long long key = l2 ? sortable_u64(sx) : ~sortable_u64(sx);
+                        if (key <= s_bound[colx]) push(colx, key, (int)rowx);
+                    }
                 }
+            };
+            if constexpr (S) {
+                const int row16 = 4 * ((lane >> 2) & 3) + p;                 // D[i = p][j = lane & 3] of block (lane >> 2) & 3
+                consume((a0[0] + a0[1]) + (a0[2] + a0[3]), row16, lane & 3);
+                if (hi) consume((a1[0] + a1[1]) + (a1[2] + a1[3]), row16, 4 + (lane & 3));
+            } else {
+                f64x4 dot = acc[0];                                          // D[row = p + 4 reg][query r]
+#pragma unroll
+                for (int c = 1; c < kExMChains; ++c) dot += acc[c];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) consume(dot[reg], p + 4 * reg, r);
             }
                 step_tail();
             }
+            };
+            if (ng <= 8) mfma_pass(std::true_type{});
+            else mfma_pass(std::false_type{});
         }
         __syncthreads();
         exm_cut_lists(l_key, l_id, s_cnt, s_bound, (1u << ng) - 1u, a.k);
@@ -988,7 +975,7 @@ static int launch_exact_mfma(const ExactArgs& a, int grid, hipStream_t st) {
         return PRAG_OK;                                                                                 \
     }
     // (row segments in flight per lane: 16 B each on fp16 rows, 32 B on float32 rows - sized so that no form spills)
-    PRAG_EXM(4, 4, 4) PRAG_EXM(8, 4, 2) PRAG_EXM(12, 6, 4) PRAG_EXM(16, 4, 2) PRAG_EXM(20, 5, 4) PRAG_EXM(24, 4, 4)
+    PRAG_EXM(4, 4, 4) PRAG_EXM(8, 8, 4) PRAG_EXM(12, 6, 4) PRAG_EXM(16, 8, 4) PRAG_EXM(20, 10, 5) PRAG_EXM(24, 8, 4)
 #undef PRAG_EXM
     set_error("internal: exact_mfma_kernel has no d = %d form", a.d);
     return PRAG_EUNSUPPORTED;

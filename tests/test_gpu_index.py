@@ -704,13 +704,26 @@ def test_grouped_exact_scan_is_bit_identical_to_the_single_query_scan(monkeypatc
                                             (768, "f32", onp.METRIC_COS), (768, "f16", onp.METRIC_COS)])
 def test_exact_scan_on_the_float64_matrix_pipe(monkeypatch, d, store, metric):
     """exact_mfma_kernel at every row length it is built for (d = 128 ... 768), both storages, all metrics: 37 queries
-    (two full groups of 16 and a ragged one), each the exact copy of a row that occurs 40 times - more copies than any
-    candidate list holds, so no certificate clears and every query is recomputed by the float64 scan - on a corpus
-    whose size is no multiple of the kernel's 128-row step.  Results the definition's; the copies come back lowest id
-    first; identical to the one-query-per-pass kernel."""
+    (two full groups of 16 and a ragged one of 5 - the 4 x 4 x 4 blocks' two-instruction shape), each the exact copy of a
+    row that occurs 40 times - more copies than any candidate list holds, so no certificate clears and every query is
+    recomputed by the float64 scan - on a corpus whose size is no multiple of the kernel's 128-row step.  Results the
+    definition's; the copies come back lowest id first; identical to the one-query-per-pass kernel."""
+    _matrix_pipe_case(monkeypatch, d, store, metric, 37)
+
+
+@pytest.mark.parametrize("B", [2, 3, 4, 5, 7, 8, 9, 19, 20])
+@pytest.mark.parametrize("d,store,metric", [(640, "f16", onp.METRIC_L2), (256, "f32", onp.METRIC_IP), (768, "f16", onp.METRIC_COS)])
+def test_exact_scan_small_groups_on_the_4x4x4_blocks(monkeypatch, d, store, metric, B):
+    """Groups of 2 ... 8 flagged queries take the matrix pipe's four-block shape (one instruction for <= 4 queries, two
+    for <= 8), 9 ... 16 the full tile; 19 and 20 end in ragged groups of 3 and 4 behind a full one.  Same corpus of
+    copies, same bar: the definition's results, identical to the one-query-per-pass kernel."""
+    _matrix_pipe_case(monkeypatch, d, store, metric, B)
+
+
+def _matrix_pipe_case(monkeypatch, d, store, metric, B):
     import torch
     import probing_rag_amd as pra
-    N, B, k = 20_011, 37, 10
+    N, k = 20_011, 10
     X = onp.synth_rows(71, 0, N, d)
     rng = np.random.default_rng(d)
     dup_rows = []

@@ -12,7 +12,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         ix = pra.HipFlatIndex(d, metric, store, capacity=N)
         ix.add_synthetic(42, 0, N)
         out = []
-        for B in (1, 2, 8, 16, 64):
+        for B in (1, 2, 4, 8, 16, 64):
             q = torch.randn(B, d, device="cuda")
             for _ in range(2):
                 ix.search(q, k)
