@@ -507,19 +507,28 @@ constexpr int kExMRows = 128;     // rows per workgroup step: 8 waves x 16
 constexpr int kExMChains = PRAG_EXM_CHAINS;   // independent accumulator chains per wave
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ int exm_q_off(int e, int col) { return (e * 16 + col) * 8 + (e >> 3) * 64; }
-constexpr int exm_q_off_step = 32 * 128 + 4 * 64;     // exm_q_off(e + 32, col) - exm_q_off(e, col)
+// (G queries per group: 16, or 8 for rows of more than 768 elements - their 16-query block would not fit LDS)
+template <int G>
+__device__ __forceinline__ int exm_q_off(int e, int col) { return (e * G + col) * 8 + (e >> 3) * 64; }
+template <int G>
+constexpr int exm_q_off_step = 32 * G * 8 + 4 * 64;     // exm_q_off(e + 32, col) - exm_q_off(e, col)
+// the group's lists alias the merge's big list
+template <int G>
+constexpr size_t exm_list_bytes = ((size_t)G * kExMCap * 12 > sizeof(ExTopK) ? (size_t)G * kExMCap * 12 : sizeof(ExTopK) + 15) / 16 * 16;
+constexpr int exm_group(int d) { return d <= 768 ? 16 : 8; }
 size_t exact_mfma_lds_bytes(int d) {   // queries | ||q||^2 | spare | lists | bounds, counters (256 B) | pool scratch [512]
-    return (size_t)d * 136 + 16 * 8 + 8 * 16 * 8 + (size_t)kExMG * kExMCap * 12 + 256 + 512 * 8;
+    const int G = exm_group(d);
+    return (size_t)d * (G * 8 + 8) + 16 * 8 + 8 * 16 * 8 + (G == 16 ? exm_list_bytes<16> : exm_list_bytes<8>) + 256 + 512 * 8;
 }
 
 // Sort every list of the group whose bit is set in `need` by (key, id), keep its k best, tighten its bound - all of
 // them in the SAME 36 barrier phases (the lists of a group fill at the same pace: one list at a time cost 16 x 36).
 // All threads; `need` is uniform.
+template <int G>
 __device__ __forceinline__ void exm_cut_lists(unsigned long long* l_key, int* l_id, int* s_cnt, unsigned long long* s_bound,
                                               uint32_t need, int k) {
     __syncthreads();
-    for (int i = threadIdx.x; i < kExMG * kExMCap; i += kExThreads) {
+    for (int i = threadIdx.x; i < G * kExMCap; i += kExThreads) {
         const int g = i / kExMCap, e = i - g * kExMCap;
         if (((need >> g) & 1u) && e >= min(s_cnt[g], kExMCap)) {
             l_key[i] = ~0ull;
@@ -529,7 +538,7 @@ __device__ __forceinline__ void exm_cut_lists(unsigned long long* l_key, int* l_
     for (int size = 2; size <= kExMCap; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
-            for (int pp = threadIdx.x; pp < kExMG * (kExMCap >> 1); pp += kExThreads) {
+            for (int pp = threadIdx.x; pp < G * (kExMCap >> 1); pp += kExThreads) {
                 const int g = pp / (kExMCap >> 1), p = pp - g * (kExMCap >> 1);
                 if (!((need >> g) & 1u)) continue;
                 unsigned long long* key = l_key + g * kExMCap;
@@ -548,7 +557,7 @@ __device__ __forceinline__ void exm_cut_lists(unsigned long long* l_key, int* l_
         }
     }
     __syncthreads();
-    if (threadIdx.x < kExMG && ((need >> threadIdx.x) & 1u)) {
+    if (threadIdx.x < G && ((need >> threadIdx.x) & 1u)) {
         const int g = threadIdx.x, n = min(s_cnt[g], kExMCap);
         s_cnt[g] = n < k ? n : k;
         if (n >= k && l_key[g * kExMCap + k - 1] < s_bound[g]) s_bound[g] = l_key[g * kExMCap + k - 1];
@@ -629,7 +638,7 @@ __device__ __forceinline__ void exm_merge_group(const ExactArgs& a, ExTopK& tk_b
                 else ok |= 1u << q;
             }
         }
-        if (ok) exm_cut_lists(l_key, l_id, s_cnt, s_bound, ok, a.k);
+        if (ok) exm_cut_lists<8>(l_key, l_id, s_cnt, s_bound, ok, a.k);
         for (int idx = tid; idx < 8 * a.k; idx += kExThreads) {
             const int q = idx / a.k, j = idx - q * a.k;
             if (!((ok >> q) & 1u)) continue;
@@ -652,20 +661,21 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
     static_assert(NS % H == 0 && H <= NS, "the register ring divides the row");
     extern __shared__ __attribute__((aligned(16))) char ex_smem[];
     constexpr int d = NS * 32;
-    char* s_q = ex_smem;                                                    // [d][16] doubles, padded (exm_q_off)
-    double* s_qn2 = reinterpret_cast<double*>(ex_smem + (size_t)d * 136);   // [16] ||q||^2 (L2)
+    constexpr int G = exm_group(d);                                         // queries per group
+    char* s_q = ex_smem;                                                    // [d][G] doubles, padded (exm_q_off)
+    double* s_qn2 = reinterpret_cast<double*>(ex_smem + (size_t)d * (G * 8 + 8));   // [16] ||q||^2 (L2)
     double* s_xn = s_qn2 + 16;                                              // (spare)
     char* s_lists = reinterpret_cast<char*>(s_xn + 8 * 16);
-    unsigned long long* l_key = reinterpret_cast<unsigned long long*>(s_lists);            // [16][kExMCap]
-    int* l_id = reinterpret_cast<int*>(s_lists + (size_t)kExMG * kExMCap * 8);             // [16][kExMCap]
+    unsigned long long* l_key = reinterpret_cast<unsigned long long*>(s_lists);            // [G][kExMCap]
+    int* l_id = reinterpret_cast<int*>(s_lists + (size_t)G * kExMCap * 8);                 // [G][kExMCap]
     ExTopK& tk_big = *reinterpret_cast<ExTopK*>(s_lists);
-    static_assert(sizeof(ExTopK) <= (size_t)kExMG * kExMCap * 12, "the merge list aliases the group's lists");
-    unsigned long long* s_bound = reinterpret_cast<unsigned long long*>(s_lists + (size_t)kExMG * kExMCap * 12);
+    static_assert(sizeof(ExTopK) <= exm_list_bytes<G>, "the merge list aliases the group's lists");
+    unsigned long long* s_bound = reinterpret_cast<unsigned long long*>(s_lists + exm_list_bytes<G>);   // (16 slots either way)
     int* s_cnt = reinterpret_cast<int*>(s_bound + kExMG);
     int& s_last = s_cnt[kExMG];
     // this workgroup's best key per query so far (what it publishes for the chip-wide bound): behind the 256 bytes of
     // bounds and counters
-    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_lists + (size_t)kExMG * kExMCap * 12 + 256);
+    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_lists + exm_list_bytes<G> + 256);
     if (gate_closed(a.gate)) return;
     const uint32_t nf = *a.n_flag;
     if ((uint32_t)a.f0 >= nf) return;
@@ -684,14 +694,14 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
         atomicMin(&s_best[col], key);
     };
 
-    for (int fg = a.f0; fg < f1; fg += kExMG) {
-        const int ng = min(kExMG, f1 - fg);
+    for (int fg = a.f0; fg < f1; fg += G) {
+        const int ng = min(G, f1 - fg);
         __syncthreads();
-        for (int i = tid; i < kExMG * d; i += kExThreads) {
+        for (int i = tid; i < G * d; i += kExThreads) {
             const int g = i / d, c = i - g * d;
             // (slots past the group's last query repeat the first one: same work, results never pushed)
             const int b = a.flag_list[fg + (g < ng ? g : 0)];
-            *reinterpret_cast<double*>(s_q + exm_q_off(c, g)) = (double)a.q32[(int64_t)b * d + c];
+            *reinterpret_cast<double*>(s_q + exm_q_off<G>(c, g)) = (double)a.q32[(int64_t)b * d + c];
         }
         if (tid < kExMG) {
             s_cnt[tid] = 0;
@@ -700,10 +710,10 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
         }
         __syncthreads();
         {
-            for (int gq = 2 * w; gq < 2 * w + 2; ++gq) {
+            for (int gq = w; gq < G; gq += 8) {
                 double sq = 0.0;
                 for (int c = lane; c < d; c += 64) {
-                    const double v = *reinterpret_cast<const double*>(s_q + exm_q_off(c, gq));
+                    const double v = *reinterpret_cast<const double*>(s_q + exm_q_off<G>(c, gq));
                     sq = fma(v, v, sq);
                 }
 #pragma unroll
@@ -739,8 +749,8 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
         const bool need_xsq = l2 || a.xn_max == nullptr;
         const double xn_shard = need_xsq ? 0.0 : (double)__uint_as_float(*a.xn_max) * (1.0 + 1e-6);
         // byte offset of q[k = 8 p][query r]; a step of 32 k is 32 x 128 + 4 x 64 bytes on
-        const int q_lane = exm_q_off(p * 8, r);
-        static_assert(exm_q_off_step == 4352, "step stride of the padded query block");
+        const int q_lane = exm_q_off<G>(p * 8, r & (G - 1));
+        constexpr int q_step = exm_q_off_step<G>, q_k = G * 8;             // bytes per 32 k, per k
         int steps_done = 0;
         // what follows a step's scores: capacity check / cuts, the published best key, the chip-wide bound
         auto step_tail = [&]() __attribute__((always_inline)) {
@@ -751,7 +761,7 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
             // the second step, where an empty bound re-scores all 128 x ng of them again (~45 us at 16 queries)
             if (steps_done == 0)
                 for (int g = 0; g < ng; ++g) need |= s_cnt[g] > a.k ? 1u << g : 0u;
-            if (need) exm_cut_lists(l_key, l_id, s_cnt, s_bound, need, a.k);
+            if (need) exm_cut_lists<G>(l_key, l_id, s_cnt, s_bound, need, a.k);
             // The chip-wide bound.  Every workgroup publishes its best key per query after 1, 2, 4, 8, ... steps and reads
             // the others' then: the k-th smallest of the workgroups' best keys is the worst of SOME k distinct rows, hence
             // an upper bound on the k-th best of all rows - about the k-th best of n_lists x 128 x steps rows, where a
@@ -789,7 +799,7 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
             auto mfma_pass = [&](auto small_tag) __attribute__((always_inline)) {
             constexpr bool S = decltype(small_tag)::value;
             const bool hi = ng > 4;                                          // (S: queries 4..7 in use)
-            const int q_lane_s = exm_q_off(p * 8, lane & 3);
+            const int q_lane_s = exm_q_off<G>(p * 8, lane & 3);
             for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
                 const int64_t t_next = t + gridDim.x < n_tiles ? t + gridDim.x : t;
                 const char* cur_b = row_base(t);
@@ -821,26 +831,26 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
                 else load_seg(slot, nxt_b, it + H - NS);
                 // (the step's LDS address is formed HERE: hoisted out of the loop, the NS addresses of the unrolled steps -
                 //  beyond the 64 KB a ds_read offset reaches - cost a register each and spilled)
-                int qo = (S ? q_lane_s : q_lane) + it * 4352;
+                int qo = (S ? q_lane_s : q_lane) + it * q_step;
                 asm volatile("" : "+v"(qo));
-                const char* qb = s_q + qo;                                   // (+ 128 B per k inside the piece)
+                const char* qb = s_q + qo;                                   // (+ q_k bytes per k inside the piece)
                 if constexpr (S) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const double qv = *reinterpret_cast<const double*>(qb + j * 128);
+                        const double qv = *reinterpret_cast<const double*>(qb + j * q_k);
                         a0[j % 4] = __builtin_amdgcn_mfma_f64_4x4x4f64(xd[j], qv, a0[j % 4], 0, 0, 0);
                     }
                     if (hi) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            const double qv = *reinterpret_cast<const double*>(qb + j * 128 + 32);     // query + 4
+                            const double qv = *reinterpret_cast<const double*>(qb + j * q_k + 32);     // query + 4
                             a1[j % 4] = __builtin_amdgcn_mfma_f64_4x4x4f64(xd[j], qv, a1[j % 4], 0, 0, 0);
                         }
                     }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const double qv = *reinterpret_cast<const double*>(qb + j * 128);
+                        const double qv = *reinterpret_cast<const double*>(qb + j * q_k);
                         acc[j % kExMChains] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[j], qv, acc[j % kExMChains], 0, 0, 0);
                     }
                 }
@@ -898,7 +908,7 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
                         }
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            const double qv = *reinterpret_cast<const double*>(s_q + exm_q_off(e + j, colx));
+                            const double qv = *reinterpret_cast<const double*>(s_q + exm_q_off<G>(e + j, colx));
                             if (l2) {
                                 const double df = qv - xv[j];
                                 sx = fma(df, df, sx);
@@ -928,11 +938,15 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
                 step_tail();
             }
             };
-            if (ng <= 8) mfma_pass(std::true_type{});
-            else mfma_pass(std::false_type{});
+            if constexpr (G == 8) {
+                mfma_pass(std::true_type{});
+            } else {
+                if (ng <= 8) mfma_pass(std::true_type{});
+                else mfma_pass(std::false_type{});
+            }
         }
         __syncthreads();
-        exm_cut_lists(l_key, l_id, s_cnt, s_bound, (1u << ng) - 1u, a.k);
+        exm_cut_lists<G>(l_key, l_id, s_cnt, s_bound, (1u << ng) - 1u, a.k);
         for (int g = 0; g < ng; ++g) {
             const int64_t o = ((int64_t)(fg + g - a.f0) * a.n_lists + blockIdx.x) * a.k;
             for (int j = tid; j < a.k; j += kExThreads) {
@@ -959,7 +973,7 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
 }
 
 bool exact_mfma_supported(int d, int k) {
-    return k <= kExMCap / 4 && d % 128 == 0 && d >= 128 && d <= 768;
+    return k <= kExMCap / 4 && ((d % 128 == 0 && d >= 128 && d <= 768) || d == 1024 || d == 1536);
 }
 
 template <bool F32>
@@ -976,6 +990,7 @@ static int launch_exact_mfma(const ExactArgs& a, int grid, hipStream_t st) {
     }
     // (row segments in flight per lane: 16 B each on fp16 rows, 32 B on float32 rows - sized so that no form spills)
     PRAG_EXM(4, 4, 4) PRAG_EXM(8, 8, 4) PRAG_EXM(12, 6, 4) PRAG_EXM(16, 8, 4) PRAG_EXM(20, 10, 5) PRAG_EXM(24, 8, 4)
+    PRAG_EXM(32, 16, 8) PRAG_EXM(48, 12, 6)
 #undef PRAG_EXM
     set_error("internal: exact_mfma_kernel has no d = %d form", a.d);
     return PRAG_EUNSUPPORTED;

@@ -701,10 +701,13 @@ def test_grouped_exact_scan_is_bit_identical_to_the_single_query_scan(monkeypatc
 
 @pytest.mark.parametrize("d,store,metric", [(128, "f16", onp.METRIC_L2), (256, "f32", onp.METRIC_IP), (384, "f16", onp.METRIC_COS),
                                             (512, "f32", onp.METRIC_L2), (512, "f16", onp.METRIC_IP), (768, "f16", onp.METRIC_L2),
-                                            (768, "f32", onp.METRIC_COS), (768, "f16", onp.METRIC_COS)])
+                                            (768, "f32", onp.METRIC_COS), (768, "f16", onp.METRIC_COS),
+                                            (1024, "f16", onp.METRIC_L2), (1024, "f32", onp.METRIC_IP), (1536, "f16", onp.METRIC_COS),
+                                            (1536, "f32", onp.METRIC_L2)])
 def test_exact_scan_on_the_float64_matrix_pipe(monkeypatch, d, store, metric):
-    """exact_mfma_kernel at every row length it is built for (d = 128 ... 768), both storages, all metrics: 37 queries
-    (two full groups of 16 and a ragged one of 5 - the 4 x 4 x 4 blocks' two-instruction shape), each the exact copy of a
+    """exact_mfma_kernel at every row length it is built for (d = 128 ... 768 in groups of 16 queries; 1024 and 1536 in
+    groups of 8, whose query block still fits LDS), both storages, all metrics: 37 queries (two full groups of 16 and a
+    ragged one of 5 - the 4 x 4 x 4 blocks' two-instruction shape -, or four of 8 and one of 5), each the exact copy of a
     row that occurs 40 times - more copies than any candidate list holds, so no certificate clears and every query is
     recomputed by the float64 scan - on a corpus whose size is no multiple of the kernel's 128-row step.  Results the
     definition's; the copies come back lowest id first; identical to the one-query-per-pass kernel."""
@@ -712,7 +715,8 @@ def test_exact_scan_on_the_float64_matrix_pipe(monkeypatch, d, store, metric):
 
 
 @pytest.mark.parametrize("B", [2, 3, 4, 5, 7, 8, 9, 19, 20])
-@pytest.mark.parametrize("d,store,metric", [(640, "f16", onp.METRIC_L2), (256, "f32", onp.METRIC_IP), (768, "f16", onp.METRIC_COS)])
+@pytest.mark.parametrize("d,store,metric", [(640, "f16", onp.METRIC_L2), (256, "f32", onp.METRIC_IP), (768, "f16", onp.METRIC_COS),
+                                            (1024, "f16", onp.METRIC_IP)])
 def test_exact_scan_small_groups_on_the_4x4x4_blocks(monkeypatch, d, store, metric, B):
     """Groups of 2 ... 8 flagged queries take the matrix pipe's four-block shape (one instruction for <= 4 queries, two
     for <= 8), 9 ... 16 the full tile; 19 and 20 end in ragged groups of 3 and 4 behind a full one.  Same corpus of

@@ -7,13 +7,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
     import torch
     import probing_rag_amd as pra
-    N, d, k = int(sys.argv[2]), 640, 30
+    N, d, k = int(sys.argv[2]), int(sys.argv[3]), 30
     for metric, store in (("l2", "f16"), ("ip", "f16"), ("l2", "f32")):
-        ix = pra.HipFlatIndex(d, metric, store, capacity=N)
+        ix = pra.HipFlatIndex(d, metric, store, capacity=N + 64 * 300)
         ix.add_synthetic(42, 0, N)
+        dup = None
+        if d != 640:      # (rows this long have a tiled path at k = 30: flag every query by 300 copies of it among the rows instead)
+            dup = torch.randn(64, d, device="cuda")
+            ix.add(dup.repeat_interleave(300, dim=0))
         out = []
         for B in (1, 2, 4, 8, 16, 64):
-            q = torch.randn(B, d, device="cuda")
+            q = torch.randn(B, d, device="cuda") if dup is None else dup[:B].contiguous()
             for _ in range(2):
                 ix.search(q, k)
             torch.cuda.synchronize()
@@ -22,13 +26,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             for _ in range(n):
                 ix.search(q, k)
             torch.cuda.synchronize()
-            out.append(f"B={B}: {(time.perf_counter() - t0) / n * 1e3:8.2f} ms")
+            out.append(f"B={B}: {(time.perf_counter() - t0) / n * 1e3:8.2f} ms" + ("" if dup is None else f" ({ix.last_exact_fallbacks()} flagged)"))
         print(f"{metric} {store} {N} x {d}: " + " | ".join(out), flush=True)
         ix.close()
     sys.exit(0)
-for N in (4_000_000,):
+for N, d in ((4_000_000, 640), (2_500_000, 1024)):      # (the same bytes; rows of 1024: groups of 8 on the matrix pipe)
     for mode, mfma, name in (("0", "0", "one query per pass (exact_scan_kernel)"), ("1", "0", "eight queries per pass (exact_group_kernel)"),
-                             ("1", "1", "sixteen queries per pass on the float64 matrix pipe (exact_mfma_kernel)")):
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "child", str(N)],
+                             ("1", "1", "sixteen (d <= 768) or eight queries per pass on the float64 matrix pipe (exact_mfma_kernel)")):
+        if d != 640 and mode == "0":
+            continue
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "child", str(N), str(d)],
                            env=dict(os.environ, PRAG_EXACT_GROUP=mode, PRAG_EXACT_MFMA=mfma), capture_output=True, text=True)
         print(f"== {name}\n{r.stdout.strip() or r.stderr.strip()[-400:]}", flush=True)
