@@ -26,6 +26,19 @@ constexpr int kExCap = 2048;     // LDS slots per workgroup (k <= 1024 leaves >=
 constexpr int kExCheck = 8;      // row tiles (of 32 rows) between capacity checks
 constexpr int kExThreads = 512;
 
+// Row loads of exact_mfma_kernel: ORDINARY loads.  The float64 scans streamed their rows non-temporally like the first-pass
+// scans since round 4; on THIS kernel's access pattern - 16 B pieces of 16 rows per wave instruction, two adjacent 16 B loads
+// per lane on float32 rows - that cost 8 % (fp16 rows) to 20 % (float32 rows) of the pass (the bare pattern:
+// tools/micro/row_piece_stream.hip, 5.85 against 6.34 TB/s); the one-query and eight-query kernels, whose wave instructions
+// cover 256 contiguous bytes of a row, are 1-2 % faster WITH the hint and keep it (profiles/r06y_exact_loads_ab.txt).
+__device__ __forceinline__ u32x4 exm_load(const u32x4* p) {
+#ifdef PRAG_EX_NONTEMPORAL
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 struct ExTopK {
     unsigned long long key[kExCap];
     int id[kExCap];
@@ -736,8 +749,8 @@ __global__ __launch_bounds__(kExThreads) void exact_mfma_kernel(ExactArgs a) {
             return b;
         };
         auto load_seg = [&](int slot, const char* base, int it) __attribute__((always_inline)) {
-            v0[slot] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + it * 32 * ES));
-            if constexpr (F32) v1[slot] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + it * 32 * ES + 16));
+            v0[slot] = exm_load(reinterpret_cast<const u32x4*>(base + it * 32 * ES));
+            if constexpr (F32) v1[slot] = exm_load(reinterpret_cast<const u32x4*>(base + it * 32 * ES + 16));
         };
         if ((int64_t)blockIdx.x < n_tiles) {
             const char* b0 = row_base(blockIdx.x);

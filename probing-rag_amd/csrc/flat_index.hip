@@ -2737,12 +2737,13 @@ static int search_finish(SearchRun& r, float* D, int64_t* I) {
     //  r05f_exact_group_bench.txt -, so "several" means: by construction, or the retry tier's inner searches have been
     //  leaving >= 4 queries flagged lately)
     er.mfma = ix->exact_mfma_mode != 0;
-    // ... or B >= 2 on a shape the matrix-pipe form covers (round 6): it decides on the device - one flagged query in a
-    // group is scanned with plain fmas at the one-query kernel's pace, two or more share a pass on the float64 MFMA - so no
-    // history is needed and the launch sequence is the same whatever earlier searches flagged
+    // ... or a shape the matrix-pipe form covers (round 6): it decides on the device - up to eight flagged queries of a
+    // group share a pass on the four-block float64 MFMA, nine to sixteen on the full tile, and ONE costs 1.23-1.29 ms over
+    // 4 M x 640 fp16 rows where the one-query kernel takes 1.43-1.46 (float32 rows 1.98 against 2.45) - so no history is
+    // needed, the launch sequence is the same whatever earlier searches flagged, and a single query takes it too
     er.grouped = ix->exact_group_mode != 0 &&
                  (ix->exact_group_mode == 1 || (exact_only && B >= 2) || (ix->adaptive && ix->exact_group_hint) ||
-                  (B >= 2 && er.mfma && exact_mfma_supported(ix->d, k)));
+                  (er.mfma && exact_mfma_supported(ix->d, k)));
     const bool may_flag = certify && ix->ntotal > 0;
     if (use_mm8) {
         // second tier, decided on the device (mm8_second_tier): no read-back, no host branch

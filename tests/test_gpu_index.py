@@ -724,15 +724,24 @@ def test_exact_scan_small_groups_on_the_4x4x4_blocks(monkeypatch, d, store, metr
     _matrix_pipe_case(monkeypatch, d, store, metric, B)
 
 
-def _matrix_pipe_case(monkeypatch, d, store, metric, B):
+@pytest.mark.parametrize("d,store,metric,k,B", [(640, "f16", onp.METRIC_L2, 64, 20), (1024, "f16", onp.METRIC_IP, 64, 9),
+                                                (1536, "f32", onp.METRIC_COS, 33, 5), (768, "f32", onp.METRIC_IP, 50, 16)])
+def test_exact_scan_on_the_matrix_pipe_with_deep_lists(monkeypatch, d, store, metric, k, B):
+    """k up to 64 (the kernel's limit: a quarter of its 256-slot lists): each query's row occurs 300 times, more than the
+    tiled first pass's 256 candidates, so every query goes to the float64 scan, which must return the first k copies by
+    id out of 300 exact ties."""
+    _matrix_pipe_case(monkeypatch, d, store, metric, B, k=k, copies=300)
+
+
+def _matrix_pipe_case(monkeypatch, d, store, metric, B, k=10, copies=40):
     import torch
     import probing_rag_amd as pra
-    N, k = 20_011, 10
+    N = 20_011
     X = onp.synth_rows(71, 0, N, d)
     rng = np.random.default_rng(d)
     dup_rows = []
     for i in range(B):
-        dups = np.sort(rng.choice(N, 40, replace=False))
+        dups = np.sort(rng.choice(N, copies, replace=False))
         X[dups] = X[dups[0]]
         dup_rows.append(dups)
     Q = np.stack([X[dr[0]] for dr in dup_rows]).astype(np.float32)
