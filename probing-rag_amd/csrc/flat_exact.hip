@@ -508,8 +508,9 @@ __global__ __launch_bounds__(kExThreads) void exact_group_kernel(ExactArgs a) {
 //     returned (identical rows give exactly 0).
 // Queries sit in LDS transposed and padded ([k][16 queries] doubles, 64 B more per 8 k: a wave's ds_read_b64 touches
 // every bank twice, the minimum); 16 threshold lists of 256 slots (k <= 64) alias the merge's big list.  d = 32 NS,
-// NS in {4, 8, 12, 16, 20, 24}; H row segments are in flight per lane (a register is refilled right behind its use,
-// from the next tile when the row is exhausted).
+// NS in {4, 8, 12, 16, 20, 24} in groups of 16 queries, {32, 48} (rows of 1024 / 1536 elements) in groups of 8 - what
+// fits LDS; H row segments are in flight per lane (a register is refilled right behind its use, from the next tile
+// when the row is exhausted).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kExMG = 16;
 constexpr int kExMCap = 256;
