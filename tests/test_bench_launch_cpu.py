@@ -142,11 +142,17 @@ def _strict_loads(line):
     return json.loads(line, parse_constant=_no_constants)
 
 
-def _full_record(n_ranks=1):
-    """Round 5's full single-GPU record (profiles/r05f_bench.json, 20.7 KB), optionally dressed up as an N-rank run with
-    every optional block present and over-long strings - the worst case the compact line has to survive."""
+def _full_record(n_ranks=1, source="r05f"):
+    """Round 5's full single-GPU record (profiles/r05f_bench.json, 20.7 KB) or round 6's (the BENCH_DETAIL line of
+    profiles/r06last_bench.json: more variants, more config fields), optionally dressed up as an N-rank run with every
+    optional block present and over-long strings - the worst case the compact line has to survive."""
     import json
-    full = json.load(open(os.path.join(ROOT, "profiles", "r05f_bench.json")))
+    if source == "r05f":
+        full = json.load(open(os.path.join(ROOT, "profiles", "r05f_bench.json")))
+    else:
+        first = open(os.path.join(ROOT, "profiles", "r06last_bench.json")).read().splitlines()[0]
+        assert first.startswith("BENCH_DETAIL ")
+        full = json.loads(first[len("BENCH_DETAIL "):])
     if n_ranks > 1:
         full["n_gpus"] = full["rccl_ranks"] = n_ranks
         full["per_rank"] = [{"rank": r, "device": r, "rows": 2_625_000, "gate_rows": 512, "scan_ms": 0.38689423620700836,
@@ -162,8 +168,8 @@ def _full_record(n_ranks=1):
 
 def test_the_last_line_is_compact_strict_json_with_the_contract_keys():
     import bench
-    for n in (1, 8):
-        full = _full_record(n)
+    for n, source in ((1, "r05f"), (8, "r05f"), (1, "r06last"), (8, "r06last")):
+        full = _full_record(n, source)
         rec, line = bench.compact_record(full)
         assert len(line) < bench.COMPACT_LIMIT == 6000 and "\n" not in line
         got = _strict_loads(line)

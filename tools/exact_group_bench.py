@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Exact float64 fallback, one query per pass against eight per pass (exact_group_kernel) and sixteen per pass on the float64 MFMA (exact_mfma_kernel): every query flagged by
-construction (k = 30 on d = 640 goes straight to the exact scan) - ms per search for 1 ... 64 queries, both kernels."""
+"""Exact float64 fallback, ms per search for 1 ... 64 flagged queries: one query per pass (exact_scan_kernel), eight per pass
+(exact_group_kernel), and the float64 matrix pipe (exact_mfma_kernel: 1-8 flagged queries on four 4 x 4 x 4 blocks, 9-16 on
+the 16 x 16 x 4 tile; rows of 1024 elements in groups of 8).  Every query is flagged by construction: 4 M x 640 rows with
+k = 30 go straight to the exact scan (no tiled path at that row length); on 2.5 M x 1024 rows every query's row occurs 300
+times (more than the tiled first pass's 256 candidates - that pass, ~1.2 ms, is inside the time printed)."""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
